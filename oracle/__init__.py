@@ -1,0 +1,225 @@
+"""ctypes face of the CPU oracle (oracle/tsc_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg and from
+nowhere else: the product package (tscode_amd) must never import this module.
+Function names follow the reference's (rmsd_pruning.py / numba_functions.py / algebra.py /
+embeds.py); each C function cites the reference lines it restates.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_f64p = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class PassStats(C.Structure):
+    _fields_ = [("k", C.c_int64), ("n_active_before", C.c_int64), ("n_active_after", C.c_int64),
+                ("pairs_evaluated", C.c_int64), ("cache_hit_exits", C.c_int64), ("new_keys", C.c_int64),
+                ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "tsc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_count_clashes.restype = C.c_int64
+        _lib.orc_vec_angle.restype = C.c_double
+        _lib.orc_clash_margin.restype = C.c_double
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=_f64p):
+    return a.ctypes.data_as(t)
+
+
+def rmsd_and_max_numba(p, q):
+    p, q = _f64(p), _f64(q)
+    r, m = C.c_double(), C.c_double()
+    lib().orc_rmsd_and_max(_p(p), _p(q), C.c_int(p.shape[0]), C.byref(r), C.byref(m))
+    return r.value, m.value
+
+
+def rmsd_pairs(heavy, pairs):
+    heavy = _f64(heavy)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64)
+    r = np.empty(len(pairs))
+    m = np.empty(len(pairs))
+    lib().orc_rmsd_pairs(_p(heavy), C.c_int(heavy.shape[1]), _p(pairs, _i64p), C.c_int64(len(pairs)), _p(r), _p(m))
+    return r, m
+
+
+def _rmsd_similarity(ref, structures, rmsd_thr=0.5):
+    ref = _f64(ref)
+    structures = _f64(structures).reshape(-1, ref.shape[0], 3)
+    return bool(lib().orc_rmsd_similarity(_p(ref), _p(structures), C.c_int64(len(structures)), C.c_int(ref.shape[0]),
+                                          C.c_double(rmsd_thr)))
+
+
+def greedy_group_filter(poses, rmsd_thr=1.0):
+    poses = _f64(poses)
+    acc = np.zeros(len(poses), dtype=np.uint8)
+    lib().orc_greedy_group_filter(_p(poses), C.c_int64(len(poses)), C.c_int(poses.shape[1]), C.c_double(rmsd_thr), _p(acc, _u8p))
+    return acc.astype(bool)
+
+
+def all_dists(a, b):
+    a, b = _f64(a), _f64(b)
+    out = np.empty((len(a), len(b)))
+    lib().orc_all_dists(_p(a), C.c_int(len(a)), _p(b), C.c_int(len(b)), _p(out))
+    return out
+
+
+def count_clashes(coords):
+    coords = _f64(coords)
+    return int(lib().orc_count_clashes(_p(coords), C.c_int(len(coords))))
+
+
+def compenetration_check(coords, ids=None, thresh=1.5, max_clashes=0, return_counts=False):
+    coords = _f64(coords)
+    ids_a = np.zeros(0, dtype=np.int64) if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+    counts = np.zeros(3, dtype=np.int64)
+    res = lib().orc_compenetration_check(_p(coords), C.c_int(len(coords)), _p(ids_a, _i64p), C.c_int(len(ids_a)),
+                                         C.c_double(thresh), C.c_int64(max_clashes), _p(counts, _i64p))
+    return (res, counts) if return_counts else res
+
+
+def compenetration_mask(coords, ids=None, thresh=1.5, max_clashes=0):
+    coords = _f64(coords)
+    ids_a = np.zeros(0, dtype=np.int64) if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+    mask = np.zeros(len(coords), dtype=np.uint8)
+    lib().orc_compenetration_mask(_p(coords), C.c_int64(len(coords)), C.c_int(coords.shape[1]), _p(ids_a, _i64p),
+                                  C.c_int(len(ids_a)), C.c_double(thresh), C.c_int64(max_clashes), _p(mask, _u8p))
+    return mask.astype(bool)
+
+
+def clash_margin(coords, ids, thresh=1.5):
+    coords = _f64(coords)
+    ids_a = np.ascontiguousarray(ids, dtype=np.int64)
+    return float(lib().orc_clash_margin(_p(coords), C.c_int64(len(coords)), C.c_int(coords.shape[1]), _p(ids_a, _i64p),
+                                        C.c_int(len(ids_a)), C.c_double(thresh)))
+
+
+def transform_batch(frag_coords, conf_idx, rot, pos):
+    """Batched get_embed (embeds.py:961-969). frag_coords[m]: f64[n_conf_m, n_m, 3]."""
+    frags = [_f64(f) for f in frag_coords]
+    n_mols = len(frags)
+    nat = np.array([f.shape[1] for f in frags], dtype=np.int64)
+    conf_idx = np.ascontiguousarray(conf_idx, dtype=np.int32).reshape(-1, n_mols)
+    rot = _f64(rot).reshape(-1, n_mols, 3, 3)
+    pos = _f64(pos).reshape(-1, n_mols, 3)
+    n_poses = len(rot)
+    out = np.empty((n_poses, int(nat.sum()), 3))
+    ptrs = (_f64p * n_mols)(*[_p(f) for f in frags])
+    lib().orc_transform_batch(ptrs, _p(nat, _i64p), C.c_int(n_mols), conf_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                              _p(rot), _p(pos), C.c_int64(n_poses), _p(out))
+    return out
+
+
+def transform_coords(coords, rot, pos):
+    coords = _f64(coords)
+    return transform_batch([coords[None]], np.zeros((1, 1), np.int32), _f64(rot)[None, None], _f64(pos)[None, None])[0]
+
+
+def quaternion_to_rotation_matrix(q):
+    q = _f64(q)
+    out = np.empty((3, 3))
+    lib().orc_quaternion_to_rotation_matrix(_p(q), _p(out))
+    return out
+
+
+def rot_mat_from_pointer(pointer, angle):
+    pointer = _f64(pointer)
+    out = np.empty((3, 3))
+    lib().orc_rot_mat_from_pointer(_p(pointer), C.c_double(angle), _p(out))
+    return out
+
+
+def align_vec_pair(ref, tgt):
+    ref, tgt = _f64(ref), _f64(tgt)
+    out = np.empty((3, 3))
+    lib().orc_align_vec_pair(_p(ref), _p(tgt), _p(out))
+    return out
+
+
+def rotation_matrix_from_vectors(v1, v2):
+    v1, v2 = _f64(v1), _f64(v2)
+    out = np.empty((3, 3))
+    lib().orc_rotation_matrix_from_vectors(_p(v1), _p(v2), _p(out))
+    return out
+
+
+def vec_angle(v1, v2):
+    v1, v2 = _f64(v1), _f64(v2)
+    return float(lib().orc_vec_angle(_p(v1), _p(v2)))
+
+
+def prune_heavy(heavy, rmsd_thr=0.5, mode=0, row_parallel=False, trace=False):
+    """Prune on the heavy-atom array f64[N, h, 3]. Returns dict(mask, stats[, pass_masks, keys])."""
+    heavy = _f64(heavy)
+    n, h = heavy.shape[0], heavy.shape[1]
+    mask = np.zeros(n, dtype=np.uint8)
+    stats = (PassStats * 18)()
+    n_passes = C.c_int()
+    pm = np.zeros((18, n), dtype=np.uint8) if trace else None
+    keys = np.zeros((n, 2), dtype=np.int64) if trace else None
+    n_keys = C.c_int64()
+    rc = lib().orc_prune_rmsd(_p(heavy), C.c_int64(n), C.c_int(h), C.c_double(rmsd_thr), C.c_int(mode),
+                              C.c_int(int(row_parallel)), _p(mask, _u8p), stats, C.byref(n_passes),
+                              _p(pm, _u8p) if trace else None, _p(keys, _i64p) if trace else None, C.byref(n_keys))
+    if rc != 0:
+        raise ValueError("orc_prune_rmsd: bad arguments")
+    out = {"mask": mask.astype(bool), "stats": [stats[i].as_dict() for i in range(n_passes.value)]}
+    if trace:
+        out["pass_masks"] = pm[:n_passes.value].astype(bool)
+        out["keys"] = keys[:n_keys.value]
+    return out
+
+
+def prune_conformers_rmsd(structures, atomnos, rmsd_thr=0.5, mode=0, **kw):
+    """rmsd_pruning.py:164-206: heavy gather (:178-179), passes, (structures[mask], mask)."""
+    structures = np.asarray(structures)
+    heavy = np.ascontiguousarray(structures[:, np.asarray(atomnos) != 1], dtype=np.float64)
+    res = prune_heavy(heavy, rmsd_thr, mode, **kw)
+    return structures[res["mask"]], res["mask"]
+
+
+def prune_margins(heavy, rmsd_thr=0.5, mode=0):
+    heavy = _f64(heavy)
+    a, b = C.c_double(), C.c_double()
+    lib().orc_prune_margins(_p(heavy), C.c_int64(len(heavy)), C.c_int(heavy.shape[1]), C.c_double(rmsd_thr), C.c_int(mode),
+                            C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))

@@ -1,0 +1,641 @@
+/*
+ * tsc_oracle.c -- CPU restatement of TSCoDe's geometry hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP engine in tscode_amd/.  It restates, in plain C,
+ * the algorithm of the reference (ntampellini/TSCoDe v0.4.16) for the path named in
+ * BASELINE.json; every function cites the reference file:line it follows.  It is pinned against
+ * golden vectors produced by running the reference's own Python in the build container
+ * (tests/golden/gen_golden.py -> tests/golden/G*.npz; tests/test_oracle_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (tscode_amd) never links, imports or calls it.
+ *
+ * Third-party arithmetic on the path: the reference reaches LAPACK dgesdd/dgetrf and BLAS dgemm
+ * through np.linalg.svd / np.linalg.det / "@" (rmsd_pruning.py:15,19,20,26,29; algebra.py:275-282).
+ * Those sources are not under /root/reference; the 3x3 SVD here is a one-sided Jacobi (Hestenes)
+ * SVD, which yields the same factorisation up to the usual sign/ordering freedom; the golden
+ * vectors pin the results (rmsd, max deviation, rotation matrices) to <= 1e-9.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared).
+ */
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+
+/* algebra.py:89-96  norm_of(vec) = sqrt(x*x + y*y + z*z) */
+static inline double norm_of3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+static inline double det3(const double m[9]) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+static void matmul3(const double a[9], const double b[9], double c[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+/*
+ * 3x3 SVD  A = U diag(s) Vt  with s[0] >= s[1] >= s[2] >= 0 (the np.linalg.svd contract used at
+ * rmsd_pruning.py:19 and algebra.py:275).  One-sided Jacobi: right-rotate column pairs of A until
+ * they are mutually orthogonal; column norms are the singular values.  Null columns (rank-deficient
+ * input) are completed to an orthonormal basis by cross products.
+ */
+static void svd3(const double A[9], double U[9], double s[3], double Vt[9]) {
+    double a[3][3], v[3][3]; /* a[col][row], v[col][row] */
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            a[c][r] = A[3 * r + c];
+            v[c][r] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int i = 0; i < 2; ++i)
+            for (int j = i + 1; j < 3; ++j) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < 3; ++r) {
+                    alpha += a[i][r] * a[i][r];
+                    beta += a[j][r] * a[j][r];
+                    gamma += a[i][r] * a[j][r];
+                }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = 1;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int r = 0; r < 3; ++r) {
+                    double x = a[i][r], y = a[j][r];
+                    a[i][r] = cs * x - sn * y;
+                    a[j][r] = sn * x + cs * y;
+                    x = v[i][r], y = v[j][r];
+                    v[i][r] = cs * x - sn * y;
+                    v[j][r] = sn * x + cs * y;
+                }
+            }
+        if (!rotated) break;
+    }
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int c = 0; c < 3; ++c) nrm[c] = sqrt(a[c][0] * a[c][0] + a[c][1] * a[c][1] + a[c][2] * a[c][2]);
+    for (int i = 0; i < 2; ++i) /* sort descending */
+        for (int j = i + 1; j < 3; ++j)
+            if (nrm[ord[j]] > nrm[ord[i]]) {
+                int t = ord[i];
+                ord[i] = ord[j];
+                ord[j] = t;
+            }
+    /* Left vectors: u0 from the largest column; u1 by Gram-Schmidt of the second column against u0;
+     * u2 = +-(u0 x u1), the sign taken from the third column.  This keeps U orthonormal when the
+     * input is rank deficient (columns of norm ~1e-17 are rounding noise, not directions). */
+    double u[3][3];
+    for (int k = 0; k < 3; ++k) {
+        s[k] = nrm[ord[k]];
+        for (int r = 0; r < 3; ++r) Vt[3 * k + r] = v[ord[k]][r];
+    }
+    if (!(s[0] > 0.0)) { /* A == 0 */
+        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < 3; ++r) u[k][r] = (k == r) ? 1.0 : 0.0;
+    } else {
+        const double *a0 = a[ord[0]], *a1 = a[ord[1]], *a2 = a[ord[2]];
+        for (int r = 0; r < 3; ++r) u[0][r] = a0[r] / s[0];
+        double d = a1[0] * u[0][0] + a1[1] * u[0][1] + a1[2] * u[0][2];
+        double w[3] = {a1[0] - d * u[0][0], a1[1] - d * u[0][1], a1[2] - d * u[0][2]};
+        double n = norm_of3(w);
+        if (!(n > 1e-13 * s[0])) { /* any unit vector orthogonal to u0 */
+            int m = 0;
+            if (fabs(u[0][1]) < fabs(u[0][m])) m = 1;
+            if (fabs(u[0][2]) < fabs(u[0][m])) m = 2;
+            d = u[0][m];
+            w[0] = -d * u[0][0], w[1] = -d * u[0][1], w[2] = -d * u[0][2];
+            w[m] += 1.0;
+            n = norm_of3(w);
+        }
+        for (int r = 0; r < 3; ++r) u[1][r] = w[r] / n;
+        u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+        u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+        u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+        if (u[2][0] * a2[0] + u[2][1] * a2[1] + u[2][2] * a2[2] < 0.0)
+            for (int r = 0; r < 3; ++r) u[2][r] = -u[2][r];
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) U[3 * r + k] = u[k][r];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rmsd_pruning.py:6-41  rmsd_and_max_numba(p, q)                                              */
+
+ORC_API void orc_rmsd_and_max(const double *p, const double *q, int h, double *rmsd_out, double *maxdev_out) {
+    /* :15  cov_mat = p.T @ q */
+    double cov[9] = {0};
+    for (int a = 0; a < h; ++a)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) cov[3 * i + j] += p[3 * a + i] * q[3 * a + j];
+    /* :19  v, _, w = svd(cov_mat) */
+    double v[9], s[3], w[9];
+    svd3(cov, v, s, w);
+    /* :20-23  d = det(v)*det(w) < 0  ->  v[:, -1] = -v[:, -1] */
+    if (det3(v) * det3(w) < 0.0) {
+        v[2] = -v[2];
+        v[5] = -v[5];
+        v[8] = -v[8];
+    }
+    /* :26  rot_mat = v @ w */
+    double rot[9];
+    matmul3(v, w, rot);
+    /* :29-39  p = p @ rot_mat; diff = p - q; rmsd = sqrt(sum(diff^2)/len); max_delta = max ||diff_a|| */
+    double ss = 0.0, mx = 0.0;
+    for (int a = 0; a < h; ++a) {
+        double d[3];
+        for (int j = 0; j < 3; ++j)
+            d[j] = p[3 * a] * rot[j] + p[3 * a + 1] * rot[3 + j] + p[3 * a + 2] * rot[6 + j] - q[3 * a + j];
+        ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        double n = norm_of3(d);
+        if (a == 0 || n > mx) mx = n;
+    }
+    *rmsd_out = sqrt(ss / (double)h);
+    *maxdev_out = mx;
+}
+
+ORC_API void orc_rmsd_pairs(const double *heavy, int h, const int64_t *pairs, int64_t n_pairs, double *rmsd, double *maxdev) {
+    for (int64_t k = 0; k < n_pairs; ++k)
+        orc_rmsd_and_max(heavy + (size_t)pairs[2 * k] * h * 3, heavy + (size_t)pairs[2 * k + 1] * h * 3, h, rmsd + k, maxdev + k);
+}
+
+/* rmsd_pruning.py:208-224  _rmsd_similarity(ref, structures, rmsd_thr): all atoms, no cache */
+ORC_API int orc_rmsd_similarity(const double *ref, const double *structures, int64_t count, int n, double rmsd_thr) {
+    for (int64_t s = 0; s < count; ++s) {
+        double r, m;
+        orc_rmsd_and_max(ref, structures + (size_t)s * n * 3, n, &r, &m);
+        if (r < rmsd_thr && m < 2 * rmsd_thr) return 1;
+    }
+    return 0;
+}
+
+/* embeds.py:715 / :843 greedy use of _rmsd_similarity inside one angular group:
+ * a pose is accepted iff it is not similar to any pose accepted before it. */
+ORC_API void orc_greedy_group_filter(const double *poses, int64_t count, int n, double rmsd_thr, uint8_t *accepted) {
+    int64_t *kept = (int64_t *)malloc(sizeof(int64_t) * (size_t)(count > 0 ? count : 1));
+    int64_t nk = 0;
+    for (int64_t s = 0; s < count; ++s) {
+        int sim = 0;
+        for (int64_t k = 0; k < nk && !sim; ++k) {
+            double r, m;
+            orc_rmsd_and_max(poses + (size_t)s * n * 3, poses + (size_t)kept[k] * n * 3, n, &r, &m);
+            sim = (r < rmsd_thr && m < 2 * rmsd_thr);
+        }
+        accepted[s] = (uint8_t)!sim;
+        if (!sim) kept[nk++] = s;
+    }
+    free(kept);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* algebra.py:98-157  all_dists(A, B): C[i,j] = sqrt(sum_k (A[i,k]-B[j,k])^2)                  */
+/* (the 32x32 blocking of the reference only reorders independent entries)                    */
+
+ORC_API void orc_all_dists(const double *A, int na, const double *B, int nb, double *C) {
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double d = A[3 * i + k] - B[3 * j + k];
+                acc += d * d;
+            }
+            C[(size_t)i * nb + j] = sqrt(acc);
+        }
+}
+
+static int64_t count_below(const double *A, int na, const double *B, int nb, double thresh) {
+    int64_t c = 0;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double d = A[3 * i + k] - B[3 * j + k];
+                acc += d * d;
+            }
+            c += sqrt(acc) < thresh;
+        }
+    return c;
+}
+
+/* numba_functions.py:49-56  count_clashes: ordered self pairs with 0 < d < 0.5 */
+ORC_API int64_t orc_count_clashes(const double *coords, int n) {
+    int64_t c = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double d = coords[3 * i + k] - coords[3 * j + k];
+                acc += d * d;
+            }
+            double d = sqrt(acc);
+            c += (d < 0.5) && (d > 0.0);
+        }
+    return c;
+}
+
+/* numba_functions.py:59-105  compenetration_check(coords, ids, thresh, max_clashes) -> 0/1
+ * n_ids == 0 stands for ids=None.  counts_out (optional, 3 entries) receives the per-fragment-pair
+ * counts that were accumulated before the function returned (-1 = not evaluated: early exit). */
+ORC_API int orc_compenetration_check(const double *coords, int n, const int64_t *ids, int n_ids, double thresh,
+                                     int64_t max_clashes, int64_t *counts_out) {
+    if (counts_out) counts_out[0] = counts_out[1] = counts_out[2] = -1;
+    if (n_ids == 0) { /* :71-72 */
+        int64_t c = orc_count_clashes(coords, n);
+        if (counts_out) counts_out[0] = c;
+        return c > max_clashes ? 0 : 1;
+    }
+    if (n_ids == 2) { /* :74-81  m1 = coords[0:ids[0]], m2 = coords[ids[0]:]; all_dists(m2, m1) */
+        int n1 = (int)ids[0];
+        int64_t c = count_below(coords + 3 * n1, n - n1, coords, n1, thresh);
+        if (counts_out) counts_out[0] = c;
+        return c > max_clashes ? 0 : 1;
+    }
+    /* :85-105 three fragments, cumulative count, early exits */
+    int n1 = (int)ids[0], n2 = (int)ids[1], n3 = n - n1 - n2;
+    const double *m1 = coords, *m2 = coords + 3 * n1, *m3 = coords + 3 * (n1 + n2);
+    int64_t clashes = 0, c;
+    c = count_below(m2, n2, m1, n1, thresh);
+    if (counts_out) counts_out[0] = c;
+    clashes += c;
+    if (clashes > max_clashes) return 0;
+    c = count_below(m3, n3, m2, n2, thresh);
+    if (counts_out) counts_out[1] = c;
+    clashes += c;
+    if (clashes > max_clashes) return 0;
+    c = count_below(m1, n1, m3, n3, thresh);
+    if (counts_out) counts_out[2] = c;
+    clashes += c;
+    if (clashes > max_clashes) return 0;
+    return 1;
+}
+
+/* embedder.py:1243-1248  compenetration_refining loop: mask[s] = compenetration_check(structure_s, ...) */
+ORC_API void orc_compenetration_mask(const double *coords, int64_t n_poses, int n, const int64_t *ids, int n_ids,
+                                     double thresh, int64_t max_clashes, uint8_t *mask) {
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < n_poses; ++s)
+        mask[s] = (uint8_t)orc_compenetration_check(coords + (size_t)s * n * 3, n, ids, n_ids, thresh, max_clashes, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* embeds.py:961-969  get_embed, batched: out[s] = concat_m (R[s,m] @ X_m[c[s,m]].T).T + t[s,m]  */
+/* algebra.py:390-400 transform_coords is the single-fragment case.                            */
+
+ORC_API void orc_transform_batch(const double *const *frag_coords, const int64_t *frag_natoms, int n_mols,
+                                 const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses, double *out) {
+    int n = 0;
+    for (int m = 0; m < n_mols; ++m) n += (int)frag_natoms[m];
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < n_poses; ++s) {
+        double *o = out + (size_t)s * n * 3;
+        for (int m = 0; m < n_mols; ++m) {
+            const double *X = frag_coords[m] + (size_t)conf_idx[s * n_mols + m] * frag_natoms[m] * 3;
+            const double *R = rot + ((size_t)s * n_mols + m) * 9;
+            const double *t = pos + ((size_t)s * n_mols + m) * 3;
+            for (int a = 0; a < frag_natoms[m]; ++a, o += 3)
+                for (int i = 0; i < 3; ++i) o[i] = R[3 * i] * X[3 * a] + R[3 * i + 1] * X[3 * a + 1] + R[3 * i + 2] * X[3 * a + 2] + t[i];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rotation helpers (pose parameters)                                                         */
+
+/* algebra.py:284-323  quaternion (x, y, z, w) scalar-last -> matrix */
+ORC_API void orc_quaternion_to_rotation_matrix(const double Q[4], double out[9]) {
+    double q0 = Q[3], q1 = Q[0], q2 = Q[1], q3 = Q[2];
+    out[0] = 2 * (q0 * q0 + q1 * q1) - 1;
+    out[1] = 2 * (q1 * q2 - q0 * q3);
+    out[2] = 2 * (q1 * q3 + q0 * q2);
+    out[3] = 2 * (q1 * q2 + q0 * q3);
+    out[4] = 2 * (q0 * q0 + q2 * q2) - 1;
+    out[5] = 2 * (q2 * q3 - q0 * q1);
+    out[6] = 2 * (q1 * q3 - q0 * q2);
+    out[7] = 2 * (q2 * q3 + q0 * q1);
+    out[8] = 2 * (q0 * q0 + q3 * q3) - 1;
+}
+
+/* algebra.py:325-344  rot_mat_from_pointer(pointer, angle_deg) */
+ORC_API void orc_rot_mat_from_pointer(const double pointer[3], double angle_deg, double out[9]) {
+    double n = norm_of3(pointer); /* algebra.py:80-87 norm() */
+    double u[3] = {pointer[0] / n, pointer[1] / n, pointer[2] / n};
+    double ang = angle_deg * (M_PI / 180);
+    double s = sin(ang / 2), c = cos(ang / 2);
+    double quat[4] = {s * u[0], s * u[1], s * u[2], c};
+    orc_quaternion_to_rotation_matrix(quat, out);
+}
+
+/* algebra.py:258-282  align_vec_pair(ref, tgt): B[i,k] = sum_j ref[j][i]*tgt[j][k]; SVD; det fix; u @ vh */
+ORC_API void orc_align_vec_pair(const double ref[6], const double tgt[6], double out[9]) {
+    double B[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) B[3 * i + k] = ref[i] * tgt[k] + ref[3 + i] * tgt[3 + k];
+    double u[9], s[3], vh[9], uv[9];
+    svd3(B, u, s, vh);
+    matmul3(u, vh, uv);
+    if (det3(uv) < 0) {
+        u[2] = -u[2];
+        u[5] = -u[5];
+        u[8] = -u[8];
+    }
+    matmul3(u, vh, out);
+}
+
+/* utils.py:183-208  rotation_matrix_from_vectors(vec1, vec2) (Rodrigues; exact-zero tests kept) */
+ORC_API void orc_rotation_matrix_from_vectors(const double v1[3], const double v2[3], double out[9]) {
+    double n1 = norm_of3(v1), n2 = norm_of3(v2);
+    double a[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1}, b[3] = {v2[0] / n2, v2[1] / n2, v2[2] / n2};
+    double v[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    double s = norm_of3(v);
+    if (s != 0) {
+        double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+        double k[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}, kk[9];
+        matmul3(k, k, kk);
+        double f = (1 - c) / (s * s);
+        for (int i = 0; i < 9; ++i) out[i] = ((i % 4 == 0) ? 1.0 : 0.0) + k[i] + kk[i] * f;
+        return;
+    }
+    double ab[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
+    if (norm_of3(ab) == 0) {
+        double z[3] = {0, 0, 1};
+        orc_rot_mat_from_pointer(z, 180, out);
+        return;
+    }
+    for (int i = 0; i < 9; ++i) out[i] = (i % 4 == 0) ? 1.0 : 0.0;
+}
+
+/* algebra.py:58-62  vec_angle(v1, v2) in degrees */
+ORC_API double orc_vec_angle(const double v1[3], const double v2[3]) {
+    double n1 = norm_of3(v1), n2 = norm_of3(v2);
+    double d = (v1[0] / n1) * (v2[0] / n2) + (v1[1] / n1) * (v2[1] / n2) + (v1[2] / n1) * (v2[2] / n2);
+    if (d > 1.0) d = 1.0;
+    if (d < -1.0) d = -1.0;
+    return acos(d) * 180 / M_PI;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rmsd_pruning.py:43-206  prune_conformers_rmsd                                               */
+
+typedef struct {
+    int64_t k;               /* number of chunks of this pass */
+    int64_t n_active_before; /* count_nonzero(mask) entering the pass */
+    int64_t n_active_after;
+    int64_t pairs_evaluated; /* calls of rmsd_and_max_numba (rmsd_pruning.py:70) */
+    int64_t cache_hit_exits; /* rows that returned at :66-67 */
+    int64_t new_keys;        /* keys appended at :76 */
+    double seconds;
+} orc_pass_stats;
+
+static const double ORC_KS[18] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};
+
+/*
+ * heavy: f64[N, h, 3]  (structures[:, atomnos != 1], rmsd_pruning.py:178-179)
+ * mode 0: reference-exact, including the pair cache of :65-67/:75-77
+ * mode 1: cache-free (the cache test is skipped; labelled non-parity wherever reported)
+ * mask_out: u8[N]; stats: up to 18 entries; pass_masks (optional): u8[18, N] mask after each pass
+ * keys_out (optional): i64[N, 2] the cache keys (first, first+delta) in creation order; n_keys_out
+ * row_parallel != 0: rows of a chunk are also spread over threads (NOT the reference's parallelisation,
+ *   results identical because rows of a pass are independent: SURVEY.md F4)
+ *
+ * The cache lookup "hash_value in cache" (a linear scan of a typed List in the reference, :66) is done
+ * through a per-pass bitmap: a key (a, b) can only be hit in a pass where a is a chunk start and b lies
+ * in that chunk, and then it is hit exactly by the pairs (i, j) of that chunk with a + (j - i) == b.
+ * For N > 200 000 the reference fails (float k reaches range(): SURVEY.md F6); int(k) is used here.
+ */
+ORC_API int orc_prune_rmsd(const double *heavy, int64_t N, int h, double rmsd_thr, int mode, int row_parallel,
+                           uint8_t *mask_out, orc_pass_stats *stats, int *n_passes_out, uint8_t *pass_masks,
+                           int64_t *keys_out, int64_t *n_keys_out) {
+    if (N <= 0 || h <= 0) return -1;
+    const double maxdev_thr = 2 * rmsd_thr; /* :95 */
+    uint8_t *mask = (uint8_t *)malloc((size_t)N), *out = (uint8_t *)malloc((size_t)N), *dbit = (uint8_t *)calloc((size_t)N + 1, 1);
+    int64_t *key_a = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *key_b = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *row_key = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t n_keys = 0;
+    memset(mask, 1, (size_t)N); /* :182 */
+    int n_passes = 0;
+
+    for (int ks = 0; ks < 18; ++ks) {
+        int64_t k = (int64_t)ORC_KS[ks];
+        int64_t n_active = 0;
+        for (int64_t i = 0; i < N; ++i) n_active += mask[i];
+        if (!(k == 1 || 20 * k < n_active)) continue; /* :192 */
+#ifdef _OPENMP
+        double t0 = omp_get_wtime();
+#endif
+        int64_t cs = N / k; /* :136 */
+        /* per-pass view of the cache */
+        memset(dbit, 0, (size_t)N + 1);
+        if (mode == 0)
+            for (int64_t q = 0; q < n_keys; ++q) {
+                int64_t a = key_a[q], b = key_b[q];
+                if (cs <= 0 || a % cs != 0) continue;
+                int64_t c = a / cs;
+                if (c >= k) continue;
+                int64_t last = (c == k - 1) ? N : cs * (c + 1);
+                if (b < last) dbit[b] = 1;
+            }
+        int64_t evals = 0, hits = 0;
+        /* :139 prange over chunks; each chunk is serial over rows (:98) unless row_parallel */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : evals, hits) if (!row_parallel)
+        for (int64_t chunk = 0; chunk < k; ++chunk) {
+            int64_t first = chunk * cs;                              /* :140 */
+            int64_t last = (chunk == k - 1) ? N : cs * (chunk + 1); /* :141-144 */
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : evals, hits) if (row_parallel)
+            for (int64_t i = first; i < last; ++i) {
+                row_key[i] = -1;
+                if (!mask[i]) { /* :118-119 */
+                    out[i] = 0;
+                    continue;
+                }
+                int similar = 0;
+                const double *ref = heavy + (size_t)i * h * 3;
+                for (int64_t j = i + 1; j < last; ++j) { /* :57 over structures[i+1:] of the chunk */
+                    if (!mask[j]) continue;              /* :60 */
+                    int64_t b = first + (j - i);         /* :65 hash_value = (first, first+1+(j-i-1)) */
+                    if (dbit[b]) {                       /* :66-67 */
+                        ++hits;
+                        break;
+                    }
+                    double r, m;
+                    orc_rmsd_and_max(ref, heavy + (size_t)j * h * 3, h, &r, &m); /* :70 */
+                    ++evals;
+                    if (r < rmsd_thr && m < maxdev_thr) { /* :75-77 */
+                        row_key[i] = b;
+                        similar = 1;
+                        break;
+                    }
+                }
+                out[i] = (uint8_t)!similar; /* :113 */
+            }
+        }
+        /* :204 cache.extend(computed_pairs) -- after the pass, in row order */
+        int64_t new_keys = 0;
+        for (int64_t i = 0; i < N; ++i)
+            if (row_key[i] >= 0) {
+                int64_t c = i / cs;
+                if (c >= k) c = k - 1;
+                key_a[n_keys] = c * cs;
+                key_b[n_keys] = row_key[i];
+                ++n_keys;
+                ++new_keys;
+            }
+        int64_t after = 0;
+        for (int64_t i = 0; i < N; ++i) after += out[i];
+        memcpy(mask, out, (size_t)N);
+        if (stats) {
+            stats[n_passes].k = k;
+            stats[n_passes].n_active_before = n_active;
+            stats[n_passes].n_active_after = after;
+            stats[n_passes].pairs_evaluated = evals;
+            stats[n_passes].cache_hit_exits = hits;
+            stats[n_passes].new_keys = new_keys;
+#ifdef _OPENMP
+            stats[n_passes].seconds = omp_get_wtime() - t0;
+#else
+            stats[n_passes].seconds = 0;
+#endif
+        }
+        if (pass_masks) memcpy(pass_masks + (size_t)n_passes * N, mask, (size_t)N);
+        ++n_passes;
+    }
+    memcpy(mask_out, mask, (size_t)N);
+    if (n_passes_out) *n_passes_out = n_passes;
+    if (keys_out)
+        for (int64_t q = 0; q < n_keys; ++q) {
+            keys_out[2 * q] = key_a[q];
+            keys_out[2 * q + 1] = key_b[q];
+        }
+    if (n_keys_out) *n_keys_out = n_keys;
+    free(mask);
+    free(out);
+    free(dbit);
+    free(key_a);
+    free(key_b);
+    free(row_key);
+    return 0;
+}
+
+/* Smallest margin of any pair evaluated by the reference-exact schedule to either threshold, and of any
+ * inter-fragment distance to the clash threshold: the guard band of SURVEY.md 8(d).  Evaluates the same
+ * pairs as orc_prune_rmsd(mode) and returns min |rmsd - thr| and min |maxdev - 2 thr| (the latter only over
+ * pairs whose rmsd test passed, since the reference's `and` short-circuits on values, not on evaluation). */
+ORC_API int orc_prune_margins(const double *heavy, int64_t N, int h, double rmsd_thr, int mode, double *min_rmsd_margin,
+                              double *min_maxdev_margin) {
+    const double maxdev_thr = 2 * rmsd_thr;
+    uint8_t *mask = (uint8_t *)malloc((size_t)N), *out = (uint8_t *)malloc((size_t)N), *dbit = (uint8_t *)calloc((size_t)N + 1, 1);
+    int64_t *key_a = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *key_b = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *row_key = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t n_keys = 0;
+    memset(mask, 1, (size_t)N);
+    double mr = INFINITY, mm = INFINITY;
+    for (int ks = 0; ks < 18; ++ks) {
+        int64_t k = (int64_t)ORC_KS[ks], n_active = 0;
+        for (int64_t i = 0; i < N; ++i) n_active += mask[i];
+        if (!(k == 1 || 20 * k < n_active)) continue;
+        int64_t cs = N / k;
+        memset(dbit, 0, (size_t)N + 1);
+        if (mode == 0)
+            for (int64_t q = 0; q < n_keys; ++q) {
+                int64_t a = key_a[q], b = key_b[q];
+                if (a % cs != 0 || a / cs >= k) continue;
+                int64_t c = a / cs, last = (c == k - 1) ? N : cs * (c + 1);
+                if (b < last) dbit[b] = 1;
+            }
+#pragma omp parallel for schedule(dynamic, 16) reduction(min : mr, mm)
+        for (int64_t i = 0; i < N; ++i) {
+            int64_t chunk = i / cs;
+            if (chunk >= k) chunk = k - 1;
+            int64_t first = chunk * cs, last = (chunk == k - 1) ? N : cs * (chunk + 1);
+            row_key[i] = -1;
+            if (!mask[i]) {
+                out[i] = 0;
+                continue;
+            }
+            int similar = 0;
+            for (int64_t j = i + 1; j < last; ++j) {
+                if (!mask[j]) continue;
+                int64_t b = first + (j - i);
+                if (dbit[b]) break;
+                double r, m;
+                orc_rmsd_and_max(heavy + (size_t)i * h * 3, heavy + (size_t)j * h * 3, h, &r, &m);
+                double dr = fabs(r - rmsd_thr), dm = fabs(m - maxdev_thr);
+                if (dr < mr) mr = dr;
+                if (r < rmsd_thr && dm < mm) mm = dm;
+                if (r < rmsd_thr && m < maxdev_thr) {
+                    row_key[i] = b;
+                    similar = 1;
+                    break;
+                }
+            }
+            out[i] = (uint8_t)!similar;
+        }
+        for (int64_t i = 0; i < N; ++i)
+            if (row_key[i] >= 0) {
+                int64_t c = i / cs;
+                if (c >= k) c = k - 1;
+                key_a[n_keys] = c * cs;
+                key_b[n_keys++] = row_key[i];
+            }
+        memcpy(mask, out, (size_t)N);
+    }
+    *min_rmsd_margin = mr;
+    *min_maxdev_margin = mm;
+    free(mask);
+    free(out);
+    free(dbit);
+    free(key_a);
+    free(key_b);
+    free(row_key);
+    return 0;
+}
+
+/* min over poses and inter-fragment atom pairs of |d - thresh| (guard band for the clash mask) */
+ORC_API double orc_clash_margin(const double *coords, int64_t n_poses, int n, const int64_t *ids, int n_ids, double thresh) {
+    double best = INFINITY;
+    int off[4] = {0, 0, 0, 0};
+    for (int m = 0; m < n_ids; ++m) off[m + 1] = off[m] + (int)ids[m];
+#pragma omp parallel for schedule(static) reduction(min : best)
+    for (int64_t s = 0; s < n_poses; ++s) {
+        const double *c = coords + (size_t)s * n * 3;
+        for (int fa = 0; fa < n_ids; ++fa)
+            for (int fb = fa + 1; fb < n_ids; ++fb)
+                for (int i = off[fa]; i < off[fa + 1]; ++i)
+                    for (int j = off[fb]; j < off[fb + 1]; ++j) {
+                        double acc = 0;
+                        for (int k = 0; k < 3; ++k) {
+                            double d = c[3 * i + k] - c[3 * j + k];
+                            acc += d * d;
+                        }
+                        double m = fabs(sqrt(acc) - thresh);
+                        if (m < best) best = m;
+                    }
+    }
+    return best;
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,284 @@
+"""Golden-vector generator: runs ONLY in the build container, never on the GPU box.
+
+It imports the reference's three hot-path modules (tscode.algebra,
+tscode.rmsd_pruning, tscode.numba_functions) from /root/reference and records
+their outputs on seeded inputs as small .npz fixtures next to this file.
+The reference is executed as plain NumPy: Numba is not loadable in this image
+(SURVEY.md F8), so an in-memory stand-in module named ``numba`` whose ``njit``
+is the identity decorator is put in ``sys.modules`` before the import (nothing
+is written next to the reference; no bytecode is written either).  What the
+stand-in does not reproduce (fastmath re-association, Numba's own LAPACK build)
+only moves last bits; the fixtures are compared at 1e-9 or looser.
+
+Usage:  python tests/golden/gen_golden.py [G1 G2 ...]
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+
+def _install_standins():
+    sys.dont_write_bytecode = True
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs and not isinstance(args[0], _Sig):
+            return args[0]
+        return lambda f: f
+
+    class _Sig:
+        def __getitem__(self, item):
+            return self
+
+        def __call__(self, *a, **k):
+            return self
+
+    nb = types.ModuleType("numba")
+    nb.njit = nb.jit = njit
+    nb.prange = range
+    nb.float32, nb.float64, nb.boolean = np.float32, np.float64, np.bool_
+    nb.int32 = _Sig()
+    typed = types.ModuleType("numba.typed")
+
+    class List(list):
+        pass
+
+    typed.List = List
+    nb.typed = typed
+    rmsd = types.ModuleType("rmsd")
+    rmsd.kabsch_rotate = rmsd.kabsch = rmsd.kabsch_rmsd = None   # off-path names only
+    sys.modules.update({"numba": nb, "numba.typed": typed, "rmsd": rmsd})
+    sys.path.insert(0, REFERENCE)
+    sys.path.insert(0, REPO)
+
+
+_install_standins()
+import tscode.algebra as ref_alg            # noqa: E402
+import tscode.numba_functions as ref_nf     # noqa: E402
+import tscode.rmsd_pruning as ref_rp        # noqa: E402
+from numba.typed import List                # noqa: E402
+
+from tscode_amd.synthetic import make_ensemble, make_fragment, quat_to_mat   # noqa: E402
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------- G1
+def _g1_pairs(rng, h):
+    """Pairs (p, q) of (h,3) heavy-atom sets, including the special cases SURVEY 7.3/8c lists."""
+    out = []
+    base = make_fragment(rng, h) + rng.normal(size=3) * 3.0       # not centred, like a docked pose
+
+    def rot(x, deg=None):
+        r = quat_to_mat(rng.normal(size=4))
+        if deg is not None:
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            a = np.deg2rad(deg) / 2
+            r = quat_to_mat(np.array([np.cos(a), *(np.sin(a) * ax)]))
+        return x @ r.T
+
+    out.append(("identical", base, base.copy()))
+    out.append(("translated", base, base + np.array([0.3, -0.2, 0.1])))
+    out.append(("mirrored", base, base * np.array([1.0, 1.0, -1.0])))
+    out.append(("rot_small", base, rot(base, 2.0)))
+    out.append(("rot_big", base, rot(base)))
+    planar = base.copy()
+    planar[:, 2] = 0.0
+    out.append(("planar_through_origin", planar, rot(planar, 5.0) + 0.0))
+    planar_off = planar + np.array([0.0, 0.0, 2.5])
+    out.append(("planar_offset", planar_off, planar_off + rng.normal(size=planar.shape) * 0.05))
+    coll = np.outer(np.linspace(1.0, 1.0 + 1.4 * (h - 1), h), np.array([0.6, 0.0, 0.8]))
+    out.append(("collinear", coll, coll + rng.normal(size=coll.shape) * 0.02))
+    for s in (0.01, 0.05, 0.1, 0.2, 0.3, 0.5, 1.0):
+        out.append((f"noise_{s}", base, rot(base, 3.0 * s) + rng.normal(size=base.shape) * s))
+    while len(out) < 40:
+        other = make_fragment(rng, h) + rng.normal(size=3) * 3.0
+        out.append(("random", base if len(out) % 2 else rot(base), other))
+    return out
+
+
+def gen_g1():
+    print("G1 rmsd_and_max_numba")
+    rng = np.random.default_rng(9101)
+    data = {}
+    for h in (3, 5, 9, 18, 30, 60, 120):
+        pairs = _g1_pairs(rng, h)
+        p = np.array([a for _, a, _ in pairs])
+        q = np.array([b for _, _, b in pairs])
+        res = np.array([ref_rp.rmsd_and_max_numba(a.copy(), b.copy()) for a, b in zip(p, q)])
+        data[f"p_{h}"], data[f"q_{h}"], data[f"out_{h}"] = p, q, res
+        data[f"tags_{h}"] = np.array([t for t, _, _ in pairs])
+    _save("G1_rmsd_and_max", seed=9101, **data)
+
+
+# --------------------------------------------------------------------------- G2
+def gen_g2():
+    print("G2 all_dists / compenetration_check / count_clashes")
+    rng = np.random.default_rng(9102)
+    data = {}
+    # all_dists on block-remainder sizes
+    k = 0
+    for na, nb_ in ((31, 32), (32, 33), (33, 65), (65, 31), (25, 25), (7, 3), (1, 40)):
+        a = rng.normal(size=(na, 3)) * 3
+        b = rng.normal(size=(nb_, 3)) * 3
+        data[f"ad_a{k}"], data[f"ad_b{k}"], data[f"ad_out{k}"] = a, b, ref_alg.all_dists(a, b)
+        k += 1
+    data["ad_n"] = k
+    # compenetration_check: bi- and tri-molecular poses, ids variants
+    cases = []
+    for ids in ((15, 15), (25, 25), (31, 33), (5, 8), (10, 12, 9), (33, 20, 32), (70, 70, 60)):
+        ens = make_ensemble(60, ids, seed=int(rng.integers(1 << 30)), shell=(2.5, 7.0))
+        cases.append((np.asarray(ids), ens.poses()))
+    combos = [(t, mc) for t in (1.4, 1.5) for mc in (0, 1, 3)]
+    data["cc_combos"] = np.array(combos)
+    k = 0
+    for ids, poses in cases:
+        off = np.concatenate([[0], np.cumsum(ids)])
+        frs = [poses[:, off[i]:off[i + 1]] for i in range(len(ids))]
+        order = [(1, 0)] if len(ids) == 2 else [(1, 0), (2, 1), (0, 2)]
+        data[f"cc_ids{k}"], data[f"cc_coords{k}"] = ids, poses
+        # verdict per (thresh, max_clashes) combo, and the raw counts per fragment pair in the
+        # reference's order (m2,m1),(m3,m2),(m1,m3) for the two thresholds
+        data[f"cc_out{k}"] = np.array([[ref_nf.compenetration_check(c, ids=ids, thresh=t, max_clashes=int(mc))
+                                        for c in poses] for t, mc in combos])
+        data[f"cc_counts{k}"] = np.array([[[np.count_nonzero(ref_alg.all_dists(frs[a][s], frs[b][s]) < t)
+                                            for a, b in order] for s in range(len(poses))] for t in (1.4, 1.5)])
+        k += 1
+    data["cc_n"] = k
+    # ids=None -> count_clashes (threshold 0.5, ordered pairs, d>0)
+    k = 0
+    for n in (8, 30, 50):
+        for _ in range(4):
+            c = rng.normal(size=(n, 3)) * (0.6 if _ % 2 else 2.0)
+            c[n // 2] = c[0]                       # an exact duplicate: d == 0 is not a clash
+            data[f"cl_coords{k}"] = c
+            data[f"cl_count{k}"] = ref_nf.count_clashes(c)
+            data[f"cl_check{k}"] = np.array([ref_nf.compenetration_check(c, max_clashes=mc) for mc in (0, 2, 10)])
+            k += 1
+    data["cl_n"] = k
+    _save("G2_clash", seed=9102, **data)
+
+
+# --------------------------------------------------------------------------- G3
+def _prune_traced(structures, atomnos, thr):
+    """prune_conformers_rmsd (rmsd_pruning.py:164-206) re-run pass by pass through the reference's own
+    _similarity_mask_rmsd_group so that the per-pass masks and cache keys can be recorded."""
+    heavy = np.array([s[atomnos != 1] for s in structures])
+    mask = np.ones(len(structures), dtype=np.bool_)
+    cache = List([(-1, -1)])
+    ks, masks, nkeys = [], [], []
+    for k in (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1):
+        if k == 1 or 20 * k < np.count_nonzero(mask):
+            mask, pairs = ref_rp._similarity_mask_rmsd_group(heavy, mask, cache=cache, k=k, rmsd_thr=thr)
+            cache.extend(pairs)
+            ks.append(int(k))
+            masks.append(mask.copy())
+            nkeys.append(len(cache) - 1)
+    keys = np.array(sorted(set(cache[1:])), dtype=np.int64).reshape(-1, 2)
+    return mask, np.array(ks), np.array(masks), np.array(nkeys), keys
+
+
+def gen_g3():
+    print("G3 prune_conformers_rmsd")
+    data = {}
+    cases = [
+        # (N, atoms per fragment, children, sigma_t, thr, seed)
+        (40, (5, 5), 4, 0.03, 0.5, 9301),
+        (600, (8, 7), 20, 0.03, 0.5, 9302),
+        (600, (8, 7), 3, 0.10, 0.25, 9303),
+        (720, (15, 15), 12, 0.05, 0.5, 9304),
+        (1003, (15, 15), 10, 0.03, 0.5, 9305),      # N not divisible by any k: remainder chunk
+        (2500, (15, 15), 10, 0.03, 0.5, 9306),
+    ]
+    for c, (n, apf, ch, st, thr, seed) in enumerate(cases):
+        t0 = time.time()
+        ens = make_ensemble(n, apf, seed=seed, children=ch, sigma_t=st)
+        structures = ens.poses()
+        pruned, mask = ref_rp.prune_conformers_rmsd(structures, ens.atomnos, rmsd_thr=thr)
+        mask2, ks, masks, nkeys, keys = _prune_traced(structures, ens.atomnos, thr)
+        assert np.array_equal(mask, mask2)
+        assert np.array_equal(pruned, structures[mask])
+        data[f"structures{c}"], data[f"atomnos{c}"], data[f"thr{c}"] = structures, ens.atomnos, thr
+        data[f"mask{c}"], data[f"ks{c}"], data[f"pass_masks{c}"] = mask, ks, masks
+        data[f"pass_nkeys{c}"], data[f"keys{c}"] = nkeys, keys
+        print(f"  case {c}: N={n} h={ens.n_heavy} thr={thr} survivors={mask.sum()} passes={ks.tolist()} "
+              f"keys={len(keys)} ({time.time() - t0:.1f}s)")
+    data["n_cases"] = len(cases)
+    _save("G3_prune", **data)
+
+
+# --------------------------------------------------------------------------- G4
+def gen_g4():
+    print("G4 _rmsd_similarity greedy group filter")
+    data = {}
+    for c, (seed, n, apf) in enumerate(((9401, 216, (10, 12, 9)), (9402, 36, (15, 15)), (9403, 216, (6, 5, 5)))):
+        ens = make_ensemble(n, apf, seed=seed, children=6, sigma_t=0.3, sigma_rot_deg=8.0)
+        poses = ens.poses()
+        kept, flags = [], []
+        for pose in poses:                              # embeds.py:715 greedy use, thr=1
+            new = not ref_rp._rmsd_similarity(pose, kept, rmsd_thr=1)
+            flags.append(new)
+            if new:
+                kept.append(pose)
+        data[f"poses{c}"], data[f"accepted{c}"] = poses, np.array(flags)
+        print(f"  case {c}: {n} poses -> {int(np.sum(flags))} accepted")
+    data["n_cases"] = 3
+    _save("G4_rmsd_similarity", **data)
+
+
+# --------------------------------------------------------------------------- G5
+def gen_g5():
+    print("G5 rotation helpers")
+    rng = np.random.default_rng(9105)
+    ptr = rng.normal(size=(40, 3))
+    ang = rng.uniform(-360, 360, size=40)
+    ang[:4] = (0.0, 180.0, 90.0, 360.0)
+    rmp = np.array([ref_alg.rot_mat_from_pointer(p.copy(), a) for p, a in zip(ptr, ang)])
+    quat = rng.normal(size=(20, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    q2m = np.array([ref_alg.quaternion_to_rotation_matrix(q) for q in quat])
+    ref_v = rng.normal(size=(30, 2, 3))
+    tgt_v = rng.normal(size=(30, 2, 3))
+    tgt_v[0] = ref_v[0]                                 # identity
+    tgt_v[1] = -ref_v[1]                                # inversion of both vectors
+    avp = np.array([ref_alg.align_vec_pair(r, t) for r, t in zip(ref_v, tgt_v)])
+    v1 = rng.normal(size=(30, 3))
+    v2 = rng.normal(size=(30, 3))
+    v2[0], v2[1] = v1[0] * 2.0, -v1[1]
+    va = np.array([ref_alg.vec_angle(a, b) for a, b in zip(v1, v2)])
+    coords = rng.normal(size=(17, 3))
+    tc = ref_alg.transform_coords(coords, rmp[5], np.array([1.0, -2.0, 0.5]))
+    _save("G5_rotations", seed=9105, ptr=ptr, ang=ang, rot_mat_from_pointer=rmp, quat=quat, quat_to_mat=q2m,
+          avp_ref=ref_v, avp_tgt=tgt_v, align_vec_pair=avp, va_v1=v1, va_v2=v2, vec_angle=va,
+          tc_coords=coords, tc_rot=rmp[5], tc_pos=np.array([1.0, -2.0, 0.5]), transform_coords=tc)
+
+
+# --------------------------------------------------------------------------- G6
+def gen_g6():
+    print("G6 torsion fingerprints (next-row N2)")
+    rng = np.random.default_rng(9106)
+    coords = rng.normal(size=(50, 12, 3)) * 2
+    quads = np.array([[0, 1, 2, 3], [1, 2, 3, 4], [4, 5, 6, 7], [8, 9, 10, 11], [0, 5, 9, 11]])
+    fp = np.array([ref_nf.get_torsion_fingerprint(c, quads) for c in coords])
+    sim = np.array([[ref_nf.tfd_similarity(fp[i], fp[j], thresh=t) for j in range(10)] for i in range(10) for t in (10, 90, 300)])
+    _save("G6_tfd", seed=9106, coords=coords, quadruplets=quads, fingerprints=fp, similarity=sim)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6"]
+    for g in which:
+        globals()["gen_" + g.lower()]()
