@@ -1,0 +1,186 @@
+/*
+ * tscode_hip.h -- C ABI of libtscode_hip.so, the MI355X (gfx950) engine for TSCoDe's geometry hot path.
+ *
+ * The reference (ntampellini/TSCoDe v0.4.16) is pure Python + Numba: the path has no FFI or plugin
+ * table, callers bind plain Python functions by name.  Each entry point below states the
+ * reference function (file:line under the reference root) whose work it takes over; the Python
+ * mirror that keeps the reference's call signatures is tscode_amd/ (see INTEGRATION.md for the
+ * binding a TSCoDe maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types cross the boundary.
+ *   - every function returns 0 on success and a negative tsc_status on failure; tsc_last_error()
+ *     returns a thread-local, human-readable message for the last failure on the calling thread.
+ *   - there is NO CPU path in this library: without a usable HIP device every call fails with
+ *     TSC_ERR_NO_DEVICE.
+ *   - all coordinates are C-contiguous float64 (Angstrom), index arrays int32 unless stated.
+ *   - "host" entry points take host pointers, copy in/out and synchronise before returning;
+ *     "_dev" entry points take device pointers valid on the context's device, enqueue on the
+ *     context's stream and return without synchronising unless stated.
+ *   - the caller owns every buffer it passes; the library keeps no pointer after return except
+ *     inside a tsc_prune object, which borrows `heavy` until tsc_prune_destroy.
+ */
+#ifndef TSCODE_HIP_H
+#define TSCODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSC_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    TSC_OK = 0,
+    TSC_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unsupported shape) */
+    TSC_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime failure at context creation */
+    TSC_ERR_HIP = -3,       /* a HIP call failed; message has the HIP error string */
+    TSC_ERR_NOMEM = -4,     /* device or host allocation failed */
+    TSC_ERR_STATE = -5      /* call sequence violated (prune stepping API) */
+} tsc_status;
+
+typedef struct tsc_ctx tsc_ctx;     /* one per (process, device); owns a stream and scratch memory */
+typedef struct tsc_prune tsc_prune; /* state of one prune_conformers_rmsd run (stepping API) */
+
+/* ---- library / context ------------------------------------------------------------------ */
+int tsc_version(void);
+const char *tsc_last_error(void);
+int tsc_device_count(void); /* >= 0, or a negative tsc_status */
+int tsc_ctx_create(int device, tsc_ctx **out);
+int tsc_ctx_destroy(tsc_ctx *ctx);
+/* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
+int tsc_ctx_synchronize(tsc_ctx *ctx);
+/* Device memory helpers for hosts that do not bring their own allocator (tests, C callers). */
+int tsc_malloc(tsc_ctx *ctx, size_t bytes, void **dptr);
+int tsc_free(tsc_ctx *ctx, void *dptr);
+int tsc_memcpy_h2d(tsc_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+int tsc_memcpy_d2h(tsc_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+/* HIP-event timing of everything enqueued on the context's stream between begin and end (ms). */
+int tsc_timer_begin(tsc_ctx *ctx);
+int tsc_timer_end(tsc_ctx *ctx, float *elapsed_ms); /* synchronises */
+
+/* ---- K1: batched rigid-body embedding ------------------------------------------------------
+ * Replaces get_embed (tscode/embeds.py:961-969) and transform_coords (tscode/algebra.py:390-400),
+ * batched over poses:  out[s] = concat_m ( rot[s,m] @ X_m[conf_idx[s,m]].T ).T + pos[s,m].
+ *   frags      f64, all fragments back to back; fragment m is [n_conf[m], n_atoms[m], 3] at frags + frag_off[m]
+ *   frag_off   i64[n_mols] offsets into frags, in doubles
+ *   conf_idx   i32[n_poses, n_mols];  rot f64[n_poses, n_mols, 3, 3];  pos f64[n_poses, n_mols, 3]
+ *   out        f64[n_poses, sum(n_atoms), 3]
+ * n_mols <= 8. */
+int tsc_transform_batch(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                        const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                        const double *pos, int64_t n_poses, double *out);
+int tsc_transform_batch_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off_host, const int32_t *n_atoms_host,
+                            const int32_t *n_conf_host, int n_mols, const int32_t *conf_idx, const double *rot,
+                            const double *pos, int64_t n_poses, double *out);
+
+/* ---- K2: compenetration (clash) mask ---------------------------------------------------------
+ * Replaces compenetration_check (tscode/numba_functions.py:59-105), count_clashes (:49-56) and the
+ * all_dists it calls (tscode/algebra.py:98-157), batched as in compenetration_refining
+ * (tscode/embedder.py:1243-1248):  mask[s] = compenetration_check(coords[s], ids, thresh, max_clashes).
+ *   coords f64[n_poses, n_atoms, 3]; ids i32[n_ids] fragment lengths (contiguous ranges), n_ids in {0,2,3};
+ *   n_ids == 0 is ids=None: count_clashes (ordered self pairs with 0 < d < 0.5; thresh is ignored).
+ *   mask u8[n_poses] (1 = passes); counts (optional, may be NULL) i32[n_poses] = total pair count
+ *   (for 3 fragments the count over all three fragment pairs: the reference's early exits do not
+ *   change the verdict, total <= max_clashes). */
+int tsc_clash_mask(tsc_ctx *ctx, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
+                   double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts);
+int tsc_clash_mask_dev(tsc_ctx *ctx, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids_host, int n_ids,
+                       double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts);
+/* Fused K1+K2: the clash verdict of every pose straight from its (rot, pos), no pose materialised
+ * (the embed loops of tscode/embeds.py:116-118 and :713-714 do get_embed then compenetration_check). */
+int tsc_embed_clash_mask_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off_host, const int32_t *n_atoms_host,
+                             const int32_t *n_conf_host, int n_mols, const int32_t *conf_idx, const double *rot,
+                             const double *pos, int64_t n_poses, double thresh, int64_t max_clashes, uint8_t *mask,
+                             int32_t *counts);
+/* All-distances matrix of one pair of point sets (tscode/algebra.py:98-157), for value parity tests. */
+int tsc_all_dists(tsc_ctx *ctx, const double *a, int na, const double *b, int nb, double *out);
+
+/* ---- ordered compaction helpers (device) --------------------------------------------------------
+ * n_kept = count_nonzero(mask); dst[rank(s)] = src[s] for mask[s] != 0, order preserved (NumPy's
+ * structures[mask], tscode/rmsd_pruning.py:206, tscode/embedder.py:1250-1251).  row_bytes % 8 == 0.
+ * tsc_gather_heavy_dev additionally keeps only the listed atoms: dst[rank(s), a] = src[s, heavy_idx[a]]
+ * (structures[:, atomnos != 1], tscode/rmsd_pruning.py:178-179); mask may be NULL (keep all). */
+int tsc_compact_rows_dev(tsc_ctx *ctx, const void *src, const uint8_t *mask, int64_t n_rows, int64_t row_bytes, void *dst,
+                         int64_t *n_kept_host);
+int tsc_gather_heavy_dev(tsc_ctx *ctx, const double *coords, const uint8_t *mask, int64_t n_poses, int n_atoms,
+                         const int32_t *heavy_idx_host, int n_heavy, double *heavy_out, int64_t *n_kept_host);
+
+/* ---- K3: Kabsch RMSD (no centring) ------------------------------------------------------------
+ * Replaces rmsd_and_max_numba (tscode/rmsd_pruning.py:6-41) on listed pairs of one heavy-atom array:
+ * (rmsd[k], maxdev[k]) = rmsd_and_max_numba(heavy[pairs[k,0]], heavy[pairs[k,1]]).
+ *   heavy f64[n_structs, h, 3]; pairs i32[n_pairs, 2]. */
+int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
+                   double *rmsd, double *maxdev);
+int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
+                       double *rmsd, double *maxdev);
+
+/* Per-pass statistics of a prune run (one entry per executed k of the schedule). */
+typedef struct {
+    int64_t k;               /* number of chunks (tscode/rmsd_pruning.py:186-188) */
+    int64_t n_active_before; /* count_nonzero(mask) entering the pass */
+    int64_t n_active_after;
+    int64_t pairs_evaluated; /* pair evaluations the reference's sequential scan performs in this pass (:70) */
+    int64_t pairs_computed;  /* pair evaluations the tile kernel actually computed (>= pairs_evaluated) */
+    int64_t candidates;      /* pairs that reached the explicit-rotation path */
+    int64_t new_keys;        /* cache keys appended (:76, :204) */
+    double gpu_ms;           /* HIP-event time of the whole pass on this device */
+    double tile_ms;          /* HIP-event time of the pass's RMSD tile kernel alone */
+} tsc_pass_stats;
+
+#define TSC_MAX_PASSES 18
+
+/* prune_conformers_rmsd (tscode/rmsd_pruning.py:164-206) on the heavy-atom array:
+ *   heavy f64[n, h, 3] = structures[:, atomnos != 1]; rmsd_thr as in the reference (max deviation
+ *   threshold is 2*rmsd_thr, :95);
+ *   mode 0 = reference-exact, including the pair-cache behaviour of :65-67 / :75-77;
+ *   mode 1 = cache-free (the cache test is skipped);
+ *   mask u8[n] out (1 = kept); stats (optional) up to TSC_MAX_PASSES entries, n_passes out (optional).
+ * For n > 200 000 the reference itself fails (a float k reaches range()); the schedule is used with int(k). */
+int tsc_prune_rmsd(tsc_ctx *ctx, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
+                   tsc_pass_stats *stats, int *n_passes);
+int tsc_prune_rmsd_dev(tsc_ctx *ctx, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
+                       tsc_pass_stats *stats, int *n_passes); /* synchronises (the schedule gate reads counts) */
+
+/* Stepping form of the same run, for one-process-per-GPU sharding of a pass (rows of a pass are
+ * independent: tscode/rmsd_pruning.py:92,101-113).  Every rank holds the full `heavy` array and calls
+ *   tsc_prune_create; loop { k = tsc_prune_next_pass; if k == 0 break;
+ *                            tsc_prune_pass_local(rank, world);      // this rank's row tiles -> best[]
+ *                            <all-reduce MIN over tsc_prune_best_ptr, n_active int32 entries>   (RCCL)
+ *                            tsc_prune_pass_finish; }                 // identical mask/cache update on every rank
+ *   tsc_prune_mask_dev gives the device mask; tsc_prune_destroy frees the state. */
+int tsc_prune_create(tsc_ctx *ctx, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out);
+int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the schedule is exhausted; synchronises */
+int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous */
+int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i32[n_entries], valid until finish */
+/* Make the run keep best[] in a caller-owned device buffer of n int32 (e.g. a torch tensor that
+ * torch.distributed can all-reduce); call right after tsc_prune_create. */
+int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev_i32_n);
+int tsc_prune_pass_finish(tsc_prune *p);                          /* asynchronous */
+int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev);
+int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes); /* synchronises */
+int tsc_prune_destroy(tsc_prune *p);
+
+/* ---- whole pipeline on one device ----------------------------------------------------------------
+ * generate -> clash-filter -> similarity-prune, the sequence RunEmbedding.run drives through
+ * generate_candidates / compenetration_refining / similarity_refining (tscode/embedder.py:1136-1154,
+ * 1230-1266, 1356-1368), with everything resident in HBM:
+ *   K1+K2 fused verdicts, ordered compaction of the passing poses (all atoms + heavy atoms), K3 prune.
+ * Inputs as tsc_transform_batch_dev plus heavy_idx (indices of atoms with atomnos != 1).
+ * Outputs (device, caller-allocated for the worst case n_poses):
+ *   clash_mask u8[n_poses]; structures f64[n_pass, n_atoms, 3] (poses that pass the clash check, in order);
+ *   keep_mask u8[n_pass] (prune verdict on those); n_pass_host / n_keep_host scalars on the host.
+ * timings_ms (optional, host) float[4] = {embed+clash, compaction, prune, total} from HIP events. */
+int tsc_pipeline_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off_host, const int32_t *n_atoms_host,
+                     const int32_t *n_conf_host, int n_mols, const int32_t *conf_idx, const double *rot, const double *pos,
+                     int64_t n_poses, const int32_t *heavy_idx_host, int n_heavy, double clash_thresh, int64_t max_clashes,
+                     double rmsd_thr, int mode, uint8_t *clash_mask, double *structures, uint8_t *keep_mask,
+                     int64_t *n_pass_host, int64_t *n_keep_host, tsc_pass_stats *stats, int *n_passes, float *timings_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSCODE_HIP_H */

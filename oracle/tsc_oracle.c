@@ -67,7 +67,7 @@ static void svd3(const double A[9], double U[9], double s[3], double Vt[9]) {
                     beta += a[j][r] * a[j][r];
                     gamma += a[i][r] * a[j][r];
                 }
-                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;
                 rotated = 1;
                 double zeta = (beta - alpha) / (2.0 * gamma);
                 double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

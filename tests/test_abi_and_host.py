@@ -1,0 +1,127 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the
+host-side mirrors of the reference's small helpers match the golden vectors, install() patches
+every binding site.  No compute call is made (there is no GPU here)."""
+
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "tscode_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from tscode_amd import _lib
+    from tscode_amd.build import build
+    build()
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/tscode_hip.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "ctypes prototype table and header disagree"
+    assert lib.tsc_version() == 100
+
+
+def test_product_does_not_import_oracle():
+    import tscode_amd  # noqa: F401
+    pkg = os.path.join(ROOT, "tscode_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "liboracle" not in src and "tsc_oracle" not in src, f"{f} references the oracle library"
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tscode_amd import _lib
+    from tscode_amd.engine import Engine
+    with pytest.raises(_lib.TscodeHipError):
+        Engine(0)
+    import tscode_amd
+    with pytest.raises(_lib.TscodeHipError):
+        tscode_amd.prune_conformers_rmsd(np.zeros((4, 3, 3)), np.array([6, 6, 1]))
+
+
+def test_host_rotation_helpers_match_golden():
+    from tscode_amd import algebra as alg
+    g = load_golden("G5_rotations")
+    for p, a, ref in zip(g["ptr"], g["ang"], g["rot_mat_from_pointer"]):
+        assert np.allclose(alg.rot_mat_from_pointer(p, a), ref, atol=1e-14, rtol=0)
+    for q, ref in zip(g["quat"], g["quat_to_mat"]):
+        assert np.allclose(alg.quaternion_to_rotation_matrix(q), ref, atol=1e-15, rtol=0)
+    for r, t, ref in zip(g["avp_ref"], g["avp_tgt"], g["align_vec_pair"]):
+        assert np.allclose(alg.align_vec_pair(r, t), ref, atol=1e-12, rtol=0)
+    for a, b, ref in zip(g["va_v1"], g["va_v2"], g["vec_angle"]):
+        assert abs(alg.vec_angle(a, b) - ref) < 1e-9
+
+
+def test_rotation_matrix_from_vectors_matches_oracle(oracle):
+    from tscode_amd import algebra as alg
+    rng = np.random.default_rng(5)
+    cases = [(rng.normal(size=3), rng.normal(size=3)) for _ in range(20)]
+    v = rng.normal(size=3)
+    cases += [(v, 2.5 * v), (v, -v), (np.array([0, 0, 1.0]), np.array([0, 0, -3.0]))]   # parallel / antiparallel
+    for a, b in cases:
+        got, ref = alg.rotation_matrix_from_vectors(a, b), oracle.rotation_matrix_from_vectors(a, b)
+        assert np.allclose(got, ref, atol=1e-13, rtol=0)
+        if np.linalg.norm(np.cross(a, b)) > 1e-9:
+            assert np.allclose(got @ (a / np.linalg.norm(a)), b / np.linalg.norm(b), atol=1e-12)
+
+
+def test_fragment_set_layout():
+    from tscode_amd.engine import FragmentSet
+    fs = FragmentSet([np.zeros((2, 5, 3)), np.ones((7, 3)), np.zeros((3, 4, 3))])
+    assert fs.n_mols == 3 and fs.n_total == 16
+    assert fs.n_atoms.tolist() == [5, 7, 4] and fs.n_conf.tolist() == [2, 1, 3]
+    assert fs.frag_off.tolist() == [0, 30, 51] and fs.flat.size == 30 + 21 + 36
+    assert np.all(fs.flat[30:51] == 1)
+
+
+def test_install_patches_every_binding_site():
+    import tscode_amd
+    names = ["tscode.rmsd_pruning", "tscode.embedder", "tscode.operators", "tscode.optimization_methods",
+             "tscode.atropisomer_module", "tscode.numba_functions", "tscode.embeds", "tscode.algebra", "tscode.automep"]
+    fake = {}
+    for n in names:
+        m = types.ModuleType(n)
+        for attr in ("prune_conformers_rmsd", "compenetration_check", "_rmsd_similarity", "get_embed", "rmsd_and_max_numba",
+                     "all_dists", "count_clashes"):
+            setattr(m, attr, "reference")
+        fake[n] = m
+    done = tscode_amd.install(modules=fake)
+    assert ("tscode.embedder", "prune_conformers_rmsd") in done and ("tscode.embeds", "compenetration_check") in done
+    for n in ("tscode.rmsd_pruning", "tscode.embedder", "tscode.operators", "tscode.optimization_methods", "tscode.atropisomer_module"):
+        assert fake[n].prune_conformers_rmsd is tscode_amd.prune_conformers_rmsd
+    for n in ("tscode.numba_functions", "tscode.embedder", "tscode.embeds"):
+        assert fake[n].compenetration_check is tscode_amd.compenetration_check
+    assert fake["tscode.embeds"].get_embed is tscode_amd.get_embed
+    assert fake["tscode.operators"].compenetration_check == "reference"     # operators.py does not bind it
+    tscode_amd.uninstall(modules=fake)
+    assert fake["tscode.embedder"].prune_conformers_rmsd == "reference"
+    assert "tscode" not in sys.modules                                       # the package never imports tscode
+
+
+def test_synthetic_configs_are_deterministic():
+    from tscode_amd.synthetic import make_config
+    a, b = make_config("C2", 500), make_config("C2", 500)
+    assert np.array_equal(a.rot, b.rot) and np.array_equal(a.pos, b.pos)
+    assert a.n_atoms == 30 and a.n_heavy == 18
+    c3 = make_config("C3", 100)
+    assert c3.n_atoms == 50 and c3.n_heavy == 30
+    p = a.poses(0, 10)
+    assert p.shape == (10, 30, 3)
+    assert np.allclose(p[:, :15], a.frag_coords[0][0])                       # fragment 0 is fixed

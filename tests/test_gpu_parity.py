@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): surviving-index set and clash masks bit-exact; RMSD / max-deviation /
+distance values within 1e-5 abs in fp64 (they agree to ~1e-12; the asserted tolerance is 1e-9 so that
+a regression shows long before the stated bar).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+VAL_TOL = 1e-9          # asserted; the stated bar is 1e-5 abs
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import tscode_amd
+    return tscode_amd.get_engine(0)
+
+
+# ----------------------------------------------------------------------------- K3 values
+def test_rmsd_pairs_golden(eng):
+    g = load_golden("G1_rmsd_and_max")
+    for h in (3, 5, 9, 18, 30, 60, 120):
+        p, q, ref = g[f"p_{h}"], g[f"q_{h}"], g[f"out_{h}"]
+        n = len(p)
+        pairs = np.stack([np.arange(n), np.arange(n) + n], axis=1)
+        r, m = eng.rmsd_pairs(np.concatenate([p, q]), pairs)
+        assert np.abs(r - ref[:, 0]).max() < VAL_TOL, (h, np.abs(r - ref[:, 0]).max())
+        assert np.abs(m - ref[:, 1]).max() < VAL_TOL, (h, g[f"tags_{h}"][np.abs(m - ref[:, 1]).argmax()])
+
+
+def test_rmsd_pairs_vs_oracle_random(eng, oracle):
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 400)
+    heavy = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    rng = np.random.default_rng(0)
+    pairs = rng.integers(0, len(heavy), size=(5000, 2))
+    r, m = eng.rmsd_pairs(heavy, pairs)
+    ro, mo = oracle.rmsd_pairs(heavy, pairs)
+    assert np.abs(r - ro).max() < VAL_TOL and np.abs(m - mo).max() < VAL_TOL
+
+
+def test_dropin_rmsd_functions(eng, oracle):
+    import tscode_amd
+    g = load_golden("G1_rmsd_and_max")
+    p, q, ref = g["p_18"][10], g["q_18"][10], g["out_18"][10]
+    r, m = tscode_amd.rmsd_and_max_numba(p, q)
+    assert abs(r - ref[0]) < VAL_TOL and abs(m - ref[1]) < VAL_TOL
+    g4 = load_golden("G4_rmsd_similarity")
+    poses, acc = g4["poses1"], g4["accepted1"]
+    kept = []
+    for pose, a in zip(poses, acc):                       # embeds.py:715 greedy use, thr=1
+        new = not tscode_amd._rmsd_similarity(pose, kept, rmsd_thr=1)
+        assert new == bool(a)
+        if new:
+            kept.append(pose)
+
+
+# ----------------------------------------------------------------------------- K2
+def test_all_dists_golden(eng):
+    g = load_golden("G2_clash")
+    for k in range(int(g["ad_n"])):
+        out = eng.all_dists(g[f"ad_a{k}"], g[f"ad_b{k}"])
+        assert np.abs(out - g[f"ad_out{k}"]).max() < 1e-12
+
+
+def test_clash_mask_golden(eng):
+    g = load_golden("G2_clash")
+    combos = g["cc_combos"]
+    for k in range(int(g["cc_n"])):
+        ids, coords = g[f"cc_ids{k}"], g[f"cc_coords{k}"]
+        for ci, (thresh, mc) in enumerate(combos):
+            mask, counts = eng.clash_mask(coords, ids, float(thresh), int(mc), return_counts=True)
+            assert np.array_equal(mask, g[f"cc_out{k}"][ci].astype(bool)), (k, thresh, mc)
+            assert np.array_equal(counts, g[f"cc_counts{k}"][0 if thresh == 1.4 else 1].sum(axis=1))
+
+
+def test_count_clashes_golden(eng):
+    import tscode_amd
+    g = load_golden("G2_clash")
+    for k in range(int(g["cl_n"])):
+        c = g[f"cl_coords{k}"]
+        assert tscode_amd.count_clashes(c) == int(g[f"cl_count{k}"])
+        got = [tscode_amd.compenetration_check(c, max_clashes=mc) for mc in (0, 2, 10)]
+        assert got == g[f"cl_check{k}"].tolist()
+
+
+@pytest.mark.parametrize("cfg,n", [("C2", 10_000), ("C3", 20_000), ("C5", 3_000)])
+def test_clash_mask_vs_oracle(eng, oracle, cfg, n):
+    from tscode_amd.synthetic import make_config
+    ens = make_config(cfg, n)
+    poses = ens.poses()
+    assert oracle.clash_margin(poses, ens.ids, 1.5) > 1e-9            # guard band
+    for mc in (0, 2):
+        mask, counts = eng.clash_mask(poses, ens.ids, 1.5, mc, return_counts=True)
+        ref = oracle.compenetration_mask(poses, ens.ids, 1.5, mc)
+        assert np.array_equal(mask, ref)
+    assert 0.02 < mask.mean() < 0.98
+    # drop-in single-pose call
+    import tscode_amd
+    for s in (0, 1, 2):
+        assert tscode_amd.compenetration_check(poses[s], ens.ids, 1.5, 0) == oracle.compenetration_check(poses[s], ens.ids, 1.5, 0)
+
+
+def test_clash_edge_shapes(eng, oracle):
+    rng = np.random.default_rng(3)
+    for ids in ((1, 1), (1, 70), (70, 1), (64, 65), (3, 2, 1), (1, 1, 1), (40, 90, 70)):
+        n = sum(ids)
+        coords = rng.normal(size=(37, n, 3)) * 2.5
+        for mc in (0, 5):
+            assert np.array_equal(eng.clash_mask(coords, ids, 1.5, mc), oracle.compenetration_mask(coords, ids, 1.5, mc)), ids
+    coords = rng.normal(size=(9, 20, 3)) * 0.7
+    assert np.array_equal(eng.clash_mask(coords, None, 0.5, 3), oracle.compenetration_mask(coords, None, 0.5, 3))
+    assert eng.clash_mask(np.zeros((0, 5, 3)), (2, 3)).shape == (0,)
+
+
+# ----------------------------------------------------------------------------- K1
+def test_transform_batch_vs_oracle(eng, oracle):
+    from tscode_amd import FragmentSet
+    from tscode_amd.synthetic import make_config
+    for cfg, n in (("C2", 3000), ("C5", 500)):
+        ens = make_config(cfg, n)
+        out = eng.transform_batch(FragmentSet(ens.frag_coords), ens.conf_idx, ens.rot, ens.pos)
+        ref = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
+        assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-12
+        assert np.abs(out - ens.poses()).max() < 1e-12
+    # several conformers per fragment, conformer picked per pose
+    rng = np.random.default_rng(1)
+    frags = [rng.normal(size=(4, 7, 3)), rng.normal(size=(3, 5, 3))]
+    ci = np.stack([rng.integers(0, 4, 200), rng.integers(0, 3, 200)], axis=1).astype(np.int32)
+    from tscode_amd.synthetic import quat_to_mat
+    rot = quat_to_mat(rng.normal(size=(200, 2, 4)))
+    pos = rng.normal(size=(200, 2, 3))
+    out = eng.transform_batch(FragmentSet(frags), ci, rot, pos)
+    assert np.abs(out - oracle.transform_batch(frags, ci, rot, pos)).max() < 1e-12
+
+
+def test_dropin_embed_functions(eng):
+    import tscode_amd
+    g = load_golden("G5_rotations")
+    out = tscode_amd.transform_coords(g["tc_coords"], g["tc_rot"], g["tc_pos"])
+    assert np.abs(out - g["transform_coords"]).max() < 1e-13
+
+    class Mol:                                           # duck-typed Hypermolecule (hypermolecule_class.py:171-184)
+        def __init__(self, coords, rot, pos):
+            self.atomcoords, self.rotation, self.position = coords, rot, pos
+    rng = np.random.default_rng(2)
+    m1 = Mol(rng.normal(size=(2, 6, 3)), np.eye(3), np.zeros(3))
+    m2 = Mol(rng.normal(size=(3, 4, 3)), g["tc_rot"], np.array([1.0, 2.0, 3.0]))
+    got = tscode_amd.get_embed((m1, m2), (1, 2))
+    ref = np.concatenate([(m.rotation @ m.atomcoords[c].T).T + m.position for m, c in zip((m1, m2), (1, 2))])
+    assert np.abs(got - ref).max() < 1e-13
+    # string-embed pose parameters: reactive centres coincide (embeds.py:114)
+    poses, rot, pos = tscode_amd.string_embed_poses(m1.atomcoords[0], m2.atomcoords[0], m1.atomcoords[0][2], m2.atomcoords[0][1],
+                                                    np.array([0.3, -1.0, 0.2]), np.array([1.0, 0.1, -0.4]), range(0, 360, 10))
+    assert poses.shape == (36, 10, 3)
+    assert np.abs(poses[:, 6 + 1] - m1.atomcoords[0][2]).max() < 1e-12
+
+
+# ----------------------------------------------------------------------------- prune
+def test_prune_golden(eng):
+    import tscode_amd
+    g = load_golden("G3_prune")
+    for c in range(int(g["n_cases"])):
+        structures, atomnos, thr = g[f"structures{c}"], g[f"atomnos{c}"], float(g[f"thr{c}"])
+        pruned, mask = tscode_amd.prune_conformers_rmsd(structures, atomnos, thr)
+        assert np.array_equal(mask, g[f"mask{c}"]), f"case {c}: {mask.sum()} vs {g[f'mask{c}'].sum()}"
+        assert np.array_equal(pruned, structures[g[f"mask{c}"]])
+        stats = tscode_amd.last_prune_stats()
+        assert [s["k"] for s in stats] == g[f"ks{c}"].tolist()
+        assert [s["n_active_after"] for s in stats] == g[f"pass_masks{c}"].sum(axis=1).tolist()
+        assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_prune_c2_vs_oracle(eng, oracle, mode):
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2")
+    poses = ens.poses()
+    poses = poses[oracle.compenetration_mask(poses, ens.ids, 1.5, 0)]
+    heavy = np.ascontiguousarray(poses[:, ens.atomnos != 1])
+    mr, mm = oracle.prune_margins(heavy, 0.5, mode)
+    assert mr > 1e-6 and mm > 1e-6, "guard band violated: re-draw the ensemble (SURVEY 8d)"
+    ref = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=True)
+    mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+    assert np.array_equal(mask, ref["mask"]), (mask.sum(), ref["mask"].sum())
+    assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
+    for s, r in zip(stats, ref["stats"]):
+        assert s["n_active_after"] == r["n_active_after"]
+        assert s["pairs_evaluated"] == r["pairs_evaluated"]      # the reference's sequential work, reproduced exactly
+        assert s["new_keys"] == r["new_keys"]
+        assert s["pairs_computed"] >= s["pairs_evaluated"]
+    print(f"C2 mode {mode}: {len(heavy)} -> {mask.sum()}; margins rmsd {mr:.2e} maxdev {mm:.2e}")
+
+
+def test_prune_edge_cases(eng, oracle):
+    rng = np.random.default_rng(7)
+    cases = []
+    one = rng.normal(size=(1, 5, 3)) * 3
+    cases.append(one)                                                   # N = 1
+    cases.append(np.concatenate([one, one]))                            # N = 2 identical
+    cases.append(np.repeat(rng.normal(size=(1, 12, 3)) * 3, 300, axis=0))    # all identical: every row finds j = i+1
+    cases.append(rng.normal(size=(19, 1, 3)) * 3)                       # h = 1
+    cases.append(rng.normal(size=(450, 32, 3)) * 3)                     # h = 32 (largest single-tile size), nothing similar
+    base = rng.normal(size=(50, 7, 3)) * 3
+    cases.append((base[:, None] + rng.normal(size=(50, 9, 7, 3)) * 0.02).reshape(-1, 7, 3))   # clusters in order, N = 450
+    cases.append(np.concatenate([base] * 13)[rng.permutation(650)])     # exact duplicates, shuffled, N = 650 (k = 20.. passes)
+    for heavy in cases:
+        heavy = np.ascontiguousarray(heavy)
+        for mode in (0, 1):
+            ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
+            mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+            assert np.array_equal(mask, ref["mask"]), (heavy.shape, mode, mask.sum(), ref["mask"].sum())
+            assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+    import tscode_amd
+    assert tscode_amd.prune_conformers_rmsd(np.zeros((0, 4, 3)), np.array([6, 6, 1, 1]))[1].shape == (0,)
+    with pytest.raises(Exception):
+        eng.prune_heavy(np.zeros((10, 33, 3)))                           # h > 32: refused loudly, not silently wrong
+
+
+def test_prune_sharded_rows_equal_single(eng, oracle):
+    """The stepping API with the row tiles of each pass dealt to 3 'ranks' (run one after the other on
+    this GPU, merging through the atomicMin target) gives the same mask as the one-shot call."""
+    import ctypes as C
+
+    from tscode_amd import _lib
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 6000)
+    heavy = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    ref_mask, ref_stats = eng.prune_heavy(heavy, 0.5, 0)
+    lib = eng.lib
+    d_heavy = C.c_void_p()
+    _lib.check(lib.tsc_malloc(eng._h, heavy.nbytes, C.byref(d_heavy)))
+    _lib.check(lib.tsc_memcpy_h2d(eng._h, d_heavy, _lib.ptr(heavy), heavy.nbytes))
+    # three steppers (one per rank) over the same heavy array; after each pass the best[]
+    # arrays are min-merged on the host and written back, as the all-reduce(MIN) would do.
+    steppers = [eng.prune_stepper(d_heavy.value, len(heavy), heavy.shape[1], 0.5, 0) for _ in range(3)]
+    while True:
+        ks_now = [s.next_pass() for s in steppers]
+        assert len(set(ks_now)) == 1
+        if ks_now[0] == 0:
+            break
+        bests = []
+        for rank, s in enumerate(steppers):
+            s.pass_local(rank, 3)
+            p, n = s.best_ptr()
+            b = np.empty(n, dtype=np.int32)
+            _lib.check(lib.tsc_memcpy_d2h(eng._h, _lib.ptr(b), C.c_void_p(p), b.nbytes))
+            bests.append(b)
+        merged = np.minimum.reduce(bests)
+        for s in steppers:
+            p, n = s.best_ptr()
+            _lib.check(lib.tsc_memcpy_h2d(eng._h, C.c_void_p(p), _lib.ptr(merged), merged.nbytes))
+            s.pass_finish()
+    masks = []
+    for s in steppers:
+        m = np.empty(len(heavy), dtype=np.uint8)
+        _lib.check(lib.tsc_memcpy_d2h(eng._h, _lib.ptr(m), C.c_void_p(s.mask_ptr()), m.nbytes))
+        masks.append(m.astype(bool))
+        assert [x["n_active_after"] for x in s.stats()] == [x["n_active_after"] for x in ref_stats]
+        s.close()
+    for m in masks:
+        assert np.array_equal(m, ref_mask)
+    _lib.check(lib.tsc_free(eng._h, d_heavy))
+
+
+def test_pipeline_c2_vs_oracle(eng, oracle):
+    import torch
+
+    from tscode_amd import FragmentSet
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2")
+    fs = FragmentSet(ens.frag_coords)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_frags, d_ci, d_rot, d_pos = t(fs.flat), t(ens.conf_idx), t(ens.rot), t(ens.pos)
+    n, na = ens.n_poses, ens.n_atoms
+    clash = torch.empty(n, dtype=torch.uint8, device=dev)
+    structures = torch.empty((n, na, 3), dtype=torch.float64, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    heavy_idx = np.flatnonzero(ens.atomnos != 1).astype(np.int32)
+    torch.cuda.synchronize()
+    res = eng.pipeline_dev(fs, d_frags, d_ci, d_rot, d_pos, n, heavy_idx, 1.5, 0, 0.5, 0, clash, structures, keep)
+    poses = ens.poses()
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    assert np.array_equal(clash.cpu().numpy().astype(bool), cm)
+    assert res["n_pass"] == cm.sum()
+    got = structures[:res["n_pass"]].cpu().numpy()
+    assert np.abs(got - poses[cm]).max() < 1e-12
+    _, mask = oracle.prune_conformers_rmsd(poses[cm], ens.atomnos, 0.5)
+    assert np.array_equal(keep[:res["n_pass"]].cpu().numpy().astype(bool), mask)
+    assert res["n_keep"] == mask.sum()
+    print("C2 pipeline:", res["n_pass"], "pass the clash check,", res["n_keep"], "survive;", res["ms"])
+
+
+# ----------------------------------------------------------------------------- full size, by properties
+def test_full_size_properties_c3(eng):
+    """BASELINE config 3 (100k x 50) at full size, checked through size-independent properties:
+    determinism, mode-1 idempotence (survivors of the cache-free prune are pairwise dissimilar, so pruning
+    them again keeps all of them) and survivor-set nesting (every pass only removes)."""
+    import torch
+
+    from tscode_amd import FragmentSet
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C3")
+    fs = FragmentSet(ens.frag_coords)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_frags, d_ci, d_rot, d_pos = t(fs.flat), t(ens.conf_idx), t(ens.rot), t(ens.pos)
+    n, na = ens.n_poses, ens.n_atoms
+    heavy_idx = np.flatnonzero(ens.atomnos != 1).astype(np.int32)
+    out = {}
+    for mode in (0, 1):
+        runs = []
+        for rep in range(2):
+            clash = torch.empty(n, dtype=torch.uint8, device=dev)
+            structures = torch.empty((n, na, 3), dtype=torch.float64, device=dev)
+            keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            res = eng.pipeline_dev(fs, d_frags, d_ci, d_rot, d_pos, n, heavy_idx, 1.5, 0, 0.5, mode, clash, structures, keep)
+            runs.append((clash.cpu().numpy(), keep.cpu().numpy(), res))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])   # deterministic
+        res = runs[0][2]
+        assert res["n_keep"] == int(runs[0][1][:res["n_pass"]].sum())
+        acts = [s["n_active_after"] for s in res["stats"]]
+        assert all(a >= b for a, b in zip([res["n_pass"]] + acts, acts))
+        out[mode] = (structures[:res["n_pass"]], keep[:res["n_pass"]].cpu().numpy().astype(bool), res)
+        print(f"C3 mode {mode}: pass {res['n_pass']}, keep {res['n_keep']}, ms {res['ms']}")
+    # idempotence of the cache-free prune
+    structures, keep1, res1 = out[1]
+    surv = structures[torch.from_numpy(np.flatnonzero(keep1)).to(dev)][:, torch.from_numpy(heavy_idx.astype(np.int64)).to(dev)].contiguous()
+    mask2 = torch.empty(len(surv), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.prune_heavy_dev(surv, len(surv), len(heavy_idx), 0.5, 1, mask2)
+    eng.synchronize()
+    assert int(mask2.sum().item()) == len(surv)
+    assert out[1][2]["n_keep"] < out[0][2]["n_keep"]          # the reference-exact mode keeps more

@@ -1,0 +1,20 @@
+"""tscode_amd -- MI355X (gfx950) engine for TSCoDe's geometry hot path.
+
+Drop-in mirrors of the reference's functions (same names and signatures):
+
+    from tscode_amd import prune_conformers_rmsd, compenetration_check, get_embed
+    import tscode_amd; tscode_amd.install()      # patch an already imported tscode
+
+Everything numeric runs in libtscode_hip.so (hand-written HIP kernels behind the C ABI of
+include/tscode_hip.h).  There is no CPU fallback; importing this package does not touch the GPU.
+"""
+
+from .algebra import (align_vec_pair, all_dists, norm, norm_of, quaternion_to_rotation_matrix,  # noqa: F401
+                      rot_mat_from_pointer, rotation_matrix_from_vectors, transform_coords, vec_angle)
+from .embeds import embed_batch, get_embed, string_embed_poses  # noqa: F401
+from .engine import Engine, FragmentSet, device_count, get_engine  # noqa: F401
+from .install import install, uninstall  # noqa: F401
+from .numba_functions import compenetration_check, compenetration_mask, count_clashes  # noqa: F401
+from .rmsd_pruning import _rmsd_similarity, last_prune_stats, prune_conformers_rmsd, rmsd_and_max_numba  # noqa: F401
+
+__version__ = "0.1.0"

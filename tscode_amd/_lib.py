@@ -1,0 +1,120 @@
+"""ctypes binding of libtscode_hip.so (include/tscode_hip.h).
+
+There is no fallback: if the shared library is missing, or no gfx950 device is usable, the
+product fails loudly (``TscodeHipError``).  Nothing in this package imports the CPU oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtscode_hip.so")
+
+TSC_MAX_PASSES = 18
+
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+c_f32p = C.POINTER(C.c_float)
+
+
+class TscodeHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libtscode_hip error {code}: {message}")
+        self.code = code
+
+
+class PassStats(C.Structure):
+    _fields_ = [("k", C.c_int64), ("n_active_before", C.c_int64), ("n_active_after", C.c_int64),
+                ("pairs_evaluated", C.c_int64), ("pairs_computed", C.c_int64), ("candidates", C.c_int64),
+                ("new_keys", C.c_int64), ("gpu_ms", C.c_double), ("tile_ms", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+# name -> (restype, argtypes); mirrors include/tscode_hip.h one to one
+_vp = C.c_void_p
+_SIGNATURES = {
+    "tsc_version": (C.c_int, []),
+    "tsc_last_error": (C.c_char_p, []),
+    "tsc_device_count": (C.c_int, []),
+    "tsc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "tsc_ctx_destroy": (C.c_int, [_vp]),
+    "tsc_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "tsc_ctx_synchronize": (C.c_int, [_vp]),
+    "tsc_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "tsc_free": (C.c_int, [_vp, _vp]),
+    "tsc_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tsc_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tsc_timer_begin": (C.c_int, [_vp]),
+    "tsc_timer_end": (C.c_int, [_vp, c_f32p]),
+    "tsc_transform_batch": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
+    "tsc_transform_batch_dev": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
+    "tsc_clash_mask": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, C.c_double, C.c_int64, _vp, _vp]),
+    "tsc_clash_mask_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, C.c_double, C.c_int64, _vp, _vp]),
+    "tsc_embed_clash_mask_dev": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_double,
+                                           C.c_int64, _vp, _vp]),
+    "tsc_all_dists": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "tsc_compact_rows_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, c_i64p]),
+    "tsc_gather_heavy_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, _vp, c_i64p]),
+    "tsc_rmsd_pairs": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "tsc_rmsd_pairs_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "tsc_prune_rmsd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
+    "tsc_prune_rmsd_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
+    "tsc_prune_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "tsc_prune_next_pass": (C.c_int, [_vp, c_i64p]),
+    "tsc_prune_pass_local": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "tsc_prune_best_ptr": (C.c_int, [_vp, C.POINTER(_vp), c_i64p]),
+    "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),
+    "tsc_prune_pass_finish": (C.c_int, [_vp]),
+    "tsc_prune_mask_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "tsc_prune_stats": (C.c_int, [_vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
+    "tsc_prune_destroy": (C.c_int, [_vp]),
+    "tsc_pipeline_dev": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, c_i32p, C.c_int,
+                                   C.c_double, C.c_int64, C.c_double, C.c_int, _vp, _vp, _vp, c_i64p, c_i64p,
+                                   C.POINTER(PassStats), C.POINTER(C.c_int), c_f32p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libtscode_hip.so and declare every prototype.  Raises if the library is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise TscodeHipError(-2, f"{LIB_PATH} not found: build it with `python -m tscode_amd.build` "
+                                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TscodeHipError(rc, load().tsc_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    """Device pointer of a torch tensor / raw int, or host pointer of a contiguous NumPy array."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())      # torch.Tensor

@@ -1,0 +1,48 @@
+"""Build libtscode_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m tscode_amd.build [--force] [--verbose]
+"""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtscode_hip.so")
+SOURCES = ["tscode_hip.hip"]
+HEADERS = ["common.hpp", "scan.hpp", "embed_clash.hpp", "rmsd.hpp", os.path.join("..", "..", "include", "tscode_hip.h")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(OUT)

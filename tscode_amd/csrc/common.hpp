@@ -1,0 +1,140 @@
+// common.hpp -- context, error plumbing and the stream-ordered scratch cache of libtscode_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#include "../../include/tscode_hip.h"
+
+namespace tsc {
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define TSC_HIP(call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return ::tsc::fail(e_ == hipErrorOutOfMemory ? TSC_ERR_NOMEM : TSC_ERR_HIP, "%s failed: %s (%s:%d)", \
+                               #call, hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define TSC_TRY(call)          \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+#define TSC_REQUIRE(cond, ...)                                        \
+    do {                                                              \
+        if (!(cond)) return ::tsc::fail(TSC_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+template <typename T>
+__host__ __device__ inline T ceil_div(T a, T b) {
+    return (a + b - 1) / b;
+}
+
+}  // namespace tsc
+
+// One per (process, device).  All work is enqueued on `stream`; scratch blocks are recycled in
+// stream order, so a block handed back by one call can be reused by the next without a sync.
+struct tsc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::multimap<size_t, void *> cache;  // free scratch blocks by size
+    std::map<void *, size_t> live;        // blocks handed out
+    void *pinned = nullptr;               // small pinned host buffer for scalar read-backs
+    size_t pinned_bytes = 0;
+
+    int alloc(size_t bytes, void **out) {
+        if (bytes == 0) bytes = 8;
+        bytes = (bytes + 255) & ~size_t(255);
+        auto it = cache.lower_bound(bytes);
+        if (it != cache.end() && it->first <= bytes * 2 + (1u << 20)) {
+            *out = it->second;
+            live[*out] = it->first;
+            cache.erase(it);
+            return 0;
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            // drop the cache and retry once
+            (void)hipGetLastError();
+            trim();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return tsc::fail(TSC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        live[p] = bytes;
+        *out = p;
+        return 0;
+    }
+    void release(void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        cache.emplace(it->second, p);
+        live.erase(it);
+    }
+    void trim() {
+        (void)hipStreamSynchronize(stream);
+        for (auto &kv : cache) (void)hipFree(kv.second);
+        cache.clear();
+    }
+};
+
+namespace tsc {
+
+// RAII bundle of scratch blocks of one call: everything goes back to the cache on scope exit.
+struct Scratch {
+    tsc_ctx *ctx;
+    std::vector<void *> blocks;
+    explicit Scratch(tsc_ctx *c) : ctx(c) {}
+    ~Scratch() {
+        for (void *p : blocks) ctx->release(p);
+    }
+    template <typename T>
+    int get(size_t count, T **out) {
+        void *p = nullptr;
+        int rc = ctx->alloc(count * sizeof(T), &p);
+        if (rc) return rc;
+        blocks.push_back(p);
+        *out = static_cast<T *>(p);
+        return 0;
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace tsc

@@ -1,0 +1,186 @@
+// embed_clash.hpp -- K1 (batched rigid-body embedding) and K2 (compenetration mask) kernels.
+//
+// K1  out[s] = concat_m (R[s,m] @ X_m[c[s,m]].T).T + t[s,m]         reference embeds.py:961-969
+// K2  mask[s] = count(all_dists(frag_b, frag_a) < thresh) <= max     reference numba_functions.py:59-105
+//
+// Both are HBM-streaming kernels: K1 writes n*24 B per pose, K2 reads n*24 B per pose.  K2 stages each
+// pose once in LDS (one pose per LP-lane group of a wavefront), every lane owns one atom of the
+// "later" fragments and walks the atoms of the earlier fragments, which all lanes of the group read
+// from the same LDS address (a broadcast); the per-pose count is reduced with cross-lane shuffles.
+#pragma once
+#include "common.hpp"
+
+namespace tsc {
+
+constexpr int MAX_MOLS = 8;
+
+struct FragTable {
+    int n_mols;
+    int n_total;                 // atoms per pose
+    long long frag_off[MAX_MOLS];  // offset of fragment m in `frags`, in doubles
+    int n_atoms[MAX_MOLS];
+    int n_conf[MAX_MOLS];
+    int atom_off[MAX_MOLS + 1];  // first atom of fragment m inside a pose
+};
+
+__device__ inline int frag_of_atom(const FragTable &ft, int a) {
+    int m = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_MOLS; ++k)
+        if (k < ft.n_mols && a >= ft.atom_off[k]) m = k;
+    return m;
+}
+
+// one atom of one pose: R x + t
+__device__ inline void embed_atom(const double *__restrict__ frags, const FragTable &ft, const int32_t *__restrict__ conf_idx,
+                                  const double *__restrict__ rot, const double *__restrict__ pos, int64_t s, int a, double out[3]) {
+    int m = frag_of_atom(ft, a);
+    int64_t sm = s * ft.n_mols + m;
+    const double *X = frags + ft.frag_off[m] + (int64_t(conf_idx[sm]) * ft.n_atoms[m] + (a - ft.atom_off[m])) * 3;
+    const double *R = rot + sm * 9;
+    const double *t = pos + sm * 3;
+    double x0 = X[0], x1 = X[1], x2 = X[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = R[3 * i] * x0 + R[3 * i + 1] * x1 + R[3 * i + 2] * x2 + t[i];
+}
+
+// K1: one thread per (pose, atom); consecutive threads write consecutive 24-byte triples.
+// idx (optional): only the listed poses are embedded, out row r <- pose idx[r] (used after the clash
+// filter); heavy_sel/heavy_out (optional): additionally write the heavy-atom subset of each pose.
+__global__ __launch_bounds__(256) void k_transform(const double *__restrict__ frags, FragTable ft,
+                                                    const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
+                                                    const double *__restrict__ pos, const int32_t *__restrict__ idx,
+                                                    int64_t n_out, double *__restrict__ out,
+                                                    const int32_t *__restrict__ heavy_slot, int n_heavy,
+                                                    double *__restrict__ heavy_out) {
+    const int n = ft.n_total;
+    const int64_t total = n_out * n;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        int64_t r = e / n;
+        int a = int(e - r * n);
+        int64_t s = idx ? idx[r] : r;
+        double v[3];
+        embed_atom(frags, ft, conf_idx, rot, pos, s, a, v);
+        if (out) {
+            out[e * 3 + 0] = v[0];
+            out[e * 3 + 1] = v[1];
+            out[e * 3 + 2] = v[2];
+        }
+        if (heavy_out) {
+            int hs = heavy_slot[a];  // position of atom a among the heavy atoms, or -1
+            if (hs >= 0) {
+                double *h = heavy_out + (r * n_heavy + hs) * 3;
+                h[0] = v[0];
+                h[1] = v[1];
+                h[2] = v[2];
+            }
+        }
+    }
+}
+
+struct ClashArgs {
+    int64_t n_poses;
+    int n;          // atoms per pose
+    int first_row;  // first atom that owns a row of the count (atoms of fragments >= 1; 0 for ids=None)
+    int self_mode;  // 1: ids=None -> count_clashes semantics (all ordered pairs i != j with 0 < d < 0.5)
+    int lp;         // lanes per pose (power of two, <= 64)
+    int n_mols;
+    int atom_off[MAX_MOLS + 1];
+    double sq_bound;  // d < thresh  <=>  d2 < sq_bound   (exact: see clash_sq_bound)
+    long long max_clashes;
+};
+
+// Smallest double x with sqrt(x) >= thresh, so that (sqrt(d2) < thresh) == (d2 < x) for every d2:
+// IEEE sqrt is correctly rounded and monotone.  Lets the kernels compare squared distances while
+// giving the verdict of the reference's `all_dists(...) < thresh` (algebra.py:133-155, sqrt then <).
+inline double clash_sq_bound(double thresh) {
+    if (!(thresh > 0)) return 0.0;
+    double x = thresh * thresh;
+    while (std::sqrt(x) >= thresh) x = std::nextafter(x, 0.0);
+    while (std::sqrt(x) < thresh) x = std::nextafter(x, INFINITY);
+    return x;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
+                                                const double *__restrict__ frags, FragTable ft,
+                                                const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
+                                                const double *__restrict__ pos, uint8_t *__restrict__ mask,
+                                                int32_t *__restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) double s_xyz[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = a.n, lp = a.lp, ppw = 64 / lp;
+    double *w_xyz = s_xyz + size_t(wid) * ppw * n * 3;
+    const int64_t waves_total = int64_t(gridDim.x) * 4;
+    for (int64_t wv = int64_t(blockIdx.x) * 4 + wid; wv * ppw < a.n_poses; wv += waves_total) {
+        const int64_t pose0 = wv * ppw;
+        const int np = int(min<int64_t>(ppw, a.n_poses - pose0));
+        // ---- stage np poses in LDS
+        if (FUSED) {
+            for (int e = lane; e < np * n; e += 64) {
+                int sub = e / n, at = e - sub * n;
+                double v[3];
+                embed_atom(frags, ft, conf_idx, rot, pos, pose0 + sub, at, v);
+                w_xyz[e * 3 + 0] = v[0];
+                w_xyz[e * 3 + 1] = v[1];
+                w_xyz[e * 3 + 2] = v[2];
+            }
+        } else {
+            const double *src = coords + pose0 * n * 3;
+            for (int e = lane; e < np * n * 3; e += 64) w_xyz[e] = src[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- count close pairs: lane owns atom ia of pose `sub`, walks earlier-fragment atoms j
+        const int sub = lane / lp, li = lane - sub * lp;
+        const double *p = w_xyz + size_t(sub) * n * 3;
+        int cnt = 0;
+        if (sub < np) {
+            for (int ia = a.first_row + li; ia < n; ia += lp) {
+                const double x = p[ia * 3], y = p[ia * 3 + 1], z = p[ia * 3 + 2];
+                int jend = n;
+                if (!a.self_mode) {
+                    jend = 0;
+#pragma unroll
+                    for (int k = 1; k < MAX_MOLS; ++k)
+                        if (k < a.n_mols && ia >= a.atom_off[k]) jend = a.atom_off[k];
+                }
+                for (int j = 0; j < jend; ++j) {
+                    double dx = x - p[j * 3], dy = y - p[j * 3 + 1], dz = z - p[j * 3 + 2];
+                    double d2 = dx * dx + dy * dy + dz * dz;
+                    bool hit = a.self_mode ? (d2 < a.sq_bound && d2 > 0.0) : (d2 < a.sq_bound);
+                    cnt += hit ? 1 : 0;
+                }
+            }
+        }
+        for (int off = lp >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (sub < np && li == 0) {
+            mask[pose0 + sub] = (long long)cnt <= a.max_clashes ? 1 : 0;
+            if (counts) counts[pose0 + sub] = cnt;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// all_dists (algebra.py:98-157): out[i, j] = sqrt(sum_k (A[i,k] - B[j,k])^2)
+__global__ __launch_bounds__(256) void k_all_dists(const double *__restrict__ A, int na, const double *__restrict__ B, int nb,
+                                                    double *__restrict__ out) {
+    int64_t total = int64_t(na) * nb;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        int i = int(e / nb), j = int(e - int64_t(i) * nb);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double d = A[i * 3 + k] - B[j * 3 + k];
+            acc += d * d;
+        }
+        out[e] = sqrt(acc);
+    }
+}
+
+inline int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace tsc

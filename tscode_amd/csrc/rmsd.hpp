@@ -1,0 +1,431 @@
+// rmsd.hpp -- K3: Kabsch-rotation RMSD (no centring) and the per-pass kernels of prune_conformers_rmsd.
+//
+// Reference: tscode/rmsd_pruning.py.  rmsd_and_max_numba(p, q) (:6-41) rotates p onto q with the optimal
+// PROPER rotation about the origin (SVD of H = p^T q with the det sign fix, no centring) and returns the
+// RMSD and the largest per-atom deviation.  Two formulations of that same optimum are used here:
+//
+//  * the FILTER (tile kernel, every pair): the optimum satisfies  h * rmsd^2 = Gp + Gq - 2 * lmax,  where
+//    lmax = s1 + s2 + sign(det H) * s3 is the largest root of the quartic  P(l) = l^4 + c2 l^2 + c1 l + c0,
+//    c2 = -2 |H|_F^2, c1 = -8 det H, c0 = |H|_F^4 - 4 |cof H|_F^2   (characteristic polynomial of Horn's
+//    4x4 quaternion matrix).  With L = (Gp + Gq - h thr^2) / 2, rmsd >= thr  <=>  lmax <= L, and since all
+//    four roots are real, L > lmax  <=>  P(L) > 0, P'(L) > 0, P''(L) > 0 (for L > 0).  A pair is REJECTED
+//    only when the three values exceed a rounding-error bound, so a rejection is always right; every
+//    other pair goes to
+//  * the EXACT path (explicit rotation): the quaternion of the optimal rotation is the top eigenvector of
+//    Horn's matrix (cyclic Jacobi, fp64); p is rotated, the residual is formed atom by atom and
+//    rmsd = sqrt(sum |d|^2 / h), maxdev = max |d| are compared with the thresholds exactly as the
+//    reference does (:75).  Values agree with the reference's LAPACK path to ~1e-13.
+//
+// No MFMA, no LDS tiles for q: a lane owns one column structure q_j in registers (<= 32 heavy atoms after
+// padding), the row structure p_i is wavefront-uniform and is read through the scalar cache, so the
+// inner loop is 9 v_fma_f64 per atom with one SGPR operand each.
+#pragma once
+#include "common.hpp"
+
+namespace tsc {
+
+// ---------------------------------------------------------------------------------------------------
+// exact path
+
+// Cyclic Jacobi on a symmetric 4x4 (full storage, constant indices only so it lives in registers).
+// Returns the eigenvector of the largest eigenvalue in q[4].
+__device__ inline void top_eigvec4(double A[4][4], double q[4]) {
+    double V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dia += A[i][i] * A[i][i];
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        }
+        if (!(off > 1e-32 * dia)) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int r = p + 1; r < 4; ++r) {
+                double apq = A[p][r];
+                if (apq != 0.0) {
+                    double theta = (A[r][r] - A[p][p]) / (2.0 * apq);
+                    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    t = theta < 0.0 ? -t : t;
+                    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // columns p, r of A and V
+                        double akp = A[k][p], akr = A[k][r];
+                        A[k][p] = c * akp - s * akr;
+                        A[k][r] = s * akp + c * akr;
+                        double vkp = V[k][p], vkr = V[k][r];
+                        V[k][p] = c * vkp - s * vkr;
+                        V[k][r] = s * vkp + c * vkr;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // rows p, r of A
+                        double apk = A[p][k], ark = A[r][k];
+                        A[p][k] = c * apk - s * ark;
+                        A[r][k] = s * apk + c * ark;
+                    }
+                }
+            }
+        }
+    }
+    double best = A[0][0];
+    q[0] = V[0][0], q[1] = V[1][0], q[2] = V[2][0], q[3] = V[3][0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        bool b = A[k][k] > best;
+        best = b ? A[k][k] : best;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = b ? V[i][k] : q[i];
+    }
+}
+
+// rmsd_and_max_numba (rmsd_pruning.py:6-41) for one pair; p, q point at h consecutive xyz triples.
+__device__ inline void rmsd_and_max_pair(const double *__restrict__ p, const double *__restrict__ q, int h, double &rmsd,
+                                         double &maxdev) {
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int a = 0; a < h; ++a) {  // :15 cov_mat = p.T @ q
+        double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
+        double qx = q[3 * a], qy = q[3 * a + 1], qz = q[3 * a + 2];
+        S[0][0] += px * qx, S[0][1] += px * qy, S[0][2] += px * qz;
+        S[1][0] += py * qx, S[1][1] += py * qy, S[1][2] += py * qz;
+        S[2][0] += pz * qx, S[2][1] += pz * qy, S[2][2] += pz * qz;
+    }
+    // Horn's matrix: its top eigenvector is the quaternion (w, x, y, z) of the proper rotation R that
+    // maximises sum_a (R p_a) . q_a -- the rotation :19-26 builds from the SVD with the det sign fix.
+    double N[4][4];
+    N[0][0] = S[0][0] + S[1][1] + S[2][2];
+    N[1][1] = S[0][0] - S[1][1] - S[2][2];
+    N[2][2] = -S[0][0] + S[1][1] - S[2][2];
+    N[3][3] = -S[0][0] - S[1][1] + S[2][2];
+    N[0][1] = N[1][0] = S[1][2] - S[2][1];
+    N[0][2] = N[2][0] = S[2][0] - S[0][2];
+    N[0][3] = N[3][0] = S[0][1] - S[1][0];
+    N[1][2] = N[2][1] = S[0][1] + S[1][0];
+    N[1][3] = N[3][1] = S[2][0] + S[0][2];
+    N[2][3] = N[3][2] = S[1][2] + S[2][1];
+    double e[4];
+    top_eigvec4(N, e);
+    double nn = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    double w = e[0] * nn, x = e[1] * nn, y = e[2] * nn, z = e[3] * nn;
+    double R00 = w * w + x * x - y * y - z * z, R01 = 2 * (x * y - w * z), R02 = 2 * (x * z + w * y);
+    double R10 = 2 * (x * y + w * z), R11 = w * w - x * x + y * y - z * z, R12 = 2 * (y * z - w * x);
+    double R20 = 2 * (x * z - w * y), R21 = 2 * (y * z + w * x), R22 = w * w - x * x - y * y + z * z;
+    double ss = 0.0, mx = 0.0;
+    for (int a = 0; a < h; ++a) {  // :29-39
+        double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
+        double dx = R00 * px + R01 * py + R02 * pz - q[3 * a];
+        double dy = R10 * px + R11 * py + R12 * pz - q[3 * a + 1];
+        double dz = R20 * px + R21 * py + R22 * pz - q[3 * a + 2];
+        double d2 = dx * dx + dy * dy + dz * dz;
+        ss += d2;
+        mx = d2 > mx ? d2 : mx;
+    }
+    rmsd = sqrt(ss / double(h));
+    maxdev = sqrt(mx);  // max_a sqrt(d2_a) == sqrt(max_a d2_a): sqrt is monotone
+}
+
+__global__ __launch_bounds__(256) void k_rmsd_pairs(const double *__restrict__ heavy, int h, const int32_t *__restrict__ pairs,
+                                                     int64_t n_pairs, double *__restrict__ rmsd, double *__restrict__ maxdev) {
+    for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < n_pairs; k += int64_t(gridDim.x) * blockDim.x) {
+        double r, m;
+        rmsd_and_max_pair(heavy + int64_t(pairs[2 * k]) * h * 3, heavy + int64_t(pairs[2 * k + 1]) * h * 3, h, r, m);
+        rmsd[k] = r;
+        maxdev[k] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-pass helper kernels (see prune.hpp for the pass sequence)
+
+struct PassGeom {
+    int64_t n;   // structures
+    int64_t k;   // chunks in this pass
+    int64_t cs;  // chunk size n // k (rmsd_pruning.py:136)
+};
+
+__device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, int64_t &last) {
+    int64_t c = i / g.cs;
+    if (c >= g.k) c = g.k - 1;
+    first = c * g.cs;                                 // :140
+    last = (c == g.k - 1) ? g.n : first + g.cs;       // :141-144
+}
+
+// Cache view of one pass: a key (a, b) = (first, first + (j - i)) (:65) can be hit only where a is a chunk
+// start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
+__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a,
+                                                     const int32_t *__restrict__ key_b, const int32_t *__restrict__ n_keys,
+                                                     unsigned long long *__restrict__ dbit) {
+    int nk = *n_keys;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
+        int64_t a = key_a[q], b = key_b[q];
+        if (a % g.cs != 0) continue;
+        int64_t c = a / g.cs;
+        if (c >= g.k) continue;
+        int64_t last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
+        if (b < last) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
+    }
+}
+
+__device__ inline unsigned long long extract64(const unsigned long long *__restrict__ bits, int64_t start) {
+    int64_t w = start >> 6;
+    int sh = int(start & 63);
+    unsigned long long lo = bits[w] >> sh;
+    unsigned long long hi = sh ? (bits[w + 1] << (64 - sh)) : 0ull;
+    return lo | hi;
+}
+
+// One wavefront per active row i: cend[r] = rank of the first active column j in (i, last) with
+// (first + (j - i)) in the cache view (the row returns "not similar" there, :66-67), else rank of `last`.
+// Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
+__global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, int n_active, const int32_t *__restrict__ act_idx,
+                                                    const int32_t *__restrict__ pos, const unsigned long long *__restrict__ mbit,
+                                                    const unsigned long long *__restrict__ dbit, int32_t *__restrict__ cend) {
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_active) return;
+    int64_t i = act_idx[r], first, last;
+    chunk_of(g, i, first, last);
+    int64_t found = last;
+    if (use_cache) {
+        const int64_t len = last - i - 1;  // candidate deltas d = 1 .. len
+        for (int64_t base = 0; base < len; base += 64 * 64) {
+            int64_t d0 = 1 + base + int64_t(lane) * 64;
+            unsigned long long w = 0;
+            if (d0 <= len) {
+                w = extract64(mbit, i + d0) & extract64(dbit, first + d0);
+                int64_t rem = len - d0 + 1;
+                if (rem < 64) w &= (1ull << rem) - 1ull;
+            }
+            unsigned long long hit = __ballot(w != 0);
+            if (hit) {
+                int fl = __ffsll((long long)hit) - 1;
+                unsigned long long wl = __shfl(w, fl);
+                found = i + 1 + base + int64_t(fl) * 64 + (__ffsll((long long)wl) - 1);
+                break;
+            }
+        }
+    }
+    if (lane == 0) cend[r] = pos[found];
+}
+
+// Gather the active structures into the two layouts the tile kernel reads:
+//   Xr[r][HP3]   row-major, zero-padded to HP atoms  (row structures: wavefront-uniform scalar reads)
+//   Xc[d][ld]    coordinate-major                    (column structures: lane = column, coalesced)
+//   G[r] = sum |x|^2
+// One block moves 64 structures through an LDS tile so that both global sides are coalesced.
+__global__ __launch_bounds__(256) void k_compact_coords(const double *__restrict__ heavy, int h, int hp3,
+                                                         const int32_t *__restrict__ act_idx, int n_active,
+                                                         double *__restrict__ Xr, double *__restrict__ Xc, int64_t ld,
+                                                         double *__restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) double s_tile[];  // [64][hp3 + 1]
+    const int h3 = h * 3, pitch = hp3 + 1;
+    const int r0 = blockIdx.x * 64;
+    const int nr = min(64, n_active - r0);
+    for (int e = threadIdx.x; e < 64 * hp3; e += 256) {
+        int rr = e / hp3, d = e - rr * hp3;
+        double v = 0.0;
+        if (rr < nr && d < h3) v = heavy[int64_t(act_idx[r0 + rr]) * h3 + d];
+        s_tile[rr * pitch + d] = v;
+        if (rr < nr) Xr[int64_t(r0 + rr) * hp3 + d] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * hp3; e += 256) {
+        int d = e >> 6, rr = e & 63;
+        Xc[int64_t(d) * ld + r0 + rr] = s_tile[rr * pitch + d];  // rows >= nr are zeros
+    }
+    if (threadIdx.x < 64) {
+        double g = 0.0;
+        for (int d = 0; d < h3; ++d) {
+            double v = s_tile[threadIdx.x * pitch + d];
+            g += v * v;
+        }
+        G[r0 + threadIdx.x] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the tile kernel
+
+struct TileArgs {
+    long long ld;     // leading dimension of Xc (structures per coordinate row)
+    int n_active;
+    int h;
+    int n_tiles;      // row tiles of TI rows
+    int tile_begin;   // first tile of this rank
+    int tile_stride;  // world size (row tiles are dealt round-robin to ranks)
+    int seg_cols;     // columns per grid.y segment (multiple of 64)
+    double thr, maxdev_thr;
+    double half_h_thr2;  // h * thr^2 / 2
+};
+
+// Fast sign test described at the top of this file.  true = certainly rmsd >= thr.
+__device__ inline bool certainly_dissimilar(const double H[9], double L) {
+    const double F = H[0] * H[0] + H[1] * H[1] + H[2] * H[2] + H[3] * H[3] + H[4] * H[4] + H[5] * H[5] + H[6] * H[6] +
+                     H[7] * H[7] + H[8] * H[8];
+    const double C0 = H[4] * H[8] - H[5] * H[7], C1 = H[5] * H[6] - H[3] * H[8], C2 = H[3] * H[7] - H[4] * H[6];
+    const double C3 = H[2] * H[7] - H[1] * H[8], C4 = H[0] * H[8] - H[2] * H[6], C5 = H[1] * H[6] - H[0] * H[7];
+    const double C6 = H[1] * H[5] - H[2] * H[4], C7 = H[2] * H[3] - H[0] * H[5], C8 = H[0] * H[4] - H[1] * H[3];
+    const double det = H[0] * C0 + H[1] * C1 + H[2] * C2;
+    const double CF = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
+    const double c2 = -2.0 * F, c1 = -8.0 * det, c0 = F * F - 4.0 * CF;
+    const double L2 = L * L;
+    const double t4 = L2 * L2, t2 = c2 * L2, t1 = c1 * L;
+    constexpr double KAPPA = 1e-12;  // >> accumulated rounding of the coefficients for h up to ~1000 atoms
+    const double P = t4 + t2 + t1 + c0;
+    const double eP = KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(c0) + 4.0 * CF + F * F);
+    const double P1 = 4.0 * L2 * L + 2.0 * c2 * L + c1;
+    const double e1 = KAPPA * (4.0 * L2 * fabs(L) + 2.0 * fabs(c2 * L) + fabs(c1));
+    const double P2 = 6.0 * L2 + c2;
+    const double e2 = KAPPA * (6.0 * L2 + fabs(c2));
+    return (L > 0.0) && (P > eP) && (P1 > e1) && (P2 > e2);
+}
+
+// One wavefront = one work item = (row tile of TI consecutive active rows) x (one column segment).
+// Lane = column.  For every 64-column tile: load q_j into registers, then for each live row accumulate
+// H = p_i^T q_j, run the sign test, remember survivors as per-lane bits; after the row loop the few
+// survivors take the exact path and the smallest similar column of each row goes to best[] (atomicMin).
+// A row stops being visited once it has a similar column to its left (the reference returns at the
+// first similar column, rmsd_pruning.py:75-77).
+template <int HP, int TI>
+__global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__ Xr, const double *__restrict__ Xc,
+                                                       const double *__restrict__ G, const int32_t *__restrict__ cend,
+                                                       int32_t *__restrict__ best, unsigned long long *__restrict__ counters,
+                                                       TileArgs a) {
+    // Xr [n_active][HP*3] row structures; Xc [HP*3][ld] column structures; G [ld] squared norms;
+    // cend [n_active] exclusive column bound of each row; best [n_active] atomicMin target (INT_MAX = none);
+    // counters[0] pairs computed, counters[1] pairs sent to the exact path.
+    static_assert(TI <= 32, "row liveness is a 32-bit lane mask");
+    constexpr int HP3 = HP * 3;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * 4 + wid;
+    const int tile = a.tile_begin + slot * a.tile_stride;
+    if (tile >= a.n_tiles) return;
+    const int r0 = tile * TI;
+    const int nrows = min(TI, a.n_active - r0);
+    const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
+    const int seg_hi = seg_lo + a.seg_cols;
+
+    int my_cend = 0, my_best = 0;
+    if (lane < nrows) {
+        my_cend = cend[r0 + lane];
+        my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool live0 = lane < nrows && my_cend > max(r0 + lane + 1, seg_lo) && my_best >= seg_lo;
+    unsigned alive = unsigned(__ballot(live0));
+    if (!alive) return;
+    int cmax = live0 ? my_cend : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
+
+    unsigned long long n_computed = 0, n_cand = 0;
+    for (int c0 = seg_lo; c0 < cmax && alive; c0 += 64) {
+        const int col = c0 + lane;
+        double q[HP3];
+        {
+            const double *xc = Xc + col;
+#pragma unroll
+            for (int d = 0; d < HP3; ++d, xc += a.ld) q[d] = *xc;
+        }
+        const double Gq = G[col];
+        unsigned mycand = 0;  // bit t: this lane's column survived the sign test against row t
+        unsigned candrows = 0;
+        for (int t = 0; t < nrows; ++t) {
+            if (!((alive >> t) & 1u)) continue;
+            const int r = r0 + t;
+            const int ce = __builtin_amdgcn_readlane(my_cend, t);
+            if (ce <= c0 || r >= c0 + 63) continue;
+            const double *__restrict__ pr = Xr + int64_t(r) * HP3;
+            double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < HP; ++k) {
+                const double px = pr[3 * k], py = pr[3 * k + 1], pz = pr[3 * k + 2];
+                H[0] = fma(px, q[3 * k], H[0]), H[1] = fma(px, q[3 * k + 1], H[1]), H[2] = fma(px, q[3 * k + 2], H[2]);
+                H[3] = fma(py, q[3 * k], H[3]), H[4] = fma(py, q[3 * k + 1], H[4]), H[5] = fma(py, q[3 * k + 2], H[5]);
+                H[6] = fma(pz, q[3 * k], H[6]), H[7] = fma(pz, q[3 * k + 1], H[7]), H[8] = fma(pz, q[3 * k + 2], H[8]);
+            }
+            const double L = 0.5 * (G[r] + Gq) - a.half_h_thr2;
+            const bool valid = col > r && col < ce;
+            const bool cand = valid && !certainly_dissimilar(H, L);
+            const unsigned long long vm = __ballot(valid);
+            n_computed += __popcll(vm);
+            if (__ballot(cand)) candrows |= 1u << t;
+            mycand |= cand ? (1u << t) : 0u;
+        }
+        // exact path for the survivors of this column tile
+        while (candrows) {
+            const int t = __ffs(candrows) - 1;
+            candrows &= candrows - 1;
+            const int r = r0 + t;
+            bool sim = false;
+            if ((mycand >> t) & 1u) {
+                double rm, md;
+                rmsd_and_max_pair(Xr + int64_t(r) * HP3, Xr + int64_t(col) * HP3, a.h, rm, md);
+                sim = rm < a.thr && md < a.maxdev_thr;  // rmsd_pruning.py:75
+            }
+            n_cand += __popcll(__ballot((mycand >> t) & 1u));
+            const unsigned long long sm = __ballot(sim);
+            if (sm) {
+                if (lane == 0) atomicMin(&best[r], c0 + __ffsll((long long)sm) - 1);
+                alive &= ~(1u << t);
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_computed);
+        atomicAdd(&counters[1], n_cand);
+    }
+}
+
+// Apply a finished pass: rows with a similar column are removed (:113) and leave one cache key each
+// (:76, appended after the pass at :204); counts what the reference's sequential scan would have evaluated.
+struct ApplyCounters {
+    unsigned long long pairs_evaluated;
+    int removed;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, int n_active, const int32_t *__restrict__ act_idx,
+                                                     const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
+                                                     uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
+                                                     int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
+                                                     ApplyCounters *__restrict__ cnt) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ev = 0;
+    int rem = 0;
+    if (r < n_active) {
+        int b = best[r];
+        if (b != INT_MAX) {
+            int64_t i = act_idx[r], j = act_idx[b], first, last;
+            chunk_of(g, i, first, last);
+            mask[i] = 0;
+            int slot = atomicAdd(n_keys, 1);
+            key_a[slot] = int32_t(first);
+            key_b[slot] = int32_t(first + (j - i));
+            ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
+            rem = 1;
+        } else {
+            ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ev += __shfl_down(ev, off);
+        rem += __shfl_down(rem, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (ev || rem)) {
+        atomicAdd(&cnt->pairs_evaluated, ev);
+        atomicAdd(&cnt->removed, rem);
+    }
+}
+
+__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = v;
+}
+
+}  // namespace tsc

@@ -1,0 +1,150 @@
+// scan.hpp -- ordered compaction primitives: exclusive scan of a byte mask, bit packing, row gathers.
+// NumPy's structures[mask] keeps order, and the pruning result depends on that order, so every
+// compaction here is a stable one driven by an exclusive prefix sum (no atomics).
+#pragma once
+#include "common.hpp"
+
+namespace tsc {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;                             // bytes per thread: one 64-bit load
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;     // 2048 mask bytes per block
+
+__device__ inline uint64_t load_mask8(const uint8_t *__restrict__ mask, int64_t base, int64_t n) {
+    // 8 mask bytes starting at base (base % 8 == 0), zero beyond n; mask is hipMalloc-aligned.
+    if (base + 8 <= n) return *reinterpret_cast<const uint64_t *>(mask + base);
+    uint64_t v = 0;
+    for (int b = 0; b < 8; ++b)
+        if (base + b < n) v |= uint64_t(mask[base + b]) << (8 * b);
+    return v;
+}
+
+__device__ inline int count_nonzero_bytes(uint64_t v) {
+    // number of non-zero bytes in v
+    uint64_t t = v | (v >> 4);
+    t |= t >> 2;
+    t |= t >> 1;
+    t &= 0x0101010101010101ull;
+    return __popcll(t);
+}
+
+// pass 1: per-block count of non-zero mask bytes
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t *__restrict__ mask, int64_t n,
+                                                                   int32_t *__restrict__ bsum) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    int64_t base = (int64_t(blockIdx.x) * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    int c = (base < n) ? count_nonzero_bytes(load_mask8(mask, base, n)) : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// pass 2: one block turns block counts into exclusive block offsets; total -> *total_out (and bsum[nb])
+__global__ __launch_bounds__(1024) void k_scan_offsets(int32_t *__restrict__ bsum, int nb, int32_t *__restrict__ total_out) {
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int start = 0; start < nb; start += 1024) {
+        int i = start + threadIdx.x;
+        int v = (i < nb) ? bsum[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            int t = (int(threadIdx.x) >= off) ? s_part[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = s_part[threadIdx.x];
+        int carry = s_carry;
+        if (i < nb) bsum[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bsum[nb] = s_carry;
+        if (total_out) *total_out = s_carry;
+    }
+}
+
+// pass 3: pos[i] = number of non-zero mask bytes before i (pos[n] = total); optionally the list of
+// kept indices (act_idx[pos[i]] = i) and the mask as a bit array (bit i of mbit = mask[i] != 0).
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
+                                                              const int32_t *__restrict__ boff, int32_t *__restrict__ pos,
+                                                              int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int64_t base = (int64_t(blockIdx.x) * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    uint64_t v = (base < n) ? load_mask8(mask, base, n) : 0;
+    int c = count_nonzero_bytes(v);
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += s_w[w];
+    int run = boff[blockIdx.x] + woff + incl - c;
+    uint8_t bits = 0;
+    for (int b = 0; b < SCAN_ITEMS; ++b) {
+        int64_t i = base + b;
+        if (i >= n) break;
+        bool on = ((v >> (8 * b)) & 0xff) != 0;
+        if (pos) pos[i] = run;
+        if (on) {
+            if (act_idx) act_idx[run] = int32_t(i);
+            bits |= uint8_t(1u << b);
+            ++run;
+        }
+    }
+    if (mbit_bytes && base < n) mbit_bytes[base >> 3] = bits;
+    if (pos && base <= n && n < base + SCAN_ITEMS) pos[n] = run;  // the thread owning the tail writes pos[n]
+}
+
+// Enqueue the three passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
+// act_idx / mbit are produced); total_dev (optional) receives count_nonzero(mask).
+inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
+                     uint8_t *mbit_bytes, int32_t *total_dev) {
+    int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, bsum, nb, total_dev);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, pos, act_idx, mbit_bytes);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+inline size_t scan_bsum_count(int64_t n) { return size_t(ceil_div<int64_t>(n + 1, SCAN_TILE)) + 2; }
+
+// dst[r] = src[idx[r]] for rows of row_words 8-byte words; idx == nullptr means identity.
+// sel (optional) picks words inside the row: dst[r][w] = src[idx[r]][sel[w]] for w < out_words
+// (used for the heavy-atom gather, where a "word" is one coordinate triple = 3 doubles handled as 3 words).
+__global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ src, const int32_t *__restrict__ idx,
+                                                      int64_t n_out, int row_words, const int32_t *__restrict__ sel,
+                                                      int out_words, uint64_t *__restrict__ dst) {
+    int64_t total = n_out * out_words;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        int64_t r = e / out_words;
+        int w = int(e - r * out_words);
+        int64_t s = idx ? idx[r] : r;
+        int sw = sel ? sel[w] : w;
+        dst[e] = src[s * row_words + sw];
+    }
+}
+
+inline int launch_gather_rows(hipStream_t st, const void *src, const int32_t *idx, int64_t n_out, int row_words,
+                              const int32_t *sel, int out_words, void *dst) {
+    if (n_out <= 0) return 0;
+    int64_t total = n_out * out_words;
+    int blocks = int(std::min<int64_t>(ceil_div<int64_t>(total, 256), 256 * 16));
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, static_cast<const uint64_t *>(src), idx, n_out,
+                       row_words, sel, out_words, static_cast<uint64_t *>(dst));
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tsc

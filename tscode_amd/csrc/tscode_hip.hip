@@ -1,0 +1,843 @@
+// tscode_hip.hip -- the C ABI of include/tscode_hip.h on top of the kernels in this directory.
+// gfx950 only.  There is deliberately no CPU implementation behind these entry points.
+#include "common.hpp"
+#include "embed_clash.hpp"
+#include "rmsd.hpp"
+#include "scan.hpp"
+
+#include <algorithm>
+
+using namespace tsc;
+
+// --------------------------------------------------------------------------------------------------
+// library / context
+
+extern "C" __attribute__((visibility("default"))) int tsc_version(void) { return TSC_VERSION; }
+extern "C" __attribute__((visibility("default"))) const char *tsc_last_error(void) { return g_err; }
+
+extern "C" __attribute__((visibility("default"))) int tsc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TSC_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    return n;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device, tsc_ctx **out) {
+    TSC_REQUIRE(out != nullptr, "tsc_ctx_create: out is null");
+    *out = nullptr;
+    int n = tsc_device_count();
+    if (n < 0) return n;
+    if (n == 0) return fail(TSC_ERR_NO_DEVICE, "no HIP device visible: libtscode_hip has no CPU path");
+    TSC_REQUIRE(device >= 0 && device < n, "tsc_ctx_create: device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    TSC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TSC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    DeviceGuard guard(device);
+    tsc_ctx *c = new (std::nothrow) tsc_ctx();
+    if (!c) return fail(TSC_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) {
+        c->pinned_bytes = 4096;
+        e = hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return fail(TSC_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c) {
+    if (!c) return 0;
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->cache) (void)hipFree(kv.second);
+    for (auto &kv : c->live) (void)hipFree(kv.first);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+static hipStream_t g_dummy;
+extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_stream(tsc_ctx *c, void *hip_stream) {
+    TSC_REQUIRE(c != nullptr, "null context");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    if (hip_stream) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        c->stream = static_cast<hipStream_t>(hip_stream);
+        c->own_stream = false;
+    } else if (!c->own_stream) {
+        TSC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    (void)g_dummy;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_ctx_synchronize(tsc_ctx *c) {
+    TSC_REQUIRE(c != nullptr, "null context");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_malloc(tsc_ctx *c, size_t bytes, void **dptr) {
+    TSC_REQUIRE(c && dptr, "null argument");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int tsc_free(tsc_ctx *c, void *dptr) {
+    TSC_REQUIRE(c != nullptr, "null context");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    if (dptr) TSC_HIP(hipFree(dptr));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int tsc_memcpy_h2d(tsc_ctx *c, void *dst, const void *src, size_t bytes) {
+    TSC_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+    DeviceGuard guard(c->device);
+    if (bytes) {
+        TSC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        TSC_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int tsc_memcpy_d2h(tsc_ctx *c, void *dst, const void *src, size_t bytes) {
+    TSC_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+    DeviceGuard guard(c->device);
+    if (bytes) {
+        TSC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        TSC_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int tsc_timer_begin(tsc_ctx *c) {
+    TSC_REQUIRE(c != nullptr, "null context");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int tsc_timer_end(tsc_ctx *c, float *ms) {
+    TSC_REQUIRE(c && ms, "null argument");
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipEventRecord(c->ev1, c->stream));
+    TSC_HIP(hipEventSynchronize(c->ev1));
+    TSC_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// helpers
+
+static int make_frag_table(const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols, FragTable *ft) {
+    TSC_REQUIRE(frag_off && n_atoms && n_conf, "null fragment table");
+    TSC_REQUIRE(n_mols >= 1 && n_mols <= MAX_MOLS, "n_mols = %d not in 1..%d", n_mols, MAX_MOLS);
+    memset(ft, 0, sizeof(*ft));
+    ft->n_mols = n_mols;
+    int off = 0;
+    for (int m = 0; m < n_mols; ++m) {
+        TSC_REQUIRE(n_atoms[m] > 0 && n_conf[m] > 0 && frag_off[m] >= 0, "bad fragment %d", m);
+        ft->frag_off[m] = frag_off[m];
+        ft->n_atoms[m] = n_atoms[m];
+        ft->n_conf[m] = n_conf[m];
+        ft->atom_off[m] = off;
+        off += n_atoms[m];
+    }
+    for (int m = n_mols; m <= MAX_MOLS; ++m) ft->atom_off[m] = off;
+    ft->n_total = off;
+    return 0;
+}
+
+static inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 16) {
+    return int(std::max<int64_t>(1, std::min<int64_t>(ceil_div<int64_t>(work_items, per_block), cap)));
+}
+
+template <typename T>
+static int upload(tsc_ctx *c, Scratch &s, const T *host, size_t count, T **dev) {
+    TSC_TRY(s.get(count ? count : 1, dev));
+    if (count) TSC_HIP(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K1
+
+extern "C" __attribute__((visibility("default"))) int tsc_transform_batch_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                       const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                       const double *pos, int64_t n_poses, double *out) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && out, "tsc_transform_batch_dev: null argument");
+    TSC_REQUIRE(n_poses >= 0, "negative n_poses");
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    if (n_poses == 0) return 0;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256)), dim3(256), 0, c->stream, frags, ft, conf_idx, rot,
+                       pos, (const int32_t *)nullptr, n_poses, out, (const int32_t *)nullptr, 0, (double *)nullptr);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+static int64_t frags_total_doubles(const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols) {
+    int64_t end = 0;
+    for (int m = 0; m < n_mols; ++m) end = std::max<int64_t>(end, frag_off[m] + int64_t(n_conf[m]) * n_atoms[m] * 3);
+    return end;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_transform_batch(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                   const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                   const double *pos, int64_t n_poses, double *out) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && out, "tsc_transform_batch: null argument");
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    TSC_REQUIRE(n_poses >= 0, "negative n_poses");
+    for (int64_t i = 0; i < n_poses * n_mols; ++i)
+        TSC_REQUIRE(conf_idx[i] >= 0 && conf_idx[i] < n_conf[i % n_mols], "conf_idx[%lld] out of range", (long long)i);
+    if (n_poses == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_frags, *d_rot, *d_pos, *d_out;
+    int32_t *d_ci;
+    TSC_TRY(upload(c, s, frags, size_t(frags_total_doubles(frag_off, n_atoms, n_conf, n_mols)), &d_frags));
+    TSC_TRY(upload(c, s, conf_idx, size_t(n_poses) * n_mols, &d_ci));
+    TSC_TRY(upload(c, s, rot, size_t(n_poses) * n_mols * 9, &d_rot));
+    TSC_TRY(upload(c, s, pos, size_t(n_poses) * n_mols * 3, &d_pos));
+    TSC_TRY(s.get(size_t(n_poses) * ft.n_total * 3, &d_out));
+    TSC_TRY(tsc_transform_batch_dev(c, d_frags, frag_off, n_atoms, n_conf, n_mols, d_ci, d_rot, d_pos, n_poses, d_out));
+    TSC_HIP(hipMemcpyAsync(out, d_out, size_t(n_poses) * ft.n_total * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2
+
+static int make_clash_args(int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids, double thresh, int64_t max_clashes,
+                           ClashArgs *a) {
+    TSC_REQUIRE(n_poses >= 0 && n_atoms > 0, "bad sizes");
+    TSC_REQUIRE(n_ids == 0 || n_ids == 2 || n_ids == 3, "ids must have 0 (None), 2 or 3 entries, got %d", n_ids);
+    memset(a, 0, sizeof(*a));
+    a->n_poses = n_poses;
+    a->n = n_atoms;
+    a->max_clashes = max_clashes;
+    if (n_ids == 0) {
+        a->self_mode = 1;
+        a->first_row = 0;
+        a->n_mols = 1;
+        a->sq_bound = clash_sq_bound(0.5);  // numba_functions.py:54
+        for (int m = 1; m <= MAX_MOLS; ++m) a->atom_off[m] = n_atoms;
+    } else {
+        TSC_REQUIRE(ids != nullptr, "ids is null");
+        int off = 0;
+        // like the reference (numba_functions.py:77-78, 88-90) the LAST fragment takes whatever is left
+        for (int m = 0; m < n_ids; ++m) {
+            a->atom_off[m] = off;
+            TSC_REQUIRE(ids[m] >= 0, "negative fragment length");
+            off += ids[m];
+        }
+        TSC_REQUIRE(off - ids[n_ids - 1] <= n_atoms, "fragment lengths exceed the atom count");
+        for (int m = n_ids; m <= MAX_MOLS; ++m) a->atom_off[m] = n_atoms;
+        a->n_mols = n_ids;
+        a->first_row = a->atom_off[1];
+        a->sq_bound = clash_sq_bound(thresh);
+    }
+    int rows = std::max(1, n_atoms - a->first_row);
+    a->lp = std::min(64, std::max(4, pow2_ceil(rows)));
+    return 0;
+}
+
+template <bool FUSED>
+static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
+                        const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
+    if (a.n_poses == 0) return 0;
+    const int ppw = 64 / a.lp;
+    size_t lds = size_t(4) * ppw * a.n * 3 * sizeof(double);
+    TSC_REQUIRE(lds <= 160 * 1024, "pose too large for the LDS staging of the clash kernel (%d atoms)", a.n);
+    int64_t waves = ceil_div<int64_t>(a.n_poses, ppw);
+    int blocks = grid_for(waves, 4, 256 * 8);
+    if (lds > 64 * 1024)
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clash<FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_clash<FUSED>, dim3(blocks), dim3(256), lds, c->stream, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_clash_mask_dev(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
+                                  double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts) {
+    TSC_REQUIRE(c && coords && mask, "tsc_clash_mask_dev: null argument");
+    ClashArgs a;
+    TSC_TRY(make_clash_args(n_poses, n_atoms, ids, n_ids, thresh, max_clashes, &a));
+    DeviceGuard guard(c->device);
+    FragTable ft;
+    memset(&ft, 0, sizeof(ft));
+    return launch_clash<false>(c, a, coords, nullptr, ft, nullptr, nullptr, nullptr, mask, counts);
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_clash_mask(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
+                              double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts) {
+    TSC_REQUIRE(c && coords && mask, "tsc_clash_mask: null argument");
+    ClashArgs a;
+    TSC_TRY(make_clash_args(n_poses, n_atoms, ids, n_ids, thresh, max_clashes, &a));
+    if (n_poses == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_coords;
+    uint8_t *d_mask;
+    int32_t *d_counts = nullptr;
+    TSC_TRY(upload(c, s, coords, size_t(n_poses) * n_atoms * 3, &d_coords));
+    TSC_TRY(s.get(size_t(n_poses), &d_mask));
+    if (counts) TSC_TRY(s.get(size_t(n_poses), &d_counts));
+    TSC_TRY(tsc_clash_mask_dev(c, d_coords, n_poses, n_atoms, ids, n_ids, thresh, max_clashes, d_mask, d_counts));
+    TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n_poses), hipMemcpyDeviceToHost, c->stream));
+    if (counts) TSC_HIP(hipMemcpyAsync(counts, d_counts, size_t(n_poses) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_mask_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                        const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                        const double *pos, int64_t n_poses, double thresh, int64_t max_clashes, uint8_t *mask,
+                                        int32_t *counts) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && mask, "tsc_embed_clash_mask_dev: null argument");
+    TSC_REQUIRE(n_mols == 2 || n_mols == 3, "the fused embed+clash path needs 2 or 3 fragments, got %d", n_mols);
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    ClashArgs a;
+    TSC_TRY(make_clash_args(n_poses, ft.n_total, n_atoms, n_mols, thresh, max_clashes, &a));
+    DeviceGuard guard(c->device);
+    return launch_clash<true>(c, a, nullptr, frags, ft, conf_idx, rot, pos, mask, counts);
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_all_dists(tsc_ctx *c, const double *A, int na, const double *B, int nb, double *out) {
+    TSC_REQUIRE(c && A && B && out && na >= 0 && nb >= 0, "tsc_all_dists: bad argument");
+    if (na == 0 || nb == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *dA, *dB, *dO;
+    TSC_TRY(upload(c, s, A, size_t(na) * 3, &dA));
+    TSC_TRY(upload(c, s, B, size_t(nb) * 3, &dB));
+    TSC_TRY(s.get(size_t(na) * nb, &dO));
+    hipLaunchKernelGGL(k_all_dists, dim3(grid_for(int64_t(na) * nb, 256)), dim3(256), 0, c->stream, dA, na, dB, nb, dO);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(out, dO, size_t(na) * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// ordered compaction
+
+static int read_i32(tsc_ctx *c, const int32_t *dev, int32_t *host_out) {
+    TSC_HIP(hipMemcpyAsync(c->pinned, dev, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    *host_out = *static_cast<int32_t *>(c->pinned);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_compact_rows_dev(tsc_ctx *c, const void *src, const uint8_t *mask, int64_t n_rows, int64_t row_bytes, void *dst,
+                                    int64_t *n_kept_host) {
+    TSC_REQUIRE(c && src && mask && dst, "tsc_compact_rows_dev: null argument");
+    TSC_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_bytes > 0 && row_bytes % 8 == 0 && row_bytes / 8 < INT32_MAX, "bad sizes");
+    if (n_rows == 0) {
+        if (n_kept_host) *n_kept_host = 0;
+        return 0;
+    }
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    int32_t *bsum, *act, *total;
+    TSC_TRY(s.get(scan_bsum_count(n_rows), &bsum));
+    TSC_TRY(s.get(size_t(n_rows), &act));
+    TSC_TRY(s.get(1, &total));
+    TSC_TRY(scan_mask(c->stream, mask, n_rows, bsum, nullptr, act, nullptr, total));
+    int32_t kept = 0;
+    TSC_TRY(read_i32(c, total, &kept));
+    TSC_TRY(launch_gather_rows(c->stream, src, act, kept, int(row_bytes / 8), nullptr, int(row_bytes / 8), dst));
+    if (n_kept_host) *n_kept_host = kept;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_gather_heavy_dev(tsc_ctx *c, const double *coords, const uint8_t *mask, int64_t n_poses, int n_atoms,
+                                    const int32_t *heavy_idx, int n_heavy, double *heavy_out, int64_t *n_kept_host) {
+    TSC_REQUIRE(c && coords && heavy_idx && heavy_out, "tsc_gather_heavy_dev: null argument");
+    TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX && n_atoms > 0 && n_heavy > 0 && n_heavy <= n_atoms, "bad sizes");
+    if (n_poses == 0) {
+        if (n_kept_host) *n_kept_host = 0;
+        return 0;
+    }
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    std::vector<int32_t> sel(size_t(n_heavy) * 3);
+    for (int a = 0; a < n_heavy; ++a) {
+        TSC_REQUIRE(heavy_idx[a] >= 0 && heavy_idx[a] < n_atoms, "heavy_idx[%d] out of range", a);
+        for (int k = 0; k < 3; ++k) sel[size_t(a) * 3 + k] = heavy_idx[a] * 3 + k;
+    }
+    int32_t *d_sel, *act = nullptr;
+    TSC_TRY(upload(c, s, sel.data(), sel.size(), &d_sel));
+    int32_t kept = int32_t(n_poses);
+    if (mask) {
+        int32_t *bsum, *total;
+        TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
+        TSC_TRY(s.get(size_t(n_poses), &act));
+        TSC_TRY(s.get(1, &total));
+        TSC_TRY(scan_mask(c->stream, mask, n_poses, bsum, nullptr, act, nullptr, total));
+        TSC_TRY(read_i32(c, total, &kept));
+    } else {
+        TSC_HIP(hipStreamSynchronize(c->stream));  // sel upload reads a stack-local vector
+    }
+    TSC_TRY(launch_gather_rows(c->stream, coords, act, kept, n_atoms * 3, d_sel, n_heavy * 3, heavy_out));
+    if (!mask) TSC_HIP(hipStreamSynchronize(c->stream));
+    if (n_kept_host) *n_kept_host = kept;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3: pairs
+
+extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs_dev(tsc_ctx *c, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
+                                  double *rmsd, double *maxdev) {
+    TSC_REQUIRE(c && heavy && pairs && rmsd && maxdev, "tsc_rmsd_pairs_dev: null argument");
+    TSC_REQUIRE(n_structs >= 0 && h > 0 && n_pairs >= 0, "bad sizes");
+    if (n_pairs == 0) return 0;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_rmsd_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, c->stream, heavy, h, pairs, n_pairs, rmsd, maxdev);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
+                              double *rmsd, double *maxdev) {
+    TSC_REQUIRE(c && heavy && pairs && rmsd && maxdev, "tsc_rmsd_pairs: null argument");
+    TSC_REQUIRE(n_structs >= 0 && h > 0 && n_pairs >= 0, "bad sizes");
+    for (int64_t k = 0; k < 2 * n_pairs; ++k)
+        TSC_REQUIRE(pairs[k] >= 0 && pairs[k] < n_structs, "pairs[%lld] = %d out of range", (long long)k, pairs[k]);
+    if (n_pairs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_heavy, *d_r, *d_m;
+    int32_t *d_pairs;
+    TSC_TRY(upload(c, s, heavy, size_t(n_structs) * h * 3, &d_heavy));
+    TSC_TRY(upload(c, s, pairs, size_t(n_pairs) * 2, &d_pairs));
+    TSC_TRY(s.get(size_t(n_pairs), &d_r));
+    TSC_TRY(s.get(size_t(n_pairs), &d_m));
+    TSC_TRY(tsc_rmsd_pairs_dev(c, d_heavy, n_structs, h, d_pairs, n_pairs, d_r, d_m));
+    TSC_HIP(hipMemcpyAsync(rmsd, d_r, size_t(n_pairs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(maxdev, d_m, size_t(n_pairs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3: prune_conformers_rmsd
+
+static const double KS[TSC_MAX_PASSES] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};  // :186-188
+
+constexpr int TILE_ROWS = 16;
+constexpr int MAX_HP = 32;
+
+struct DevCounters {  // zeroed before every pass
+    unsigned long long tile[2];  // pairs computed, candidates
+    ApplyCounters apply;
+};
+
+struct tsc_prune {
+    tsc_ctx *ctx = nullptr;
+    const double *heavy = nullptr;
+    int64_t n = 0, npad = 0;
+    int h = 0, hp = 0;
+    double thr = 0;
+    int mode = 0;
+    // device state
+    uint8_t *mask = nullptr;
+    int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
+    int32_t *bsum = nullptr, *total = nullptr;
+    unsigned long long *mbit = nullptr, *dbit = nullptr;
+    size_t bit_words = 0;
+    double *Xr = nullptr, *Xc = nullptr, *G = nullptr;
+    DevCounters *counters = nullptr;
+    std::vector<void *> blocks;
+    // host state
+    int next_ks = 0;           // next index into KS to consider
+    int64_t n_active = 0;      // count_nonzero(mask) as of the last finished pass
+    int64_t cur_k = 0;         // pass in flight (0 = none)
+    bool local_done = false;
+    tsc_pass_stats stats[TSC_MAX_PASSES];
+    int n_passes = 0;
+    bool stats_pending = false;  // counters of the last finished pass not yet read back
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evt0 = nullptr, evt1 = nullptr;
+};
+
+template <typename T>
+static int palloc(tsc_prune *p, size_t count, T **out) {
+    void *q = nullptr;
+    TSC_TRY(p->ctx->alloc(count * sizeof(T), &q));
+    p->blocks.push_back(q);
+    *out = static_cast<T *>(q);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prune *p) {
+    if (!p) return 0;
+    DeviceGuard guard(p->ctx->device);
+    for (void *q : p->blocks) p->ctx->release(q);
+    for (hipEvent_t e : {p->ev0, p->ev1, p->evt0, p->evt1})
+        if (e) (void)hipEventDestroy(e);
+    delete p;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
+    TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
+    TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
+    TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
+    TSC_REQUIRE(h <= MAX_HP, "h = %d heavy atoms: this build supports up to %d", h, MAX_HP);
+    TSC_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (reference-exact) or 1 (cache-free)");
+    TSC_REQUIRE(rmsd_thr > 0, "rmsd_thr must be positive");
+    *out = nullptr;
+    DeviceGuard guard(c->device);
+    tsc_prune *p = new (std::nothrow) tsc_prune();
+    if (!p) return fail(TSC_ERR_NOMEM, "out of host memory");
+    p->ctx = c;
+    p->heavy = heavy_dev;
+    p->n = n;
+    p->npad = (n + 63) / 64 * 64 + 64;
+    p->h = h;
+    p->hp = (h + 3) / 4 * 4;
+    p->thr = rmsd_thr;
+    p->mode = mode;
+    p->bit_words = size_t(n / 64 + 4);
+    const size_t hp3 = size_t(p->hp) * 3;
+    int rc = 0;
+    if (!rc) rc = palloc(p, size_t(n), &p->mask);
+    if (!rc) rc = palloc(p, size_t(n) + 1, &p->pos);
+    if (!rc) rc = palloc(p, size_t(n), &p->act);
+    if (!rc) rc = palloc(p, size_t(n), &p->cend);
+    if (!rc) rc = palloc(p, size_t(n), &p->best);
+    if (!rc) rc = palloc(p, size_t(n), &p->key_a);
+    if (!rc) rc = palloc(p, size_t(n), &p->key_b);
+    if (!rc) rc = palloc(p, 4, &p->n_keys);
+    if (!rc) rc = palloc(p, scan_bsum_count(n), &p->bsum);
+    if (!rc) rc = palloc(p, 4, &p->total);
+    if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
+    if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
+    if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xr);
+    if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xc);
+    if (!rc) rc = palloc(p, size_t(p->npad), &p->G);
+    if (!rc) rc = palloc(p, 1, &p->counters);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        hipStream_t st = c->stream;
+        e = hipMemsetAsync(p->mask, 1, size_t(n), st);  // rmsd_pruning.py:182 out_mask = ones
+        if (e == hipSuccess) e = hipMemsetAsync(p->n_keys, 0, 4 * sizeof(int32_t), st);  // :183 cache = [(-1,-1)] never matches
+        if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->Xc, 0, size_t(p->npad) * hp3 * sizeof(double), st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->Xr, 0, size_t(p->npad) * hp3 * sizeof(double), st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
+        if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+        if (e == hipSuccess) e = hipEventCreate(&p->evt0);
+        if (e == hipSuccess) e = hipEventCreate(&p->evt1);
+    }
+    if (rc || e != hipSuccess) {
+        if (!rc) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
+        tsc_prune_destroy(p);
+        return rc;
+    }
+    p->n_active = n;
+    *out = p;
+    return 0;
+}
+
+// Read back the counters of the pass that finished last (needs a sync; called from next_pass / stats).
+static int collect_pass(tsc_prune *p) {
+    if (!p->stats_pending) return 0;
+    tsc_ctx *c = p->ctx;
+    TSC_HIP(hipMemcpyAsync(c->pinned, p->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipEventSynchronize(p->ev1));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    DevCounters dc;
+    memcpy(&dc, c->pinned, sizeof(dc));
+    tsc_pass_stats &s = p->stats[p->n_passes - 1];
+    s.pairs_computed = int64_t(dc.tile[0]);
+    s.candidates = int64_t(dc.tile[1]);
+    s.pairs_evaluated = int64_t(dc.apply.pairs_evaluated);
+    s.new_keys = dc.apply.removed;
+    s.n_active_after = s.n_active_before - dc.apply.removed;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) s.gpu_ms = ms;
+    if (hipEventElapsedTime(&ms, p->evt0, p->evt1) == hipSuccess) s.tile_ms = ms;
+    p->n_active = s.n_active_after;
+    p->stats_pending = false;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out) {
+    TSC_REQUIRE(p && k_out, "null argument");
+    if (p->cur_k != 0) return fail(TSC_ERR_STATE, "tsc_prune_next_pass: previous pass not finished");
+    DeviceGuard guard(p->ctx->device);
+    TSC_TRY(collect_pass(p));
+    *k_out = 0;
+    while (p->next_ks < TSC_MAX_PASSES) {
+        int64_t k = int64_t(KS[p->next_ks++]);  // int(k): the reference itself fails for float k
+        if (k == 1 || 20 * k < p->n_active) {   // rmsd_pruning.py:192
+            p->cur_k = k;
+            p->local_done = false;
+            *k_out = k;
+            return 0;
+        }
+    }
+    return 0;
+}
+
+template <int HP>
+static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const TileArgs &a) {
+    hipLaunchKernelGGL((k_rmsd_tile<HP, TILE_ROWS>), grid, dim3(256), 0, st, (const double *)p->Xr, (const double *)p->Xc,
+                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters->tile, a);
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_local: no pass open (call tsc_prune_next_pass)");
+    tsc_ctx *c = p->ctx;
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->stream;
+    const int64_t n = p->n, k = p->cur_k;
+    const int A = int(p->n_active);
+    PassGeom g{n, k, n / k};
+    const int hp3 = p->hp * 3;
+    TSC_HIP(hipEventRecord(p->ev0, st));
+    TSC_HIP(hipMemsetAsync(p->counters, 0, sizeof(DevCounters), st));
+    // 1. ranks of the active structures, their index list and the mask as bits
+    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total));
+    // 2. compacted coordinate layouts
+    {
+        size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
+        hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, A, p->Xr, p->Xc,
+                           p->npad, p->G);
+    }
+    // 3. cache view of this pass and the stop column of every row
+    const int use_cache = (p->mode == 0);
+    if (use_cache) {
+        TSC_HIP(hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st));
+        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit);
+    }
+    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, A, p->act, p->pos, p->mbit, p->dbit, p->cend);
+    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(A, 256)), dim3(256), 0, st, p->best, int64_t(A), INT_MAX);
+    // 4. tiles: rows dealt round-robin over ranks, columns cut into segments for load balance
+    TileArgs a;
+    a.ld = p->npad, a.n_active = A, a.h = p->h;
+    a.n_tiles = ceil_div(A, TILE_ROWS);
+    a.tile_begin = rank, a.tile_stride = world;
+    a.seg_cols = 2048;
+    a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+    a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+    const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
+    const int max_range = int(std::min<int64_t>(A, longest_chunk));
+    const int n_seg = ceil_div(max_range + 64, a.seg_cols);
+    const int my_tiles = (a.n_tiles - rank + world - 1) / world;
+    dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
+    TSC_HIP(hipEventRecord(p->evt0, st));
+    switch (p->hp) {
+        case 4: launch_tile<4>(st, grid, p, a); break;
+        case 8: launch_tile<8>(st, grid, p, a); break;
+        case 12: launch_tile<12>(st, grid, p, a); break;
+        case 16: launch_tile<16>(st, grid, p, a); break;
+        case 20: launch_tile<20>(st, grid, p, a); break;
+        case 24: launch_tile<24>(st, grid, p, a); break;
+        case 28: launch_tile<28>(st, grid, p, a); break;
+        case 32: launch_tile<32>(st, grid, p, a); break;
+        default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
+    }
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipEventRecord(p->evt1, st));
+    p->local_done = true;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries) {
+    TSC_REQUIRE(p && best_dev && n_entries, "null argument");
+    if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_best_ptr: no pass open");
+    *best_dev = p->best;
+    *n_entries = p->n_active;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev) {
+    TSC_REQUIRE(p && best_dev, "null argument");
+    if (p->cur_k != 0 || p->n_passes != 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
+    p->best = static_cast<int32_t *>(best_dev);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_prune *p) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
+    tsc_ctx *c = p->ctx;
+    DeviceGuard guard(c->device);
+    const int A = int(p->n_active);
+    PassGeom g{p->n, p->cur_k, p->n / p->cur_k};
+    hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div(A, 256)), dim3(256), 0, c->stream, g, A, p->act, p->cend, p->best, p->mask, p->key_a,
+                       p->key_b, p->n_keys, &p->counters->apply);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipEventRecord(p->ev1, c->stream));
+    tsc_pass_stats &s = p->stats[p->n_passes++];
+    memset(&s, 0, sizeof(s));
+    s.k = p->cur_k;
+    s.n_active_before = p->n_active;
+    p->stats_pending = true;
+    p->cur_k = 0;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev) {
+    TSC_REQUIRE(p && mask_dev, "null argument");
+    *mask_dev = p->mask;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    DeviceGuard guard(p->ctx->device);
+    TSC_TRY(collect_pass(p));
+    if (stats) memcpy(stats, p->stats, sizeof(tsc_pass_stats) * size_t(p->n_passes));
+    if (n_passes) *n_passes = p->n_passes;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
+                                  tsc_pass_stats *stats, int *n_passes) {
+    TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd_dev: null argument");
+    if (n == 0) {
+        if (n_passes) *n_passes = 0;
+        return 0;
+    }
+    tsc_prune *p = nullptr;
+    TSC_TRY(tsc_prune_create(c, heavy, n, h, rmsd_thr, mode, &p));
+    int rc = 0;
+    for (;;) {
+        int64_t k = 0;
+        if ((rc = tsc_prune_next_pass(p, &k)) != 0 || k == 0) break;
+        if ((rc = tsc_prune_pass_local(p, 0, 1)) != 0) break;
+        if ((rc = tsc_prune_pass_finish(p)) != 0) break;
+    }
+    if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
+    if (!rc) {
+        DeviceGuard guard(c->device);
+        hipError_t e = hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
+    }
+    tsc_prune_destroy(p);
+    return rc;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
+                              tsc_pass_stats *stats, int *n_passes) {
+    TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd: null argument");
+    TSC_REQUIRE(n >= 0 && h > 0, "bad sizes");
+    if (n == 0) {
+        if (n_passes) *n_passes = 0;
+        return 0;
+    }
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_heavy;
+    uint8_t *d_mask;
+    TSC_TRY(upload(c, s, heavy, size_t(n) * h * 3, &d_heavy));
+    TSC_TRY(s.get(size_t(n), &d_mask));
+    TSC_TRY(tsc_prune_rmsd_dev(c, d_heavy, n, h, rmsd_thr, mode, d_mask, stats, n_passes));
+    TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// pipeline
+
+extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
+                                int n_mols, const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses,
+                                const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, double rmsd_thr, int mode,
+                                uint8_t *clash_mask, double *structures, uint8_t *keep_mask, int64_t *n_pass_host, int64_t *n_keep_host,
+                                tsc_pass_stats *stats, int *n_passes, float *timings_ms) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && clash_mask && structures && keep_mask, "tsc_pipeline_dev: null argument");
+    TSC_REQUIRE(n_poses > 0 && n_poses < INT32_MAX, "bad n_poses");
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    TSC_REQUIRE(n_heavy > 0 && n_heavy <= ft.n_total, "bad n_heavy");
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->stream;
+    Scratch s(c);
+    hipEvent_t ev[4];
+    for (auto &e : ev) TSC_HIP(hipEventCreate(&e));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard() {
+            for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]);
+        }
+    } evg{ev};
+    // heavy_slot[a] = rank of atom a among the heavy atoms, -1 for the others
+    std::vector<int32_t> slot(size_t(ft.n_total), -1);
+    for (int a = 0; a < n_heavy; ++a) {
+        TSC_REQUIRE(heavy_idx[a] >= 0 && heavy_idx[a] < ft.n_total && (a == 0 || heavy_idx[a] > heavy_idx[a - 1]),
+                    "heavy_idx must be strictly increasing atom indices");
+        slot[size_t(heavy_idx[a])] = a;
+    }
+    int32_t *d_slot, *bsum, *act, *total;
+    double *d_heavy;
+    TSC_TRY(upload(c, s, slot.data(), slot.size(), &d_slot));
+    TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
+    TSC_TRY(s.get(size_t(n_poses), &act));
+    TSC_TRY(s.get(1, &total));
+    TSC_HIP(hipEventRecord(ev[0], st));
+    // K1+K2 fused verdicts
+    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
+                                     clash_mask, nullptr));
+    TSC_HIP(hipEventRecord(ev[1], st));
+    // ordered compaction: embed only the passing poses, all atoms + heavy atoms
+    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
+    int32_t n_pass = 0;
+    TSC_TRY(read_i32(c, total, &n_pass));  // also makes the stack-local `slot` upload safe
+    if (n_pass_host) *n_pass_host = n_pass;
+    int64_t n_keep = 0;
+    int np = 0;
+    if (n_pass > 0) {
+        TSC_TRY(s.get(size_t(n_pass) * n_heavy * 3, &d_heavy));
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(int64_t(n_pass) * ft.n_total, 256)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos,
+                           (const int32_t *)act, int64_t(n_pass), structures, (const int32_t *)d_slot, n_heavy, d_heavy);
+        TSC_HIP(hipGetLastError());
+        TSC_HIP(hipEventRecord(ev[2], st));
+        TSC_TRY(tsc_prune_rmsd_dev(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, stats, &np));
+        for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
+        if (!stats) {  // count survivors without the stats array
+            TSC_TRY(scan_mask(st, keep_mask, n_pass, bsum, nullptr, nullptr, nullptr, total));
+            int32_t t = 0;
+            TSC_TRY(read_i32(c, total, &t));
+            n_keep = t;
+        }
+    } else {
+        TSC_HIP(hipEventRecord(ev[2], st));
+    }
+    TSC_HIP(hipEventRecord(ev[3], st));
+    TSC_HIP(hipEventSynchronize(ev[3]));
+    if (n_passes) *n_passes = np;
+    if (n_keep_host) *n_keep_host = n_keep;
+    if (timings_ms) {
+        TSC_HIP(hipEventElapsedTime(&timings_ms[0], ev[0], ev[1]));
+        TSC_HIP(hipEventElapsedTime(&timings_ms[1], ev[1], ev[2]));
+        TSC_HIP(hipEventElapsedTime(&timings_ms[2], ev[2], ev[3]));
+        TSC_HIP(hipEventElapsedTime(&timings_ms[3], ev[0], ev[3]));
+    }
+    return 0;
+}

@@ -1,0 +1,58 @@
+"""Mirror of the pose-generation boundary of tscode/embeds.py on the MI355X engine.
+
+get_embed keeps the reference's duck-typed signature (objects with .rotation, .position,
+.atomcoords); embed_batch is the batched form the embed loops should call instead of one
+get_embed per pose: all (R, t) of a run are built on the host, then K1 (+K2) run once.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors
+from .engine import FragmentSet, get_engine
+
+__all__ = ["get_embed", "embed_batch", "string_embed_poses"]
+
+
+def get_embed(mols, conf_ids):
+    """tscode/embeds.py:961-969: concatenated coordinates of every molecule in its current pose."""
+    mols = list(mols)
+    frags = FragmentSet([np.asarray(m.atomcoords[c], dtype=np.float64) for m, c in zip(mols, conf_ids)])
+    rot = np.stack([np.asarray(m.rotation, dtype=np.float64) for m in mols])[None]
+    pos = np.stack([np.asarray(m.position, dtype=np.float64) for m in mols])[None]
+    return get_engine().transform_batch(frags, np.zeros((1, len(mols)), np.int32), rot, pos)[0]
+
+
+def embed_batch(frag_coords, conf_idx, rot, pos):
+    """Batched get_embed: frag_coords[m] f64[n_conf_m, n_m, 3]; conf_idx i32[N, n_mols];
+    rot f64[N, n_mols, 3, 3]; pos f64[N, n_mols, 3]  ->  f64[N, sum n_m, 3]."""
+    return get_engine().transform_batch(FragmentSet(frag_coords), conf_idx, rot, pos)
+
+
+def string_embed_poses(coords1, coords2, p1, p2, ref_vec, mol_vec, angles):
+    """Pose parameters of the string-embed inner loop (tscode/embeds.py:98-116) for one
+    (conformer pair, reactive-centre pair), then the batched embed:
+
+        R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec)                    (:108)
+        R  = rot_mat_from_pointer(ref_vec, angle) @ R0   for angle != 0         (:110-112)
+        t  = p1 - R @ p2                                                        (:114)
+
+    molecule 1 stays at identity.  Returns (poses f64[len(angles), n1+n2, 3], rot, pos).
+    The reactive centres coincide by construction: R @ p2 + t == p1.
+    """
+    coords1 = np.asarray(coords1, dtype=np.float64)
+    coords2 = np.asarray(coords2, dtype=np.float64)
+    p1, p2 = np.asarray(p1, dtype=np.float64), np.asarray(p2, dtype=np.float64)
+    ref_vec, mol_vec = np.asarray(ref_vec, dtype=np.float64), np.asarray(mol_vec, dtype=np.float64)
+    r0 = rotation_matrix_from_vectors(mol_vec, -ref_vec)
+    n = len(angles)
+    rot = np.zeros((n, 2, 3, 3))
+    pos = np.zeros((n, 2, 3))
+    rot[:, 0] = np.eye(3)
+    for i, angle in enumerate(angles):
+        r = r0 if angle == 0 else rot_mat_from_pointer(ref_vec, angle) @ r0
+        rot[i, 1] = r
+        pos[i, 1] = p1 - r @ p2
+    poses = embed_batch([coords1[None], coords2[None]], np.zeros((n, 2), np.int32), rot, pos)
+    return poses, rot, pos

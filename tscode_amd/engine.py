@@ -1,0 +1,282 @@
+"""Engine: one libtscode_hip context (one GPU, one stream) and typed Python entry points.
+
+Host methods take and return NumPy arrays (the drop-in functions are built on them);
+``*_dev`` methods take anything with ``data_ptr()`` (torch tensors on the engine's GPU) and
+leave results on the device.  Every call goes through the C ABI of include/tscode_hip.h.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import PassStats, TSC_MAX_PASSES, check, ptr
+
+__all__ = ["Engine", "FragmentSet", "get_engine", "device_count"]
+
+
+def device_count() -> int:
+    n = _lib.load().tsc_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+class FragmentSet:
+    """Rigid fragments in the layout tsc_transform_batch expects:
+    fragment m is a conformer stack f64[n_conf_m, n_m, 3]; all stacks sit back to back in one buffer."""
+
+    def __init__(self, frag_coords):
+        stacks = []
+        for f in frag_coords:
+            f = np.ascontiguousarray(f, dtype=np.float64)
+            if f.ndim == 2:
+                f = f[None]
+            if f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError("each fragment must be (n_conf, n_atoms, 3) or (n_atoms, 3)")
+            stacks.append(f)
+        self.n_mols = len(stacks)
+        self.n_atoms = np.array([s.shape[1] for s in stacks], dtype=np.int32)
+        self.n_conf = np.array([s.shape[0] for s in stacks], dtype=np.int32)
+        sizes = np.array([s.size for s in stacks], dtype=np.int64)
+        self.frag_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        self.flat = np.ascontiguousarray(np.concatenate([s.ravel() for s in stacks]))
+        self.n_total = int(self.n_atoms.sum())
+
+    def table_args(self):
+        return (self.frag_off.ctypes.data_as(_lib.c_i64p), self.n_atoms.ctypes.data_as(_lib.c_i32p),
+                self.n_conf.ctypes.data_as(_lib.c_i32p), C.c_int(self.n_mols))
+
+
+def _ids_arg(ids):
+    if ids is None:
+        return None, 0, np.zeros(0, dtype=np.int32)
+    a = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+    return a.ctypes.data_as(_lib.c_i32p), len(a), a
+
+
+def _stats_list(stats, n):
+    return [stats[i].as_dict() for i in range(n)]
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.tsc_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.tsc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stream / timing ------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        check(self.lib.tsc_ctx_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        check(self.lib.tsc_ctx_synchronize(self._h))
+
+    def timer_begin(self):
+        check(self.lib.tsc_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        check(self.lib.tsc_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- K1 ---------------------------------------------------------------------------------
+    def transform_batch(self, frags: FragmentSet, conf_idx, rot, pos) -> np.ndarray:
+        conf_idx = np.ascontiguousarray(conf_idx, dtype=np.int32).reshape(-1, frags.n_mols)
+        rot = np.ascontiguousarray(rot, dtype=np.float64).reshape(-1, frags.n_mols, 3, 3)
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, frags.n_mols, 3)
+        n = len(rot)
+        if not (len(conf_idx) == n == len(pos)):
+            raise ValueError("conf_idx, rot and pos disagree on the number of poses")
+        out = np.empty((n, frags.n_total, 3), dtype=np.float64)
+        check(self.lib.tsc_transform_batch(self._h, ptr(frags.flat), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
+                                           C.c_int64(n), ptr(out)))
+        return out
+
+    def transform_batch_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, out):
+        check(self.lib.tsc_transform_batch_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
+                                               C.c_int64(n_poses), ptr(out)))
+
+    # ---- K2 ---------------------------------------------------------------------------------
+    def clash_mask(self, coords, ids=None, thresh=1.5, max_clashes=0, return_counts=False):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.ndim != 3 or coords.shape[2] != 3:
+            raise ValueError("coords must be (n_poses, n_atoms, 3)")
+        n, na = coords.shape[0], coords.shape[1]
+        ids_p, n_ids, _keep = _ids_arg(ids)
+        mask = np.zeros(n, dtype=np.uint8)
+        counts = np.zeros(n, dtype=np.int32) if return_counts else None
+        check(self.lib.tsc_clash_mask(self._h, ptr(coords), C.c_int64(n), C.c_int(na), ids_p, C.c_int(n_ids), C.c_double(thresh),
+                                      C.c_int64(int(max_clashes)), ptr(mask), ptr(counts)))
+        return (mask.astype(bool), counts) if return_counts else mask.astype(bool)
+
+    def clash_mask_dev(self, coords, n_poses, n_atoms, ids, thresh, max_clashes, mask, counts=None):
+        ids_p, n_ids, _keep = _ids_arg(ids)
+        check(self.lib.tsc_clash_mask_dev(self._h, ptr(coords), C.c_int64(n_poses), C.c_int(n_atoms), ids_p, C.c_int(n_ids),
+                                          C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(mask), ptr(counts)))
+
+    def embed_clash_mask_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, thresh, max_clashes, mask, counts=None):
+        check(self.lib.tsc_embed_clash_mask_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
+                                                C.c_int64(n_poses), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(mask),
+                                                ptr(counts)))
+
+    def all_dists(self, a, b) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != 3 or b.shape[1] != 3:
+            raise AssertionError("all_dists needs (n, 3) arrays")          # reference: assert A.shape[1]==B.shape[1]
+        out = np.empty((len(a), len(b)), dtype=np.float64)
+        check(self.lib.tsc_all_dists(self._h, ptr(a), C.c_int(len(a)), ptr(b), C.c_int(len(b)), ptr(out)))
+        return out
+
+    # ---- compaction ---------------------------------------------------------------------------
+    def compact_rows_dev(self, src, mask, n_rows, row_bytes, dst) -> int:
+        kept = C.c_int64()
+        check(self.lib.tsc_compact_rows_dev(self._h, ptr(src), ptr(mask), C.c_int64(n_rows), C.c_int64(row_bytes), ptr(dst),
+                                            C.byref(kept)))
+        return kept.value
+
+    def gather_heavy_dev(self, coords, mask, n_poses, n_atoms, heavy_idx, heavy_out) -> int:
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        kept = C.c_int64()
+        check(self.lib.tsc_gather_heavy_dev(self._h, ptr(coords), ptr(mask), C.c_int64(n_poses), C.c_int(n_atoms),
+                                            heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)), ptr(heavy_out),
+                                            C.byref(kept)))
+        return kept.value
+
+    # ---- K3 ---------------------------------------------------------------------------------
+    def rmsd_pairs(self, heavy, pairs):
+        heavy = np.ascontiguousarray(heavy, dtype=np.float64)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        r = np.empty(len(pairs), dtype=np.float64)
+        m = np.empty(len(pairs), dtype=np.float64)
+        check(self.lib.tsc_rmsd_pairs(self._h, ptr(heavy), C.c_int64(heavy.shape[0]), C.c_int(heavy.shape[1]), ptr(pairs),
+                                      C.c_int64(len(pairs)), ptr(r), ptr(m)))
+        return r, m
+
+    def prune_heavy(self, heavy, rmsd_thr=0.5, mode=0):
+        """prune_conformers_rmsd on the heavy-atom array f64[N, h, 3]. Returns (mask bool[N], per-pass stats)."""
+        heavy = np.ascontiguousarray(heavy, dtype=np.float64)
+        if heavy.ndim != 3 or heavy.shape[2] != 3:
+            raise ValueError("heavy must be (N, h, 3)")
+        n, h = heavy.shape[0], heavy.shape[1]
+        mask = np.zeros(n, dtype=np.uint8)
+        stats = (PassStats * TSC_MAX_PASSES)()
+        np_ = C.c_int()
+        check(self.lib.tsc_prune_rmsd(self._h, ptr(heavy), C.c_int64(n), C.c_int(h), C.c_double(rmsd_thr), C.c_int(mode), ptr(mask),
+                                      stats, C.byref(np_)))
+        return mask.astype(bool), _stats_list(stats, np_.value)
+
+    def prune_heavy_dev(self, heavy, n, h, rmsd_thr, mode, mask):
+        stats = (PassStats * TSC_MAX_PASSES)()
+        np_ = C.c_int()
+        check(self.lib.tsc_prune_rmsd_dev(self._h, ptr(heavy), C.c_int64(n), C.c_int(h), C.c_double(rmsd_thr), C.c_int(mode),
+                                          ptr(mask), stats, C.byref(np_)))
+        return _stats_list(stats, np_.value)
+
+    def prune_stepper(self, heavy_dev, n, h, rmsd_thr, mode):
+        return PruneStepper(self, heavy_dev, n, h, rmsd_thr, mode)
+
+    # ---- pipeline -----------------------------------------------------------------------------
+    def pipeline_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, heavy_idx, clash_thresh, max_clashes,
+                     rmsd_thr, mode, clash_mask, structures, keep_mask):
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        n_pass, n_keep = C.c_int64(), C.c_int64()
+        stats = (PassStats * TSC_MAX_PASSES)()
+        np_ = C.c_int()
+        tm = (C.c_float * 4)()
+        check(self.lib.tsc_pipeline_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
+                                        C.c_int64(n_poses), heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)),
+                                        C.c_double(clash_thresh), C.c_int64(int(max_clashes)), C.c_double(rmsd_thr), C.c_int(mode),
+                                        ptr(clash_mask), ptr(structures), ptr(keep_mask), C.byref(n_pass), C.byref(n_keep), stats,
+                                        C.byref(np_), tm))
+        return {"n_pass": n_pass.value, "n_keep": n_keep.value, "stats": _stats_list(stats, np_.value),
+                "ms": {"embed_clash": tm[0], "compact": tm[1], "prune": tm[2], "total": tm[3]}}
+
+
+class PruneStepper:
+    """Stepping form of one prune run (tsc_prune_*), used to shard a pass over ranks."""
+
+    def __init__(self, engine: Engine, heavy_dev, n, h, rmsd_thr, mode):
+        self.e = engine
+        self.n = int(n)
+        h_ = C.c_void_p()
+        check(engine.lib.tsc_prune_create(engine._h, ptr(heavy_dev), C.c_int64(n), C.c_int(h), C.c_double(rmsd_thr), C.c_int(mode),
+                                          C.byref(h_)))
+        self._p = h_
+        self._keep = heavy_dev
+
+    def next_pass(self) -> int:
+        k = C.c_int64()
+        check(self.e.lib.tsc_prune_next_pass(self._p, C.byref(k)))
+        return k.value
+
+    def pass_local(self, rank=0, world=1):
+        check(self.e.lib.tsc_prune_pass_local(self._p, C.c_int(rank), C.c_int(world)))
+
+    def best_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.e.lib.tsc_prune_best_ptr(self._p, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def use_best_buffer(self, best_dev):
+        check(self.e.lib.tsc_prune_use_best_buffer(self._p, ptr(best_dev)))
+        self._keep_best = best_dev
+
+    def pass_finish(self):
+        check(self.e.lib.tsc_prune_pass_finish(self._p))
+
+    def mask_ptr(self) -> int:
+        p = C.c_void_p()
+        check(self.e.lib.tsc_prune_mask_dev(self._p, C.byref(p)))
+        return p.value
+
+    def stats(self):
+        stats = (PassStats * TSC_MAX_PASSES)()
+        np_ = C.c_int()
+        check(self.e.lib.tsc_prune_stats(self._p, stats, C.byref(np_)))
+        return _stats_list(stats, np_.value)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.e.lib.tsc_prune_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_engines = {}
+_engines_lock = threading.Lock()
+
+
+def get_engine(device: int | None = None) -> Engine:
+    """Process-wide engine for a device (default: LOCAL_RANK or 0).  multiembed-style use from several
+    processes is safe: each process owns its own HIP context (Threading)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("TSCODE_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _engines_lock:
+        eng = _engines.get(device)
+        if eng is None:
+            eng = _engines[device] = Engine(device)
+    return eng

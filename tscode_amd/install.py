@@ -1,0 +1,54 @@
+"""Patch a live TSCoDe so that its hot path runs on the MI355X engine.
+
+TSCoDe binds the hot-path functions by name at import time (``from tscode.rmsd_pruning import
+prune_conformers_rmsd`` in embedder.py:56, operators.py:39, optimization_methods.py:32,
+atropisomer_module.py:33; ``compenetration_check`` in embedder.py:48, embeds.py:28; ...), so the
+replacement has to be set on every importing module, not only on the defining one.
+This module never imports tscode itself: it only touches modules already in sys.modules.
+"""
+
+from __future__ import annotations
+
+import sys
+
+from . import algebra, embeds, numba_functions, rmsd_pruning
+
+# attribute -> (replacement, modules that bind it)
+_PATCHES = {
+    "prune_conformers_rmsd": (rmsd_pruning.prune_conformers_rmsd,
+                              ("tscode.rmsd_pruning", "tscode.embedder", "tscode.operators", "tscode.optimization_methods",
+                               "tscode.atropisomer_module")),
+    "rmsd_and_max_numba": (rmsd_pruning.rmsd_and_max_numba, ("tscode.rmsd_pruning", "tscode.automep")),
+    "_rmsd_similarity": (rmsd_pruning._rmsd_similarity, ("tscode.rmsd_pruning", "tscode.embeds")),
+    "compenetration_check": (numba_functions.compenetration_check, ("tscode.numba_functions", "tscode.embedder", "tscode.embeds")),
+    "count_clashes": (numba_functions.count_clashes, ("tscode.numba_functions", "tscode.embedder")),
+    "get_embed": (embeds.get_embed, ("tscode.embeds",)),
+    "all_dists": (algebra.all_dists, ("tscode.algebra", "tscode.numba_functions", "tscode.graph_manipulations")),
+    "transform_coords": (algebra.transform_coords, ("tscode.algebra",)),
+}
+
+_saved = {}
+
+
+def install(modules=None):
+    """Replace the hot-path functions in every already-imported tscode module.
+    Returns the list of (module, attribute) pairs that were patched."""
+    mods = sys.modules if modules is None else modules
+    done = []
+    for attr, (fn, names) in _PATCHES.items():
+        for name in names:
+            mod = mods.get(name)
+            if mod is not None and hasattr(mod, attr):
+                _saved.setdefault((name, attr), getattr(mod, attr))
+                setattr(mod, attr, fn)
+                done.append((name, attr))
+    return done
+
+
+def uninstall(modules=None):
+    mods = sys.modules if modules is None else modules
+    for (name, attr), fn in list(_saved.items()):
+        mod = mods.get(name)
+        if mod is not None:
+            setattr(mod, attr, fn)
+        del _saved[(name, attr)]
