@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- conformers/sec of the geometry hot path on the BASELINE config 3 workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode 0|1] [--config C3] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic ensemble that is already resident in HBM:
+fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_conformers_rmsd
+(reference-exact mode), verdict masks left on the device.  With N > 1 (one process per GPU) the SAME
+ensemble is sharded over the ranks (strong scaling): pose blocks for embed/clash, one RCCL all-gather of
+the surviving heavy-atom coordinates, row tiles of every prune pass dealt round-robin with an
+all-reduce(MIN) per pass.
+
+Rank 0 prints ONE JSON line (see the keys below).  The CPU baseline leg (rank 0, N = 1 only) times the
+oracle -- this repo's C restatement of the reference algorithm, "port" -- on a bounded sample of the same
+generator; it is a reported baseline, not the thing measured.
+"""
+
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 157.3 / 2), no MFMA on this path
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", type=int, default=0, help="0 = reference-exact (parity), 1 = cache-free")
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=40000, help="poses of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_name, n_sample, mode):
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample. Only called on rank 0 at N=1."""
+    import numpy as np
+    import oracle
+    from tscode_amd.synthetic import make_config
+    ens = make_config(cfg_name, n_sample)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    oracle.set_num_threads(cores)
+    t0 = time.perf_counter()
+    poses = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    st = poses[cm]
+    heavy = np.ascontiguousarray(st[:, ens.atomnos != 1])
+    res = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=False)     # chunk-parallel like the reference's prange
+    dt = time.perf_counter() - t0
+    evals = sum(s["pairs_evaluated"] for s in res["stats"])
+    return {"value": n_sample / dt, "unit": "conformers/s", "cores": cores, "kind": "port",
+            "sample": f"{cfg_name} generator at N={n_sample} (embed + clash + prune mode {mode}; {int(cm.sum())} pass the clash check, "
+                      f"{int(res['mask'].sum())} survive; {evals} pair evaluations; chunk-parallel like the reference's prange)",
+            "seconds": dt, "pair_evals_per_s": evals / dt}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+
+    from tscode_amd.pipeline import DevicePipeline
+    from tscode_amd.synthetic import make_config
+
+    ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble, keeps only its block
+    pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = pipe.step()
+    sync()
+    t0 = time.perf_counter()
+    tile_ms = 0.0
+    evals = 0
+    computed = 0
+    stage_ms = {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}
+    for _ in range(args.steps):
+        res = pipe.step()
+        tile_ms += sum(s["tile_ms"] for s in res["stats"])
+        evals += sum(s["pairs_evaluated"] for s in res["stats"])
+        computed += sum(s["pairs_computed"] for s in res["stats"])
+        for k in stage_ms:
+            stage_ms[k] += res.get("ms", {}).get(k, 0.0)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # verdict fingerprint (after the timed region)
+    n_pass, n_keep = res["n_pass"], res["n_keep"]
+    keep = pipe.d_keep[:n_pass].cpu().numpy()
+    digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
+    expected = None
+    exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")
+    if os.path.exists(exp_path):
+        expected = json.load(open(exp_path)).get(f"{args.config}:{ens.n_poses}:mode{args.mode}")
+    parity = None
+    if expected is not None:
+        parity = bool(expected["n_pass"] == n_pass and expected["n_keep"] == n_keep and expected["keep_sha256_16"] == digest)
+
+    if rank == 0:
+        h = ens.n_heavy
+        n = ens.n_poses
+        flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
+        tile_s = tile_ms / 1e3
+        # algorithmic bytes of the prune: sum over passes (A_p * h * 24 + 2 N)  
+        b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
+        b_k12 = n * ens.frag_coords.__len__() * 96 + n_pass * ens.n_atoms * 24 + n
+        ms_per_step = dt / args.steps * 1e3
+        out = {
+            "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
+            "value": n * args.steps / dt,
+            "unit": "conformers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} conformers x {ens.n_atoms} atoms ({h} heavy), 2 rigid fragments, "
+                                   f"10 children per parent, seed {ens.seed}; clash_thresh 1.5, max_clashes 0, rmsd_thr 0.5, "
+                                   f"mode {args.mode} ({'reference-exact' if args.mode == 0 else 'cache-free'})",
+                       "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": digest,
+                       "parity_vs_recorded_oracle": parity, "parallelism": f"conformer-axis shards x{world}"},
+            "roofline": {
+                "kernel": "k_rmsd_tile (all-pairs Kabsch RMSD, one launch per pass)",
+                "bound": "fp64_valu",
+                "achieved": (evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None,
+                "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ((evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 / FP64_VALU_PEAK_TFLOPS) if tile_s > 0 else None,
+                "traffic": None,
+                "launches_per_step": len(res["stats"]),
+                "kernel_ms_per_step": tile_ms / args.steps,
+                "algorithmic_pair_evals_per_step": evals / args.steps,
+                "computed_pair_evals_per_step": computed / args.steps,
+                "flops_per_eval": flops_per_eval,
+                "hbm": {"bound": "hbm", "achieved": b_k3 / (tile_s / args.steps) / 1e9 if tile_s > 0 else None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "algorithmic_bytes": b_k3},
+            },
+            "pipeline_hbm": {"algorithmic_bytes": b_k12 + b_k3, "achieved_GBs": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9,
+                             "peak_GBs": HBM_PEAK_GBS},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "computed": s["pairs_computed"],
+                        "cand": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4)} for s in res["stats"]],
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, n), args.mode)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

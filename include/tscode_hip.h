@@ -161,6 +161,7 @@ int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i3
 int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev_i32_n);
 int tsc_prune_pass_finish(tsc_prune *p);                          /* asynchronous */
 int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev);
+int tsc_prune_copy_mask_dev(tsc_prune *p, uint8_t *dst_dev); /* dst[0..n) <- mask, asynchronous on the stream */
 int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes); /* synchronises */
 int tsc_prune_destroy(tsc_prune *p);
 

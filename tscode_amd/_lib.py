@@ -75,6 +75,7 @@ _SIGNATURES = {
     "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),
     "tsc_prune_pass_finish": (C.c_int, [_vp]),
     "tsc_prune_mask_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "tsc_prune_copy_mask_dev": (C.c_int, [_vp, _vp]),
     "tsc_prune_stats": (C.c_int, [_vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_destroy": (C.c_int, [_vp]),
     "tsc_pipeline_dev": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, c_i32p, C.c_int,
@@ -96,6 +97,14 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise TscodeHipError(-2, f"{LIB_PATH} not found: build it with `python -m tscode_amd.build` "
                                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+            # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7, and the
+            # copy that is loaded first serves every later NEEDED entry of that soname.  If this library
+            # came first it would pull in /opt/rocm's runtime and torch would then find "no HIP GPUs";
+            # importing torch first (it does not touch the GPU) makes both share torch's copy.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(lib, name)          # AttributeError here = header/library mismatch

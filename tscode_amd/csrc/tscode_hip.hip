@@ -708,6 +708,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_mask_dev(tsc_pru
     return 0;
 }
 
+extern "C" __attribute__((visibility("default"))) int tsc_prune_copy_mask_dev(tsc_prune *p, uint8_t *dst) {
+    TSC_REQUIRE(p && dst, "null argument");
+    DeviceGuard guard(p->ctx->device);
+    TSC_HIP(hipMemcpyAsync(dst, p->mask, size_t(p->n), hipMemcpyDeviceToDevice, p->ctx->stream));
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes) {
     TSC_REQUIRE(p != nullptr, "null argument");
     DeviceGuard guard(p->ctx->device);

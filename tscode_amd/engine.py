@@ -247,6 +247,9 @@ class PruneStepper:
         check(self.e.lib.tsc_prune_mask_dev(self._p, C.byref(p)))
         return p.value
 
+    def copy_mask(self, dst_dev):
+        check(self.e.lib.tsc_prune_copy_mask_dev(self._p, ptr(dst_dev)))
+
     def stats(self):
         stats = (PassStats * TSC_MAX_PASSES)()
         np_ = C.c_int()
