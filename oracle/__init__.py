@@ -223,3 +223,15 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(C.c_int(int(n)))
+
+
+def prune_pass_rows(heavy, mask, keys, k, rank, world, tile_rows, best, rmsd_thr=0.5, mode=0):
+    """One pass restricted to the rows of one rank (multi-rank protocol tests). best: int32[A], updated in place."""
+    heavy = _f64(heavy)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1, 2)
+    assert best.dtype == np.int32 and best.flags.c_contiguous
+    lib().orc_prune_pass_rows(_p(heavy), C.c_int64(len(heavy)), C.c_int(heavy.shape[1]), C.c_double(rmsd_thr), C.c_int(mode),
+                              _p(mask, _u8p), _p(keys, _i64p), C.c_int64(len(keys)), C.c_int64(k), C.c_int(rank), C.c_int(world),
+                              C.c_int(tile_rows), best.ctypes.data_as(C.POINTER(C.c_int32)))
+    return best

@@ -639,3 +639,55 @@ ORC_API void orc_set_num_threads(int n) {
     (void)n;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* One pass of rmsd_pruning.py:82-121 restricted to a subset of rows, for the multi-rank protocol tests.
+ * Rows of a pass are independent (in_mask is read-only during a pass, :92,:101-113), so a rank may own
+ * any subset of them.  The active rows are numbered 0..A-1 in index order ("compacted rank"); the row of
+ * rank r belongs to this caller iff (r / tile_rows) % world == rank.  best[r] receives the compacted rank
+ * of the first similar column the reference would stop at (:75-77), INT32_MAX if the row survives, and
+ * is left untouched for rows of other ranks.  keys: the cache so far, as (first, first + delta) pairs. */
+ORC_API int orc_prune_pass_rows(const double *heavy, int64_t N, int h, double rmsd_thr, int mode, const uint8_t *mask,
+                                const int64_t *keys, int64_t n_keys, int64_t k, int rank, int world, int tile_rows, int32_t *best) {
+    const double maxdev_thr = 2 * rmsd_thr;
+    int64_t cs = N / k;
+    uint8_t *dbit = (uint8_t *)calloc((size_t)N + 1, 1);
+    int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t run = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        pos[i] = run;
+        run += mask[i] != 0;
+    }
+    pos[N] = run;
+    if (mode == 0)
+        for (int64_t q = 0; q < n_keys; ++q) {
+            int64_t a = keys[2 * q], b = keys[2 * q + 1];
+            if (a % cs != 0 || a / cs >= k) continue;
+            int64_t c = a / cs, last = (c == k - 1) ? N : cs * (c + 1);
+            if (b < last) dbit[b] = 1;
+        }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < N; ++i) {
+        if (!mask[i]) continue;
+        int32_t r = pos[i];
+        if ((r / tile_rows) % world != rank) continue;
+        int64_t chunk = i / cs;
+        if (chunk >= k) chunk = k - 1;
+        int64_t first = chunk * cs, last = (chunk == k - 1) ? N : cs * (chunk + 1);
+        int32_t found = INT32_MAX;
+        for (int64_t j = i + 1; j < last; ++j) {
+            if (!mask[j]) continue;
+            if (dbit[first + (j - i)]) break;
+            double rr, mm;
+            orc_rmsd_and_max(heavy + (size_t)i * h * 3, heavy + (size_t)j * h * 3, h, &rr, &mm);
+            if (rr < rmsd_thr && mm < maxdev_thr) {
+                found = pos[j];
+                break;
+            }
+        }
+        best[r] = found;
+    }
+    free(dbit);
+    free(pos);
+    return 0;
+}

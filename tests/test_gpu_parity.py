@@ -339,3 +339,36 @@ def test_full_size_properties_c3(eng):
     eng.synchronize()
     assert int(mask2.sum().item()) == len(surv)
     assert out[1][2]["n_keep"] < out[0][2]["n_keep"]          # the reference-exact mode keeps more
+
+
+class _SoloDist:
+    """torch.distributed stand-in for a world of one rank: collectives are identities."""
+
+    class ReduceOp:
+        SUM, MIN = "sum", "min"
+
+    @staticmethod
+    def all_reduce(t, op=None, group=None):
+        return None
+
+    @staticmethod
+    def all_gather_into_tensor(out, inp, group=None):
+        out[:inp.numel()].copy_(inp)
+
+
+def test_shard_backend_world1_equals_one_shot(eng, oracle):
+    """The GPU backend of the multi-rank protocol (HipShardBackend + sharded_step), driven with a single
+    rank, gives the verdicts of the one-call pipeline and of the oracle."""
+    from tscode_amd.pipeline import HipShardBackend, sharded_step
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 5000)
+    be = HipShardBackend(ens, 0, 0, 1, 1.5, 0, 0.5, 0)
+    res = sharded_step(be, 0, 1, _SoloDist)
+    be.torch.cuda.synchronize()
+    poses = ens.poses()
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    _, mask = oracle.prune_conformers_rmsd(poses[cm], ens.atomnos, 0.5)
+    assert res["n_pass"] == cm.sum() and res["n_keep"] == mask.sum()
+    assert np.array_equal(be.keep[:res["n_pass"]].cpu().numpy().astype(bool), mask)
+    assert np.abs(be.structures[:res["n_pass"]].cpu().numpy() - poses[cm]).max() < 1e-12
+    eng.set_stream(None)

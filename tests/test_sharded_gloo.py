@@ -1,0 +1,157 @@
+"""The multi-rank protocol of tscode_amd.pipeline.sharded_step under gloo on CPU, world_size 2 and 3.
+
+The protocol code (block sharding, count exchange, padded all-gather of heavy-atom shards, per-pass
+all-reduce(MIN) of best[], identical mask/cache update on every rank) is the product's; the arithmetic
+behind it comes from a TEST-ONLY backend built on the CPU oracle, because the product has no CPU path.
+Every rank must end with the mask the single-process oracle gives.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+KS = (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1)
+INT_MAX = np.iinfo(np.int32).max
+
+
+class OracleStepper:
+    """Stepping form of prune_conformers_rmsd on CPU tensors (mirror of tsc_prune_* for the tests)."""
+
+    def __init__(self, oracle, heavy, best_tensor, thr, mode, tile_rows):
+        self.o, self.heavy, self.best_t = oracle, heavy, best_tensor
+        self.thr, self.mode, self.tile_rows = thr, mode, tile_rows
+        self.n = len(heavy)
+        self.mask = np.ones(self.n, dtype=np.uint8)
+        self.keys = np.zeros((0, 2), dtype=np.int64)
+        self.ks = list(KS)
+        self._stats = []
+        self.k = 0
+
+    def next_pass(self):
+        while self.ks:
+            k = int(self.ks.pop(0))
+            if k == 1 or 20 * k < int(self.mask.sum()):
+                self.k = k
+                self.act = np.flatnonzero(self.mask)
+                return k
+        return 0
+
+    def n_active(self):
+        return len(self.act)
+
+    def pass_local(self, rank, world):
+        best = self.best_t.numpy()                      # shares memory with the torch tensor
+        best[:len(self.act)] = INT_MAX
+        self.o.prune_pass_rows(self.heavy, self.mask, self.keys, self.k, rank, world, self.tile_rows, best, self.thr, self.mode)
+
+    def pass_finish(self):
+        best = self.best_t.numpy()[:len(self.act)]
+        cs = self.n // self.k
+        rows = np.flatnonzero(best != INT_MAX)
+        i, j = self.act[rows], self.act[best[rows]]
+        first = np.minimum(i // cs, self.k - 1) * cs
+        self.keys = np.concatenate([self.keys, np.stack([first, first + (j - i)], axis=1)])
+        before = int(self.mask.sum())
+        self.mask[i] = 0
+        self._stats.append({"k": self.k, "n_active_before": before, "n_active_after": int(self.mask.sum())})
+        self.k = 0
+
+    def stats(self):
+        return self._stats
+
+    def copy_mask(self, dst):
+        import torch
+        dst[:self.n].copy_(torch.from_numpy(self.mask))
+
+    def close(self):
+        pass
+
+
+class OracleShardBackend:
+    def __init__(self, oracle, ens, rank, world, thr=0.5, mode=0, tile_rows=16):
+        import torch
+
+        from tscode_amd.pipeline import block_bounds
+        self.o, self.ens, self.thr, self.mode, self.tile_rows = oracle, ens, thr, mode, tile_rows
+        n, h = ens.n_poses, ens.n_heavy
+        self.lo, self.hi = block_bounds(n, rank, world)
+        self.h = h
+        self.max_local = (n + world - 1) // world + 1
+        self.heavy_local = torch.zeros((max(self.hi - self.lo, 1), h, 3), dtype=torch.float64)
+        self.heavy_pad = torch.zeros((self.max_local, h, 3), dtype=torch.float64)
+        self.gather = torch.zeros((world * self.max_local, h, 3), dtype=torch.float64)
+        self.heavy_all = torch.zeros((n, h, 3), dtype=torch.float64)
+        self.best = torch.zeros(n, dtype=torch.int32)
+        self.keep = torch.zeros(n, dtype=torch.uint8)
+        self.counts = torch.zeros(world, dtype=torch.int64)
+
+    def embed_clash_block(self):
+        import torch
+        e = self.ens
+        sl = slice(self.lo, self.hi)
+        poses = self.o.transform_batch(e.frag_coords, e.conf_idx[sl], e.rot[sl], e.pos[sl])
+        cm = self.o.compenetration_mask(poses, e.ids, 1.5, 0)
+        heavy = np.ascontiguousarray(poses[cm][:, e.atomnos != 1])
+        self.heavy_local[:len(heavy)].copy_(torch.from_numpy(heavy))
+        return len(heavy)
+
+    def make_stepper(self, n_pass):
+        return OracleStepper(self.o, self.heavy_all[:n_pass].numpy(), self.best, self.thr, self.mode, self.tile_rows)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_poses, mode, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from tscode_amd.pipeline import sharded_step
+    from tscode_amd.synthetic import make_config
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    oracle.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ens = make_config("C2", n_poses)
+        backend = OracleShardBackend(oracle, ens, rank, world, mode=mode)
+        res = sharded_step(backend, rank, world, dist)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keep=backend.keep[:res["n_pass"]].numpy(), n_pass=res["n_pass"],
+                 n_keep=res["n_keep"], counts=np.array(res["counts"]), ks=np.array([s["k"] for s in res["stats"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_poses,mode", [(2, 3000, 0), (3, 2001, 0), (2, 1500, 1)])
+def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode):
+    import torch.multiprocessing as mp
+
+    from tscode_amd.synthetic import make_config
+    mp.spawn(_worker, args=(world, _free_port(), n_poses, mode, str(tmp_path)), nprocs=world, join=True)
+    ens = make_config("C2", n_poses)
+    poses = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    ref = oracle.prune_heavy(np.ascontiguousarray(poses[cm][:, ens.atomnos != 1]), 0.5, mode=mode)
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert int(got["n_pass"]) == int(cm.sum())
+        assert got["counts"].sum() == cm.sum() and len(got["counts"]) == world
+        assert np.array_equal(got["keep"].astype(bool), ref["mask"]), f"rank {rank}"
+        assert int(got["n_keep"]) == int(ref["mask"].sum())
+        assert got["ks"].tolist() == [s["k"] for s in ref["stats"]]
+
+
+def test_block_bounds_cover_the_pose_axis():
+    from tscode_amd.pipeline import block_bounds
+    for n in (0, 1, 7, 100, 100001):
+        for world in (1, 2, 3, 8):
+            b = [block_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
