@@ -178,6 +178,8 @@ def main():
                 "algorithmic_pair_evals_per_step": evals / args.steps,
                 "computed_pair_evals_per_step": computed / args.steps,
                 "flops_per_eval": flops_per_eval,
+                # what the kernel really executes per computed pair: 18*HP fmac flops + ~110 for the sign test
+                "executed_tflops": ((computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110) / (tile_s / args.steps) / 1e12) if tile_s > 0 else None,
                 "hbm": {"bound": "hbm", "achieved": b_k3 / (tile_s / args.steps) / 1e9 if tile_s > 0 else None, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "algorithmic_bytes": b_k3},
             },
