@@ -53,6 +53,9 @@ int tsc_ctx_destroy(tsc_ctx *ctx);
 /* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
 int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
 int tsc_ctx_synchronize(tsc_ctx *ctx);
+/* Tunables.  "prune_algo": 0 = automatic (default), 1 = register-tiled all-pairs kernel (<= 32 heavy atoms),
+ * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 64). */
+int tsc_ctx_set_option(tsc_ctx *ctx, const char *name, double value);
 /* Device memory helpers for hosts that do not bring their own allocator (tests, C callers). */
 int tsc_malloc(tsc_ctx *ctx, size_t bytes, void **dptr);
 int tsc_free(tsc_ctx *ctx, void *dptr);
@@ -124,11 +127,14 @@ typedef struct {
     int64_t n_active_before; /* count_nonzero(mask) entering the pass */
     int64_t n_active_after;
     int64_t pairs_evaluated; /* pair evaluations the reference's sequential scan performs in this pass (:70) */
-    int64_t pairs_computed;  /* pair evaluations the tile kernel actually computed (>= pairs_evaluated) */
+    int64_t pairs_computed;  /* pairs for which the GPU formed H = p^T q and ran the sign test */
     int64_t candidates;      /* pairs that reached the explicit-rotation path */
+    int64_t pairs_screened;  /* pairs looked at by the descriptor sieve (0 when the register-tiled kernel ran) */
     int64_t new_keys;        /* cache keys appended (:76, :204) */
     double gpu_ms;           /* HIP-event time of the whole pass on this device */
-    double tile_ms;          /* HIP-event time of the pass's RMSD tile kernel alone */
+    double tile_ms;          /* HIP-event time of the pass's pair kernel alone */
+    int32_t algo;            /* pair kernel used: 1 = register-tiled all-pairs, 2 = descriptor sieve */
+    int32_t reserved;
 } tsc_pass_stats;
 
 #define TSC_MAX_PASSES 18

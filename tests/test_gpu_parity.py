@@ -162,7 +162,7 @@ def test_dropin_embed_functions(eng):
 
 
 # ----------------------------------------------------------------------------- prune
-def test_prune_golden(eng):
+def test_prune_golden(eng, algo):
     import tscode_amd
     g = load_golden("G3_prune")
     for c in range(int(g["n_cases"])):
@@ -176,8 +176,16 @@ def test_prune_golden(eng):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["algo-auto", "algo-tile", "algo-sieve"])
+def algo(request, eng):
+    """Runs a test once per pair kernel: automatic choice, register-tiled all-pairs, descriptor sieve."""
+    eng.set_option("prune_algo", request.param)
+    yield request.param
+    eng.set_option("prune_algo", 0)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
-def test_prune_c2_vs_oracle(eng, oracle, mode):
+def test_prune_c2_vs_oracle(eng, oracle, mode, algo):
     from tscode_amd.synthetic import make_config
     ens = make_config("C2")
     poses = ens.poses()
@@ -193,11 +201,12 @@ def test_prune_c2_vs_oracle(eng, oracle, mode):
         assert s["n_active_after"] == r["n_active_after"]
         assert s["pairs_evaluated"] == r["pairs_evaluated"]      # the reference's sequential work, reproduced exactly
         assert s["new_keys"] == r["new_keys"]
-        assert s["pairs_computed"] >= s["pairs_evaluated"]
+        assert max(s["pairs_computed"], s["pairs_screened"]) >= s["pairs_evaluated"]   # the GPU looks at a superset
+        assert s["algo"] in (1, 2) and (algo == 0 or s["algo"] == algo)
     print(f"C2 mode {mode}: {len(heavy)} -> {mask.sum()}; margins rmsd {mr:.2e} maxdev {mm:.2e}")
 
 
-def test_prune_edge_cases(eng, oracle):
+def test_prune_edge_cases(eng, oracle, algo):
     rng = np.random.default_rng(7)
     cases = []
     one = rng.normal(size=(1, 5, 3)) * 3
@@ -218,8 +227,31 @@ def test_prune_edge_cases(eng, oracle):
             assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
     import tscode_amd
     assert tscode_amd.prune_conformers_rmsd(np.zeros((0, 4, 3)), np.array([6, 6, 1, 1]))[1].shape == (0,)
-    with pytest.raises(Exception):
-        eng.prune_heavy(np.zeros((10, 33, 3)))                           # h > 32: refused loudly, not silently wrong
+    if algo == 1:
+        with pytest.raises(Exception):
+            eng.prune_heavy(np.zeros((10, 33, 3)))                       # register-tiled kernel: h > 32 refused loudly
+
+
+def test_prune_many_heavy_atoms(eng, oracle):
+    """More than 32 heavy atoms (BASELINE config 5 has 120): the sieve kernel takes any size."""
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C5", 2500)
+    poses = ens.poses()
+    poses = poses[oracle.compenetration_mask(poses, ens.ids, 1.5, 0)]
+    heavy = np.ascontiguousarray(poses[:, ens.atomnos != 1])
+    assert heavy.shape[1] == 120
+    for mode in (0, 1):
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=True)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"]), (mode, mask.sum(), ref["mask"].sum())
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+    rng = np.random.default_rng(11)
+    for h in (33, 47, 64, 257):
+        base = rng.normal(size=(40, h, 3)) * 4
+        heavy = np.ascontiguousarray((base[:, None] + rng.normal(size=(40, 6, h, 3)) * 0.03).reshape(-1, h, 3)[rng.permutation(240)])
+        ref = oracle.prune_heavy(heavy, 0.5, mode=0)
+        mask, _ = eng.prune_heavy(heavy, 0.5, 0)
+        assert np.array_equal(mask, ref["mask"]), h
 
 
 def test_prune_sharded_rows_equal_single(eng, oracle):

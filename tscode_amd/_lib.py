@@ -33,7 +33,8 @@ class TscodeHipError(RuntimeError):
 class PassStats(C.Structure):
     _fields_ = [("k", C.c_int64), ("n_active_before", C.c_int64), ("n_active_after", C.c_int64),
                 ("pairs_evaluated", C.c_int64), ("pairs_computed", C.c_int64), ("candidates", C.c_int64),
-                ("new_keys", C.c_int64), ("gpu_ms", C.c_double), ("tile_ms", C.c_double)]
+                ("pairs_screened", C.c_int64), ("new_keys", C.c_int64), ("gpu_ms", C.c_double), ("tile_ms", C.c_double),
+                ("algo", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -49,6 +50,7 @@ _SIGNATURES = {
     "tsc_ctx_destroy": (C.c_int, [_vp]),
     "tsc_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "tsc_ctx_synchronize": (C.c_int, [_vp]),
+    "tsc_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "tsc_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "tsc_free": (C.c_int, [_vp, _vp]),
     "tsc_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

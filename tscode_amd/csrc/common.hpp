@@ -66,6 +66,8 @@ struct tsc_ctx {
     std::map<void *, size_t> live;        // blocks handed out
     void *pinned = nullptr;               // small pinned host buffer for scalar read-backs
     size_t pinned_bytes = 0;
+    int prune_algo = 0;                   // tsc_ctx_set_option("prune_algo"): 0 auto, 1 register-tiled, 2 sieve
+    int seg_cols = 2048;                  // columns per pair-kernel work item
 
     int alloc(size_t bytes, void **out) {
         if (bytes == 0) bytes = 8;

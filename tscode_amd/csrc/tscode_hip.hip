@@ -4,6 +4,7 @@
 #include "embed_clash.hpp"
 #include "rmsd.hpp"
 #include "scan.hpp"
+#include "sieve.hpp"
 
 #include <algorithm>
 
@@ -444,10 +445,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c,
 static const double KS[TSC_MAX_PASSES] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};  // :186-188
 
 constexpr int TILE_ROWS = 16;
-constexpr int MAX_HP = 32;
+constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel takes any h
+
+enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2 };
 
 struct DevCounters {  // zeroed before every pass
-    unsigned long long tile[2];  // pairs computed, candidates
+    unsigned long long tile[3];  // pairs whose H was formed, pairs sent to the exact path, pairs screened by descriptor
+    unsigned long long pad;
     ApplyCounters apply;
 };
 
@@ -455,16 +459,19 @@ struct tsc_prune {
     tsc_ctx *ctx = nullptr;
     const double *heavy = nullptr;
     int64_t n = 0, npad = 0;
-    int h = 0, hp = 0;
+    int h = 0, hp = 0, hd = 0;
     double thr = 0;
     int mode = 0;
+    int algo = ALGO_AUTO;     // requested
+    int cur_algo = ALGO_SIEVE;  // used by the next pass
     // device state
     uint8_t *mask = nullptr;
     int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
     int32_t *bsum = nullptr, *total = nullptr;
     unsigned long long *mbit = nullptr, *dbit = nullptr;
     size_t bit_words = 0;
-    double *Xr = nullptr, *Xc = nullptr, *G = nullptr;
+    double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel (lazy)
+    double *Dall = nullptr, *Gall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel
     DevCounters *counters = nullptr;
     std::vector<void *> blocks;
     // host state
@@ -497,13 +504,45 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
     return 0;
 }
 
+// Descriptors of every structure for the sieve: principal axes of the atom-norm vectors (sieve.hpp).
+static int build_descriptors(tsc_prune *p) {
+    tsc_ctx *c = p->ctx;
+    hipStream_t st = c->stream;
+    const int h = p->h, hd = p->hd, m = hd + 1;
+    Scratch s(c);
+    double *d_M, *d_Q;
+    TSC_TRY(s.get(size_t(m) * m, &d_M));
+    TSC_TRY(s.get(size_t(KD) * hd, &d_Q));
+    TSC_HIP(hipMemsetAsync(d_M, 0, size_t(m) * m * sizeof(double), st));
+    const int n_samples = int(std::min<int64_t>(p->n, DESC_SAMPLE));
+    const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
+    {
+        // the moments kernel reads only the first hd atoms of a structure: pass hd as its atom count and h*3 as row pitch
+        // by giving it a view in which one "structure" is h atoms wide: handled through stride arithmetic below
+        size_t lds = size_t(32) * m * sizeof(double);
+        if (lds > 64 * 1024) TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(k_norm_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, p->heavy, p->n, h, hd, stride, n_samples, d_M);
+        TSC_HIP(hipGetLastError());
+    }
+    std::vector<double> M(size_t(m) * m), Q;
+    TSC_HIP(hipMemcpyAsync(M.data(), d_M, M.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    TSC_HIP(hipStreamSynchronize(st));
+    descriptor_basis(M, hd, n_samples, Q);
+    TSC_HIP(hipMemcpyAsync(d_Q, Q.data(), Q.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), size_t(KD) * hd * sizeof(double), st, p->heavy, p->n, h, hd,
+                       (const double *)d_Q, p->Dall, p->Gall);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipStreamSynchronize(st));  // Q lives in a host vector and in scratch that is released on return
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
     TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
-    TSC_REQUIRE(h <= MAX_HP, "h = %d heavy atoms: this build supports up to %d", h, MAX_HP);
     TSC_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (reference-exact) or 1 (cache-free)");
     TSC_REQUIRE(rmsd_thr > 0, "rmsd_thr must be positive");
+    TSC_REQUIRE(c->prune_algo != ALGO_TILE || h <= MAX_HP, "prune_algo=1 (register-tiled kernel) supports at most %d heavy atoms, got %d", MAX_HP, h);
     *out = nullptr;
     DeviceGuard guard(c->device);
     tsc_prune *p = new (std::nothrow) tsc_prune();
@@ -514,10 +553,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     p->npad = (n + 63) / 64 * 64 + 64;
     p->h = h;
     p->hp = (h + 3) / 4 * 4;
+    p->hd = std::min(h, DESC_MAX_ATOMS);
     p->thr = rmsd_thr;
     p->mode = mode;
+    p->algo = c->prune_algo;
+    p->cur_algo = (p->algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
     p->bit_words = size_t(n / 64 + 4);
-    const size_t hp3 = size_t(p->hp) * 3;
     int rc = 0;
     if (!rc) rc = palloc(p, size_t(n), &p->mask);
     if (!rc) rc = palloc(p, size_t(n) + 1, &p->pos);
@@ -531,10 +572,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) rc = palloc(p, 4, &p->total);
     if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
     if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
-    if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xr);
-    if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xc);
-    if (!rc) rc = palloc(p, size_t(p->npad), &p->G);
     if (!rc) rc = palloc(p, 1, &p->counters);
+    if (!rc && p->algo != ALGO_TILE) {
+        rc = palloc(p, size_t(n) * KD, &p->Dall);
+        if (!rc) rc = palloc(p, size_t(n), &p->Gall);
+        if (!rc) rc = palloc(p, size_t(p->npad) * KD, &p->Dr);
+        if (!rc) rc = palloc(p, size_t(p->npad) * KD, &p->Dc);
+    }
     hipError_t e = hipSuccess;
     if (!rc) {
         hipStream_t st = c->stream;
@@ -542,21 +586,34 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         if (e == hipSuccess) e = hipMemsetAsync(p->n_keys, 0, 4 * sizeof(int32_t), st);  // :183 cache = [(-1,-1)] never matches
         if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->Xc, 0, size_t(p->npad) * hp3 * sizeof(double), st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->Xr, 0, size_t(p->npad) * hp3 * sizeof(double), st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
+        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * KD * sizeof(double), st);
         if (e == hipSuccess) e = hipEventCreate(&p->ev0);
         if (e == hipSuccess) e = hipEventCreate(&p->ev1);
         if (e == hipSuccess) e = hipEventCreate(&p->evt0);
         if (e == hipSuccess) e = hipEventCreate(&p->evt1);
+        if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
     }
-    if (rc || e != hipSuccess) {
-        if (!rc) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
+    if (!rc && p->Dall) rc = build_descriptors(p);
+    if (rc) {
         tsc_prune_destroy(p);
         return rc;
     }
     p->n_active = n;
     *out = p;
+    return 0;
+}
+
+// Buffers of the register-tiled kernel, on first use.
+static int ensure_tile_buffers(tsc_prune *p) {
+    if (p->Xr) return 0;
+    const size_t hp3 = size_t(p->hp) * 3;
+    TSC_TRY(palloc(p, size_t(p->npad) * hp3, &p->Xr));
+    TSC_TRY(palloc(p, size_t(p->npad) * hp3, &p->Xc));
+    TSC_TRY(palloc(p, size_t(p->npad), &p->G));
+    hipStream_t st = p->ctx->stream;
+    TSC_HIP(hipMemsetAsync(p->Xc, 0, size_t(p->npad) * hp3 * sizeof(double), st));
+    TSC_HIP(hipMemsetAsync(p->Xr, 0, size_t(p->npad) * hp3 * sizeof(double), st));
+    TSC_HIP(hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st));
     return 0;
 }
 
@@ -572,6 +629,7 @@ static int collect_pass(tsc_prune *p) {
     tsc_pass_stats &s = p->stats[p->n_passes - 1];
     s.pairs_computed = int64_t(dc.tile[0]);
     s.candidates = int64_t(dc.tile[1]);
+    s.pairs_screened = int64_t(dc.tile[2]);
     s.pairs_evaluated = int64_t(dc.apply.pairs_evaluated);
     s.new_keys = dc.apply.removed;
     s.n_active_after = s.n_active_before - dc.apply.removed;
@@ -580,6 +638,11 @@ static int collect_pass(tsc_prune *p) {
     if (hipEventElapsedTime(&ms, p->evt0, p->evt1) == hipSuccess) s.tile_ms = ms;
     p->n_active = s.n_active_after;
     p->stats_pending = false;
+    // automatic choice for the next pass: the sieve pays while it drops most pairs; when more than a quarter of
+    // the screened pairs still need H, the register-tiled kernel (all pairs, no screening) is the faster one
+    if (p->algo == ALGO_AUTO && p->h <= MAX_HP && s.algo == ALGO_SIEVE && s.pairs_screened > 100000 &&
+        s.pairs_computed * 4 > s.pairs_screened)
+        p->cur_algo = ALGO_TILE;
     return 0;
 }
 
@@ -617,16 +680,21 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int64_t n = p->n, k = p->cur_k;
     const int A = int(p->n_active);
     PassGeom g{n, k, n / k};
-    const int hp3 = p->hp * 3;
+    const int algo = p->cur_algo;
+    if (algo == ALGO_TILE) TSC_TRY(ensure_tile_buffers(p));
     TSC_HIP(hipEventRecord(p->ev0, st));
     TSC_HIP(hipMemsetAsync(p->counters, 0, sizeof(DevCounters), st));
     // 1. ranks of the active structures, their index list and the mask as bits
     TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total));
-    // 2. compacted coordinate layouts
-    {
+    // 2. what the pair kernel reads, gathered for the active structures
+    if (algo == ALGO_TILE) {
+        const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
         hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, A, p->Xr, p->Xc,
                            p->npad, p->G);
+    } else {
+        hipLaunchKernelGGL(k_compact_desc, dim3(ceil_div(A, 256)), dim3(256), 0, st, (const double *)p->Dall, (const int32_t *)p->act, A,
+                           p->Dr, p->Dc, p->npad);
     }
     // 3. cache view of this pass and the stop column of every row
     const int use_cache = (p->mode == 0);
@@ -636,30 +704,41 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     }
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, A, p->act, p->pos, p->mbit, p->dbit, p->cend);
     hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(A, 256)), dim3(256), 0, st, p->best, int64_t(A), INT_MAX);
-    // 4. tiles: rows dealt round-robin over ranks, columns cut into segments for load balance
-    TileArgs a;
-    a.ld = p->npad, a.n_active = A, a.h = p->h;
-    a.n_tiles = ceil_div(A, TILE_ROWS);
-    a.tile_begin = rank, a.tile_stride = world;
-    a.seg_cols = 2048;
-    a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
-    a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+    // 4. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
+    const int seg_cols = c->seg_cols;
+    const int n_tiles = ceil_div(A, TILE_ROWS);
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
-    const int n_seg = ceil_div(max_range + 64, a.seg_cols);
-    const int my_tiles = (a.n_tiles - rank + world - 1) / world;
+    const int n_seg = ceil_div(max_range + 64, seg_cols);
+    const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
     TSC_HIP(hipEventRecord(p->evt0, st));
-    switch (p->hp) {
-        case 4: launch_tile<4>(st, grid, p, a); break;
-        case 8: launch_tile<8>(st, grid, p, a); break;
-        case 12: launch_tile<12>(st, grid, p, a); break;
-        case 16: launch_tile<16>(st, grid, p, a); break;
-        case 20: launch_tile<20>(st, grid, p, a); break;
-        case 24: launch_tile<24>(st, grid, p, a); break;
-        case 28: launch_tile<28>(st, grid, p, a); break;
-        case 32: launch_tile<32>(st, grid, p, a); break;
-        default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
+    if (algo == ALGO_TILE) {
+        TileArgs a;
+        a.ld = p->npad, a.n_active = A, a.h = p->h;
+        a.n_tiles = n_tiles, a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        switch (p->hp) {
+            case 4: launch_tile<4>(st, grid, p, a); break;
+            case 8: launch_tile<8>(st, grid, p, a); break;
+            case 12: launch_tile<12>(st, grid, p, a); break;
+            case 16: launch_tile<16>(st, grid, p, a); break;
+            case 20: launch_tile<20>(st, grid, p, a); break;
+            case 24: launch_tile<24>(st, grid, p, a); break;
+            case 28: launch_tile<28>(st, grid, p, a); break;
+            case 32: launch_tile<32>(st, grid, p, a); break;
+            default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
+        }
+    } else {
+        SieveArgs a;
+        a.ld = p->npad, a.n_active = A, a.h = p->h;
+        a.n_tiles = n_tiles, a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.desc_limit = double(p->h) * p->thr * p->thr * (1.0 + 1e-9);
+        hipLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters->tile, a);
     }
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipEventRecord(p->evt1, st));
@@ -697,6 +776,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     memset(&s, 0, sizeof(s));
     s.k = p->cur_k;
     s.n_active_before = p->n_active;
+    s.algo = p->cur_algo;
     p->stats_pending = true;
     p->cur_k = 0;
     return 0;
@@ -768,6 +848,23 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c,
     TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// Tunables: "prune_algo" 0 = automatic (sieve, falling back to the register-tiled kernel when the sieve stops
+// paying), 1 = register-tiled all-pairs kernel (h <= 32), 2 = descriptor sieve; "seg_cols" = columns per work item.
+extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx *c, const char *name, double value) {
+    TSC_REQUIRE(c && name, "null argument");
+    if (strcmp(name, "prune_algo") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1 || value == 2, "prune_algo must be 0, 1 or 2");
+        c->prune_algo = int(value);
+        return 0;
+    }
+    if (strcmp(name, "seg_cols") == 0) {
+        TSC_REQUIRE(value >= 64 && value <= 32768 && int(value) % 64 == 0, "seg_cols must be a multiple of 64 in [64, 32768]");
+        c->seg_cols = int(value);
+        return 0;
+    }
+    return fail(TSC_ERR_INVALID, "unknown option '%s'", name);
 }
 
 // --------------------------------------------------------------------------------------------------

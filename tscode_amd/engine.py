@@ -88,6 +88,10 @@ class Engine:
     def synchronize(self):
         check(self.lib.tsc_ctx_synchronize(self._h))
 
+    def set_option(self, name: str, value: float):
+        """Tunables of the library: "prune_algo" (0 auto, 1 register-tiled, 2 sieve), "seg_cols"."""
+        check(self.lib.tsc_ctx_set_option(self._h, name.encode(), C.c_double(value)))
+
     def timer_begin(self):
         check(self.lib.tsc_timer_begin(self._h))
 
