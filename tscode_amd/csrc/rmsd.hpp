@@ -43,7 +43,7 @@ __device__ inline void top_eigvec4(double A[4][4], double q[4]) {
 #pragma unroll
             for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
         }
-        if (!(off > 1e-32 * dia)) break;
+        if (!(off > 1e-30 * dia)) break;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -84,49 +84,127 @@ __device__ inline void top_eigvec4(double A[4][4], double q[4]) {
     }
 }
 
-// rmsd_and_max_numba (rmsd_pruning.py:6-41) for one pair; p, q point at h consecutive xyz triples.
-__device__ inline void rmsd_and_max_pair(const double *__restrict__ p, const double *__restrict__ q, int h, double &rmsd,
-                                         double &maxdev) {
-    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int a = 0; a < h; ++a) {  // :15 cov_mat = p.T @ q
-        double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
-        double qx = q[3 * a], qy = q[3 * a + 1], qz = q[3 * a + 2];
-        S[0][0] += px * qx, S[0][1] += px * qy, S[0][2] += px * qz;
-        S[1][0] += py * qx, S[1][1] += py * qy, S[1][2] += py * qz;
-        S[2][0] += pz * qx, S[2][1] += pz * qy, S[2][2] += pz * qz;
-    }
-    // Horn's matrix: its top eigenvector is the quaternion (w, x, y, z) of the proper rotation R that
-    // maximises sum_a (R p_a) . q_a -- the rotation :19-26 builds from the SVD with the det sign fix.
+// 3x3 determinant of the minor of the symmetric 4x4 A that drops row I and column J, with the cofactor sign.
+template <int I, int J>
+__device__ inline double cofactor4(const double (&A)[4][4]) {
+    constexpr int r0 = (I == 0) ? 1 : 0, r1 = (I <= 1) ? 2 : 1, r2 = (I <= 2) ? 3 : 2;
+    constexpr int c0 = (J == 0) ? 1 : 0, c1 = (J <= 1) ? 2 : 1, c2 = (J <= 2) ? 3 : 2;
+    const double d = A[r0][c0] * (A[r1][c1] * A[r2][c2] - A[r1][c2] * A[r2][c1]) -
+                     A[r0][c1] * (A[r1][c0] * A[r2][c2] - A[r1][c2] * A[r2][c0]) +
+                     A[r0][c2] * (A[r1][c0] * A[r2][c1] - A[r1][c1] * A[r2][c0]);
+    return ((I + J) & 1) ? -d : d;
+}
+
+// The explicit-rotation half of rmsd_and_max_numba (rmsd_pruning.py:19-39) given S = p^T q (:15) and the squared
+// norms Gp, Gq.  The quaternion of the optimal proper rotation is the top eigenvector of Horn's matrix N(S):
+//   fast path : largest root of the characteristic quartic by Newton from the upper bound (Gp+Gq)/2 (monotone), then
+//               the eigenvector as the best-conditioned column of adj(N - l I);
+//   fallback  : cyclic Jacobi, when the top eigenvalue is (nearly) degenerate and the adjugate collapses
+//               (collinear / planar-through-origin / mirror-symmetric cases).
+// A group of `lpp` consecutive lanes (a power of two, all converged, all holding the same S) may share one pair:
+// lane `sub` of the group then takes atoms sub, sub + lpp, ... of the residual loop and the group reduces.
+__device__ inline void exact_rmsd_maxdev(const double *__restrict__ p, const double *__restrict__ q, int h, const double S[9],
+                                         double Gp, double Gq, double &rmsd, double &maxdev, int sub = 0, int lpp = 1) {
     double N[4][4];
-    N[0][0] = S[0][0] + S[1][1] + S[2][2];
-    N[1][1] = S[0][0] - S[1][1] - S[2][2];
-    N[2][2] = -S[0][0] + S[1][1] - S[2][2];
-    N[3][3] = -S[0][0] - S[1][1] + S[2][2];
-    N[0][1] = N[1][0] = S[1][2] - S[2][1];
-    N[0][2] = N[2][0] = S[2][0] - S[0][2];
-    N[0][3] = N[3][0] = S[0][1] - S[1][0];
-    N[1][2] = N[2][1] = S[0][1] + S[1][0];
-    N[1][3] = N[3][1] = S[2][0] + S[0][2];
-    N[2][3] = N[3][2] = S[1][2] + S[2][1];
+    N[0][0] = S[0] + S[4] + S[8];
+    N[1][1] = S[0] - S[4] - S[8];
+    N[2][2] = -S[0] + S[4] - S[8];
+    N[3][3] = -S[0] - S[4] + S[8];
+    N[0][1] = N[1][0] = S[5] - S[7];
+    N[0][2] = N[2][0] = S[6] - S[2];
+    N[0][3] = N[3][0] = S[1] - S[3];
+    N[1][2] = N[2][1] = S[1] + S[3];
+    N[1][3] = N[3][1] = S[6] + S[2];
+    N[2][3] = N[3][2] = S[5] + S[7];
+    // characteristic quartic l^4 + c2 l^2 + c1 l + c0 (see the sign test below)
+    const double F = S[0] * S[0] + S[1] * S[1] + S[2] * S[2] + S[3] * S[3] + S[4] * S[4] + S[5] * S[5] + S[6] * S[6] + S[7] * S[7] + S[8] * S[8];
+    const double C0 = S[4] * S[8] - S[5] * S[7], C1 = S[5] * S[6] - S[3] * S[8], C2 = S[3] * S[7] - S[4] * S[6];
+    const double C3 = S[2] * S[7] - S[1] * S[8], C4 = S[0] * S[8] - S[2] * S[6], C5 = S[1] * S[6] - S[0] * S[7];
+    const double C6 = S[1] * S[5] - S[2] * S[4], C7 = S[2] * S[3] - S[0] * S[5], C8 = S[0] * S[4] - S[1] * S[3];
+    const double det = S[0] * C0 + S[1] * C1 + S[2] * C2;
+    const double CF = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
+    const double c2 = -2.0 * F, c1 = -8.0 * det, c0 = F * F - 4.0 * CF;
+    double lam = 0.5 * (Gp + Gq);
+    bool newton_ok = lam > 0.0;
+    for (int it = 0; it < 40 && newton_ok; ++it) {
+        const double l2 = lam * lam;
+        const double P = l2 * l2 + c2 * l2 + c1 * lam + c0, P1 = 4.0 * l2 * lam + 2.0 * c2 * lam + c1;
+        if (!(P1 > 0.0)) {
+            newton_ok = false;
+            break;
+        }
+        const double dl = P / P1;
+        lam -= dl;
+        if (fabs(dl) <= 1e-15 * fabs(lam)) break;
+    }
     double e[4];
-    top_eigvec4(N, e);
-    double nn = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    double w = e[0] * nn, x = e[1] * nn, y = e[2] * nn, z = e[3] * nn;
-    double R00 = w * w + x * x - y * y - z * z, R01 = 2 * (x * y - w * z), R02 = 2 * (x * z + w * y);
-    double R10 = 2 * (x * y + w * z), R11 = w * w - x * x + y * y - z * z, R12 = 2 * (y * z - w * x);
-    double R20 = 2 * (x * z - w * y), R21 = 2 * (y * z + w * x), R22 = w * w - x * x - y * y + z * z;
+    bool have = false;
+    if (newton_ok) {
+        double A[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[i][j] = N[i][j] - (i == j ? lam : 0.0);
+        const double d0 = cofactor4<0, 0>(A), d1 = cofactor4<1, 1>(A), d2 = cofactor4<2, 2>(A), d3 = cofactor4<3, 3>(A);
+        double scale = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) scale = fmax(scale, fabs(A[i][j]));
+        const double a0 = fabs(d0), a1 = fabs(d1), a2 = fabs(d2), a3 = fabs(d3);
+        const double best = fmax(fmax(a0, a1), fmax(a2, a3));
+        if (best > 1e-4 * scale * scale * scale) {  // adj(A) = c v v^T with |c| large enough: any big column is v
+            have = true;
+            if (a0 == best) {
+                e[0] = d0, e[1] = cofactor4<0, 1>(A), e[2] = cofactor4<0, 2>(A), e[3] = cofactor4<0, 3>(A);
+            } else if (a1 == best) {
+                e[0] = cofactor4<1, 0>(A), e[1] = d1, e[2] = cofactor4<1, 2>(A), e[3] = cofactor4<1, 3>(A);
+            } else if (a2 == best) {
+                e[0] = cofactor4<2, 0>(A), e[1] = cofactor4<2, 1>(A), e[2] = d2, e[3] = cofactor4<2, 3>(A);
+            } else {
+                e[0] = cofactor4<3, 0>(A), e[1] = cofactor4<3, 1>(A), e[2] = cofactor4<3, 2>(A), e[3] = d3;
+            }
+        }
+    }
+    if (!have) top_eigvec4(N, e);
+    const double nn = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double w = e[0] * nn, x = e[1] * nn, y = e[2] * nn, z = e[3] * nn;
+    const double R00 = w * w + x * x - y * y - z * z, R01 = 2 * (x * y - w * z), R02 = 2 * (x * z + w * y);
+    const double R10 = 2 * (x * y + w * z), R11 = w * w - x * x + y * y - z * z, R12 = 2 * (y * z - w * x);
+    const double R20 = 2 * (x * z - w * y), R21 = 2 * (y * z + w * x), R22 = w * w - x * x - y * y + z * z;
     double ss = 0.0, mx = 0.0;
-    for (int a = 0; a < h; ++a) {  // :29-39
-        double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
-        double dx = R00 * px + R01 * py + R02 * pz - q[3 * a];
-        double dy = R10 * px + R11 * py + R12 * pz - q[3 * a + 1];
-        double dz = R20 * px + R21 * py + R22 * pz - q[3 * a + 2];
-        double d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll 2
+    for (int a = sub; a < h; a += lpp) {  // :29-39
+        const double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
+        const double dx = R00 * px + R01 * py + R02 * pz - q[3 * a];
+        const double dy = R10 * px + R11 * py + R12 * pz - q[3 * a + 1];
+        const double dz = R20 * px + R21 * py + R22 * pz - q[3 * a + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
         ss += d2;
         mx = d2 > mx ? d2 : mx;
     }
+    for (int off = lpp >> 1; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
     rmsd = sqrt(ss / double(h));
     maxdev = sqrt(mx);  // max_a sqrt(d2_a) == sqrt(max_a d2_a): sqrt is monotone
+}
+
+// rmsd_and_max_numba (rmsd_pruning.py:6-41) for one pair; p, q point at h consecutive xyz triples.
+__device__ inline void rmsd_and_max_pair(const double *__restrict__ p, const double *__restrict__ q, int h, double &rmsd,
+                                         double &maxdev) {
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gp = 0.0, Gq = 0.0;
+    for (int a = 0; a < h; ++a) {  // :15 cov_mat = p.T @ q
+        const double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
+        const double qx = q[3 * a], qy = q[3 * a + 1], qz = q[3 * a + 2];
+        S[0] += px * qx, S[1] += px * qy, S[2] += px * qz;
+        S[3] += py * qx, S[4] += py * qy, S[5] += py * qz;
+        S[6] += pz * qx, S[7] += pz * qy, S[8] += pz * qz;
+        Gp += px * px + py * py + pz * pz;
+        Gq += qx * qx + qy * qy + qz * qz;
+    }
+    exact_rmsd_maxdev(p, q, h, S, Gp, Gq, rmsd, maxdev);
 }
 
 __global__ __launch_bounds__(256) void k_rmsd_pairs(const double *__restrict__ heavy, int h, const int32_t *__restrict__ pairs,
@@ -137,6 +215,18 @@ __global__ __launch_bounds__(256) void k_rmsd_pairs(const double *__restrict__ h
         rmsd[k] = r;
         maxdev[k] = m;
     }
+}
+
+// Statistics counters of a pass.  Thousands of wavefronts report at the end of a kernel; same-address atomics
+// serialise at ~12 ns each (MI355X_MICROARCH.md, "fanin"), which for 10^4 reports is longer than the kernels
+// themselves, so the counters are spread over 64 buckets on separate 128-byte lines and summed on the host.
+constexpr int CNT_BUCKETS = 64;
+enum { CNT_FORMED = 0, CNT_EXACT = 1, CNT_SCREENED = 2, CNT_EVALUATED = 3, CNT_REMOVED = 4, CNT_WORDS = 16 };
+struct PassCounters {
+    unsigned long long w[CNT_BUCKETS][CNT_WORDS];
+};
+__device__ inline void count_add(PassCounters *c, unsigned bucket, int what, unsigned long long v) {
+    if (v) atomicAdd(&c->w[bucket & (CNT_BUCKETS - 1)][what], v);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -184,7 +274,8 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 // Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, int n_active, const int32_t *__restrict__ act_idx,
                                                     const int32_t *__restrict__ pos, const unsigned long long *__restrict__ mbit,
-                                                    const unsigned long long *__restrict__ dbit, int32_t *__restrict__ cend) {
+                                                    const unsigned long long *__restrict__ dbit, int32_t *__restrict__ cend,
+                                                    int32_t *__restrict__ best) {
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_active) return;
@@ -210,7 +301,10 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, in
             }
         }
     }
-    if (lane == 0) cend[r] = pos[found];
+    if (lane == 0) {
+        cend[r] = pos[found];
+        best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
+    }
 }
 
 // Gather the active structures into the two layouts the tile kernel reads:
@@ -294,7 +388,7 @@ __device__ inline bool certainly_dissimilar(const double H[9], double L) {
 template <int HP, int TI>
 __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__ Xr, const double *__restrict__ Xc,
                                                        const double *__restrict__ G, const int32_t *__restrict__ cend,
-                                                       int32_t *__restrict__ best, unsigned long long *__restrict__ counters,
+                                                       int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                        TileArgs a) {
     // Xr [n_active][HP*3] row structures; Xc [HP*3][ld] column structures; G [ld] squared norms;
     // cend [n_active] exclusive column bound of each row; best [n_active] atomicMin target (INT_MAX = none);
@@ -378,49 +472,55 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
         }
     }
     if (lane == 0) {
-        atomicAdd(&counters[0], n_computed);
-        atomicAdd(&counters[1], n_cand);
+        count_add(counters, unsigned(slot), CNT_FORMED, n_computed);
+        count_add(counters, unsigned(slot), CNT_EXACT, n_cand);
     }
 }
 
 // Apply a finished pass: rows with a similar column are removed (:113) and leave one cache key each
 // (:76, appended after the pass at :204); counts what the reference's sequential scan would have evaluated.
-struct ApplyCounters {
-    unsigned long long pairs_evaluated;
-    int removed;
-    int pad;
-};
-
 __global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, int n_active, const int32_t *__restrict__ act_idx,
                                                      const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
                                                      uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
                                                      int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
-                                                     ApplyCounters *__restrict__ cnt) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+                                                     PassCounters *__restrict__ cnt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     unsigned long long ev = 0;
-    int rem = 0;
+    bool removed = false;
+    int64_t first = 0, delta = 0;
     if (r < n_active) {
-        int b = best[r];
+        const int b = best[r];
         if (b != INT_MAX) {
-            int64_t i = act_idx[r], j = act_idx[b], first, last;
+            const int64_t i = act_idx[r], j = act_idx[b];
+            int64_t last;
             chunk_of(g, i, first, last);
             mask[i] = 0;
-            int slot = atomicAdd(n_keys, 1);
-            key_a[slot] = int32_t(first);
-            key_b[slot] = int32_t(first + (j - i));
+            delta = j - i;
+            removed = true;
             ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
-            rem = 1;
         } else {
             ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        ev += __shfl_down(ev, off);
-        rem += __shfl_down(rem, off);
+    // one slot reservation per wavefront for the keys of its removed rows (order inside the cache is irrelevant)
+    const unsigned long long rm = __ballot(removed);
+    const int n_rm = __popcll(rm);
+    int base = 0;
+    if (n_rm) {
+        if (lane == 0) base = atomicAdd(n_keys, n_rm);
+        base = __shfl(base, 0);
+        if (removed) {
+            const int slot = base + __popcll(rm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            key_a[slot] = int32_t(first);
+            key_b[slot] = int32_t(first + delta);
+        }
     }
-    if ((threadIdx.x & 63) == 0 && (ev || rem)) {
-        atomicAdd(&cnt->pairs_evaluated, ev);
-        atomicAdd(&cnt->removed, rem);
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+    if (lane == 0) {
+        const unsigned bucket = blockIdx.x * 4 + (threadIdx.x >> 6);
+        count_add(cnt, bucket, CNT_EVALUATED, ev);
+        count_add(cnt, bucket, CNT_REMOVED, (unsigned long long)n_rm);
     }
 }
 

@@ -1,23 +1,26 @@
 // sieve.hpp -- K3 with a rotation-invariant descriptor sieve in front of the Kabsch evaluation.
 //
-// rmsd_and_max_numba (tscode/rmsd_pruning.py:6-41) rotates p onto q ABOUT THE ORIGIN (it never centres),
-// and a rotation about the origin keeps every atom's distance from the origin.  With n_a(p) = |p_a|:
+// rmsd_and_max_numba (tscode/rmsd_pruning.py:6-41) rotates p onto q ABOUT THE ORIGIN (it never centres).
+// Write dev_a = |p_a R - q_a| for the deviation of atom a after the optimal rotation R; h * rmsd^2 = sum_a dev_a^2.
+// Two families of quantities are untouched by R, and each bounds the deviations from below:
 //
-//     |p_a R - q_a| >= | n_a(p) - n_a(q) |            for every rotation R and atom a, hence
-//     h * rmsd(p, q)^2 >= sum_a (n_a(p) - n_a(q))^2  >=  | Q^T (n(p) - n(q)) |^2
+//   family 0  atom norms:           n_a(x) = |x_a|                      dev_a           >= | n_a(p) - n_a(q) |
+//   family 1  atom-pair distances:  d_ab(x) = |x_a - x_b|               dev_a + dev_b   >= | d_ab(p) - d_ab(q) |
+//             over DISJOINT pairs (a, b = a + h/2), so that             dev_a^2 + dev_b^2 >= (d_ab(p) - d_ab(q))^2 / 2
 //
-// for any matrix Q with orthonormal columns.  A pair whose right-hand side exceeds h * thr^2 cannot satisfy
-// rmsd < thr (:75), so it is dropped without forming H = p^T q.  Q (KD columns) is taken along the leading
-// principal axes of the norm vectors of the ensemble, where they differ most; the choice of Q only affects how
-// many pairs are dropped, never the result.  Everything that survives goes through the same sign test and
-// explicit-rotation path as the tile kernel (rmsd.hpp), so the verdicts are those of the reference.
+// Hence, with f0(x) = (n_a)_a and f1(x) = (d_ab / sqrt 2)_(a,b):   h * rmsd(p,q)^2 >= |f(p) - f(q)|^2 >= |Q^T (f(p) - f(q))|^2
+// for either family and any Q with orthonormal columns.  A pair for which one of the two right-hand sides exceeds
+// h * thr^2 cannot have rmsd < thr (:75) and is dropped without forming H = p^T q.  Q (KD columns per family) spans the
+// leading principal axes of the feature vectors of the ensemble; the choice of Q (and of the atom pairs) only
+// changes how many pairs are dropped, never a verdict.  Everything that survives takes the same sign test and
+// explicit-rotation path as the register-tiled kernel (rmsd.hpp).
 //
-// Structure of the pass kernel (one wavefront = 16 rows x one column segment, lane = column):
-//   screen : per 64-column tile the lane holds its column's descriptor (KD doubles, coalesced load), the row's
-//            descriptor is wave-uniform (one scalar load); 2*KD flops per pair; survivors are pushed to a
-//            per-wavefront LDS queue (ballot + prefix popcount);
-//   drain  : whenever the queue holds 64 pairs, lane l takes pair l: H from the two structures in memory
-//            (they sit in L1/L2), sign test, exact path; atomicMin(best[row], column).
+// Pass kernel: one wavefront = 16 rows x one column segment, lane = column.
+//   screen : the lane keeps its column's descriptor (2*KD doubles, coalesced load per 64-column tile); the 16 row
+//            descriptors sit in LDS and are read as broadcasts; 4*KD flops per pair; survivors go to a per-wavefront
+//            LDS queue (ballot + prefix popcount);
+//   drain  : whenever the queue holds 64 pairs, lane l takes pair l: H from the two structures in memory (L1/L2
+//            resident), sign test, exact path; atomicMin(best[row], column).
 // Any number of heavy atoms is supported (no register-resident structure).
 #pragma once
 #include "common.hpp"
@@ -25,29 +28,35 @@
 
 namespace tsc {
 
-constexpr int KD = 8;           // descriptor dimensions
+constexpr int KD = 8;              // descriptor dimensions per family
+constexpr int NFAM = 2;            // feature families
+constexpr int DW = KD * NFAM;      // doubles per structure descriptor
 constexpr int DESC_SAMPLE = 4096;  // structures used to estimate the principal axes
-constexpr int DESC_MAX_ATOMS = 256;
+constexpr int DESC_MAX_FEAT = 256; // features per family that enter the descriptor (any subset keeps the bound valid)
 
-// second-moment matrix of the (sampled) norm vectors, with a constant 1 appended:
-// M[a][b] = sum_s n_a(s) n_b(s), a, b in [0, h]  (index h = the constant) -> mean and covariance on the host.
-// Only the first hd (<= DESC_MAX_ATOMS) atoms of a structure enter the descriptor; any subset keeps the bound valid.
-__global__ __launch_bounds__(256) void k_norm_moments(const double *__restrict__ heavy, int64_t n, int h_row, int h, int64_t stride_structs,
-                                                       int n_samples, double *__restrict__ M) {
-    extern __shared__ __attribute__((aligned(16))) double s_n[];  // [chunk][h + 1]
-    const int m = h + 1;
+// feature a of family fam of the structure at x (h atoms, xyz triples)
+__device__ inline double feature(const double *__restrict__ x, int h, int fam, int a) {
+    if (fam == 0) return sqrt(x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2]);
+    const int b = a + h / 2;
+    const double dx = x[3 * a] - x[3 * b], dy = x[3 * a + 1] - x[3 * b + 1], dz = x[3 * a + 2] - x[3 * b + 2];
+    return sqrt(0.5 * (dx * dx + dy * dy + dz * dz));
+}
+
+inline int n_features(int h, int fam) { return std::min(fam == 0 ? h : h / 2, DESC_MAX_FEAT); }
+
+// Second-moment matrix of the sampled feature vectors of one family, with a constant 1 appended:
+// M[a][b] = sum_s f_a(s) f_b(s), a, b in [0, nf]  (index nf = the constant) -> mean and covariance on the host.
+__global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int fam, int nf, int64_t stride_structs,
+                                                          int n_samples, double *__restrict__ M) {
+    extern __shared__ __attribute__((aligned(16))) double s_n[];  // [chunk][nf + 1]
+    const int m = nf + 1;
     constexpr int CHUNK = 32;
     const int n_chunks = (n_samples + CHUNK - 1) / CHUNK;
     for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const int s0 = ch * CHUNK, ns = min(CHUNK, n_samples - s0);
         for (int e = threadIdx.x; e < ns * m; e += blockDim.x) {
             int s = e / m, a = e - s * m;
-            double v = 1.0;
-            if (a < h) {
-                const double *x = heavy + (int64_t(s0 + s) * stride_structs * h_row + a) * 3;
-                v = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-            }
-            s_n[s * m + a] = v;
+            s_n[s * m + a] = (a < nf) ? feature(heavy + int64_t(s0 + s) * stride_structs * h * 3, h, fam, a) : 1.0;
         }
         __syncthreads();
         for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
@@ -61,44 +70,49 @@ __global__ __launch_bounds__(256) void k_norm_moments(const double *__restrict__
     }
 }
 
-// D[i][k] = sum_a Q[k][a] * |x_ia|  and  G[i] = sum_a |x_ia|^2 for every structure (original index space)
-__global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int hd, const double *__restrict__ Q,
-                                                      double *__restrict__ D, double *__restrict__ G) {
-    extern __shared__ __attribute__((aligned(16))) double s_q[];  // [KD][hd]
-    for (int e = threadIdx.x; e < KD * hd; e += blockDim.x) s_q[e] = Q[e];
+// D[i][fam*KD + k] = sum_a Q_fam[k][a] * f_fam,a(x_i)   and   G[i] = sum_a |x_ia|^2   (original index space)
+__global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
+                                                      const double *__restrict__ Q, double *__restrict__ D, double *__restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) double s_q[];  // [KD][nf0] then [KD][nf1]
+    for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += blockDim.x) s_q[e] = Q[e];
     __syncthreads();
     int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double *x = heavy + i * h * 3;
-    double d[KD], g = 0.0;
+    double d[DW], g = 0.0;
 #pragma unroll
-    for (int k = 0; k < KD; ++k) d[k] = 0.0;
+    for (int k = 0; k < DW; ++k) d[k] = 0.0;
     for (int a = 0; a < h; ++a) {
-        double n2 = x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2];
+        const double n2 = x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2];
         g += n2;
-        if (a < hd) {
-            double nr = sqrt(n2);
+        if (a < nf0) {
+            const double f = sqrt(n2);
 #pragma unroll
-            for (int k = 0; k < KD; ++k) d[k] = fma(s_q[k * hd + a], nr, d[k]);
+            for (int k = 0; k < KD; ++k) d[k] = fma(s_q[k * nf0 + a], f, d[k]);
+        }
+        if (a < nf1) {
+            const double f = feature(x, h, 1, a);
+            const double *q1 = s_q + KD * nf0;
+#pragma unroll
+            for (int k = 0; k < KD; ++k) d[KD + k] = fma(q1[k * nf1 + a], f, d[KD + k]);
         }
     }
 #pragma unroll
-    for (int k = 0; k < KD; ++k) D[i * KD + k] = d[k];
+    for (int k = 0; k < DW; ++k) D[i * DW + k] = d[k];
     G[i] = g;
 }
 
 // per pass: descriptors of the active structures in the two layouts the sieve reads
-//   Dr[r][KD] (rows, scalar loads)   Dc[k][ld] (columns, lane = column)
+//   Dr[r][DW] (rows: staged in LDS per work item)   Dc[k][ld] (columns: lane = column)
 __global__ __launch_bounds__(256) void k_compact_desc(const double *__restrict__ D, const int32_t *__restrict__ act, int n_active,
                                                        double *__restrict__ Dr, double *__restrict__ Dc, int64_t ld) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;  // e = k * n_active_pad + r would need a division; use 2D split below
-    int r = e;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_active) return;
-    const double *src = D + int64_t(act[r]) * KD;
+    const double *src = D + int64_t(act[r]) * DW;
 #pragma unroll
-    for (int k = 0; k < KD; ++k) {
+    for (int k = 0; k < DW; ++k) {
         double v = src[k];
-        Dr[int64_t(r) * KD + k] = v;
+        Dr[int64_t(r) * DW + k] = v;
         Dc[int64_t(k) * ld + r] = v;
     }
 }
@@ -117,33 +131,42 @@ struct SieveArgs {
 };
 
 // H = p^T q and the sign test / exact path for one pair read from memory.  Returns true iff the pair is
-// similar in the reference's sense (rmsd < thr and maxdev < 2 thr, rmsd_pruning.py:75); *exact_taken tells
-// whether the explicit-rotation path ran.
+// similar in the reference's sense (rmsd < thr and maxdev < 2 thr, rmsd_pruning.py:75); exact_taken tells
+// whether the explicit-rotation path ran.  `lpp` consecutive lanes (power of two) share the pair: lane `sub`
+// takes atoms sub, sub + lpp, ... and the group sums H with a butterfly, so a batch of few pairs has a short
+// critical path (lpp = 64 / batch size) while a full batch runs one pair per lane (lpp = 1).
 __device__ inline bool pair_is_similar(const double *__restrict__ p, const double *__restrict__ q, int h, double Gp, double Gq,
-                                       double half_h_thr2, double thr, double maxdev_thr, bool &exact_taken) {
+                                       double half_h_thr2, double thr, double maxdev_thr, bool &exact_taken, int sub, int lpp) {
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int a = 0; a < h; ++a) {
+#pragma unroll 2
+    for (int a = sub; a < h; a += lpp) {
         const double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
         const double qx = q[3 * a], qy = q[3 * a + 1], qz = q[3 * a + 2];
         H[0] = fma(px, qx, H[0]), H[1] = fma(px, qy, H[1]), H[2] = fma(px, qz, H[2]);
         H[3] = fma(py, qx, H[3]), H[4] = fma(py, qy, H[4]), H[5] = fma(py, qz, H[5]);
         H[6] = fma(pz, qx, H[6]), H[7] = fma(pz, qy, H[7]), H[8] = fma(pz, qz, H[8]);
     }
+    for (int off = lpp >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], off);
+    }
     exact_taken = false;
     if (certainly_dissimilar(H, 0.5 * (Gp + Gq) - half_h_thr2)) return false;
     exact_taken = true;
     double rm, md;
-    rmsd_and_max_pair(p, q, h, rm, md);
+    exact_rmsd_maxdev(p, q, h, H, Gp, Gq, rm, md, sub, lpp);
     return rm < thr && md < maxdev_thr;
 }
 
 template <int TI>
-__global__ __launch_bounds__(256) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                     const double *__restrict__ Gall, const double *__restrict__ Dr,
-                                                     const double *__restrict__ Dc, const int32_t *__restrict__ cend,
-                                                     int32_t *__restrict__ best, unsigned long long *__restrict__ counters, SieveArgs a) {
+__global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                                        const double *__restrict__ Gall, const double *__restrict__ Dr,
+                                                        const double *__restrict__ Dc, const int32_t *__restrict__ cend,
+                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
-    __shared__ unsigned s_queue[4][128];
+    constexpr int QCAP = TI * 64 + 64;  // one column tile can add TI*64 pairs on top of a remainder below 64
+    __shared__ unsigned s_queue[4][QCAP];
+    __shared__ __attribute__((aligned(16))) double s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * 4 + wid;
@@ -167,28 +190,44 @@ __global__ __launch_bounds__(256) void k_rmsd_sieve(const double *__restrict__ h
     for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
     cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
 
+    // the row descriptors of this work item: nrows * DW consecutive doubles of Dr -> LDS
+    double *rowdesc = s_rowdesc[wid];
+    for (int e = lane; e < nrows * DW; e += 64) rowdesc[e] = Dr[int64_t(r0) * DW + e];
+    __builtin_amdgcn_wave_barrier();
+
     const int h3 = a.h * 3;
     unsigned *queue = s_queue[wid];
     int qn = 0;
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // evaluate queue entries [base, base + cnt), cnt <= 64, one per lane
+    // evaluate queue entries [base, base + cnt), cnt <= 64: lpp = 64 / pow2ceil(cnt) lanes per pair
     auto drain = [&](int base, int cnt) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int g = lane / lpp, sub = lane - g * lpp;
+        const bool mine = g < cnt;
         bool sim = false, exact = false;
-        int t = 0, col = 0;
-        if (lane < cnt) {
-            const unsigned e = queue[base + lane];
+        int t = 0, r = r0, col = seg_lo;
+        const double *pp = heavy, *pq = heavy;
+        double Gi = 0.0, Gj = 0.0;
+        if (mine) {
+            const unsigned e = queue[base + g];
             t = int(e >> 16);
             col = seg_lo + int(e & 0xffffu);
-            const int r = r0 + t;
+            r = r0 + t;
             const int64_t i = act[r], j = act[col];
-            sim = pair_is_similar(heavy + i * h3, heavy + j * h3, a.h, Gall[i], Gall[j], a.half_h_thr2, a.thr, a.maxdev_thr, exact);
-            if (sim) atomicMin(&best[r], col);
+            pp = heavy + i * h3, pq = heavy + j * h3;
+            Gi = Gall[i], Gj = Gall[j];
         }
+        // a lane group is either wholly busy or wholly idle, so the group shuffles inside the evaluation only ever
+        // involve converged lanes
+        if (mine) sim = pair_is_similar(pp, pq, a.h, Gi, Gj, a.half_h_thr2, a.thr, a.maxdev_thr, exact, sub, lpp);
+        exact = exact && sub == 0;
+        if (sim && sub == 0) atomicMin(&best[r], col);
         n_eval += cnt;
         n_exact += __popcll(__ballot(exact));
-        unsigned long long sm = __ballot(sim);
+        unsigned long long sm = __ballot(sim && sub == 0);
         while (sm) {  // rows that found a similar column stop being screened (the reference returns there, :75-77)
             const int l = __ffsll((long long)sm) - 1;
             sm &= sm - 1;
@@ -197,50 +236,58 @@ __global__ __launch_bounds__(256) void k_rmsd_sieve(const double *__restrict__ h
     };
 
     for (int c0 = seg_lo; c0 < cmax && alive; c0 += 64) {
-        const int col = c0 + lane;
-        double dq[KD];
+        {   // ---- screen one 64-column tile against every live row (the column descriptor dies with this block)
+            const int col = c0 + lane;
+            double dq[DW];
 #pragma unroll
-        for (int k = 0; k < KD; ++k) dq[k] = Dc[int64_t(k) * a.ld + col];
-        for (int t = 0; t < nrows; ++t) {
-            if (!((alive >> t) & 1u)) continue;
-            const int r = r0 + t;
-            const int ce = __builtin_amdgcn_readlane(my_cend, t);
-            if (ce <= c0 || r >= c0 + 63) continue;
-            const double *__restrict__ dr = Dr + int64_t(r) * KD;
-            double s = 0.0;
+            for (int k = 0; k < DW; ++k) dq[k] = Dc[int64_t(k) * a.ld + col];
+            const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + 63;
+            unsigned rows = unsigned(__ballot(here));
+            while (rows) {
+                const int t = __ffs(rows) - 1;
+                rows &= rows - 1;
+                const int r = r0 + t;
+                const int ce = __builtin_amdgcn_readlane(my_cend, t);
+                const double *dr = rowdesc + t * DW;
+                double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                const double d = dr[k] - dq[k];
-                s = fma(d, d, s);
-            }
-            const bool valid = col > r && col < ce;
-            const bool pass = valid && !(s > a.desc_limit);
-            n_screened += __popcll(__ballot(valid));
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned(t) << 16) | unsigned(col - seg_lo);
-                qn += __popcll(m);
-                __builtin_amdgcn_wave_barrier();
-                if (qn >= 64) {
-                    drain(qn - 64, 64);
-                    qn -= 64;
+                for (int k = 0; k < KD; ++k) {
+                    const double d0 = dr[k] - dq[k], d1 = dr[KD + k] - dq[KD + k];
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
+                const bool valid = col > r && col < ce;
+                const bool pass = valid && !(s0 > a.desc_limit) && !(s1 > a.desc_limit);
+                n_screened += __popcll(__ballot(valid));
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned(t) << 16) | unsigned(col - seg_lo);
+                    qn += __popcll(m);
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- drain full batches between tiles; a remainder below 64 waits for the next tile
+        while (qn >= 64) {
+            drain(qn - 64, 64);
+            qn -= 64;
         }
     }
     if (qn > 0) drain(0, qn);
     if (lane == 0) {
-        atomicAdd(&counters[0], n_eval);
-        atomicAdd(&counters[1], n_exact);
-        atomicAdd(&counters[2], n_screened);
+        count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
+        count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
+        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
     }
 }
 
-// Orthonormal basis (KD x h, row-major) of the dominant subspace of the covariance of the norm vectors:
+// Orthonormal basis (KD x nf, row-major) of the dominant subspace of the covariance of the feature vectors:
 // block power iteration with modified Gram-Schmidt.  Any orthonormal Q is valid for the bound; this one is
-// merely good.  M is the (h+1) x (h+1) second-moment matrix of k_norm_moments (upper triangle filled).
-inline void descriptor_basis(const std::vector<double> &M, int h, int n_samples, std::vector<double> &Q) {
-    const int m = h + 1;
+// merely good.  M is the (nf+1) x (nf+1) second-moment matrix of k_feature_moments (upper triangle filled).
+inline void descriptor_basis(const double *M, int nf, int n_samples, double *Q) {
+    const int h = nf, m = nf + 1, kd = KD;
+    for (int e = 0; e < kd * h; ++e) Q[e] = 0.0;
+    if (h == 0) return;
     std::vector<double> C(size_t(h) * h);
     const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
     for (int a = 0; a < h; ++a)
@@ -249,65 +296,56 @@ inline void descriptor_basis(const std::vector<double> &M, int h, int n_samples,
             double c = M[size_t(a) * m + b] * inv - mu_a * mu_b;
             C[size_t(a) * h + b] = C[size_t(b) * h + a] = c;
         }
-    const int kd = KD;
-    Q.assign(size_t(kd) * h, 0.0);
+    std::vector<double> V(size_t(kd) * h), Z(size_t(kd) * h);
     // deterministic start: spread unit vectors + a small ramp so that no start vector is orthogonal to everything
     for (int k = 0; k < kd; ++k)
-        for (int a = 0; a < h; ++a) Q[size_t(k) * h + a] = ((a % kd) == k ? 1.0 : 0.0) + 1e-3 * ((a * 7 + k * 13) % 11 - 5);
-    std::vector<double> Z(size_t(kd) * h);
-    auto orthonormalise = [&](std::vector<double> &V) {
+        for (int a = 0; a < h; ++a) V[size_t(k) * h + a] = ((a % kd) == k ? 1.0 : 0.0) + 1e-3 * ((a * 7 + k * 13) % 11 - 5);
+    auto orthonormalise = [&](std::vector<double> &W) {
         for (int k = 0; k < kd; ++k) {
-            double *v = &V[size_t(k) * h];
-            for (int rep = 0; rep < 2; ++rep)
-                for (int j = 0; j < k; ++j) {
-                    const double *u = &V[size_t(j) * h];
-                    double d = 0;
-                    for (int a = 0; a < h; ++a) d += u[a] * v[a];
-                    for (int a = 0; a < h; ++a) v[a] -= d * u[a];
-                }
-            double nn = 0;
-            for (int a = 0; a < h; ++a) nn += v[a] * v[a];
-            nn = std::sqrt(nn);
-            if (!(nn > 1e-200)) {  // degenerate direction: fall back to a unit vector not yet spanned
-                for (int a = 0; a < h; ++a) v[a] = 0.0;
-                if (k < h) v[k] = 1.0;
-                for (int j = 0; j < k; ++j) {
-                    const double *u = &V[size_t(j) * h];
-                    double d = 0;
-                    for (int a = 0; a < h; ++a) d += u[a] * v[a];
-                    for (int a = 0; a < h; ++a) v[a] -= d * u[a];
-                }
-                nn = 0;
+            double *v = &W[size_t(k) * h];
+            auto project_out = [&]() {
+                for (int rep = 0; rep < 2; ++rep)
+                    for (int j = 0; j < k; ++j) {
+                        const double *u = &W[size_t(j) * h];
+                        double d = 0;
+                        for (int a = 0; a < h; ++a) d += u[a] * v[a];
+                        for (int a = 0; a < h; ++a) v[a] -= d * u[a];
+                    }
+                double nn = 0;
                 for (int a = 0; a < h; ++a) nn += v[a] * v[a];
-                nn = std::sqrt(nn);
-                if (!(nn > 1e-200)) {  // h < KD: no direction left, a zero row keeps the bound valid
-                    for (int a = 0; a < h; ++a) v[a] = 0.0;
-                    continue;
-                }
+                return std::sqrt(nn);
+            };
+            double nn = project_out();
+            for (int trial = 0; !(nn > 1e-150) && trial < h; ++trial) {  // degenerate: try the unit vectors in turn
+                for (int a = 0; a < h; ++a) v[a] = (a == trial) ? 1.0 : 0.0;
+                nn = project_out();
+            }
+            if (!(nn > 1e-150)) {  // nf < KD: no direction left; a zero row keeps the bound valid
+                for (int a = 0; a < h; ++a) v[a] = 0.0;
+                continue;
             }
             for (int a = 0; a < h; ++a) v[a] /= nn;
         }
     };
-    orthonormalise(Q);
+    orthonormalise(V);
     for (int it = 0; it < 24; ++it) {
-        for (int k = 0; k < kd; ++k)
+        for (int k = 0; k < kd; ++k) {
+            const double *q = &V[size_t(k) * h];
+            double nz = 0;
             for (int a = 0; a < h; ++a) {
                 double acc = 0;
                 const double *crow = &C[size_t(a) * h];
-                const double *q = &Q[size_t(k) * h];
                 for (int b = 0; b < h; ++b) acc += crow[b] * q[b];
                 Z[size_t(k) * h + a] = acc;
+                nz += acc * acc;
             }
-        // keep the previous direction where C annihilates it (zero variance): the bound stays valid
-        for (int k = 0; k < kd; ++k) {
-            double nn = 0;
-            for (int a = 0; a < h; ++a) nn += Z[size_t(k) * h + a] * Z[size_t(k) * h + a];
-            if (!(nn > 1e-280))
-                for (int a = 0; a < h; ++a) Z[size_t(k) * h + a] = Q[size_t(k) * h + a];
+            if (!(nz > 1e-280))  // C annihilates this direction (no variance there): keep it, the bound stays valid
+                for (int a = 0; a < h; ++a) Z[size_t(k) * h + a] = q[a];
         }
         orthonormalise(Z);
-        Q.swap(Z);
+        V.swap(Z);
     }
+    for (int e = 0; e < kd * h; ++e) Q[e] = V[e];
 }
 
 }  // namespace tsc

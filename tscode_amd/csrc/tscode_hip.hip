@@ -45,7 +45,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) {
-        c->pinned_bytes = 4096;
+        c->pinned_bytes = 16384;
         e = hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault);
     }
     if (e != hipSuccess) {
@@ -449,17 +449,13 @@ constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel take
 
 enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2 };
 
-struct DevCounters {  // zeroed before every pass
-    unsigned long long tile[3];  // pairs whose H was formed, pairs sent to the exact path, pairs screened by descriptor
-    unsigned long long pad;
-    ApplyCounters apply;
-};
+using DevCounters = PassCounters;  // zeroed before every pass, summed on the host after it
 
 struct tsc_prune {
     tsc_ctx *ctx = nullptr;
     const double *heavy = nullptr;
     int64_t n = 0, npad = 0;
-    int h = 0, hp = 0, hd = 0;
+    int h = 0, hp = 0;
     double thr = 0;
     int mode = 0;
     int algo = ALGO_AUTO;     // requested
@@ -504,33 +500,38 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
     return 0;
 }
 
-// Descriptors of every structure for the sieve: principal axes of the atom-norm vectors (sieve.hpp).
+// Descriptors of every structure for the sieve: leading principal axes of the two feature families (sieve.hpp).
 static int build_descriptors(tsc_prune *p) {
     tsc_ctx *c = p->ctx;
     hipStream_t st = c->stream;
-    const int h = p->h, hd = p->hd, m = hd + 1;
-    Scratch s(c);
-    double *d_M, *d_Q;
-    TSC_TRY(s.get(size_t(m) * m, &d_M));
-    TSC_TRY(s.get(size_t(KD) * hd, &d_Q));
-    TSC_HIP(hipMemsetAsync(d_M, 0, size_t(m) * m * sizeof(double), st));
+    const int h = p->h;
+    const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
     const int n_samples = int(std::min<int64_t>(p->n, DESC_SAMPLE));
     const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
-    {
-        // the moments kernel reads only the first hd atoms of a structure: pass hd as its atom count and h*3 as row pitch
-        // by giving it a view in which one "structure" is h atoms wide: handled through stride arithmetic below
+    Scratch s(c);
+    double *d_M[NFAM], *d_Q;
+    std::vector<double> M[NFAM];
+    TSC_TRY(s.get(size_t(KD) * (nf[0] + nf[1]) + 1, &d_Q));
+    for (int f = 0; f < NFAM; ++f) {
+        const int m = nf[f] + 1;
+        M[f].assign(size_t(m) * m, 0.0);
+        TSC_TRY(s.get(size_t(m) * m, &d_M[f]));
+        if (nf[f] == 0) continue;
+        TSC_HIP(hipMemsetAsync(d_M[f], 0, size_t(m) * m * sizeof(double), st));
         size_t lds = size_t(32) * m * sizeof(double);
-        if (lds > 64 * 1024) TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_norm_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, p->heavy, p->n, h, hd, stride, n_samples, d_M);
+        if (lds > 64 * 1024)
+            TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, p->heavy, h, f, nf[f], stride, n_samples, d_M[f]);
         TSC_HIP(hipGetLastError());
+        TSC_HIP(hipMemcpyAsync(M[f].data(), d_M[f], M[f].size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    std::vector<double> M(size_t(m) * m), Q;
-    TSC_HIP(hipMemcpyAsync(M.data(), d_M, M.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     TSC_HIP(hipStreamSynchronize(st));
-    descriptor_basis(M, hd, n_samples, Q);
+    std::vector<double> Q(size_t(KD) * (nf[0] + nf[1]) + 1, 0.0);
+    descriptor_basis(M[0].data(), nf[0], n_samples, Q.data());
+    descriptor_basis(M[1].data(), nf[1], n_samples, Q.data() + size_t(KD) * nf[0]);
     TSC_HIP(hipMemcpyAsync(d_Q, Q.data(), Q.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), size_t(KD) * hd * sizeof(double), st, p->heavy, p->n, h, hd,
-                       (const double *)d_Q, p->Dall, p->Gall);
+    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), size_t(KD) * (nf[0] + nf[1]) * sizeof(double), st, p->heavy,
+                       p->n, h, nf[0], nf[1], (const double *)d_Q, p->Dall, p->Gall);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipStreamSynchronize(st));  // Q lives in a host vector and in scratch that is released on return
     return 0;
@@ -553,7 +554,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     p->npad = (n + 63) / 64 * 64 + 64;
     p->h = h;
     p->hp = (h + 3) / 4 * 4;
-    p->hd = std::min(h, DESC_MAX_ATOMS);
     p->thr = rmsd_thr;
     p->mode = mode;
     p->algo = c->prune_algo;
@@ -574,10 +574,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
     if (!rc) rc = palloc(p, 1, &p->counters);
     if (!rc && p->algo != ALGO_TILE) {
-        rc = palloc(p, size_t(n) * KD, &p->Dall);
+        rc = palloc(p, size_t(n) * DW, &p->Dall);
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
-        if (!rc) rc = palloc(p, size_t(p->npad) * KD, &p->Dr);
-        if (!rc) rc = palloc(p, size_t(p->npad) * KD, &p->Dc);
+        if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dr);
+        if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dc);
     }
     hipError_t e = hipSuccess;
     if (!rc) {
@@ -586,7 +586,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         if (e == hipSuccess) e = hipMemsetAsync(p->n_keys, 0, 4 * sizeof(int32_t), st);  // :183 cache = [(-1,-1)] never matches
         if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
-        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * KD * sizeof(double), st);
+        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * DW * sizeof(double), st);
+        if (e == hipSuccess && p->Dr) e = hipMemsetAsync(p->Dr, 0, size_t(p->npad) * DW * sizeof(double), st);
         if (e == hipSuccess) e = hipEventCreate(&p->ev0);
         if (e == hipSuccess) e = hipEventCreate(&p->ev1);
         if (e == hipSuccess) e = hipEventCreate(&p->evt0);
@@ -624,15 +625,17 @@ static int collect_pass(tsc_prune *p) {
     TSC_HIP(hipMemcpyAsync(c->pinned, p->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipEventSynchronize(p->ev1));
     TSC_HIP(hipStreamSynchronize(c->stream));
-    DevCounters dc;
-    memcpy(&dc, c->pinned, sizeof(dc));
+    const DevCounters *dc = static_cast<const DevCounters *>(c->pinned);
+    unsigned long long sum[CNT_WORDS] = {0};
+    for (int b = 0; b < CNT_BUCKETS; ++b)
+        for (int w = 0; w < CNT_WORDS; ++w) sum[w] += dc->w[b][w];
     tsc_pass_stats &s = p->stats[p->n_passes - 1];
-    s.pairs_computed = int64_t(dc.tile[0]);
-    s.candidates = int64_t(dc.tile[1]);
-    s.pairs_screened = int64_t(dc.tile[2]);
-    s.pairs_evaluated = int64_t(dc.apply.pairs_evaluated);
-    s.new_keys = dc.apply.removed;
-    s.n_active_after = s.n_active_before - dc.apply.removed;
+    s.pairs_computed = int64_t(sum[CNT_FORMED]);
+    s.candidates = int64_t(sum[CNT_EXACT]);
+    s.pairs_screened = int64_t(sum[CNT_SCREENED]);
+    s.pairs_evaluated = int64_t(sum[CNT_EVALUATED]);
+    s.new_keys = int64_t(sum[CNT_REMOVED]);
+    s.n_active_after = s.n_active_before - int64_t(sum[CNT_REMOVED]);
     float ms = 0;
     if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) s.gpu_ms = ms;
     if (hipEventElapsedTime(&ms, p->evt0, p->evt1) == hipSuccess) s.tile_ms = ms;
@@ -667,7 +670,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_pr
 template <int HP>
 static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const TileArgs &a) {
     hipLaunchKernelGGL((k_rmsd_tile<HP, TILE_ROWS>), grid, dim3(256), 0, st, (const double *)p->Xr, (const double *)p->Xc,
-                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters->tile, a);
+                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, a);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
@@ -702,13 +705,15 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         TSC_HIP(hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st));
         hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit);
     }
-    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, A, p->act, p->pos, p->mbit, p->dbit, p->cend);
-    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(A, 256)), dim3(256), 0, st, p->best, int64_t(A), INT_MAX);
+    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, A, p->act, p->pos, p->mbit, p->dbit, p->cend, p->best);
     // 4. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
-    const int seg_cols = c->seg_cols;
     const int n_tiles = ceil_div(A, TILE_ROWS);
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
+    // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
+    // work (many small chunks), long ones amortise the per-item setup when it has a lot
+    int seg_cols = c->seg_cols;
+    while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     const int n_seg = ceil_div(max_range + 64, seg_cols);
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
@@ -738,7 +743,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.desc_limit = double(p->h) * p->thr * p->thr * (1.0 + 1e-9);
         hipLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters->tile, a);
+                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters, a);
     }
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipEventRecord(p->evt1, st));
@@ -769,7 +774,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     const int A = int(p->n_active);
     PassGeom g{p->n, p->cur_k, p->n / p->cur_k};
     hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div(A, 256)), dim3(256), 0, c->stream, g, A, p->act, p->cend, p->best, p->mask, p->key_a,
-                       p->key_b, p->n_keys, &p->counters->apply);
+                       p->key_b, p->n_keys, p->counters);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipEventRecord(p->ev1, c->stream));
     tsc_pass_stats &s = p->stats[p->n_passes++];
