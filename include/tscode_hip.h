@@ -159,7 +159,11 @@ int tsc_prune_rmsd_dev(tsc_ctx *ctx, const double *heavy, int64_t n, int h, doub
  *                            tsc_prune_pass_finish; }                 // identical mask/cache update on every rank
  *   tsc_prune_mask_dev gives the device mask; tsc_prune_destroy frees the state. */
 int tsc_prune_create(tsc_ctx *ctx, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out);
-int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the schedule is exhausted; synchronises */
+int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the schedule is exhausted; does not wait:
+                                                                      the gate of rmsd_pruning.py:192 is evaluated on the
+                                                                      device, a pass whose gate is closed does nothing */
+int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs);        /* upper bound of the pairs of the open pass: lets every
+                                                                      rank decide alike whether sharding it pays */
 int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous */
 int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i32[n_entries], valid until finish */
 /* Make the run keep best[] in a caller-owned device buffer of n int32 (e.g. a torch tensor that

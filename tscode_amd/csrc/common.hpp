@@ -68,6 +68,7 @@ struct tsc_ctx {
     size_t pinned_bytes = 0;
     int prune_algo = 0;                   // tsc_ctx_set_option("prune_algo"): 0 auto, 1 register-tiled, 2 sieve
     int seg_cols = 2048;                  // columns per pair-kernel work item
+    std::vector<hipEvent_t> event_pool;   // recycled timing events of prune runs
 
     int alloc(size_t bytes, void **out) {
         if (bytes == 0) bytes = 8;

@@ -229,6 +229,58 @@ __device__ inline void count_add(PassCounters *c, unsigned bucket, int what, uns
     if (v) atomicAdd(&c->w[bucket & (CNT_BUCKETS - 1)][what], v);
 }
 
+// Device-resident control block of a prune run.  The host enqueues every pass that COULD run (20 k < N) without
+// waiting for counts; k_pass_step evaluates the reference's gate `k == 1 or 20*k < count_nonzero(mask)`
+// (rmsd_pruning.py:192) on the device and the kernels of a pass that is gated off return immediately.
+struct PruneState {
+    int n_active;  // count_nonzero(mask) after the last finished pass
+    int pass_on;   // gate of the pass in flight
+    int A;         // active structures entering the pass in flight (== n_active at its start)
+    int pad;
+};
+struct PassRecord {  // one per schedule slot, read back once at the end of the run
+    long long k, n_before, n_after, formed, exact, screened, evaluated, removed;
+    int on, algo;
+};
+
+// Closes the pass in slot `prev` (sums its counters, updates n_active) and opens the pass in slot `cur` (gate, A,
+// zeroed counters and cache-view bitmap).  prev / cur = -1: nothing to close / open.  One block of 256 threads.
+__global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec,
+                                                    int prev, int cur, long long k_cur, int algo_cur, unsigned long long *__restrict__ dbit,
+                                                    int bit_words) {
+    __shared__ unsigned long long s_sum[CNT_WORDS];
+    const bool closing = prev >= 0 && st->pass_on != 0;
+    if (closing && threadIdx.x < CNT_WORDS) {
+        unsigned long long v = 0;
+        for (int b = 0; b < CNT_BUCKETS; ++b) v += cnt->w[b][threadIdx.x];
+        s_sum[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (closing) {
+            PassRecord &r = rec[prev];
+            r.formed = (long long)s_sum[CNT_FORMED], r.exact = (long long)s_sum[CNT_EXACT], r.screened = (long long)s_sum[CNT_SCREENED];
+            r.evaluated = (long long)s_sum[CNT_EVALUATED], r.removed = (long long)s_sum[CNT_REMOVED];
+            st->n_active -= int(s_sum[CNT_REMOVED]);
+            r.n_after = st->n_active;
+        }
+        int on = 0;
+        if (cur >= 0) {
+            on = (k_cur == 1 || 20 * k_cur < (long long)st->n_active) ? 1 : 0;  // rmsd_pruning.py:192
+            PassRecord &r = rec[cur];
+            r.k = k_cur, r.n_before = st->n_active, r.n_after = st->n_active, r.on = on, r.algo = algo_cur;
+            r.formed = r.exact = r.screened = r.evaluated = r.removed = 0;
+        }
+        st->A = st->n_active;
+        st->pass_on = on;
+    }
+    __syncthreads();
+    unsigned long long *c = &cnt->w[0][0];
+    for (int e = threadIdx.x; e < CNT_BUCKETS * CNT_WORDS; e += 256) c[e] = 0;
+    if (cur >= 0)
+        for (int e = threadIdx.x; e < bit_words; e += 256) dbit[e] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-pass helper kernels (see prune.hpp for the pass sequence)
 
@@ -249,7 +301,8 @@ __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, in
 // start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
 __global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a,
                                                      const int32_t *__restrict__ key_b, const int32_t *__restrict__ n_keys,
-                                                     unsigned long long *__restrict__ dbit) {
+                                                     unsigned long long *__restrict__ dbit, const PruneState *__restrict__ st) {
+    if (st->pass_on == 0) return;
     int nk = *n_keys;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
         int64_t a = key_a[q], b = key_b[q];
@@ -272,14 +325,23 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 // One wavefront per active row i: cend[r] = rank of the first active column j in (i, last) with
 // (first + (j - i)) in the cache view (the row returns "not similar" there, :66-67), else rank of `last`.
 // Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
-__global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, int n_active, const int32_t *__restrict__ act_idx,
-                                                    const int32_t *__restrict__ pos, const unsigned long long *__restrict__ mbit,
-                                                    const unsigned long long *__restrict__ dbit, int32_t *__restrict__ cend,
-                                                    int32_t *__restrict__ best) {
+// The same wavefront also initialises best[r] and, for the sieve, copies the row's descriptor (dw doubles of D, original
+// index space) into the two compacted layouts Dr[r][dw] / Dc[k][ld].
+__global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
+                                                    const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
+                                                    const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
+                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, const double *__restrict__ D, int dw,
+                                                    double *__restrict__ Dr, double *__restrict__ Dc, int64_t ld) {
+    if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_active) return;
+    if (r >= st->A) return;
     int64_t i = act_idx[r], first, last;
+    if (D && lane < dw) {
+        const double v = D[i * dw + lane];
+        Dr[int64_t(r) * dw + lane] = v;
+        Dc[int64_t(lane) * ld + r] = v;
+    }
     chunk_of(g, i, first, last);
     int64_t found = last;
     if (use_cache) {
@@ -313,12 +375,15 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, in
 //   G[r] = sum |x|^2
 // One block moves 64 structures through an LDS tile so that both global sides are coalesced.
 __global__ __launch_bounds__(256) void k_compact_coords(const double *__restrict__ heavy, int h, int hp3,
-                                                         const int32_t *__restrict__ act_idx, int n_active,
+                                                         const int32_t *__restrict__ act_idx, const PruneState *__restrict__ st,
                                                          double *__restrict__ Xr, double *__restrict__ Xc, int64_t ld,
                                                          double *__restrict__ G) {
     extern __shared__ __attribute__((aligned(16))) double s_tile[];  // [64][hp3 + 1]
+    if (st->pass_on == 0) return;
+    const int n_active = st->A;
     const int h3 = h * 3, pitch = hp3 + 1;
     const int r0 = blockIdx.x * 64;
+    if (r0 >= n_active) return;
     const int nr = min(64, n_active - r0);
     for (int e = threadIdx.x; e < 64 * hp3; e += 256) {
         int rr = e / hp3, d = e - rr * hp3;
@@ -347,9 +412,7 @@ __global__ __launch_bounds__(256) void k_compact_coords(const double *__restrict
 
 struct TileArgs {
     long long ld;     // leading dimension of Xc (structures per coordinate row)
-    int n_active;
     int h;
-    int n_tiles;      // row tiles of TI rows
     int tile_begin;   // first tile of this rank
     int tile_stride;  // world size (row tiles are dealt round-robin to ranks)
     int seg_cols;     // columns per grid.y segment (multiple of 64)
@@ -389,7 +452,7 @@ template <int HP, int TI>
 __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__ Xr, const double *__restrict__ Xc,
                                                        const double *__restrict__ G, const int32_t *__restrict__ cend,
                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                       TileArgs a) {
+                                                       const PruneState *__restrict__ st, TileArgs a) {
     // Xr [n_active][HP*3] row structures; Xc [HP*3][ld] column structures; G [ld] squared norms;
     // cend [n_active] exclusive column bound of each row; best [n_active] atomicMin target (INT_MAX = none);
     // counters[0] pairs computed, counters[1] pairs sent to the exact path.
@@ -397,11 +460,13 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
     constexpr int HP3 = HP * 3;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (st->pass_on == 0) return;
+    const int n_active = st->A;
     const int slot = blockIdx.x * 4 + wid;
     const int tile = a.tile_begin + slot * a.tile_stride;
-    if (tile >= a.n_tiles) return;
     const int r0 = tile * TI;
-    const int nrows = min(TI, a.n_active - r0);
+    if (r0 >= n_active) return;
+    const int nrows = min(TI, n_active - r0);
     const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
     const int seg_hi = seg_lo + a.seg_cols;
 
@@ -479,11 +544,13 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
 
 // Apply a finished pass: rows with a similar column are removed (:113) and leave one cache key each
 // (:76, appended after the pass at :204); counts what the reference's sequential scan would have evaluated.
-__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, int n_active, const int32_t *__restrict__ act_idx,
+__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ act_idx,
                                                      const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
                                                      uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
                                                      int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
                                                      PassCounters *__restrict__ cnt) {
+    if (st->pass_on == 0) return;
+    const int n_active = st->A;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     unsigned long long ev = 0;

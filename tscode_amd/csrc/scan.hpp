@@ -29,9 +29,11 @@ __device__ inline int count_nonzero_bytes(uint64_t v) {
 }
 
 // pass 1: per-block count of non-zero mask bytes
+// gate (optional): the kernels of a speculatively enqueued pass return at once when *gate == 0.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t *__restrict__ mask, int64_t n,
-                                                                   int32_t *__restrict__ bsum) {
+                                                                   int32_t *__restrict__ bsum, const int *__restrict__ gate) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
+    if (gate && *gate == 0) return;
     int64_t base = (int64_t(blockIdx.x) * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
     int c = (base < n) ? count_nonzero_bytes(load_mask8(mask, base, n)) : 0;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -41,9 +43,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t 
 }
 
 // pass 2: one block turns block counts into exclusive block offsets; total -> *total_out (and bsum[nb])
-__global__ __launch_bounds__(1024) void k_scan_offsets(int32_t *__restrict__ bsum, int nb, int32_t *__restrict__ total_out) {
+__global__ __launch_bounds__(1024) void k_scan_offsets(int32_t *__restrict__ bsum, int nb, int32_t *__restrict__ total_out,
+                                                        const int *__restrict__ gate) {
     __shared__ int s_part[1024];
     __shared__ int s_carry;
+    if (gate && *gate == 0) return;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (int start = 0; start < nb; start += 1024) {
@@ -74,8 +78,10 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(int32_t *__restrict__ bsu
 // kept indices (act_idx[pos[i]] = i) and the mask as a bit array (bit i of mbit = mask[i] != 0).
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
                                                               const int32_t *__restrict__ boff, int32_t *__restrict__ pos,
-                                                              int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes) {
+                                                              int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
+                                                              const int *__restrict__ gate) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
+    if (gate && *gate == 0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int64_t base = (int64_t(blockIdx.x) * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
     uint64_t v = (base < n) ? load_mask8(mask, base, n) : 0;
@@ -109,11 +115,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__re
 // Enqueue the three passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
 // act_idx / mbit are produced); total_dev (optional) receives count_nonzero(mask).
 inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
-                     uint8_t *mbit_bytes, int32_t *total_dev) {
+                     uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr) {
     int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum);
-    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, bsum, nb, total_dev);
-    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, pos, act_idx, mbit_bytes);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, gate);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, bsum, nb, total_dev, gate);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, pos, act_idx, mbit_bytes, gate);
     TSC_HIP(hipGetLastError());
     return 0;
 }

@@ -102,26 +102,9 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
     G[i] = g;
 }
 
-// per pass: descriptors of the active structures in the two layouts the sieve reads
-//   Dr[r][DW] (rows: staged in LDS per work item)   Dc[k][ld] (columns: lane = column)
-__global__ __launch_bounds__(256) void k_compact_desc(const double *__restrict__ D, const int32_t *__restrict__ act, int n_active,
-                                                       double *__restrict__ Dr, double *__restrict__ Dc, int64_t ld) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_active) return;
-    const double *src = D + int64_t(act[r]) * DW;
-#pragma unroll
-    for (int k = 0; k < DW; ++k) {
-        double v = src[k];
-        Dr[int64_t(r) * DW + k] = v;
-        Dc[int64_t(k) * ld + r] = v;
-    }
-}
-
 struct SieveArgs {
     long long ld;
-    int n_active;
     int h;
-    int n_tiles;
     int tile_begin;
     int tile_stride;
     int seg_cols;
@@ -162,18 +145,21 @@ template <int TI>
 __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const double *__restrict__ Dr,
                                                         const double *__restrict__ Dc, const int32_t *__restrict__ cend,
-                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters, SieveArgs a) {
+                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                        const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
     constexpr int QCAP = TI * 64 + 64;  // one column tile can add TI*64 pairs on top of a remainder below 64
     __shared__ unsigned s_queue[4][QCAP];
     __shared__ __attribute__((aligned(16))) double s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (st->pass_on == 0) return;
+    const int n_active = st->A;
     const int slot = blockIdx.x * 4 + wid;
     const int tile = a.tile_begin + slot * a.tile_stride;
-    if (tile >= a.n_tiles) return;
     const int r0 = tile * TI;
-    const int nrows = min(TI, a.n_active - r0);
+    if (r0 >= n_active) return;
+    const int nrows = min(TI, n_active - r0);
     const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
     const int seg_hi = seg_lo + a.seg_cols;
 

@@ -62,6 +62,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->cache) (void)hipFree(kv.second);
     for (auto &kv : c->live) (void)hipFree(kv.first);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -441,6 +442,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c,
 
 // --------------------------------------------------------------------------------------------------
 // K3: prune_conformers_rmsd
+//
+// A run is a sequence of passes over the schedule of rmsd_pruning.py:186-188.  Nothing in a pass waits for the
+// host: the gate of :192 is evaluated on the device (k_pass_step) and every pass that COULD run (20 k < N) is
+// enqueued with grids sized for N structures; kernels of a pass that is gated off, and blocks beyond the number
+// of still-active structures, return at once.  The host reads the per-pass records once, at the end.
 
 static const double KS[TSC_MAX_PASSES] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};  // :186-188
 
@@ -449,8 +455,6 @@ constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel take
 
 enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2 };
 
-using DevCounters = PassCounters;  // zeroed before every pass, summed on the host after it
-
 struct tsc_prune {
     tsc_ctx *ctx = nullptr;
     const double *heavy = nullptr;
@@ -458,27 +462,30 @@ struct tsc_prune {
     int h = 0, hp = 0;
     double thr = 0;
     int mode = 0;
-    int algo = ALGO_AUTO;     // requested
-    int cur_algo = ALGO_SIEVE;  // used by the next pass
+    int algo = ALGO_SIEVE;  // pair kernel of this run
     // device state
     uint8_t *mask = nullptr;
     int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
     int32_t *bsum = nullptr, *total = nullptr;
     unsigned long long *mbit = nullptr, *dbit = nullptr;
     size_t bit_words = 0;
-    double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel (lazy)
+    double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     double *Dall = nullptr, *Gall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel
-    DevCounters *counters = nullptr;
+    PassCounters *counters = nullptr;
+    PruneState *state = nullptr;
+    PassRecord *records = nullptr;  // [TSC_MAX_PASSES]
     std::vector<void *> blocks;
     // host state
-    int next_ks = 0;           // next index into KS to consider
-    int64_t n_active = 0;      // count_nonzero(mask) as of the last finished pass
-    int64_t cur_k = 0;         // pass in flight (0 = none)
+    int next_ks = 0;       // next index into KS to consider
+    int cur_slot = -1;     // schedule slot of the pass in flight (-1 = none)
+    int last_slot = -1;    // slot of the last pass that was enqueued and not yet closed on the device
+    int64_t cur_k = 0;
     bool local_done = false;
+    bool slot_used[TSC_MAX_PASSES] = {false};
+    hipEvent_t ev[TSC_MAX_PASSES][4] = {{nullptr}};  // per slot: pass begin, pair kernel begin, pair kernel end, pass end
     tsc_pass_stats stats[TSC_MAX_PASSES];
     int n_passes = 0;
-    bool stats_pending = false;  // counters of the last finished pass not yet read back
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evt0 = nullptr, evt1 = nullptr;
+    bool collected = false;
 };
 
 template <typename T>
@@ -494,8 +501,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
     if (!p) return 0;
     DeviceGuard guard(p->ctx->device);
     for (void *q : p->blocks) p->ctx->release(q);
-    for (hipEvent_t e : {p->ev0, p->ev1, p->evt0, p->evt1})
-        if (e) (void)hipEventDestroy(e);
+    for (auto &slot : p->ev)
+        for (hipEvent_t e : slot)
+            if (e) p->ctx->event_pool.push_back(e);
     delete p;
     return 0;
 }
@@ -537,6 +545,16 @@ static int build_descriptors(tsc_prune *p) {
     return 0;
 }
 
+static int get_event(tsc_ctx *c, hipEvent_t *e) {
+    if (!c->event_pool.empty()) {
+        *e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return 0;
+    }
+    TSC_HIP(hipEventCreate(e));
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
@@ -556,8 +574,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     p->hp = (h + 3) / 4 * 4;
     p->thr = rmsd_thr;
     p->mode = mode;
-    p->algo = c->prune_algo;
-    p->cur_algo = (p->algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
+    p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
     p->bit_words = size_t(n / 64 + 4);
     int rc = 0;
     if (!rc) rc = palloc(p, size_t(n), &p->mask);
@@ -573,25 +590,38 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
     if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
     if (!rc) rc = palloc(p, 1, &p->counters);
-    if (!rc && p->algo != ALGO_TILE) {
+    if (!rc) rc = palloc(p, 1, &p->state);
+    if (!rc) rc = palloc(p, TSC_MAX_PASSES, &p->records);
+    if (!rc && p->algo == ALGO_SIEVE) {
         rc = palloc(p, size_t(n) * DW, &p->Dall);
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
         if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dr);
         if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dc);
     }
+    if (!rc && p->algo == ALGO_TILE) {
+        const size_t hp3 = size_t(p->hp) * 3;
+        rc = palloc(p, size_t(p->npad) * hp3, &p->Xr);
+        if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xc);
+        if (!rc) rc = palloc(p, size_t(p->npad), &p->G);
+    }
     hipError_t e = hipSuccess;
     if (!rc) {
         hipStream_t st = c->stream;
+        PruneState init{int(n), 0, int(n), 0};
+        memcpy(c->pinned, &init, sizeof(init));
         e = hipMemsetAsync(p->mask, 1, size_t(n), st);  // rmsd_pruning.py:182 out_mask = ones
+        if (e == hipSuccess) e = hipMemcpyAsync(p->state, c->pinned, sizeof(init), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(p->n_keys, 0, 4 * sizeof(int32_t), st);  // :183 cache = [(-1,-1)] never matches
+        if (e == hipSuccess) e = hipMemsetAsync(p->records, 0, sizeof(PassRecord) * TSC_MAX_PASSES, st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, sizeof(PassCounters), st);
         if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
         if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * DW * sizeof(double), st);
         if (e == hipSuccess && p->Dr) e = hipMemsetAsync(p->Dr, 0, size_t(p->npad) * DW * sizeof(double), st);
-        if (e == hipSuccess) e = hipEventCreate(&p->ev0);
-        if (e == hipSuccess) e = hipEventCreate(&p->ev1);
-        if (e == hipSuccess) e = hipEventCreate(&p->evt0);
-        if (e == hipSuccess) e = hipEventCreate(&p->evt1);
+        if (e == hipSuccess && p->Xc) e = hipMemsetAsync(p->Xc, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
+        if (e == hipSuccess && p->Xr) e = hipMemsetAsync(p->Xr, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
+        if (e == hipSuccess && p->G) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the pinned staging buffer is reused below
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
     }
     if (!rc && p->Dall) rc = build_descriptors(p);
@@ -599,66 +629,22 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         tsc_prune_destroy(p);
         return rc;
     }
-    p->n_active = n;
     *out = p;
-    return 0;
-}
-
-// Buffers of the register-tiled kernel, on first use.
-static int ensure_tile_buffers(tsc_prune *p) {
-    if (p->Xr) return 0;
-    const size_t hp3 = size_t(p->hp) * 3;
-    TSC_TRY(palloc(p, size_t(p->npad) * hp3, &p->Xr));
-    TSC_TRY(palloc(p, size_t(p->npad) * hp3, &p->Xc));
-    TSC_TRY(palloc(p, size_t(p->npad), &p->G));
-    hipStream_t st = p->ctx->stream;
-    TSC_HIP(hipMemsetAsync(p->Xc, 0, size_t(p->npad) * hp3 * sizeof(double), st));
-    TSC_HIP(hipMemsetAsync(p->Xr, 0, size_t(p->npad) * hp3 * sizeof(double), st));
-    TSC_HIP(hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st));
-    return 0;
-}
-
-// Read back the counters of the pass that finished last (needs a sync; called from next_pass / stats).
-static int collect_pass(tsc_prune *p) {
-    if (!p->stats_pending) return 0;
-    tsc_ctx *c = p->ctx;
-    TSC_HIP(hipMemcpyAsync(c->pinned, p->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-    TSC_HIP(hipEventSynchronize(p->ev1));
-    TSC_HIP(hipStreamSynchronize(c->stream));
-    const DevCounters *dc = static_cast<const DevCounters *>(c->pinned);
-    unsigned long long sum[CNT_WORDS] = {0};
-    for (int b = 0; b < CNT_BUCKETS; ++b)
-        for (int w = 0; w < CNT_WORDS; ++w) sum[w] += dc->w[b][w];
-    tsc_pass_stats &s = p->stats[p->n_passes - 1];
-    s.pairs_computed = int64_t(sum[CNT_FORMED]);
-    s.candidates = int64_t(sum[CNT_EXACT]);
-    s.pairs_screened = int64_t(sum[CNT_SCREENED]);
-    s.pairs_evaluated = int64_t(sum[CNT_EVALUATED]);
-    s.new_keys = int64_t(sum[CNT_REMOVED]);
-    s.n_active_after = s.n_active_before - int64_t(sum[CNT_REMOVED]);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) s.gpu_ms = ms;
-    if (hipEventElapsedTime(&ms, p->evt0, p->evt1) == hipSuccess) s.tile_ms = ms;
-    p->n_active = s.n_active_after;
-    p->stats_pending = false;
-    // automatic choice for the next pass: the sieve pays while it drops most pairs; when more than a quarter of
-    // the screened pairs still need H, the register-tiled kernel (all pairs, no screening) is the faster one
-    if (p->algo == ALGO_AUTO && p->h <= MAX_HP && s.algo == ALGO_SIEVE && s.pairs_screened > 100000 &&
-        s.pairs_computed * 4 > s.pairs_screened)
-        p->cur_algo = ALGO_TILE;
     return 0;
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out) {
     TSC_REQUIRE(p && k_out, "null argument");
     if (p->cur_k != 0) return fail(TSC_ERR_STATE, "tsc_prune_next_pass: previous pass not finished");
-    DeviceGuard guard(p->ctx->device);
-    TSC_TRY(collect_pass(p));
     *k_out = 0;
     while (p->next_ks < TSC_MAX_PASSES) {
-        int64_t k = int64_t(KS[p->next_ks++]);  // int(k): the reference itself fails for float k
-        if (k == 1 || 20 * k < p->n_active) {   // rmsd_pruning.py:192
+        const int slot = p->next_ks++;
+        const int64_t k = int64_t(KS[slot]);  // int(k): the reference itself fails for float k
+        // count_nonzero(mask) <= n, so a pass with 20 k >= n can never pass the gate of :192; the others are enqueued
+        // and gated on the device
+        if (k == 1 || 20 * k < p->n) {
             p->cur_k = k;
+            p->cur_slot = slot;
             p->local_done = false;
             *k_out = k;
             return 0;
@@ -667,10 +653,19 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_pr
     return 0;
 }
 
+// Rough size of the open pass in pairs (n structures, every row against half of an average chunk); it depends only
+// on n and k, so every rank of a sharded run computes the same number.
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs) {
+    TSC_REQUIRE(p && pairs, "null argument");
+    if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_pass_estimate: no pass open");
+    *pairs = p->n * (p->n / p->cur_k) / 2;
+    return 0;
+}
+
 template <int HP>
 static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const TileArgs &a) {
     hipLaunchKernelGGL((k_rmsd_tile<HP, TILE_ROWS>), grid, dim3(256), 0, st, (const double *)p->Xr, (const double *)p->Xc,
-                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, a);
+                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
@@ -681,32 +676,34 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     DeviceGuard guard(c->device);
     hipStream_t st = c->stream;
     const int64_t n = p->n, k = p->cur_k;
-    const int A = int(p->n_active);
+    const int slot = p->cur_slot;
+    const int A = int(n);  // grids are sized for the upper bound; kernels read the true count from the state block
     PassGeom g{n, k, n / k};
-    const int algo = p->cur_algo;
-    if (algo == ALGO_TILE) TSC_TRY(ensure_tile_buffers(p));
-    TSC_HIP(hipEventRecord(p->ev0, st));
-    TSC_HIP(hipMemsetAsync(p->counters, 0, sizeof(DevCounters), st));
+    const int *gate = &p->state->pass_on;
+    for (int i = 0; i < 4; ++i)
+        if (!p->ev[slot][i]) TSC_TRY(get_event(c, &p->ev[slot][i]));
+    TSC_HIP(hipEventRecord(p->ev[slot][0], st));
+    // 0. close the previous pass, open this one: gate (:192), counters, cache-view bitmap
+    hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, p->last_slot, slot, (long long)k, p->algo, p->dbit,
+                       int(p->bit_words));
+    p->last_slot = slot;
+    p->slot_used[slot] = true;
     // 1. ranks of the active structures, their index list and the mask as bits
-    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total));
-    // 2. what the pair kernel reads, gathered for the active structures
-    if (algo == ALGO_TILE) {
+    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total, gate));
+    // 2. cache view of this pass; stop column, best[] and compacted descriptor of every row
+    const int use_cache = (p->mode == 0);
+    if (use_cache)
+        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit,
+                           (const PruneState *)p->state);
+    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
+                       p->dbit, p->cend, p->best, (const double *)p->Dall, DW, p->Dr, p->Dc, p->npad);
+    if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
-        hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, A, p->Xr, p->Xc,
-                           p->npad, p->G);
-    } else {
-        hipLaunchKernelGGL(k_compact_desc, dim3(ceil_div(A, 256)), dim3(256), 0, st, (const double *)p->Dall, (const int32_t *)p->act, A,
-                           p->Dr, p->Dc, p->npad);
+        hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, (const PruneState *)p->state,
+                           p->Xr, p->Xc, p->npad, p->G);
     }
-    // 3. cache view of this pass and the stop column of every row
-    const int use_cache = (p->mode == 0);
-    if (use_cache) {
-        TSC_HIP(hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st));
-        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit);
-    }
-    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, A, p->act, p->pos, p->mbit, p->dbit, p->cend, p->best);
-    // 4. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
+    // 3. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
     const int n_tiles = ceil_div(A, TILE_ROWS);
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
@@ -717,11 +714,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int n_seg = ceil_div(max_range + 64, seg_cols);
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
-    TSC_HIP(hipEventRecord(p->evt0, st));
-    if (algo == ALGO_TILE) {
+    TSC_HIP(hipEventRecord(p->ev[slot][1], st));
+    if (p->algo == ALGO_TILE) {
         TileArgs a;
-        a.ld = p->npad, a.n_active = A, a.h = p->h;
-        a.n_tiles = n_tiles, a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.ld = p->npad, a.h = p->h;
+        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         switch (p->hp) {
@@ -737,16 +734,17 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         }
     } else {
         SieveArgs a;
-        a.ld = p->npad, a.n_active = A, a.h = p->h;
-        a.n_tiles = n_tiles, a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.ld = p->npad, a.h = p->h;
+        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.desc_limit = double(p->h) * p->thr * p->thr * (1.0 + 1e-9);
         hipLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters, a);
+                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                           (const PruneState *)p->state, a);
     }
     TSC_HIP(hipGetLastError());
-    TSC_HIP(hipEventRecord(p->evt1, st));
+    TSC_HIP(hipEventRecord(p->ev[slot][2], st));
     p->local_done = true;
     return 0;
 }
@@ -755,13 +753,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_pru
     TSC_REQUIRE(p && best_dev && n_entries, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_best_ptr: no pass open");
     *best_dev = p->best;
-    *n_entries = p->n_active;
+    *n_entries = p->n;  // entries beyond the (device-side) active count are not touched by the pass
     return 0;
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev) {
     TSC_REQUIRE(p && best_dev, "null argument");
-    if (p->cur_k != 0 || p->n_passes != 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
+    if (p->cur_k != 0 || p->last_slot >= 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
     p->best = static_cast<int32_t *>(best_dev);
     return 0;
 }
@@ -771,19 +769,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
-    const int A = int(p->n_active);
     PassGeom g{p->n, p->cur_k, p->n / p->cur_k};
-    hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div(A, 256)), dim3(256), 0, c->stream, g, A, p->act, p->cend, p->best, p->mask, p->key_a,
-                       p->key_b, p->n_keys, p->counters);
+    hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), 0, c->stream, g, (const PruneState *)p->state, p->act, p->cend,
+                       p->best, p->mask, p->key_a, p->key_b, p->n_keys, p->counters);
     TSC_HIP(hipGetLastError());
-    TSC_HIP(hipEventRecord(p->ev1, c->stream));
-    tsc_pass_stats &s = p->stats[p->n_passes++];
-    memset(&s, 0, sizeof(s));
-    s.k = p->cur_k;
-    s.n_active_before = p->n_active;
-    s.algo = p->cur_algo;
-    p->stats_pending = true;
+    TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
     p->cur_k = 0;
+    p->cur_slot = -1;
+    p->collected = false;
     return 0;
 }
 
@@ -800,10 +793,37 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_copy_mask_dev(ts
     return 0;
 }
 
+// Close the last pass on the device, read the records back (the one synchronisation of a run) and build the
+// per-pass statistics of the passes whose gate was open.
 extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes) {
     TSC_REQUIRE(p != nullptr, "null argument");
-    DeviceGuard guard(p->ctx->device);
-    TSC_TRY(collect_pass(p));
+    if (p->cur_k != 0) return fail(TSC_ERR_STATE, "tsc_prune_stats: a pass is still open");
+    tsc_ctx *c = p->ctx;
+    DeviceGuard guard(c->device);
+    if (!p->collected) {
+        hipStream_t st = c->stream;
+        if (p->last_slot >= 0) {
+            hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, p->last_slot, -1, 0ll, 0, p->dbit, 0);
+            p->last_slot = -1;
+        }
+        static_assert(sizeof(PassRecord) * TSC_MAX_PASSES <= 4096, "records fit the pinned staging buffer");
+        TSC_HIP(hipMemcpyAsync(c->pinned, p->records, sizeof(PassRecord) * TSC_MAX_PASSES, hipMemcpyDeviceToHost, st));
+        TSC_HIP(hipStreamSynchronize(st));
+        const PassRecord *rec = static_cast<const PassRecord *>(c->pinned);
+        p->n_passes = 0;
+        for (int slot = 0; slot < TSC_MAX_PASSES; ++slot) {
+            if (!p->slot_used[slot] || !rec[slot].on) continue;
+            tsc_pass_stats &s = p->stats[p->n_passes++];
+            memset(&s, 0, sizeof(s));
+            s.k = rec[slot].k, s.n_active_before = rec[slot].n_before, s.n_active_after = rec[slot].n_after;
+            s.pairs_evaluated = rec[slot].evaluated, s.pairs_computed = rec[slot].formed, s.candidates = rec[slot].exact;
+            s.pairs_screened = rec[slot].screened, s.new_keys = rec[slot].removed, s.algo = rec[slot].algo;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
+            if (hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
+        }
+        p->collected = true;
+    }
     if (stats) memcpy(stats, p->stats, sizeof(tsc_pass_stats) * size_t(p->n_passes));
     if (n_passes) *n_passes = p->n_passes;
     return 0;
@@ -825,12 +845,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx
         if ((rc = tsc_prune_pass_local(p, 0, 1)) != 0) break;
         if ((rc = tsc_prune_pass_finish(p)) != 0) break;
     }
-    if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
     if (!rc) {
         DeviceGuard guard(c->device);
         hipError_t e = hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
     }
+    if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
     tsc_prune_destroy(p);
     return rc;
 }
@@ -855,8 +875,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c,
     return 0;
 }
 
-// Tunables: "prune_algo" 0 = automatic (sieve, falling back to the register-tiled kernel when the sieve stops
-// paying), 1 = register-tiled all-pairs kernel (h <= 32), 2 = descriptor sieve; "seg_cols" = columns per work item.
+// Tunables: "prune_algo" 0 / 2 = descriptor sieve (any size), 1 = register-tiled all-pairs kernel (h <= 32);
+// "seg_cols" = columns per work item.
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx *c, const char *name, double value) {
     TSC_REQUIRE(c && name, "null argument");
     if (strcmp(name, "prune_algo") == 0) {

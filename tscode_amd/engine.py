@@ -231,6 +231,11 @@ class PruneStepper:
         check(self.e.lib.tsc_prune_next_pass(self._p, C.byref(k)))
         return k.value
 
+    def pass_estimate(self) -> int:
+        n = C.c_int64()
+        check(self.e.lib.tsc_prune_pass_estimate(self._p, C.byref(n)))
+        return n.value
+
     def pass_local(self, rank=0, world=1):
         check(self.e.lib.tsc_prune_pass_local(self._p, C.c_int(rank), C.c_int(world)))
 

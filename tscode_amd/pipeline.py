@@ -24,7 +24,12 @@ import numpy as np
 
 from .engine import FragmentSet, get_engine
 
-__all__ = ["DevicePipeline", "HipShardBackend", "sharded_step", "block_bounds"]
+__all__ = ["DevicePipeline", "HipShardBackend", "sharded_step", "block_bounds", "SHARD_MIN_PAIRS"]
+
+# A pass smaller than this many pairs (estimate n * (n / k) / 2, identical on every rank) is not worth a collective:
+# every rank runs it whole and reaches the same verdicts on its own.  On MI355X such a pass takes tens of
+# microseconds, the same as one small all-reduce over xGMI.
+SHARD_MIN_PAIRS = 50_000_000
 
 
 def block_bounds(n: int, rank: int, world: int):
@@ -38,7 +43,7 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
     backend interface (all tensors live where the backend computes):
         embed_clash_block() -> n_pass_local      fills backend.heavy_local[:n_pass_local]  (h, 3 per row)
         heavy_pad, gather, heavy_all, counts, keep, max_local, best      preallocated tensors / int
-        make_stepper(n_pass) -> stepper with next_pass(), pass_local(rank, world), n_active(), pass_finish(),
+        make_stepper(n_pass) -> stepper with next_pass(), pass_estimate(), pass_local(rank, world), n_active(), pass_finish(),
                                 stats(), copy_mask(dst), close(); it keeps best[] in backend.best
     """
     n_pass_local = int(backend.embed_clash_block())
@@ -63,8 +68,11 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
                 k = st.next_pass()
                 if k == 0:
                     break
-                st.pass_local(rank, world)
-                dist.all_reduce(backend.best[:st.n_active()], op=dist.ReduceOp.MIN, group=group)
+                if world > 1 and st.pass_estimate() >= SHARD_MIN_PAIRS:
+                    st.pass_local(rank, world)          # this rank's row tiles only ...
+                    dist.all_reduce(backend.best[:st.n_active()], op=dist.ReduceOp.MIN, group=group)   # ... merged
+                else:
+                    st.pass_local(0, 1)                 # small pass: replicated, no exchange
                 st.pass_finish()
             stats = st.stats()
             st.copy_mask(backend.keep)
@@ -80,6 +88,9 @@ class _HipStepper:
 
     def next_pass(self):
         return self.s.next_pass()
+
+    def pass_estimate(self):
+        return self.s.pass_estimate()
 
     def pass_local(self, rank, world):
         self.s.pass_local(rank, world)
