@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", type=int, default=0, help="0 = reference-exact (parity), 1 = cache-free")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
+    ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="poses of the CPU baseline sample")
     return ap.parse_args()
@@ -57,6 +58,7 @@ def cpu_baseline(cfg_name, n_sample, mode):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("TSCODE_BENCH_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU
     oracle.set_num_threads(cores)
     t0 = time.perf_counter()
     poses = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
@@ -96,6 +98,8 @@ def main():
 
     ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble, keeps only its block
     pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
+    from tscode_amd import get_engine
+    get_engine(local_rank).set_option("prune_algo", args.algo)
 
     def sync():
         torch.cuda.synchronize()
@@ -111,12 +115,14 @@ def main():
     tile_ms = 0.0
     evals = 0
     computed = 0
+    screened = 0
     stage_ms = {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}
     for _ in range(args.steps):
         res = pipe.step()
         tile_ms += sum(s["tile_ms"] for s in res["stats"])
         evals += sum(s["pairs_evaluated"] for s in res["stats"])
         computed += sum(s["pairs_computed"] for s in res["stats"])
+        screened += sum(s["pairs_screened"] for s in res["stats"])
         for k in stage_ms:
             stage_ms[k] += res.get("ms", {}).get(k, 0.0)
     sync()
@@ -147,6 +153,14 @@ def main():
         b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
         b_k12 = n * ens.frag_coords.__len__() * 96 + n_pass * ens.n_atoms * 24 + n
         ms_per_step = dt / args.steps * 1e3
+        achieved_alg = (evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
+        # executed arithmetic: descriptor screen = 2 families x 8 dims x (sub + fma) = 48 flop per screened pair;
+        # H + sign test = 18 h + 110 flop per pair that reaches them (register-tiled kernel: every computed pair, h padded to 4)
+        if screened:
+            exec_flops = (screened / args.steps) * 48 + (computed / args.steps) * (18 * h + 110)
+        else:
+            exec_flops = (computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110)
+        executed_tflops = exec_flops / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
             "value": n * args.steps / dt,
@@ -166,28 +180,33 @@ def main():
                        "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": digest,
                        "parity_vs_recorded_oracle": parity, "parallelism": f"conformer-axis shards x{world}"},
             "roofline": {
-                "kernel": "k_rmsd_tile (all-pairs Kabsch RMSD, one launch per pass)",
+                "kernel": ("k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile") +
+                          " (all-pairs Kabsch RMSD of a pass, one launch per pass)",
                 "bound": "fp64_valu",
-                "achieved": (evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None,
+                # SURVEY.md 8(d) accounting: the reference's own pair evaluations x (46 h + 500) flop each, over the
+                # kernel's HIP-event time.  The sieve kernel reaches the same verdicts without forming H for most
+                # pairs, so this figure can exceed the FP64 peak; executed_tflops is what the instructions really do.
+                "achieved": achieved_alg,
                 "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": ((evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 / FP64_VALU_PEAK_TFLOPS) if tile_s > 0 else None,
+                "frac": (achieved_alg / FP64_VALU_PEAK_TFLOPS) if achieved_alg else None,
                 "traffic": None,
                 "launches_per_step": len(res["stats"]),
                 "kernel_ms_per_step": tile_ms / args.steps,
                 "algorithmic_pair_evals_per_step": evals / args.steps,
-                "computed_pair_evals_per_step": computed / args.steps,
                 "flops_per_eval": flops_per_eval,
-                # what the kernel really executes per computed pair: 18*HP fmac flops + ~110 for the sign test
-                "executed_tflops": ((computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110) / (tile_s / args.steps) / 1e12) if tile_s > 0 else None,
+                "pairs_screened_per_step": screened / args.steps,
+                "pairs_with_H_formed_per_step": computed / args.steps,
+                "executed_tflops": executed_tflops,
+                "executed_frac": (executed_tflops / FP64_VALU_PEAK_TFLOPS) if executed_tflops else None,
                 "hbm": {"bound": "hbm", "achieved": b_k3 / (tile_s / args.steps) / 1e9 if tile_s > 0 else None, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "algorithmic_bytes": b_k3},
             },
             "pipeline_hbm": {"algorithmic_bytes": b_k12 + b_k3, "achieved_GBs": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9,
                              "peak_GBs": HBM_PEAK_GBS},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-            "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "computed": s["pairs_computed"],
-                        "cand": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4)} for s in res["stats"]],
+            "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
+                        "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4)} for s in res["stats"]],
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, n), args.mode)
