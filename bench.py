@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
     ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="poses of the CPU baseline sample")
     return ap.parse_args()
@@ -76,6 +78,11 @@ def cpu_baseline(cfg_name, n_sample, mode):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: everything libraries print there (RCCL prints a version banner at
+    # communicator creation) is sent to stderr; the line itself goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -87,7 +94,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     pg = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -97,7 +104,8 @@ def main():
     from tscode_amd.synthetic import make_config
 
     ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble, keeps only its block
-    pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
+    pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
+                          force_sharded=args.force_sharded)
     from tscode_amd import get_engine
     get_engine(local_rank).set_option("prune_algo", args.algo)
 
@@ -210,8 +218,9 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, n), args.mode)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -101,7 +101,7 @@ inline double clash_sq_bound(double thresh) {
     return x;
 }
 
-template <bool FUSED>
+template <bool FUSED, bool SELF>
 __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
                                                 const double *__restrict__ frags, FragTable ft,
                                                 const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
@@ -138,16 +138,18 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
             for (int ia = a.first_row + li; ia < n; ia += lp) {
                 const double x = p[ia * 3], y = p[ia * 3 + 1], z = p[ia * 3 + 2];
                 int jend = n;
-                if (!a.self_mode) {
+                if (!SELF) {
                     jend = 0;
 #pragma unroll
                     for (int k = 1; k < MAX_MOLS; ++k)
                         if (k < a.n_mols && ia >= a.atom_off[k]) jend = a.atom_off[k];
                 }
+                // four independent partner atoms per trip: their LDS reads are issued together
+#pragma unroll 4
                 for (int j = 0; j < jend; ++j) {
-                    double dx = x - p[j * 3], dy = y - p[j * 3 + 1], dz = z - p[j * 3 + 2];
-                    double d2 = dx * dx + dy * dy + dz * dz;
-                    bool hit = a.self_mode ? (d2 < a.sq_bound && d2 > 0.0) : (d2 < a.sq_bound);
+                    const double dx = x - p[j * 3], dy = y - p[j * 3 + 1], dz = z - p[j * 3 + 2];
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const bool hit = SELF ? (d2 < a.sq_bound && d2 > 0.0) : (d2 < a.sq_bound);
                     cnt += hit ? 1 : 0;
                 }
             }

@@ -260,20 +260,27 @@ static int make_clash_args(int64_t n_poses, int n_atoms, const int32_t *ids, int
     return 0;
 }
 
-template <bool FUSED>
-static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
-                        const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
-    if (a.n_poses == 0) return 0;
+template <bool FUSED, bool SELF>
+static int launch_clash_impl(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
+                             const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
     const int ppw = 64 / a.lp;
     size_t lds = size_t(4) * ppw * a.n * 3 * sizeof(double);
     TSC_REQUIRE(lds <= 160 * 1024, "pose too large for the LDS staging of the clash kernel (%d atoms)", a.n);
     int64_t waves = ceil_div<int64_t>(a.n_poses, ppw);
     int blocks = grid_for(waves, 4, 256 * 8);
     if (lds > 64 * 1024)
-        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clash<FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k_clash<FUSED>, dim3(blocks), dim3(256), lds, c->stream, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clash<FUSED, SELF>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL((k_clash<FUSED, SELF>), dim3(blocks), dim3(256), lds, c->stream, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
     TSC_HIP(hipGetLastError());
     return 0;
+}
+
+template <bool FUSED>
+static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
+                        const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
+    if (a.n_poses == 0) return 0;
+    if (a.self_mode) return launch_clash_impl<FUSED, true>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+    return launch_clash_impl<FUSED, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_clash_mask_dev(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,

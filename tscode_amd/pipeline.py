@@ -165,12 +165,13 @@ class HipShardBackend:
 
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
-                 process_group=None):
+                 process_group=None, force_sharded=False):
         import torch
         self.torch, self.ens = torch, ens
         self.rank, self.world, self.pg = int(rank), int(world), process_group
         self.params = (clash_thresh, max_clashes, rmsd_thr, mode)
-        if self.world > 1:
+        self.sharded = self.world > 1 or force_sharded
+        if self.sharded:
             self.backend = HipShardBackend(ens, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
             self.d_keep, self.d_clash, self.d_structures = self.backend.keep, self.backend.clash, self.backend.structures
             return
@@ -191,7 +192,7 @@ class DevicePipeline:
     def step(self):
         """One pass of the hot path over the resident ensemble.  Returns counts/statistics; the verdicts
         stay on the device (d_clash, d_structures, d_keep)."""
-        if self.world == 1:
+        if not self.sharded:
             c, m, r, mode = self.params
             return self.eng.pipeline_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx,
                                          c, m, r, mode, self.d_clash, self.d_structures, self.d_keep)
