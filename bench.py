@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
     ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
+    ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (seg_cols, drain_min), repeatable")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -108,6 +109,9 @@ def main():
                           force_sharded=args.force_sharded)
     from tscode_amd import get_engine
     get_engine(local_rank).set_option("prune_algo", args.algo)
+    for opt in args.opt:
+        name, val = opt.split("=")
+        get_engine(local_rank).set_option(name, float(val))
 
     def sync():
         torch.cuda.synchronize()

@@ -67,7 +67,8 @@ struct tsc_ctx {
     void *pinned = nullptr;               // small pinned host buffer for scalar read-backs
     size_t pinned_bytes = 0;
     int prune_algo = 0;                   // tsc_ctx_set_option("prune_algo"): 0 auto, 1 register-tiled, 2 sieve
-    int seg_cols = 2048;                  // columns per pair-kernel work item
+    int seg_cols = 0;                     // columns per pair-kernel work item (0 = chosen from the problem size)
+    int drain_min = 64;                   // sieve: queued pairs that trigger an evaluation batch
     std::vector<hipEvent_t> event_pool;   // recycled timing events of prune runs
 
     int alloc(size_t bytes, void **out) {

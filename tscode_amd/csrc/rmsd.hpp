@@ -330,15 +330,15 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
-                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, const double *__restrict__ D, int dw,
-                                                    double *__restrict__ Dr, double *__restrict__ Dc, int64_t ld) {
+                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, const float *__restrict__ D, int dw,
+                                                    float *__restrict__ Dr, float *__restrict__ Dc, int64_t ld) {
     if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= st->A) return;
     int64_t i = act_idx[r], first, last;
     if (D && lane < dw) {
-        const double v = D[i * dw + lane];
+        const float v = D[i * dw + lane];
         Dr[int64_t(r) * dw + lane] = v;
         Dc[int64_t(lane) * ld + r] = v;
     }

@@ -15,6 +15,11 @@
 // changes how many pairs are dropped, never a verdict.  Everything that survives takes the same sign test and
 // explicit-rotation path as the register-tiled kernel (rmsd.hpp).
 //
+// The screen runs in fp32 on mean-centred descriptors.  With M the largest |component| of the ensemble, every computed
+// difference is within eta = 3 * 2^-24 * 2M ... of the exact one (rounding of both operands and of the subtraction), so
+// s_exact >= s32 (1 - 2^-20) - 2 eta sqrt(KD s32); the host turns h thr^2 into the fp32 limit above which that lower
+// bound certainly exceeds h thr^2 (descriptor_limit32).  Pairs in the sliver between the two limits are simply not dropped.
+//
 // Pass kernel: one wavefront = 16 rows x one column segment, lane = column.
 //   screen : the lane keeps its column's descriptor (2*KD doubles, coalesced load per 64-column tile); the 16 row
 //            descriptors sit in LDS and are read as broadcasts; 4*KD flops per pair; survivors go to a per-wavefront
@@ -70,36 +75,60 @@ __global__ __launch_bounds__(256) void k_feature_moments(const double *__restric
     }
 }
 
-// D[i][fam*KD + k] = sum_a Q_fam[k][a] * f_fam,a(x_i)   and   G[i] = sum_a |x_ia|^2   (original index space)
+// D[i][fam*KD + k] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space; the bias is the
+// projection of the mean feature vector and cancels in every difference),  G[i] = sum_a |x_ia|^2,
+// *dmax_bits = max |D| over everything, as the bit pattern of a non-negative float (atomicMax on the integer view).
 __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
-                                                      const double *__restrict__ Q, double *__restrict__ D, double *__restrict__ G) {
+                                                      const double *__restrict__ Q, const double *__restrict__ bias, float *__restrict__ D,
+                                                      double *__restrict__ G, unsigned *__restrict__ dmax_bits) {
     extern __shared__ __attribute__((aligned(16))) double s_q[];  // [KD][nf0] then [KD][nf1]
     for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += blockDim.x) s_q[e] = Q[e];
     __syncthreads();
     int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double *x = heavy + i * h * 3;
-    double d[DW], g = 0.0;
+    float mx = 0.0f;
+    if (i < n) {
+        const double *x = heavy + i * h * 3;
+        double d[DW], g = 0.0;
 #pragma unroll
-    for (int k = 0; k < DW; ++k) d[k] = 0.0;
-    for (int a = 0; a < h; ++a) {
-        const double n2 = x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2];
-        g += n2;
-        if (a < nf0) {
-            const double f = sqrt(n2);
+        for (int k = 0; k < DW; ++k) d[k] = -bias[k];
+        for (int a = 0; a < h; ++a) {
+            const double n2 = x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2];
+            g += n2;
+            if (a < nf0) {
+                const double f = sqrt(n2);
 #pragma unroll
-            for (int k = 0; k < KD; ++k) d[k] = fma(s_q[k * nf0 + a], f, d[k]);
+                for (int k = 0; k < KD; ++k) d[k] = fma(s_q[k * nf0 + a], f, d[k]);
+            }
+            if (a < nf1) {
+                const double f = feature(x, h, 1, a);
+                const double *q1 = s_q + KD * nf0;
+#pragma unroll
+                for (int k = 0; k < KD; ++k) d[KD + k] = fma(q1[k * nf1 + a], f, d[KD + k]);
+            }
         }
-        if (a < nf1) {
-            const double f = feature(x, h, 1, a);
-            const double *q1 = s_q + KD * nf0;
 #pragma unroll
-            for (int k = 0; k < KD; ++k) d[KD + k] = fma(q1[k * nf1 + a], f, d[KD + k]);
+        for (int k = 0; k < DW; ++k) {
+            const float v = float(d[k]);
+            D[i * DW + k] = v;
+            mx = fmaxf(mx, fabsf(v));
         }
+        G[i] = g;
     }
-#pragma unroll
-    for (int k = 0; k < DW; ++k) D[i * DW + k] = d[k];
-    G[i] = g;
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(dmax_bits, __float_as_uint(mx));
+}
+
+// fp32 limit for the squared descriptor distance: any s32 above it certainly means an exact distance above `limit`.
+// dmax = largest |component|; differences of two components are within eta of exact, the 8-term sum of squares
+// carries at most 2^-20 relative error.
+inline float descriptor_limit32(double limit, double dmax) {
+    const double eta = 3.0 * std::ldexp(1.0, -24) * 2.0 * dmax;
+    const double a = 1.0 - std::ldexp(1.0, -20), b = 2.0 * eta * std::sqrt(double(KD));
+    const double x = (b + std::sqrt(b * b + 4.0 * a * limit)) / (2.0 * a);
+    const double l32 = x * x * (1.0 + 1e-6) + 1e-30;
+    float f = float(l32);
+    if (double(f) < l32) f = std::nextafter(f, INFINITY);
+    return f;
 }
 
 struct SieveArgs {
@@ -110,7 +139,8 @@ struct SieveArgs {
     int seg_cols;
     double thr, maxdev_thr;
     double half_h_thr2;   // h * thr^2 / 2
-    double desc_limit;    // h * thr^2 * (1 + 1e-9): squared descriptor distance above which a pair is dropped
+    int drain_min;        // queue length that triggers a drain between column tiles (1..64)
+    float desc_limit32;   // fp32 squared descriptor distance above which a pair is certainly dissimilar (descriptor_limit32)
 };
 
 // H = p^T q and the sign test / exact path for one pair read from memory.  Returns true iff the pair is
@@ -143,14 +173,14 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 
 template <int TI>
 __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                        const double *__restrict__ Gall, const double *__restrict__ Dr,
-                                                        const double *__restrict__ Dc, const int32_t *__restrict__ cend,
+                                                        const double *__restrict__ Gall, const float *__restrict__ Dr,
+                                                        const float *__restrict__ Dc, const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
     constexpr int QCAP = TI * 64 + 64;  // one column tile can add TI*64 pairs on top of a remainder below 64
     __shared__ unsigned s_queue[4][QCAP];
-    __shared__ __attribute__((aligned(16))) double s_rowdesc[4][TI * DW];
+    __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (st->pass_on == 0) return;
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
 
     // the row descriptors of this work item: nrows * DW consecutive doubles of Dr -> LDS
-    double *rowdesc = s_rowdesc[wid];
+    float *rowdesc = s_rowdesc[wid];
     for (int e = lane; e < nrows * DW; e += 64) rowdesc[e] = Dr[int64_t(r0) * DW + e];
     __builtin_amdgcn_wave_barrier();
 
@@ -224,7 +254,7 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     for (int c0 = seg_lo; c0 < cmax && alive; c0 += 64) {
         {   // ---- screen one 64-column tile against every live row (the column descriptor dies with this block)
             const int col = c0 + lane;
-            double dq[DW];
+            float dq[DW];
 #pragma unroll
             for (int k = 0; k < DW; ++k) dq[k] = Dc[int64_t(k) * a.ld + col];
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + 63;
@@ -234,17 +264,17 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
                 rows &= rows - 1;
                 const int r = r0 + t;
                 const int ce = __builtin_amdgcn_readlane(my_cend, t);
-                const double *dr = rowdesc + t * DW;
-                double s0 = 0.0, s1 = 0.0;
+                const float *dr = rowdesc + t * DW;
+                float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KD; ++k) {
-                    const double d0 = dr[k] - dq[k], d1 = dr[KD + k] - dq[KD + k];
-                    s0 = fma(d0, d0, s0);
-                    s1 = fma(d1, d1, s1);
+                    const float d0 = dr[k] - dq[k], d1 = dr[KD + k] - dq[KD + k];
+                    s0 = fmaf(d0, d0, s0);
+                    s1 = fmaf(d1, d1, s1);
                 }
-                const bool valid = col > r && col < ce;
-                const bool pass = valid && !(s0 > a.desc_limit) && !(s1 > a.desc_limit);
-                n_screened += __popcll(__ballot(valid));
+                // columns of this tile inside the row's range (r, ce): counted without a ballot
+                n_screened += (unsigned long long)max(0, min(ce, c0 + 64) - max(r + 1, c0));
+                const bool pass = col > r && col < ce && !(s0 > a.desc_limit32) && !(s1 > a.desc_limit32);
                 const unsigned long long m = __ballot(pass);
                 if (m) {
                     if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned(t) << 16) | unsigned(col - seg_lo);
@@ -254,9 +284,10 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
         }
         __builtin_amdgcn_wave_barrier();
         // ---- drain full batches between tiles; a remainder below 64 waits for the next tile
-        while (qn >= 64) {
-            drain(qn - 64, 64);
-            qn -= 64;
+        while (qn >= a.drain_min) {
+            const int cnt = min(qn, 64);
+            drain(qn - cnt, cnt);
+            qn -= cnt;
         }
     }
     if (qn > 0) drain(0, qn);

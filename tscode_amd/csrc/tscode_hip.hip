@@ -477,7 +477,9 @@ struct tsc_prune {
     unsigned long long *mbit = nullptr, *dbit = nullptr;
     size_t bit_words = 0;
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
-    double *Dall = nullptr, *Gall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel
+    float *Dall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel: fp32 descriptors
+    double *Gall = nullptr;
+    float desc_limit32 = 0.0f;
     PassCounters *counters = nullptr;
     PruneState *state = nullptr;
     PassRecord *records = nullptr;  // [TSC_MAX_PASSES]
@@ -526,7 +528,7 @@ static int build_descriptors(tsc_prune *p) {
     Scratch s(c);
     double *d_M[NFAM], *d_Q;
     std::vector<double> M[NFAM];
-    TSC_TRY(s.get(size_t(KD) * (nf[0] + nf[1]) + 1, &d_Q));
+    TSC_TRY(s.get(size_t(KD) * (nf[0] + nf[1]) + DW + 1, &d_Q));
     for (int f = 0; f < NFAM; ++f) {
         const int m = nf[f] + 1;
         M[f].assign(size_t(m) * m, 0.0);
@@ -541,14 +543,31 @@ static int build_descriptors(tsc_prune *p) {
         TSC_HIP(hipMemcpyAsync(M[f].data(), d_M[f], M[f].size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     TSC_HIP(hipStreamSynchronize(st));
-    std::vector<double> Q(size_t(KD) * (nf[0] + nf[1]) + 1, 0.0);
+    std::vector<double> Q(size_t(KD) * (nf[0] + nf[1]) + DW + 1, 0.0);
     descriptor_basis(M[0].data(), nf[0], n_samples, Q.data());
     descriptor_basis(M[1].data(), nf[1], n_samples, Q.data() + size_t(KD) * nf[0]);
+    // bias = projection of the sample mean of each family (centres the descriptors; cancels in differences)
+    double *bias = Q.data() + size_t(KD) * (nf[0] + nf[1]);
+    for (int f = 0, qoff = 0; f < NFAM; qoff += KD * nf[f], ++f)
+        for (int k = 0; k < KD; ++k) {
+            double b = 0.0;
+            const int m = nf[f] + 1;
+            for (int a = 0; a < nf[f]; ++a) b += Q[size_t(qoff) + size_t(k) * nf[f] + a] * (M[f][size_t(a) * m + nf[f]] / std::max(1, n_samples));
+            bias[f * KD + k] = b;
+        }
+    unsigned *d_dmax;
+    TSC_TRY(s.get(4, &d_dmax));
+    TSC_HIP(hipMemsetAsync(d_dmax, 0, 4 * sizeof(unsigned), st));
     TSC_HIP(hipMemcpyAsync(d_Q, Q.data(), Q.size() * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), size_t(KD) * (nf[0] + nf[1]) * sizeof(double), st, p->heavy,
-                       p->n, h, nf[0], nf[1], (const double *)d_Q, p->Dall, p->Gall);
+                       p->n, h, nf[0], nf[1], (const double *)d_Q, (const double *)(d_Q + size_t(KD) * (nf[0] + nf[1])), p->Dall, p->Gall, d_dmax);
     TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(c->pinned, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     TSC_HIP(hipStreamSynchronize(st));  // Q lives in a host vector and in scratch that is released on return
+    float dmax;
+    memcpy(&dmax, c->pinned, sizeof(float));
+    if (!(dmax >= 0.0f) || !std::isfinite(dmax)) dmax = 3.0e38f;  // NaN / inf coordinates: nothing is dropped by the screen
+    p->desc_limit32 = descriptor_limit32(double(p->h) * p->thr * p->thr, double(dmax));
     return 0;
 }
 
@@ -623,8 +642,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, sizeof(PassCounters), st);
         if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
-        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * DW * sizeof(double), st);
-        if (e == hipSuccess && p->Dr) e = hipMemsetAsync(p->Dr, 0, size_t(p->npad) * DW * sizeof(double), st);
+        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * DW * sizeof(float), st);
+        if (e == hipSuccess && p->Dr) e = hipMemsetAsync(p->Dr, 0, size_t(p->npad) * DW * sizeof(float), st);
         if (e == hipSuccess && p->Xc) e = hipMemsetAsync(p->Xc, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
         if (e == hipSuccess && p->Xr) e = hipMemsetAsync(p->Xr, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
         if (e == hipSuccess && p->G) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
@@ -703,7 +722,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit,
                            (const PruneState *)p->state);
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, p->cend, p->best, (const double *)p->Dall, DW, p->Dr, p->Dc, p->npad);
+                       p->dbit, p->cend, p->best, (const float *)p->Dall, DW, p->Dr, p->Dc, p->npad);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
@@ -716,7 +735,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
     // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
     // work (many small chunks), long ones amortise the per-item setup when it has a lot
-    int seg_cols = c->seg_cols;
+    // (measured on MI355X: 512 columns is best up to ~1.5e5 structures, 2048 at 1e6; "seg_cols" overrides)
+    int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 150000 ? 512 : (n <= 400000 ? 1024 : 2048));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     const int n_seg = ceil_div(max_range + 64, seg_cols);
     const int my_tiles = (n_tiles - rank + world - 1) / world;
@@ -745,9 +765,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
-        a.desc_limit = double(p->h) * p->thr * p->thr * (1.0 + 1e-9);
+        a.desc_limit32 = p->desc_limit32;
+        a.drain_min = c->drain_min;
         hipLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                           (const double *)p->Dr, (const double *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                           (const float *)p->Dr, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
                            (const PruneState *)p->state, a);
     }
     TSC_HIP(hipGetLastError());
@@ -891,8 +912,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->prune_algo = int(value);
         return 0;
     }
+    if (strcmp(name, "drain_min") == 0) {
+        TSC_REQUIRE(value >= 1 && value <= 64, "drain_min must be in [1, 64]");
+        c->drain_min = int(value);
+        return 0;
+    }
     if (strcmp(name, "seg_cols") == 0) {
-        TSC_REQUIRE(value >= 64 && value <= 32768 && int(value) % 64 == 0, "seg_cols must be a multiple of 64 in [64, 32768]");
+        TSC_REQUIRE(value == 0 || (value >= 64 && value <= 32768 && int(value) % 64 == 0), "seg_cols must be 0 (automatic) or a multiple of 64 in [64, 32768]");
         c->seg_cols = int(value);
         return 0;
     }
