@@ -122,6 +122,15 @@ int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, 
 int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                        double *rmsd, double *maxdev);
 
+/* Greedy per-group filter of the embed loops (tscode/embeds.py:715, :843): inside each group a pose is accepted iff
+ * it is not similar (tscode/rmsd_pruning.py:208-224, all atoms, rmsd < thr and maxdev < 2 thr) to any pose accepted
+ * before it in that group.  poses f64[n_poses, n_atoms, 3]; group g is poses[group_off[g] : group_off[g+1]]
+ * (group_off i32[n_groups + 1], group sizes <= 1024); accepted u8[n_poses]. */
+int tsc_greedy_group_filter(tsc_ctx *ctx, const double *poses, const int32_t *group_off, int n_groups, int n_atoms,
+                            double rmsd_thr, uint8_t *accepted);
+int tsc_greedy_group_filter_dev(tsc_ctx *ctx, const double *poses, const int32_t *group_off_dev, int n_groups, int64_t n_poses,
+                                int n_atoms, double rmsd_thr, uint8_t *accepted);
+
 /* Per-pass statistics of a prune run (one entry per executed k of the schedule). */
 typedef struct {
     int64_t k;               /* number of chunks (tscode/rmsd_pruning.py:186-188) */

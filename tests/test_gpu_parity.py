@@ -404,3 +404,26 @@ def test_shard_backend_world1_equals_one_shot(eng, oracle):
     assert np.array_equal(be.keep[:res["n_pass"]].cpu().numpy().astype(bool), mask)
     assert np.abs(be.structures[:res["n_pass"]].cpu().numpy() - poses[cm]).max() < 1e-12
     eng.set_stream(None)
+
+
+def test_greedy_group_filter(eng, oracle):
+    """the per-group greedy _rmsd_similarity filter of the embed loops, against G4 and the oracle."""
+    import tscode_amd
+    g = load_golden("G4_rmsd_similarity")
+    for c in range(int(g["n_cases"])):
+        poses, ref = g[f"poses{c}"], g[f"accepted{c}"]
+        assert np.array_equal(tscode_amd.filter_angular_groups(poses, [len(poses)], 1.0), ref)
+    # many ragged groups at once, against the oracle
+    from tscode_amd.synthetic import make_ensemble
+    ens = make_ensemble(3000, (10, 12, 9), seed=77, children=6, sigma_t=0.3, sigma_rot_deg=8.0)
+    poses = ens.poses()
+    rng = np.random.default_rng(5)
+    sizes = []
+    while sum(sizes) < len(poses):
+        sizes.append(int(min(rng.integers(1, 217), len(poses) - sum(sizes))))
+    got = tscode_amd.filter_angular_groups(poses, sizes, 1.0)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    want = np.concatenate([oracle.greedy_group_filter(poses[off[i]:off[i + 1]], 1.0) for i in range(len(sizes))])
+    assert np.array_equal(got, want)
+    assert 0.05 < got.mean() < 0.95
+    assert tscode_amd.filter_angular_groups(np.zeros((0, 4, 3)), [], 1.0).shape == (0,)

@@ -5,6 +5,7 @@
 #include "rmsd.hpp"
 #include "scan.hpp"
 #include "sieve.hpp"
+#include "group_filter.hpp"
 
 #include <algorithm>
 
@@ -923,6 +924,49 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
     return fail(TSC_ERR_INVALID, "unknown option '%s'", name);
+}
+
+// --------------------------------------------------------------------------------------------------
+// greedy per-group filter
+
+extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter_dev(tsc_ctx *c, const double *poses, const int32_t *group_off_dev, int n_groups,
+                                                                             int64_t n_poses, int n_atoms, double rmsd_thr, uint8_t *accepted) {
+    TSC_REQUIRE(c && poses && group_off_dev && accepted, "tsc_greedy_group_filter_dev: null argument");
+    TSC_REQUIRE(n_groups >= 0 && n_poses >= 0 && n_atoms > 0 && rmsd_thr > 0, "bad sizes");
+    if (n_groups == 0 || n_poses == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *G;
+    TSC_TRY(s.get(size_t(n_poses), &G));
+    hipLaunchKernelGGL(k_greedy_group_filter, dim3(ceil_div(n_groups, 4)), dim3(256), 0, c->stream, poses, group_off_dev, n_groups, n_atoms, rmsd_thr,
+                       accepted, G);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(tsc_ctx *c, const double *poses, const int32_t *group_off, int n_groups, int n_atoms,
+                                                                         double rmsd_thr, uint8_t *accepted) {
+    TSC_REQUIRE(c && poses && group_off && accepted, "tsc_greedy_group_filter: null argument");
+    TSC_REQUIRE(n_groups >= 0 && n_atoms > 0 && rmsd_thr > 0, "bad sizes");
+    if (n_groups == 0) return 0;
+    TSC_REQUIRE(group_off[0] == 0, "group_off must start at 0");
+    for (int g = 0; g < n_groups; ++g)
+        TSC_REQUIRE(group_off[g + 1] >= group_off[g] && group_off[g + 1] - group_off[g] <= GF_MAX_GROUP,
+                    "group %d: sizes must be in [0, %d]", g, GF_MAX_GROUP);
+    const int64_t n_poses = group_off[n_groups];
+    if (n_poses == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_poses;
+    int32_t *d_off;
+    uint8_t *d_acc;
+    TSC_TRY(upload(c, s, poses, size_t(n_poses) * n_atoms * 3, &d_poses));
+    TSC_TRY(upload(c, s, group_off, size_t(n_groups) + 1, &d_off));
+    TSC_TRY(s.get(size_t(n_poses), &d_acc));
+    TSC_TRY(tsc_greedy_group_filter_dev(c, d_poses, d_off, n_groups, n_poses, n_atoms, rmsd_thr, d_acc));
+    TSC_HIP(hipMemcpyAsync(accepted, d_acc, size_t(n_poses), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import numpy as np
 from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors
 from .engine import FragmentSet, get_engine
 
-__all__ = ["get_embed", "embed_batch", "string_embed_poses"]
+__all__ = ["get_embed", "embed_batch", "string_embed_poses", "filter_angular_groups"]
 
 
 def get_embed(mols, conf_ids):
@@ -56,3 +56,15 @@ def string_embed_poses(coords1, coords2, p1, p2, ref_vec, mol_vec, angles):
         pos[i, 1] = p1 - r @ p2
     poses = embed_batch([coords1[None], coords2[None]], np.zeros((n, 2), np.int32), rot, pos)
     return poses, rot, pos
+
+
+def filter_angular_groups(poses, group_sizes, rmsd_thr=1.0):
+    """The per-group greedy filter of the cyclical embed loops (tscode/embeds.py:713-717, :841-845), batched:
+
+        for pose in group:  keep pose iff  not _rmsd_similarity(pose, kept_so_far, rmsd_thr=1)
+
+    poses f64[n_poses, n, 3] with the groups laid out one after the other; group_sizes int[n_groups].
+    Returns bool[n_poses].  One GPU wavefront per group."""
+    group_sizes = np.asarray(group_sizes, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(group_sizes)]).astype(np.int32)
+    return get_engine().greedy_group_filter(poses, off, float(rmsd_thr))

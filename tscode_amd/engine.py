@@ -174,6 +174,17 @@ class Engine:
                                       C.c_int64(len(pairs)), ptr(r), ptr(m)))
         return r, m
 
+    def greedy_group_filter(self, poses, group_off, rmsd_thr=1.0):
+        """accepted bool[n_poses]: per group, keep a pose iff it is not similar to a pose kept before it."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        group_off = np.ascontiguousarray(group_off, dtype=np.int32)
+        if poses.ndim != 3 or poses.shape[2] != 3 or group_off.ndim != 1 or len(group_off) < 1 or group_off[-1] != len(poses):
+            raise ValueError("poses must be (n_poses, n_atoms, 3) and group_off[-1] == n_poses")
+        acc = np.zeros(len(poses), dtype=np.uint8)
+        check(self.lib.tsc_greedy_group_filter(self._h, ptr(poses), ptr(group_off), C.c_int(len(group_off) - 1), C.c_int(poses.shape[1]),
+                                               C.c_double(rmsd_thr), ptr(acc)))
+        return acc.astype(bool)
+
     def prune_heavy(self, heavy, rmsd_thr=0.5, mode=0):
         """prune_conformers_rmsd on the heavy-atom array f64[N, h, 3]. Returns (mask bool[N], per-pass stats)."""
         heavy = np.ascontiguousarray(heavy, dtype=np.float64)
