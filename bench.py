@@ -71,7 +71,8 @@ def cpu_baseline(cfg_name, n_sample, mode):
     res = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=False)     # chunk-parallel like the reference's prange
     dt = time.perf_counter() - t0
     evals = sum(s["pairs_evaluated"] for s in res["stats"])
-    return {"value": n_sample / dt, "unit": "conformers/s", "cores": cores, "kind": "port",
+    cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+    return {"value": n_sample / dt, "unit": "conformers/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{cfg_name} generator at N={n_sample} (embed + clash + prune mode {mode}; {int(cm.sum())} pass the clash check, "
                       f"{int(res['mask'].sum())} survive; {evals} pair evaluations; chunk-parallel like the reference's prange)",
             "seconds": dt, "pair_evals_per_s": evals / dt}
@@ -146,7 +147,7 @@ def main():
 
     # verdict fingerprint (after the timed region)
     n_pass, n_keep = res["n_pass"], res["n_keep"]
-    keep = pipe.d_keep[:n_pass].cpu().numpy()
+    keep = pipe.h_keep[:n_pass].numpy().copy()             # the host copy every step produces
     digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
     expected = None
     exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")

@@ -193,13 +193,15 @@ int tsc_prune_destroy(tsc_prune *p);
  * Inputs as tsc_transform_batch_dev plus heavy_idx (indices of atoms with atomnos != 1).
  * Outputs (device, caller-allocated for the worst case n_poses):
  *   clash_mask u8[n_poses]; structures f64[n_pass, n_atoms, 3] (poses that pass the clash check, in order);
- *   keep_mask u8[n_pass] (prune verdict on those); n_pass_host / n_keep_host scalars on the host.
+ *   keep_mask u8[n_pass] (prune verdict on those); keep_mask_host (optional, host, n_poses bytes) receives a copy of
+ *   keep_mask[0 .. n_pass) before the call returns; n_pass_host / n_keep_host scalars on the host.
  * timings_ms (optional, host) float[4] = {embed+clash, compaction, prune, total} from HIP events. */
 int tsc_pipeline_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off_host, const int32_t *n_atoms_host,
                      const int32_t *n_conf_host, int n_mols, const int32_t *conf_idx, const double *rot, const double *pos,
                      int64_t n_poses, const int32_t *heavy_idx_host, int n_heavy, double clash_thresh, int64_t max_clashes,
                      double rmsd_thr, int mode, uint8_t *clash_mask, double *structures, uint8_t *keep_mask,
-                     int64_t *n_pass_host, int64_t *n_keep_host, tsc_pass_stats *stats, int *n_passes, float *timings_ms);
+                     uint8_t *keep_mask_host, int64_t *n_pass_host, int64_t *n_keep_host, tsc_pass_stats *stats, int *n_passes,
+                     float *timings_ms);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,7 @@ _SIGNATURES = {
     "tsc_prune_stats": (C.c_int, [_vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_destroy": (C.c_int, [_vp]),
     "tsc_pipeline_dev": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int, _vp, _vp, _vp, C.c_int64, c_i32p, C.c_int,
-                                   C.c_double, C.c_int64, C.c_double, C.c_int, _vp, _vp, _vp, c_i64p, c_i64p,
+                                   C.c_double, C.c_int64, C.c_double, C.c_int, _vp, _vp, _vp, _vp, c_i64p, c_i64p,
                                    C.POINTER(PassStats), C.POINTER(C.c_int), c_f32p]),
 }
 

@@ -243,6 +243,26 @@ struct PassRecord {  // one per schedule slot, read back once at the end of the 
     int on, algo;
 };
 
+// Initial state of a run: out_mask = ones (rmsd_pruning.py:182), empty cache (:183), zeroed bitmaps, records and counters.
+__global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit,
+                                                   unsigned long long *__restrict__ dbit, int bit_words, int32_t *__restrict__ n_keys,
+                                                   PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
+                                                   PassCounters *__restrict__ cnt) {
+    const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
+    for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
+    for (int64_t e = (n / 8) * 8 + tid; e < n; e += stride) mask[e] = 1;
+    for (int64_t e = tid; e < bit_words; e += stride) mbit[e] = 0, dbit[e] = 0;
+    unsigned long long *c = &cnt->w[0][0];
+    for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
+    char *r = reinterpret_cast<char *>(rec);
+    for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride) r[e] = 0;
+    if (tid == 0) {
+        n_keys[0] = 0;
+        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->pad = 0;
+    }
+}
+
 // Closes the pass in slot `prev` (sums its counters, updates n_active) and opens the pass in slot `cur` (gate, A,
 // zeroed counters and cache-view bitmap).  prev / cur = -1: nothing to close / open.  One block of 256 threads.
 __global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec,

@@ -631,24 +631,16 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         if (!rc) rc = palloc(p, size_t(p->npad) * hp3, &p->Xc);
         if (!rc) rc = palloc(p, size_t(p->npad), &p->G);
     }
-    hipError_t e = hipSuccess;
     if (!rc) {
         hipStream_t st = c->stream;
-        PruneState init{int(n), 0, int(n), 0};
-        memcpy(c->pinned, &init, sizeof(init));
-        e = hipMemsetAsync(p->mask, 1, size_t(n), st);  // rmsd_pruning.py:182 out_mask = ones
-        if (e == hipSuccess) e = hipMemcpyAsync(p->state, c->pinned, sizeof(init), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->n_keys, 0, 4 * sizeof(int32_t), st);  // :183 cache = [(-1,-1)] never matches
-        if (e == hipSuccess) e = hipMemsetAsync(p->records, 0, sizeof(PassRecord) * TSC_MAX_PASSES, st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, sizeof(PassCounters), st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->mbit, 0, p->bit_words * 8, st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->dbit, 0, p->bit_words * 8, st);
-        if (e == hipSuccess && p->Dc) e = hipMemsetAsync(p->Dc, 0, size_t(p->npad) * DW * sizeof(float), st);
-        if (e == hipSuccess && p->Dr) e = hipMemsetAsync(p->Dr, 0, size_t(p->npad) * DW * sizeof(float), st);
+        hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
+                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters);
+        hipError_t e = hipGetLastError();
+        // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
+        // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
         if (e == hipSuccess && p->Xc) e = hipMemsetAsync(p->Xc, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
         if (e == hipSuccess && p->Xr) e = hipMemsetAsync(p->Xr, 0, size_t(p->npad) * p->hp * 3 * sizeof(double), st);
         if (e == hipSuccess && p->G) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the pinned staging buffer is reused below
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
     }
     if (!rc && p->Dall) rc = build_descriptors(p);
@@ -858,13 +850,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     return 0;
 }
 
-extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
-                                  tsc_pass_stats *stats, int *n_passes) {
-    TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd_dev: null argument");
-    if (n == 0) {
-        if (n_passes) *n_passes = 0;
-        return 0;
-    }
+// One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
+// synchronisation (the statistics read-back).
+static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
+                     tsc_pass_stats *stats, int *n_passes) {
     tsc_prune *p = nullptr;
     TSC_TRY(tsc_prune_create(c, heavy, n, h, rmsd_thr, mode, &p));
     int rc = 0;
@@ -877,11 +866,22 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx
     if (!rc) {
         DeviceGuard guard(c->device);
         hipError_t e = hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess && mask_host) e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
     }
     if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
     tsc_prune_destroy(p);
     return rc;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
+                                  tsc_pass_stats *stats, int *n_passes) {
+    TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd_dev: null argument");
+    if (n == 0) {
+        if (n_passes) *n_passes = 0;
+        return 0;
+    }
+    return prune_run(c, heavy, n, h, rmsd_thr, mode, mask, nullptr, stats, n_passes);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
@@ -975,8 +975,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(ts
 extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
                                 int n_mols, const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses,
                                 const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, double rmsd_thr, int mode,
-                                uint8_t *clash_mask, double *structures, uint8_t *keep_mask, int64_t *n_pass_host, int64_t *n_keep_host,
-                                tsc_pass_stats *stats, int *n_passes, float *timings_ms) {
+                                uint8_t *clash_mask, double *structures, uint8_t *keep_mask, uint8_t *keep_mask_host, int64_t *n_pass_host,
+                                int64_t *n_keep_host, tsc_pass_stats *stats, int *n_passes, float *timings_ms) {
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && clash_mask && structures && keep_mask, "tsc_pipeline_dev: null argument");
     TSC_REQUIRE(n_poses > 0 && n_poses < INT32_MAX, "bad n_poses");
     FragTable ft;
@@ -1024,7 +1024,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
                            (const int32_t *)act, int64_t(n_pass), structures, (const int32_t *)d_slot, n_heavy, d_heavy);
         TSC_HIP(hipGetLastError());
         TSC_HIP(hipEventRecord(ev[2], st));
-        TSC_TRY(tsc_prune_rmsd_dev(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, stats, &np));
+        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
         if (!stats) {  // count survivors without the stats array
             TSC_TRY(scan_mask(st, keep_mask, n_pass, bsum, nullptr, nullptr, nullptr, total));

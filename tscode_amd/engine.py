@@ -210,7 +210,7 @@ class Engine:
 
     # ---- pipeline -----------------------------------------------------------------------------
     def pipeline_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, heavy_idx, clash_thresh, max_clashes,
-                     rmsd_thr, mode, clash_mask, structures, keep_mask):
+                     rmsd_thr, mode, clash_mask, structures, keep_mask, keep_mask_host=None):
         heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
         n_pass, n_keep = C.c_int64(), C.c_int64()
         stats = (PassStats * TSC_MAX_PASSES)()
@@ -219,7 +219,8 @@ class Engine:
         check(self.lib.tsc_pipeline_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
                                         C.c_int64(n_poses), heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)),
                                         C.c_double(clash_thresh), C.c_int64(int(max_clashes)), C.c_double(rmsd_thr), C.c_int(mode),
-                                        ptr(clash_mask), ptr(structures), ptr(keep_mask), C.byref(n_pass), C.byref(n_keep), stats,
+                                        ptr(clash_mask), ptr(structures), ptr(keep_mask), ptr(keep_mask_host), C.byref(n_pass),
+                                        C.byref(n_keep), stats,
                                         C.byref(np_), tm))
         return {"n_pass": n_pass.value, "n_keep": n_keep.value, "stats": _stats_list(stats, np_.value),
                 "ms": {"embed_clash": tm[0], "compact": tm[1], "prune": tm[2], "total": tm[3]}}

@@ -74,8 +74,10 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
                 else:
                     st.pass_local(0, 1)                 # small pass: replicated, no exchange
                 st.pass_finish()
-            stats = st.stats()
             st.copy_mask(backend.keep)
+            if getattr(backend, "keep_host", None) is not None:      # verdicts back to the host before the run's one sync
+                backend.keep_host[:n_pass].copy_(backend.keep[:n_pass], non_blocking=True)
+            stats = st.stats()
         finally:
             st.close()
     n_keep = stats[-1]["n_active_after"] if stats else 0
@@ -145,6 +147,7 @@ class HipShardBackend:
         self.best = torch.empty(n, dtype=torch.int32, device=self.dev)
         self.keep = torch.empty(n, dtype=torch.uint8, device=self.dev)
         self.counts = torch.zeros(world, dtype=torch.int64, device=self.dev)
+        self.keep_host = torch.empty(n, dtype=torch.uint8).pin_memory()
         torch.cuda.synchronize(self.dev)
 
     def embed_clash_block(self):
@@ -174,6 +177,7 @@ class DevicePipeline:
         if self.sharded:
             self.backend = HipShardBackend(ens, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
             self.d_keep, self.d_clash, self.d_structures = self.backend.keep, self.backend.clash, self.backend.structures
+            self.h_keep = self.backend.keep_host
             return
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
@@ -187,6 +191,7 @@ class DevicePipeline:
         self.d_clash = torch.empty(n, dtype=torch.uint8, device=self.dev)
         self.d_structures = torch.empty((n, ens.n_atoms, 3), dtype=torch.float64, device=self.dev)
         self.d_keep = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.h_keep = torch.empty(n, dtype=torch.uint8).pin_memory()      # verdicts, copied back at the end of every step
         torch.cuda.synchronize(self.dev)
 
     def step(self):
@@ -195,5 +200,5 @@ class DevicePipeline:
         if not self.sharded:
             c, m, r, mode = self.params
             return self.eng.pipeline_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx,
-                                         c, m, r, mode, self.d_clash, self.d_structures, self.d_keep)
+                                         c, m, r, mode, self.d_clash, self.d_structures, self.d_keep, self.h_keep)
         return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg)
