@@ -54,7 +54,7 @@ int tsc_ctx_destroy(tsc_ctx *ctx);
 int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
 int tsc_ctx_synchronize(tsc_ctx *ctx);
 /* Tunables.  "prune_algo": 0 = automatic (default), 1 = register-tiled all-pairs kernel (<= 32 heavy atoms),
- * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 64; 0 = automatic);
+ * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 256, at most 4096; 0 = automatic);
  * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64). */
 int tsc_ctx_set_option(tsc_ctx *ctx, const char *name, double value);
 /* Device memory helpers for hosts that do not bring their own allocator (tests, C callers). */

@@ -305,15 +305,15 @@ __global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, 
 // per-pass helper kernels (see prune.hpp for the pass sequence)
 
 struct PassGeom {
-    int64_t n;   // structures
-    int64_t k;   // chunks in this pass
-    int64_t cs;  // chunk size n // k (rmsd_pruning.py:136)
+    int n;   // structures (< 2^31)
+    int k;   // chunks in this pass
+    int cs;  // chunk size n // k (rmsd_pruning.py:136)
 };
 
 __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, int64_t &last) {
-    int64_t c = i / g.cs;
+    int c = int(i) / g.cs;  // 32-bit division: n < 2^31
     if (c >= g.k) c = g.k - 1;
-    first = c * g.cs;                                 // :140
+    first = int64_t(c) * g.cs;                        // :140
     last = (c == g.k - 1) ? g.n : first + g.cs;       // :141-144
 }
 
@@ -325,11 +325,10 @@ __global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *_
     if (st->pass_on == 0) return;
     int nk = *n_keys;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
-        int64_t a = key_a[q], b = key_b[q];
-        if (a % g.cs != 0) continue;
-        int64_t c = a / g.cs;
-        if (c >= g.k) continue;
-        int64_t last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
+        const int a = key_a[q], b = key_b[q];
+        const int c = a / g.cs;
+        if (c * g.cs != a || c >= g.k) continue;
+        const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
         if (b < last) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
     }
 }

@@ -42,47 +42,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t 
     if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// pass 2: one block turns block counts into exclusive block offsets; total -> *total_out (and bsum[nb])
-__global__ __launch_bounds__(1024) void k_scan_offsets(int32_t *__restrict__ bsum, int nb, int32_t *__restrict__ total_out,
-                                                        const int *__restrict__ gate) {
-    __shared__ int s_part[1024];
-    __shared__ int s_carry;
-    if (gate && *gate == 0) return;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int start = 0; start < nb; start += 1024) {
-        int i = start + threadIdx.x;
-        int v = (i < nb) ? bsum[i] : 0;
-        s_part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            int t = (int(threadIdx.x) >= off) ? s_part[threadIdx.x - off] : 0;
-            __syncthreads();
-            s_part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        int incl = s_part[threadIdx.x];
-        int carry = s_carry;
-        if (i < nb) bsum[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        bsum[nb] = s_carry;
-        if (total_out) *total_out = s_carry;
-    }
-}
-
-// pass 3: pos[i] = number of non-zero mask bytes before i (pos[n] = total); optionally the list of
+// pass 2: pos[i] = number of non-zero mask bytes before i (pos[n] = total); optionally the list of
 // kept indices (act_idx[pos[i]] = i) and the mask as a bit array (bit i of mbit = mask[i] != 0).
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
-                                                              const int32_t *__restrict__ boff, int32_t *__restrict__ pos,
+                                                              const int32_t *__restrict__ bsum, int32_t *__restrict__ pos,
                                                               int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
-                                                              const int *__restrict__ gate) {
+                                                              int32_t *__restrict__ total_out, const int *__restrict__ gate) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
+    __shared__ int s_o[SCAN_THREADS / WAVE];
     if (gate && *gate == 0) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // exclusive offset of this block = sum of the counts of the blocks before it (a few hundred values at most)
+    int part = 0;
+    for (int i = threadIdx.x; i < int(blockIdx.x); i += SCAN_THREADS) part += bsum[i];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) s_o[wid] = part;
     int64_t base = (int64_t(blockIdx.x) * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
     uint64_t v = (base < n) ? load_mask8(mask, base, n) : 0;
     int c = count_nonzero_bytes(v);
@@ -95,7 +69,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__re
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wid; ++w) woff += s_w[w];
-    int run = boff[blockIdx.x] + woff + incl - c;
+    const int block_off = s_o[0] + s_o[1] + s_o[2] + s_o[3];
+    int run = block_off + woff + incl - c;
     uint8_t bits = 0;
     for (int b = 0; b < SCAN_ITEMS; ++b) {
         int64_t i = base + b;
@@ -109,17 +84,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__re
         }
     }
     if (mbit_bytes && base < n) mbit_bytes[base >> 3] = bits;
-    if (pos && base <= n && n < base + SCAN_ITEMS) pos[n] = run;  // the thread owning the tail writes pos[n]
+    if (base <= n && n < base + SCAN_ITEMS) {  // the thread owning the tail knows the total
+        if (pos) pos[n] = run;
+        if (total_out) *total_out = run;
+    }
 }
 
-// Enqueue the three passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
+// Enqueue the two passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
 // act_idx / mbit are produced); total_dev (optional) receives count_nonzero(mask).
 inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
                      uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr) {
     int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, gate);
-    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, bsum, nb, total_dev, gate);
-    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, pos, act_idx, mbit_bytes, gate);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, (const int32_t *)bsum, pos, act_idx, mbit_bytes, total_dev, gate);
     TSC_HIP(hipGetLastError());
     return 0;
 }

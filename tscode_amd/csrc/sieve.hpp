@@ -131,6 +131,173 @@ inline float descriptor_limit32(double limit, double dmax) {
     return f;
 }
 
+// Device-side descriptor basis: one wavefront per feature family.  Orthonormal rows spanning the leading principal
+// axes of the feature covariance by a few steps of block power iteration (the spectrum of these features decays
+// fast: one step already gives the full screening power, three are run).  Rows are re-orthonormalised by
+// CholeskyQR2: lane (i, j) accumulates the Gram entry <W_i, W_j>, lane 0 factors the 8x8 Gram matrix, every lane
+// applies L^-1 to its columns -- no cross-lane reduction on the critical path.  Whatever the iteration produced,
+// the rows are finally divided by sqrt of a Gershgorin bound of |V V^T|_2, so |V x| <= |x| holds rigorously and
+// the screen can never drop a similar pair.
+//   M      second moments of the family, (nf+1)^2, upper triangle filled, index nf = the constant 1
+//   Qout   [KD][nf] rows of the basis;  bias[k] = V_k . mean
+constexpr int BASIS_ITERS = 3;
+constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
+__global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
+                                                          int n_samples, double *__restrict__ Q, double *__restrict__ bias) {
+    __shared__ double V[KD][DESC_MAX_FEAT], Z[KD][DESC_MAX_FEAT], mu[DESC_MAX_FEAT];
+    __shared__ double Cs[BASIS_LDS_C][BASIS_LDS_C + 1];
+    __shared__ double Gm[KD][KD];  // Gram matrix of the rows being orthonormalised
+    const int fam = blockIdx.x, lane = threadIdx.x;
+    const double *M = fam == 0 ? M0 : M1;
+    const int nf = fam == 0 ? nf0 : nf1, m = nf + 1;
+    double *Qout = Q + (fam == 0 ? 0 : size_t(KD) * nf0);
+    double *bout = bias + fam * KD;
+    if (nf == 0) {
+        if (lane < KD) bout[lane] = 0.0;
+        return;
+    }
+    const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
+    for (int a = lane; a < nf; a += 64) mu[a] = M[size_t(a) * m + nf] * inv;
+    __builtin_amdgcn_wave_barrier();
+    const bool c_in_lds = nf <= BASIS_LDS_C;
+    if (c_in_lds)
+        for (int e = lane; e < nf * nf; e += 64) {
+            const int a = e / nf, b = e - a * nf;
+            Cs[a][b] = (a <= b ? M[size_t(a) * m + b] : M[size_t(b) * m + a]) * inv - mu[a] * mu[b];
+        }
+    for (int k = 0; k < KD; ++k)
+        for (int a = lane; a < nf; a += 64) V[k][a] = ((a % KD) == k ? 1.0 : 0.0) + 1e-3 * ((a * 7 + k * 13) % 11 - 5);
+    __builtin_amdgcn_wave_barrier();
+
+    // W <- rows of an orthonormal basis of span(W) (zero rows where the span is exhausted)
+    auto cholesky_qr = [&](double (*W)[DESC_MAX_FEAT]) {
+        const int gi = lane >> 3, gj = lane & 7;  // 64 lanes = the 8 x 8 Gram entries
+        double g = 0.0;
+#pragma unroll 4
+        for (int a = 0; a < nf; ++a) g = fma(W[gi][a], W[gj][a], g);
+        Gm[gi][gj] = g;
+        __builtin_amdgcn_wave_barrier();
+        // every lane factors the 8 x 8 Gram matrix in registers (constant indices only): G = L L^T, then Li = L^-1
+        double L[KD][KD], Li[KD][KD];
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < KD; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) L[i][j] = Gm[i][j];
+            tr += L[i][i];
+        }
+        bool dead[KD];
+#pragma unroll
+        for (int i = 0; i < KD; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double sacc = L[i][j];
+#pragma unroll
+                for (int t = 0; t < j; ++t) sacc = fma(-L[i][t], L[j][t], sacc);
+                if (i == j) {
+                    dead[i] = !(sacc > 1e-13 * tr) || !(tr > 0.0);
+                    L[i][i] = dead[i] ? 1.0 : sqrt(sacc);
+                } else {
+                    L[i][j] = dead[j] ? 0.0 : sacc / L[j][j];
+                }
+            }
+            if (dead[i]) {
+#pragma unroll
+                for (int j = 0; j < i; ++j) L[i][j] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+#pragma unroll
+            for (int i = j; i < KD; ++i) {
+                double sacc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int t = j; t < i; ++t) sacc = fma(-L[i][t], Li[t][j], sacc);
+                Li[i][j] = dead[i] ? 0.0 : sacc / L[i][i];
+            }
+        }
+        for (int a = lane; a < nf; a += 64) {
+            double w[KD];
+#pragma unroll
+            for (int k = 0; k < KD; ++k) w[k] = W[k][a];
+#pragma unroll
+            for (int i = 0; i < KD; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) acc = fma(Li[i][j], w[j], acc);
+                W[i][a] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    cholesky_qr(V);
+    cholesky_qr(V);
+    for (int it = 0; it < BASIS_ITERS; ++it) {
+        // Z_k = C V_k with C[a][b] = M[a][b]/ns - mu_a mu_b
+        for (int a = lane; a < nf; a += 64) {
+            double acc[KD];
+#pragma unroll
+            for (int k = 0; k < KD; ++k) acc[k] = 0.0;
+#pragma unroll 4
+            for (int b = 0; b < nf; ++b) {
+                const double cab = c_in_lds ? Cs[a][b] : ((a <= b ? M[size_t(a) * m + b] : M[size_t(b) * m + a]) * inv - mu[a] * mu[b]);
+#pragma unroll
+                for (int k = 0; k < KD; ++k) acc[k] = fma(cab, V[k][b], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KD; ++k) Z[k][a] = acc[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        cholesky_qr(Z);
+        cholesky_qr(Z);
+        // a direction that C annihilated comes back as a zero row: keep the previous row there if it is still
+        // orthogonal to the new ones?  Not needed for validity -- a zero row only weakens the screen.
+        for (int k = 0; k < KD; ++k)
+            for (int a = lane; a < nf; a += 64) V[k][a] = Z[k][a];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // Gershgorin bound of the largest eigenvalue of V V^T (= |V|_2^2): max_i sum_j |<V_i, V_j>|
+    {
+        const int gi = lane >> 3, gj = lane & 7;
+        double g = 0.0;
+        for (int a = 0; a < nf; ++a) g = fma(V[gi][a], V[gj][a], g);
+        Gm[gi][gj] = fabs(g);
+        __builtin_amdgcn_wave_barrier();
+    }
+    double gmax = 0.0;
+    for (int i = 0; i < KD; ++i) {
+        double row = 0.0;
+        for (int j = 0; j < KD; ++j) row += Gm[i][j];
+        gmax = fmax(gmax, row);
+    }
+    const double sc = gmax > 0.0 ? 1.0 / sqrt(gmax * (1.0 + 1e-12)) : 0.0;
+    for (int a = lane; a < nf; a += 64)
+        for (int k = 0; k < KD; ++k) {
+            const double v = V[k][a] * sc;
+            V[k][a] = v;
+            Qout[size_t(k) * nf + a] = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < KD) {
+        double b = 0.0;
+        for (int a = 0; a < nf; ++a) b = fma(V[lane][a], mu[a], b);
+        bout[lane] = b;
+    }
+}
+
+// fp32 limit of the screen from the largest descriptor magnitude (see descriptor_limit32 for the derivation)
+__global__ void k_descriptor_limit(const unsigned *__restrict__ dmax_bits, double limit, float *__restrict__ limit32) {
+    float dmaxf = __uint_as_float(*dmax_bits);
+    double dmax = (dmaxf >= 0.0f && dmaxf < 3.0e38f) ? double(dmaxf) : 3.0e38;  // NaN / inf: the screen drops nothing
+    const double eta = 3.0 * 5.9604644775390625e-08 * 2.0 * dmax;               // 3 * 2^-24 * 2 dmax
+    const double a = 1.0 - 9.5367431640625e-07, b = 2.0 * eta * sqrt(double(KD));  // 1 - 2^-20
+    const double x = (b + sqrt(b * b + 4.0 * a * limit)) / (2.0 * a);
+    const double l32 = x * x * (1.0 + 1e-6) + 1e-30;
+    float f = float(l32);
+    if (double(f) < l32) f = __uint_as_float(__float_as_uint(f) + 1u);  // next float up (f > 0)
+    *limit32 = (l32 < 3.0e38) ? f : 3.4e38f;
+}
+
 struct SieveArgs {
     long long ld;
     int h;
@@ -140,7 +307,7 @@ struct SieveArgs {
     double thr, maxdev_thr;
     double half_h_thr2;   // h * thr^2 / 2
     int drain_min;        // queue length that triggers a drain between column tiles (1..64)
-    float desc_limit32;   // fp32 squared descriptor distance above which a pair is certainly dissimilar (descriptor_limit32)
+    const float *desc_limit32;  // device: fp32 squared descriptor distance above which a pair is certainly dissimilar
 };
 
 // H = p^T q and the sign test / exact path for one pair read from memory.  Returns true iff the pair is
@@ -178,8 +345,9 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
-    constexpr int QCAP = TI * 64 + 64;  // one column tile can add TI*64 pairs on top of a remainder below 64
-    __shared__ unsigned s_queue[4][QCAP];
+    constexpr int QCAP = TI * 256 + 64;  // one 256-column tile can add TI*256 pairs on top of a remainder below 64
+    // an entry packs the row (4 bits) and the column offset inside the segment (12 bits: segments are <= 4096 columns)
+    __shared__ unsigned short s_queue[4][QCAP];
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -212,7 +380,8 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     __builtin_amdgcn_wave_barrier();
 
     const int h3 = a.h * 3;
-    unsigned *queue = s_queue[wid];
+    const float limit32 = *a.desc_limit32;
+    unsigned short *queue = s_queue[wid];
     int qn = 0;
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -229,8 +398,8 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
         double Gi = 0.0, Gj = 0.0;
         if (mine) {
             const unsigned e = queue[base + g];
-            t = int(e >> 16);
-            col = seg_lo + int(e & 0xffffu);
+            t = int(e >> 12);
+            col = seg_lo + int(e & 0xfffu);
             r = r0 + t;
             const int64_t i = act[r], j = act[col];
             pp = heavy + i * h3, pq = heavy + j * h3;
@@ -251,13 +420,16 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
         }
     };
 
-    for (int c0 = seg_lo; c0 < cmax && alive; c0 += 64) {
-        {   // ---- screen one 64-column tile against every live row (the column descriptor dies with this block)
-            const int col = c0 + lane;
-            float dq[DW];
+    constexpr int CPL = 4;            // columns per lane: a tile is 64 * CPL columns, so one LDS read of a row
+    constexpr int TILE_COLS = 64 * CPL;  // descriptor serves 4 x 64 pairs and the loop overhead is paid once per 256
+    for (int c0 = seg_lo; c0 < cmax && alive; c0 += TILE_COLS) {
+        {   // ---- screen one tile against every live row (the column descriptors die with this block)
+            float dq[CPL][DW];
 #pragma unroll
-            for (int k = 0; k < DW; ++k) dq[k] = Dc[int64_t(k) * a.ld + col];
-            const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + 63;
+            for (int u = 0; u < CPL; ++u)
+#pragma unroll
+                for (int k = 0; k < DW; ++k) dq[u][k] = Dc[int64_t(k) * a.ld + c0 + 64 * u + lane];
+            const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
             while (rows) {
                 const int t = __ffs(rows) - 1;
@@ -265,20 +437,27 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
                 const int r = r0 + t;
                 const int ce = __builtin_amdgcn_readlane(my_cend, t);
                 const float *dr = rowdesc + t * DW;
-                float s0 = 0.0f, s1 = 0.0f;
+                float rd[DW];
 #pragma unroll
-                for (int k = 0; k < KD; ++k) {
-                    const float d0 = dr[k] - dq[k], d1 = dr[KD + k] - dq[KD + k];
-                    s0 = fmaf(d0, d0, s0);
-                    s1 = fmaf(d1, d1, s1);
-                }
+                for (int k = 0; k < DW; ++k) rd[k] = dr[k];
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
-                n_screened += (unsigned long long)max(0, min(ce, c0 + 64) - max(r + 1, c0));
-                const bool pass = col > r && col < ce && !(s0 > a.desc_limit32) && !(s1 > a.desc_limit32);
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned(t) << 16) | unsigned(col - seg_lo);
-                    qn += __popcll(m);
+                n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
+#pragma unroll
+                for (int u = 0; u < CPL; ++u) {
+                    const int col = c0 + 64 * u + lane;
+                    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) {
+                        const float d0 = rd[k] - dq[u][k], d1 = rd[KD + k] - dq[u][KD + k];
+                        s0 = fmaf(d0, d0, s0);
+                        s1 = fmaf(d1, d1, s1);
+                    }
+                    const bool pass = col > r && col < ce && !(s0 > limit32) && !(s1 > limit32);
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(col - seg_lo));
+                        qn += __popcll(m);
+                    }
                 }
             }
         }

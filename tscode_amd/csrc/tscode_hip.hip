@@ -480,7 +480,7 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel: fp32 descriptors
     double *Gall = nullptr;
-    float desc_limit32 = 0.0f;
+    float *desc_limit32 = nullptr;  // device scalar
     PassCounters *counters = nullptr;
     PruneState *state = nullptr;
     PassRecord *records = nullptr;  // [TSC_MAX_PASSES]
@@ -519,6 +519,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
 }
 
 // Descriptors of every structure for the sieve: leading principal axes of the two feature families (sieve.hpp).
+// Everything is enqueued; nothing waits for the host.
 static int build_descriptors(tsc_prune *p) {
     tsc_ctx *c = p->ctx;
     hipStream_t st = c->stream;
@@ -528,48 +529,28 @@ static int build_descriptors(tsc_prune *p) {
     const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
     Scratch s(c);
     double *d_M[NFAM], *d_Q;
-    std::vector<double> M[NFAM];
-    TSC_TRY(s.get(size_t(KD) * (nf[0] + nf[1]) + DW + 1, &d_Q));
+    unsigned *d_dmax;
+    const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
+    TSC_TRY(s.get(q_doubles + DW + 1, &d_Q));
+    TSC_TRY(s.get(4, &d_dmax));
+    TSC_HIP(hipMemsetAsync(d_dmax, 0, 4 * sizeof(unsigned), st));
     for (int f = 0; f < NFAM; ++f) {
         const int m = nf[f] + 1;
-        M[f].assign(size_t(m) * m, 0.0);
         TSC_TRY(s.get(size_t(m) * m, &d_M[f]));
-        if (nf[f] == 0) continue;
         TSC_HIP(hipMemsetAsync(d_M[f], 0, size_t(m) * m * sizeof(double), st));
+        if (nf[f] == 0) continue;
         size_t lds = size_t(32) * m * sizeof(double);
         if (lds > 64 * 1024)
             TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, p->heavy, h, f, nf[f], stride, n_samples, d_M[f]);
-        TSC_HIP(hipGetLastError());
-        TSC_HIP(hipMemcpyAsync(M[f].data(), d_M[f], M[f].size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    TSC_HIP(hipStreamSynchronize(st));
-    std::vector<double> Q(size_t(KD) * (nf[0] + nf[1]) + DW + 1, 0.0);
-    descriptor_basis(M[0].data(), nf[0], n_samples, Q.data());
-    descriptor_basis(M[1].data(), nf[1], n_samples, Q.data() + size_t(KD) * nf[0]);
-    // bias = projection of the sample mean of each family (centres the descriptors; cancels in differences)
-    double *bias = Q.data() + size_t(KD) * (nf[0] + nf[1]);
-    for (int f = 0, qoff = 0; f < NFAM; qoff += KD * nf[f], ++f)
-        for (int k = 0; k < KD; ++k) {
-            double b = 0.0;
-            const int m = nf[f] + 1;
-            for (int a = 0; a < nf[f]; ++a) b += Q[size_t(qoff) + size_t(k) * nf[f] + a] * (M[f][size_t(a) * m + nf[f]] / std::max(1, n_samples));
-            bias[f * KD + k] = b;
-        }
-    unsigned *d_dmax;
-    TSC_TRY(s.get(4, &d_dmax));
-    TSC_HIP(hipMemsetAsync(d_dmax, 0, 4 * sizeof(unsigned), st));
-    TSC_HIP(hipMemcpyAsync(d_Q, Q.data(), Q.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), size_t(KD) * (nf[0] + nf[1]) * sizeof(double), st, p->heavy,
-                       p->n, h, nf[0], nf[1], (const double *)d_Q, (const double *)(d_Q + size_t(KD) * (nf[0] + nf[1])), p->Dall, p->Gall, d_dmax);
+    hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
+                       d_Q + q_doubles);
+    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), q_doubles * sizeof(double), st, p->heavy, p->n, h, nf[0], nf[1],
+                       (const double *)d_Q, (const double *)(d_Q + q_doubles), p->Dall, p->Gall, d_dmax);
+    hipLaunchKernelGGL(k_descriptor_limit, dim3(1), dim3(1), 0, st, (const unsigned *)d_dmax, double(p->h) * p->thr * p->thr, p->desc_limit32);
     TSC_HIP(hipGetLastError());
-    TSC_HIP(hipMemcpyAsync(c->pinned, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    TSC_HIP(hipStreamSynchronize(st));  // Q lives in a host vector and in scratch that is released on return
-    float dmax;
-    memcpy(&dmax, c->pinned, sizeof(float));
-    if (!(dmax >= 0.0f) || !std::isfinite(dmax)) dmax = 3.0e38f;  // NaN / inf coordinates: nothing is dropped by the screen
-    p->desc_limit32 = descriptor_limit32(double(p->h) * p->thr * p->thr, double(dmax));
-    return 0;
+    return 0;  // the scratch blocks go back to the stream-ordered cache: later users run after these kernels
 }
 
 static int get_event(tsc_ctx *c, hipEvent_t *e) {
@@ -624,6 +605,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
         if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dr);
         if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dc);
+        if (!rc) rc = palloc(p, 4, &p->desc_limit32);
     }
     if (!rc && p->algo == ALGO_TILE) {
         const size_t hp3 = size_t(p->hp) * 3;
@@ -697,7 +679,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int64_t n = p->n, k = p->cur_k;
     const int slot = p->cur_slot;
     const int A = int(n);  // grids are sized for the upper bound; kernels read the true count from the state block
-    PassGeom g{n, k, n / k};
+    PassGeom g{int(n), int(k), int(n / k)};
     const int *gate = &p->state->pass_on;
     for (int i = 0; i < 4; ++i)
         if (!p->ev[slot][i]) TSC_TRY(get_event(c, &p->ev[slot][i]));
@@ -731,7 +713,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // (measured on MI355X: 512 columns is best up to ~1.5e5 structures, 2048 at 1e6; "seg_cols" overrides)
     int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 150000 ? 512 : (n <= 400000 ? 1024 : 2048));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
-    const int n_seg = ceil_div(max_range + 64, seg_cols);
+    const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
     TSC_HIP(hipEventRecord(p->ev[slot][1], st));
@@ -790,7 +772,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
-    PassGeom g{p->n, p->cur_k, p->n / p->cur_k};
+    PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
     hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), 0, c->stream, g, (const PruneState *)p->state, p->act, p->cend,
                        p->best, p->mask, p->key_a, p->key_b, p->n_keys, p->counters);
     TSC_HIP(hipGetLastError());
@@ -919,7 +901,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
     if (strcmp(name, "seg_cols") == 0) {
-        TSC_REQUIRE(value == 0 || (value >= 64 && value <= 32768 && int(value) % 64 == 0), "seg_cols must be 0 (automatic) or a multiple of 64 in [64, 32768]");
+        TSC_REQUIRE(value == 0 || (value >= 256 && value <= 4096 && int(value) % 256 == 0), "seg_cols must be 0 (automatic) or a multiple of 256 in [256, 4096]");
         c->seg_cols = int(value);
         return 0;
     }
