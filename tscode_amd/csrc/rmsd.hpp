@@ -341,7 +341,7 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
     return lo | hi;
 }
 
-// One wavefront per active row i: cend[r] = rank of the first active column j in (i, last) with
+// One 16-lane group per active row i (4 rows per wavefront): cend[r] = rank of the first active column j in (i, last) with
 // (first + (j - i)) in the cache view (the row returns "not similar" there, :66-67), else rank of `last`.
 // Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
 // The same wavefront also initialises best[r] and, for the sieve, copies the row's descriptor (dw doubles of D, original
@@ -351,38 +351,46 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
                                                     int32_t *__restrict__ cend, int32_t *__restrict__ best, const float *__restrict__ D, int dw,
                                                     float *__restrict__ Dr, float *__restrict__ Dc, int64_t ld) {
+    // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
     if (st->pass_on == 0) return;
-    const int lane = threadIdx.x & 63;
-    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= st->A) return;
-    int64_t i = act_idx[r], first, last;
-    if (D && lane < dw) {
-        const float v = D[i * dw + lane];
-        Dr[int64_t(r) * dw + lane] = v;
-        Dc[int64_t(lane) * ld + r] = v;
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
+    const bool mine = r < st->A;
+    int64_t i = 0, first = 0, last = 0;
+    if (mine) {
+        i = act_idx[r];
+        if (D && sl < dw) {
+            const float v = D[i * dw + sl];
+            Dr[int64_t(r) * dw + sl] = v;
+            Dc[int64_t(sl) * ld + r] = v;
+        }
+        chunk_of(g, i, first, last);
     }
-    chunk_of(g, i, first, last);
     int64_t found = last;
     if (use_cache) {
-        const int64_t len = last - i - 1;  // candidate deltas d = 1 .. len
-        for (int64_t base = 0; base < len; base += 64 * 64) {
-            int64_t d0 = 1 + base + int64_t(lane) * 64;
+        const int64_t len = mine ? last - i - 1 : 0;  // candidate deltas d = 1 .. len
+        bool scanning = len > 0;
+        for (int64_t base = 0; __ballot(scanning) != 0; base += 16 * 64) {
             unsigned long long w = 0;
-            if (d0 <= len) {
+            const int64_t d0 = 1 + base + int64_t(sl) * 64;
+            if (scanning && d0 <= len) {
                 w = extract64(mbit, i + d0) & extract64(dbit, first + d0);
-                int64_t rem = len - d0 + 1;
+                const int64_t rem = len - d0 + 1;
                 if (rem < 64) w &= (1ull << rem) - 1ull;
             }
-            unsigned long long hit = __ballot(w != 0);
-            if (hit) {
-                int fl = __ffsll((long long)hit) - 1;
-                unsigned long long wl = __shfl(w, fl);
+            const unsigned hit = unsigned(__ballot(w != 0) >> (16 * sub)) & 0xffffu;  // this row's 16 lanes
+            if (scanning && hit) {
+                const int fl = __ffs(hit) - 1;
+                const unsigned long long wl = __shfl(w, 16 * sub + fl);
                 found = i + 1 + base + int64_t(fl) * 64 + (__ffsll((long long)wl) - 1);
-                break;
+                scanning = false;
+            } else {
+                (void)__shfl(w, 16 * sub);  // keep the shuffle convergent for every lane
+                if (base + 16 * 64 >= len) scanning = false;
             }
         }
     }
-    if (lane == 0) {
+    if (mine && sl == 0) {
         cend[r] = pos[found];
         best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
     }

@@ -696,7 +696,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     if (use_cache)
         hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit,
                            (const PruneState *)p->state);
-    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 4)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
+    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
                        p->dbit, p->cend, p->best, (const float *)p->Dall, DW, p->Dr, p->Dc, p->npad);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
