@@ -427,3 +427,57 @@ def test_greedy_group_filter(eng, oracle):
     assert np.array_equal(got, want)
     assert 0.05 < got.mean() < 0.95
     assert tscode_amd.filter_angular_groups(np.zeros((0, 4, 3)), [], 1.0).shape == (0,)
+
+
+def test_prune_random_small_ensembles(eng, oracle, algo):
+    """Many small random ensembles (sizes that exercise 1-4 passes, ragged chunk remainders, 1..40 heavy atoms,
+    loose and tight clusters, both modes): masks and the reference's pair-evaluation counts equal the oracle's."""
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for case in range(60):
+        n = int(rng.choice([1, 2, 3, 19, 20, 21, 40, 41, 63, 64, 65, 100, 101, 127, 199, 200, 201, 257, 399, 400, 401, 450]))
+        h = int(rng.integers(1, 41))
+        if algo == 1 and h > 32:
+            h = 32
+        n_par = max(1, n // int(rng.integers(1, 9)))
+        spread = float(rng.choice([0.01, 0.05, 0.15, 0.3]))
+        base = rng.normal(size=(n_par, h, 3)) * float(rng.choice([1.0, 3.0, 8.0])) + rng.normal(size=(n_par, 1, 3)) * 2
+        heavy = np.ascontiguousarray(base[rng.integers(0, n_par, size=n)] + rng.normal(size=(n, h, 3)) * spread)
+        thr = float(rng.choice([0.25, 0.5, 1.0]))
+        for mode in (0, 1):
+            mr, mm = oracle.prune_margins(heavy, thr, mode)
+            if min(mr, mm) < 1e-7:
+                continue                      # a pair sits on a threshold: not a fair bit-exact case (guard band)
+            ref = oracle.prune_heavy(heavy, thr, mode=mode)
+            mask, stats = eng.prune_heavy(heavy, thr, mode)
+            assert np.array_equal(mask, ref["mask"]), (case, n, h, thr, mode, int(mask.sum()), int(ref["mask"].sum()))
+            assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
+            assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+            checked += 1
+    assert checked > 100
+
+
+def test_prune_when_descriptors_cannot_separate(eng, oracle):
+    """Worst case for the sieve: two rigid bodies, A fixed and B rotated about the origin, with the atoms ordered so that
+    every descriptor pair (a, a + h/2) lies inside one body.  Atom norms and those pair distances (both descriptor
+    families) are then identical for all structures, nothing can be screened out, and every pair needs H.
+    The verdicts must still be the oracle's."""
+    from tscode_amd.synthetic import quat_to_mat
+    rng = np.random.default_rng(99)
+    A, B = rng.normal(size=(6, 3)) * 3, rng.normal(size=(6, 3)) * 3
+    n_par = 60
+    rots = quat_to_mat(rng.normal(size=(n_par, 4)))
+    which = rng.integers(0, n_par, size=400)
+    jitter = quat_to_mat(np.concatenate([np.ones((400, 1)), rng.normal(size=(400, 3)) * 0.004], axis=1))
+    Bs = np.einsum("nij,njk,ak->nai", rots[which], jitter, B)            # B rotated about the origin: norms unchanged
+    heavy = np.empty((400, 12, 3))
+    heavy[:, [0, 1, 2, 6, 7, 8]] = A                                     # pairs (0,6) (1,7) (2,8) inside A
+    heavy[:, [3, 4, 5, 9, 10, 11]] = Bs                                  # pairs (3,9) (4,10) (5,11) inside B
+    heavy = np.ascontiguousarray(heavy)
+    for mode in (0, 1):
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"])
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+        assert sum(s["pairs_computed"] for s in stats) >= 0.9 * sum(s["pairs_screened"] for s in stats)   # nothing screened out
+    assert 30 < ref["mask"].sum() < 400
