@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtscode_hip.so")
+LIB_PATH = os.environ.get("TSCODE_AMD_LIB") or os.path.join(_HERE, "libtscode_hip.so")   # override: A/B builds
 
 TSC_MAX_PASSES = 18
 

@@ -247,7 +247,7 @@ struct PassRecord {  // one per schedule slot, read back once at the end of the 
 __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit,
                                                    unsigned long long *__restrict__ dbit, int bit_words, int32_t *__restrict__ n_keys,
                                                    PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
-                                                   PassCounters *__restrict__ cnt) {
+                                                   PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items) {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
     for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
@@ -257,6 +257,11 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
     for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
     char *r = reinterpret_cast<char *>(rec);
     for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride) r[e] = 0;
+    // per-block counts of the mask for the exclusive scan of every pass; k_apply_pass keeps them current
+    for (int64_t e = tid; e < n_blocks; e += stride) {
+        const int64_t lo = e * block_items;
+        bsum[e] = int32_t(lo >= n ? 0 : (n - lo < block_items ? n - lo : block_items));
+    }
     if (tid == 0) {
         n_keys[0] = 0;
         st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->pad = 0;
@@ -575,13 +580,14 @@ __global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, const PruneState
                                                      const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
                                                      uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
                                                      int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
-                                                     PassCounters *__restrict__ cnt) {
+                                                     PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items) {
     if (st->pass_on == 0) return;
     const int n_active = st->A;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     unsigned long long ev = 0;
     bool removed = false;
+    int my_block = -1;
     int64_t first = 0, delta = 0;
     if (r < n_active) {
         const int b = best[r];
@@ -590,12 +596,22 @@ __global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, const PruneState
             int64_t last;
             chunk_of(g, i, first, last);
             mask[i] = 0;
+            my_block = int(i / block_items);
             delta = j - i;
             removed = true;
             ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
         } else {
             ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
         }
+    }
+    // the scan's per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a
+    // wavefront fall into one or two blocks, and thousands of single decrements of two cache lines would serialise
+    for (unsigned long long left = __ballot(removed); left;) {
+        const int l = __ffsll((long long)left) - 1;
+        const int blk = __shfl(my_block, l);
+        const unsigned long long same = __ballot(removed && my_block == blk);
+        if (lane == l) atomicSub(&bsum[blk], __popcll(same));
+        left &= ~same;
     }
     // one slot reservation per wavefront for the keys of its removed rows (order inside the cache is irrelevant)
     const unsigned long long rm = __ballot(removed);

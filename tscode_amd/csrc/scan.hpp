@@ -92,10 +92,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__re
 
 // Enqueue the two passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
 // act_idx / mbit are produced); total_dev (optional) receives count_nonzero(mask).
+// bsum_current: the caller keeps bsum up to date itself (the prune run does, through k_apply_pass), so the
+// counting pass is skipped.
 inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
-                     uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr) {
+                     uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr, bool bsum_current = false) {
     int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, gate);
+    if (!bsum_current) hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, gate);
     hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, (const int32_t *)bsum, pos, act_idx, mbit_bytes, total_dev, gate);
     TSC_HIP(hipGetLastError());
     return 0;

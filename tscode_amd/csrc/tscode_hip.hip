@@ -616,7 +616,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) {
         hipStream_t st = c->stream;
         hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
-                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters);
+                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE);
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
         // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
@@ -690,7 +690,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     p->last_slot = slot;
     p->slot_used[slot] = true;
     // 1. ranks of the active structures, their index list and the mask as bits
-    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total, gate));
+    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total, gate, true));
     // 2. cache view of this pass; stop column, best[] and compacted descriptor of every row
     const int use_cache = (p->mode == 0);
     if (use_cache)
@@ -774,7 +774,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     DeviceGuard guard(c->device);
     PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
     hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), 0, c->stream, g, (const PruneState *)p->state, p->act, p->cend,
-                       p->best, p->mask, p->key_a, p->key_b, p->n_keys, p->counters);
+                       p->best, p->mask, p->key_a, p->key_b, p->n_keys, p->counters, p->bsum, SCAN_TILE);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
     p->cur_k = 0;
