@@ -30,7 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 157.3 / 2), no MFMA on this path
+FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+PMC_PROFILE = "r01_final_pmc_hbm_counters.json"   # committed rocprofv3 --pmc summary the roofline's `traffic` is read from
 
 
 def parse():
@@ -45,6 +47,8 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (seg_cols, drain_min), repeatable")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
+    ap.add_argument("--pass-timing", type=int, default=1,
+                    help="library HIP events in the timed region: 1 = start/stop events on every pair-kernel dispatch (feeds the roofline), 0 = none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="poses of the CPU baseline sample")
     return ap.parse_args()
@@ -110,6 +114,7 @@ def main():
                           force_sharded=args.force_sharded)
     from tscode_amd import get_engine
     get_engine(local_rank).set_option("prune_algo", args.algo)
+    get_engine(local_rank).set_option("pass_timing", args.pass_timing)
     for opt in args.opt:
         name, val = opt.split("=")
         get_engine(local_rank).set_option(name, float(val))
@@ -120,30 +125,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_loop(steps):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks. Returns (seconds, last result, sums)."""
+        acc = {"tile_ms": 0.0, "evals": 0, "computed": 0, "screened": 0,
+               "stage_ms": {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}}
+        res = None
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = pipe.step()
+            acc["tile_ms"] += sum(s["tile_ms"] for s in res["stats"])
+            acc["evals"] += sum(s["pairs_evaluated"] for s in res["stats"])
+            acc["computed"] += sum(s["pairs_computed"] for s in res["stats"])
+            acc["screened"] += sum(s["pairs_screened"] for s in res["stats"])
+            for k in acc["stage_ms"]:
+                acc["stage_ms"][k] += res.get("ms", {}).get(k, 0.0)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, res, acc
+
     res = None
     for _ in range(args.warmup):
         res = pipe.step()
-    sync()
-    t0 = time.perf_counter()
-    tile_ms = 0.0
-    evals = 0
-    computed = 0
-    screened = 0
-    stage_ms = {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}
-    for _ in range(args.steps):
-        res = pipe.step()
-        tile_ms += sum(s["tile_ms"] for s in res["stats"])
-        evals += sum(s["pairs_evaluated"] for s in res["stats"])
-        computed += sum(s["pairs_computed"] for s in res["stats"])
-        screened += sum(s["pairs_screened"] for s in res["stats"])
-        for k in stage_ms:
-            stage_ms[k] += res.get("ms", {}).get(k, 0.0)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, res, acc = timed_loop(args.steps)           # THE timed region (library events as --pass-timing says)
+    tile_ms, evals, computed, screened, stage_ms = acc["tile_ms"], acc["evals"], acc["computed"], acc["screened"], acc["stage_ms"]
+    # the same K steps once more with every library event off: what a production caller sees (an event record on the
+    # stream costs about 4 us on MI355X; the kernel durations of the roofline need them, the product does not)
+    events_off = None
+    if args.pass_timing != 0:
+        get_engine(local_rank).set_option("pass_timing", 0)
+        dt0, _, _ = timed_loop(args.steps)
+        get_engine(local_rank).set_option("pass_timing", args.pass_timing)
+        events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": ens.n_poses * args.steps / dt0, "unit": "conformers/s"}
 
     # verdict fingerprint (after the timed region)
     n_pass, n_keep = res["n_pass"], res["n_keep"]
@@ -162,18 +179,40 @@ def main():
         n = ens.n_poses
         flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
         tile_s = tile_ms / 1e3
-        # algorithmic bytes of the prune: sum over passes (A_p * h * 24 + 2 N)  
+        n_launch = len(res["stats"])                        # pair-kernel launches per step (one per pass)
+        launches = n_launch * args.steps
+        avg_launch_s = tile_s / launches if launches and tile_s > 0 else None
+        # algorithmic bytes of the prune: sum over passes (A_p * h * 24 + 2 N)  (SURVEY.md 8d), per launch: the mean
         b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
+        b_launch = b_k3 / n_launch if n_launch else None
         b_k12 = n * ens.frag_coords.__len__() * 96 + n_pass * ens.n_atoms * 24 + n
         ms_per_step = dt / args.steps * 1e3
+        kernel = "k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile"
+        # HBM bytes per launch from the committed PMC passes of this same command (tools/profile.sh: FETCH_SIZE and
+        # WRITE_SIZE in separate runs, KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
+        if os.path.exists(pmc_path) and args.config == "C3" and args.n_poses is None and world == 1:
+            pmc = json.load(open(pmc_path))
+            f = next((v for k, v in pmc.get("FETCH_SIZE", {}).items() if kernel in k), None)
+            w = next((v for k, v in pmc.get("WRITE_SIZE", {}).items() if kernel in k), None)
+            if f and w:
+                traffic = (2.0 * f["per_call_KB"] + w["per_call_KB"]) * 1024.0
+                traffic_src = f"profiles/{PMC_PROFILE}: (2 x FETCH_SIZE + WRITE_SIZE) per launch, rocprofv3 --pmc, separate passes"
+        hbm_achieved = b_launch / avg_launch_s / 1e9 if avg_launch_s else None
+        # SURVEY.md 8(d) flop accounting beside it: the reference's own pair evaluations x (46 h + 500) flop each over the
+        # kernel time.  The sieve reaches the reference's verdicts without forming H for most pairs, so this "algorithmic"
+        # figure exceeds the FP64 peak; `executed` is what the instructions really do: the fp32 screen (2 families x 8
+        # components x (sub + fma) = 48 flop per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per
+        # pair that reaches them; register-tiled kernel: every computed pair, h padded to a multiple of 4)
         achieved_alg = (evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
-        # executed arithmetic: descriptor screen = 2 families x 8 dims x (sub + fma) = 48 flop per screened pair;
-        # H + sign test = 18 h + 110 flop per pair that reaches them (register-tiled kernel: every computed pair, h padded to 4)
         if screened:
-            exec_flops = (screened / args.steps) * 48 + (computed / args.steps) * (18 * h + 110)
+            f32_flops = (screened / args.steps) * 48
+            f64_flops = (computed / args.steps) * (18 * h + 110)
         else:
-            exec_flops = (computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110)
-        executed_tflops = exec_flops / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
+            f32_flops = 0.0
+            f64_flops = (computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110)
+        per_s = (lambda x: x / (tile_s / args.steps) / 1e12) if tile_s > 0 else (lambda x: None)
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
             "value": n * args.steps / dt,
@@ -191,32 +230,32 @@ def main():
                                    f"10 children per parent, seed {ens.seed}; clash_thresh 1.5, max_clashes 0, rmsd_thr 0.5, "
                                    f"mode {args.mode} ({'reference-exact' if args.mode == 0 else 'cache-free'})",
                        "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": digest,
-                       "parity_vs_recorded_oracle": parity, "parallelism": f"conformer-axis shards x{world}"},
+                       "parity_vs_recorded_oracle": parity, "parallelism": f"conformer-axis shards x{world}",
+                       "library_events_in_timed_region": args.pass_timing},
             "roofline": {
-                "kernel": ("k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile") +
-                          " (all-pairs Kabsch RMSD of a pass, one launch per pass)",
-                "bound": "fp64_valu",
-                # SURVEY.md 8(d) accounting: the reference's own pair evaluations x (46 h + 500) flop each, over the
-                # kernel's HIP-event time.  The sieve kernel reaches the same verdicts without forming H for most
-                # pairs, so this figure can exceed the FP64 peak; executed_tflops is what the instructions really do.
-                "achieved": achieved_alg,
-                "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": (achieved_alg / FP64_VALU_PEAK_TFLOPS) if achieved_alg else None,
-                "traffic": None,
-                "launches_per_step": len(res["stats"]),
+                "kernel": kernel + " (all-pairs Kabsch RMSD of one pass; one launch per pass)",
+                "bound": "hbm",
+                "achieved": hbm_achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (hbm_achieved / HBM_PEAK_GBS) if hbm_achieved else None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": b_launch,
+                "avg_launch_us": avg_launch_s * 1e6 if avg_launch_s else None,
+                "launches_per_step": n_launch,
                 "kernel_ms_per_step": tile_ms / args.steps,
-                "algorithmic_pair_evals_per_step": evals / args.steps,
-                "flops_per_eval": flops_per_eval,
-                "pairs_screened_per_step": screened / args.steps,
-                "pairs_with_H_formed_per_step": computed / args.steps,
-                "executed_tflops": executed_tflops,
-                "executed_frac": (executed_tflops / FP64_VALU_PEAK_TFLOPS) if executed_tflops else None,
-                "hbm": {"bound": "hbm", "achieved": b_k3 / (tile_s / args.steps) / 1e9 if tile_s > 0 else None, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "algorithmic_bytes": b_k3},
+                "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
+                "fp64_valu": {"algorithmic_pair_evals_per_step": evals / args.steps, "flops_per_eval": flops_per_eval,
+                              "achieved_algorithmic_TFLOPs": achieved_alg, "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
+                              "frac_algorithmic": (achieved_alg / FP64_VALU_PEAK_TFLOPS) if achieved_alg else None,
+                              "pairs_screened_per_step": screened / args.steps, "pairs_with_H_formed_per_step": computed / args.steps,
+                              "executed_fp32_TFLOPs": per_s(f32_flops), "executed_fp64_TFLOPs": per_s(f64_flops),
+                              "peak_fp32_TFLOPs": FP32_VALU_PEAK_TFLOPS},
             },
             "pipeline_hbm": {"algorithmic_bytes": b_k12 + b_k3, "achieved_GBs": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9,
-                             "peak_GBs": HBM_PEAK_GBS},
+                             "peak_GBs": HBM_PEAK_GBS, "frac": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS},
+            "events_off": events_off,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4)} for s in res["stats"]],

@@ -55,7 +55,10 @@ int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
 int tsc_ctx_synchronize(tsc_ctx *ctx);
 /* Tunables.  "prune_algo": 0 = automatic (default), 1 = register-tiled all-pairs kernel (<= 32 heavy atoms),
  * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 256, at most 4096; 0 = automatic);
- * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64). */
+ * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64);
+ * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
+ * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms),
+ * 2 = also around every whole pass (gpu_ms) and the stages of tsc_pipeline_dev. */
 int tsc_ctx_set_option(tsc_ctx *ctx, const char *name, double value);
 /* Device memory helpers for hosts that do not bring their own allocator (tests, C callers). */
 int tsc_malloc(tsc_ctx *ctx, size_t bytes, void **dptr);
@@ -141,8 +144,8 @@ typedef struct {
     int64_t candidates;      /* pairs that reached the explicit-rotation path */
     int64_t pairs_screened;  /* pairs looked at by the descriptor sieve (0 when the register-tiled kernel ran) */
     int64_t new_keys;        /* cache keys appended (:76, :204) */
-    double gpu_ms;           /* HIP-event time of the whole pass on this device */
-    double tile_ms;          /* HIP-event time of the pass's pair kernel alone */
+    double gpu_ms;           /* HIP-event time of the whole pass on this device (0 unless "pass_timing" is 2) */
+    double tile_ms;          /* HIP-event time of the pass's pair kernel alone (0 unless "pass_timing" >= 1) */
     int32_t algo;            /* pair kernel used: 1 = register-tiled all-pairs, 2 = descriptor sieve */
     int32_t reserved;
 } tsc_pass_stats;

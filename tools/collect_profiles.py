@@ -1,0 +1,28 @@
+"""Summarise a tools/profile.sh output directory into profiles/ (kernel stats csv + per-kernel HBM counters).
+
+usage: python tools/collect_profiles.py gpurun_out/DIR PREFIX     -> profiles/PREFIX_kernel_stats.csv, ..._pmc_hbm_counters.json
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (MI355X_MICROARCH.md, HBM traffic section).
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+stats = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(stats, f"profiles/{prefix}_kernel_stats.csv")
+shutil.copy(f"{src}/bench_trace.json", f"profiles/{prefix}_bench_under_rocprof.json")
+out = {}
+for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(f"{src}/{name}/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    out[ctr] = {k: {"calls": c, "total_KB": v, "per_call_KB": v / c} for k, (c, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+json.dump(out, open(f"profiles/{prefix}_pmc_hbm_counters.json", "w"), indent=1)
+for k, v in list(out["FETCH_SIZE"].items())[:8]:
+    print(k, v)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtscode_hip.so")
 SOURCES = ["tscode_hip.hip"]
-HEADERS = ["common.hpp", "scan.hpp", "embed_clash.hpp", "rmsd.hpp", os.path.join("..", "..", "include", "tscode_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "tscode_hip.h")]
 
 
 def _hipcc():

@@ -21,6 +21,7 @@
 // inner loop is 9 v_fma_f64 per atom with one SGPR operand each.
 #pragma once
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace tsc {
 
@@ -236,7 +237,7 @@ struct PruneState {
     int n_active;  // count_nonzero(mask) after the last finished pass
     int pass_on;   // gate of the pass in flight
     int A;         // active structures entering the pass in flight (== n_active at its start)
-    int pad;
+    unsigned ticket;  // blocks of k_apply_pass that have finished (the last one closes the pass)
 };
 struct PassRecord {  // one per schedule slot, read back once at the end of the run
     long long k, n_before, n_after, formed, exact, screened, evaluated, removed;
@@ -264,36 +265,48 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
     }
     if (tid == 0) {
         n_keys[0] = 0;
-        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->pad = 0;
+        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0;
     }
 }
 
 // Closes the pass in slot `prev` (sums its counters, updates n_active) and opens the pass in slot `cur` (gate, A,
-// zeroed counters and cache-view bitmap).  prev / cur = -1: nothing to close / open.  One block of 256 threads.
-__global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec,
-                                                    int prev, int cur, long long k_cur, int algo_cur, unsigned long long *__restrict__ dbit,
-                                                    int bit_words) {
-    __shared__ unsigned long long s_sum[CNT_WORDS];
-    const bool closing = prev >= 0 && st->pass_on != 0;
-    if (closing && threadIdx.x < CNT_WORDS) {
-        unsigned long long v = 0;
-        for (int b = 0; b < CNT_BUCKETS; ++b) v += cnt->w[b][threadIdx.x];
-        s_sum[threadIdx.x] = v;
+// zeroed counters and cache-view bitmap).  prev / cur = -1: nothing to close / open.  Runs in ONE block of 256
+// threads: the last block of k_apply_pass (below) or, for the first pass of a run, k_pass_step.
+struct StepArgs {
+    int prev, cur;
+    long long k_cur;
+    int algo_cur;
+    int bit_words;
+};
+
+__device__ inline void pass_step_block(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec, const StepArgs &sa,
+                                       unsigned long long *__restrict__ dbit, unsigned long long *s_sum /* 32 words of LDS */) {
+    const bool closing = sa.prev >= 0 && st->pass_on != 0;
+    if (closing) {
+        // 256 threads, two loads each (word t % 8 of buckets t / 8 and t / 8 + 32), all in flight together; the buckets
+        // were written by other blocks' atomics, so they are read at the L2, not through this CU's cache
+        static_assert(CNT_BUCKETS == 64 && CNT_REMOVED < 8, "layout of the parallel counter sum");
+        const int w = threadIdx.x & 7, b0 = threadIdx.x >> 3;
+        unsigned long long v = __hip_atomic_load(&cnt->w[b0][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                               __hip_atomic_load(&cnt->w[b0 + 32][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) < 8) s_sum[8 * (threadIdx.x >> 6) + w] = v;  // s_sum[4][8]: one partial per wavefront
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (closing) {
-            PassRecord &r = rec[prev];
+            PassRecord &r = rec[sa.prev];
+            for (int w = 0; w < 8; ++w) s_sum[w] += s_sum[8 + w] + s_sum[16 + w] + s_sum[24 + w];
             r.formed = (long long)s_sum[CNT_FORMED], r.exact = (long long)s_sum[CNT_EXACT], r.screened = (long long)s_sum[CNT_SCREENED];
             r.evaluated = (long long)s_sum[CNT_EVALUATED], r.removed = (long long)s_sum[CNT_REMOVED];
             st->n_active -= int(s_sum[CNT_REMOVED]);
             r.n_after = st->n_active;
         }
         int on = 0;
-        if (cur >= 0) {
-            on = (k_cur == 1 || 20 * k_cur < (long long)st->n_active) ? 1 : 0;  // rmsd_pruning.py:192
-            PassRecord &r = rec[cur];
-            r.k = k_cur, r.n_before = st->n_active, r.n_after = st->n_active, r.on = on, r.algo = algo_cur;
+        if (sa.cur >= 0) {
+            on = (sa.k_cur == 1 || 20 * sa.k_cur < (long long)st->n_active) ? 1 : 0;  // rmsd_pruning.py:192
+            PassRecord &r = rec[sa.cur];
+            r.k = sa.k_cur, r.n_before = st->n_active, r.n_after = st->n_active, r.on = on, r.algo = sa.algo_cur;
             r.formed = r.exact = r.screened = r.evaluated = r.removed = 0;
         }
         st->A = st->n_active;
@@ -302,8 +315,14 @@ __global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, 
     __syncthreads();
     unsigned long long *c = &cnt->w[0][0];
     for (int e = threadIdx.x; e < CNT_BUCKETS * CNT_WORDS; e += 256) c[e] = 0;
-    if (cur >= 0)
-        for (int e = threadIdx.x; e < bit_words; e += 256) dbit[e] = 0;
+    if (sa.cur >= 0)
+        for (int e = threadIdx.x; e < sa.bit_words; e += 256) dbit[e] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec,
+                                                    StepArgs sa, unsigned long long *__restrict__ dbit) {
+    __shared__ unsigned long long s_sum[32];
+    pass_step_block(st, cnt, rec, sa, dbit, s_sum);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -324,11 +343,22 @@ __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, in
 
 // Cache view of one pass: a key (a, b) = (first, first + (j - i)) (:65) can be hit only where a is a chunk
 // start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
-__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a,
-                                                     const int32_t *__restrict__ key_b, const int32_t *__restrict__ n_keys,
-                                                     unsigned long long *__restrict__ dbit, const PruneState *__restrict__ st) {
+// Opens the data of a pass in one launch: ranks of the active structures, their index list and the mask as bits
+// (the second phase of the exclusive scan, scan.hpp; k_apply_pass keeps the per-block counts current), and the
+// cache view of the pass: key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
+// Grid: scan_grid_blocks(n) blocks of SCAN_THREADS.
+__global__ __launch_bounds__(SCAN_THREADS) void k_open_pass(PassGeom g, int use_cache, const PruneState *__restrict__ st,
+                                                             const uint8_t *__restrict__ mask, const int32_t *__restrict__ bsum,
+                                                             int32_t *__restrict__ pos, int32_t *__restrict__ act_idx,
+                                                             uint8_t *__restrict__ mbit_bytes, int32_t *__restrict__ total_out,
+                                                             const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
+                                                             const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    __shared__ int s_o[SCAN_THREADS / WAVE];
     if (st->pass_on == 0) return;
-    int nk = *n_keys;
+    scan_write_block(mask, g.n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o);
+    if (!use_cache) return;
+    const int nk = *n_keys;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
         const int a = key_a[q], b = key_b[q];
         const int c = a / g.cs;
@@ -354,8 +384,7 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
-                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, const float *__restrict__ D, int dw,
-                                                    float *__restrict__ Dr, float *__restrict__ Dc, int64_t ld) {
+                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best) {
     // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
     if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
@@ -364,11 +393,6 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
     int64_t i = 0, first = 0, last = 0;
     if (mine) {
         i = act_idx[r];
-        if (D && sl < dw) {
-            const float v = D[i * dw + sl];
-            Dr[int64_t(r) * dw + sl] = v;
-            Dc[int64_t(sl) * ld + r] = v;
-        }
         chunk_of(g, i, first, last);
     }
     int64_t found = last;
@@ -452,26 +476,67 @@ struct TileArgs {
     double half_h_thr2;  // h * thr^2 / 2
 };
 
-// Fast sign test described at the top of this file.  true = certainly rmsd >= thr.
-__device__ inline bool certainly_dissimilar(const double H[9], double L) {
-    const double F = H[0] * H[0] + H[1] * H[1] + H[2] * H[2] + H[3] * H[3] + H[4] * H[4] + H[5] * H[5] + H[6] * H[6] +
-                     H[7] * H[7] + H[8] * H[8];
+// Fast tests on the characteristic quartic of Horn's matrix (described at the top of this file).
+//   PAIR_DISSIMILAR  certainly rmsd >= thr:  P, P', P'' at L = (Gp + Gq - h thr^2) / 2 all exceed their rounding bounds, so
+//                    L lies above the largest root l1 and h rmsd^2 = Gp + Gq - 2 l1 > h thr^2;
+//   PAIR_SIMILAR     certainly similar (near-duplicates, the bulk of what a prune removes): with x = (Gp + Gq) / 2 - 2 thr^2 > 0,
+//                    P''(x) > 0 and P'(x) > 0 put x above the largest root of P' (the roots of P'' are +-sqrt(|H|_F^2 / 3) and
+//                    those of P' interlace them; the other region with both signs lies below the negative root of P''),
+//                    hence above the second root l2 of P, and P(x) < 0 then puts it below the largest root l1 (all with
+//                    rounding bounds), so h rmsd^2 = Gp + Gq - 2 l1 < 4 thr^2: rmsd < 2 thr / sqrt(h) <= thr
+//                    for h >= 4, and maxdev <= sqrt(sum dev^2) = sqrt(h) rmsd < 2 thr -- both conditions of
+//                    rmsd_pruning.py:75 hold without forming the rotation (needs maxdev_thr == 2 thr, as :95 sets it);
+//   PAIR_UNDECIDED   everything else takes the explicit-rotation path.
+enum { PAIR_DISSIMILAR = 0, PAIR_SIMILAR = 1, PAIR_UNDECIDED = 2 };
+
+struct Quartic {
+    double F, CF, c2, c1, c0;
+};
+__device__ inline Quartic horn_quartic(const double H[9]) {
+    Quartic q;
+    q.F = H[0] * H[0] + H[1] * H[1] + H[2] * H[2] + H[3] * H[3] + H[4] * H[4] + H[5] * H[5] + H[6] * H[6] + H[7] * H[7] + H[8] * H[8];
     const double C0 = H[4] * H[8] - H[5] * H[7], C1 = H[5] * H[6] - H[3] * H[8], C2 = H[3] * H[7] - H[4] * H[6];
     const double C3 = H[2] * H[7] - H[1] * H[8], C4 = H[0] * H[8] - H[2] * H[6], C5 = H[1] * H[6] - H[0] * H[7];
     const double C6 = H[1] * H[5] - H[2] * H[4], C7 = H[2] * H[3] - H[0] * H[5], C8 = H[0] * H[4] - H[1] * H[3];
     const double det = H[0] * C0 + H[1] * C1 + H[2] * C2;
-    const double CF = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
-    const double c2 = -2.0 * F, c1 = -8.0 * det, c0 = F * F - 4.0 * CF;
+    q.CF = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
+    q.c2 = -2.0 * q.F, q.c1 = -8.0 * det, q.c0 = q.F * q.F - 4.0 * q.CF;
+    return q;
+}
+constexpr double QUARTIC_KAPPA = 1e-12;  // >> accumulated rounding of the coefficients for h up to ~1000 atoms
+
+__device__ inline bool quartic_above_top_root(const Quartic &q, double L) {
     const double L2 = L * L;
-    const double t4 = L2 * L2, t2 = c2 * L2, t1 = c1 * L;
-    constexpr double KAPPA = 1e-12;  // >> accumulated rounding of the coefficients for h up to ~1000 atoms
-    const double P = t4 + t2 + t1 + c0;
-    const double eP = KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(c0) + 4.0 * CF + F * F);
-    const double P1 = 4.0 * L2 * L + 2.0 * c2 * L + c1;
-    const double e1 = KAPPA * (4.0 * L2 * fabs(L) + 2.0 * fabs(c2 * L) + fabs(c1));
-    const double P2 = 6.0 * L2 + c2;
-    const double e2 = KAPPA * (6.0 * L2 + fabs(c2));
+    const double t4 = L2 * L2, t2 = q.c2 * L2, t1 = q.c1 * L;
+    const double P = t4 + t2 + t1 + q.c0;
+    const double eP = QUARTIC_KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
+    const double P1 = 4.0 * L2 * L + 2.0 * q.c2 * L + q.c1;
+    const double e1 = QUARTIC_KAPPA * (4.0 * L2 * fabs(L) + 2.0 * fabs(q.c2 * L) + fabs(q.c1));
+    const double P2 = 6.0 * L2 + q.c2;
+    const double e2 = QUARTIC_KAPPA * (6.0 * L2 + fabs(q.c2));
     return (L > 0.0) && (P > eP) && (P1 > e1) && (P2 > e2);
+}
+__device__ inline bool quartic_between_top_roots(const Quartic &q, double x) {
+    const double x2 = x * x;
+    const double t4 = x2 * x2, t2 = q.c2 * x2, t1 = q.c1 * x;
+    const double P = t4 + t2 + t1 + q.c0;
+    const double eP = QUARTIC_KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
+    const double P1 = 4.0 * x2 * x + 2.0 * q.c2 * x + q.c1;
+    const double e1 = QUARTIC_KAPPA * (4.0 * x2 * fabs(x) + 2.0 * fabs(q.c2 * x) + fabs(q.c1));
+    const double P2 = 6.0 * x2 + q.c2;
+    const double e2 = QUARTIC_KAPPA * (6.0 * x2 + fabs(q.c2));
+    return (x > 0.0) && (P2 > e2) && (P1 > e1) && (P < -eP);
+}
+
+__device__ inline bool certainly_dissimilar(const double H[9], double L) { return quartic_above_top_root(horn_quartic(H), L); }
+
+// half_sum = (Gp + Gq) / 2, half_h_thr2 = h thr^2 / 2, two_thr2 = 2 thr^2 (pass a negative two_thr2 to switch the
+// near-duplicate test off: h < 4, or a maxdev threshold other than 2 thr)
+__device__ inline int pair_verdict(const double H[9], double half_sum, double half_h_thr2, double two_thr2) {
+    const Quartic q = horn_quartic(H);
+    if (quartic_above_top_root(q, half_sum - half_h_thr2)) return PAIR_DISSIMILAR;
+    if (two_thr2 > 0.0 && quartic_between_top_roots(q, half_sum - two_thr2)) return PAIR_SIMILAR;
+    return PAIR_UNDECIDED;
 }
 
 // One wavefront = one work item = (row tile of TI consecutive active rows) x (one column segment).
@@ -576,62 +641,85 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
 
 // Apply a finished pass: rows with a similar column are removed (:113) and leave one cache key each
 // (:76, appended after the pass at :204); counts what the reference's sequential scan would have evaluated.
-__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ act_idx,
+__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, PruneState *__restrict__ st, const int32_t *__restrict__ act_idx,
                                                      const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
                                                      uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
                                                      int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
-                                                     PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items) {
-    if (st->pass_on == 0) return;
-    const int n_active = st->A;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+                                                     PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items, PassRecord *__restrict__ rec,
+                                                     StepArgs next, unsigned long long *__restrict__ dbit) {
+    __shared__ unsigned long long s_sum[32];
+    __shared__ int s_last;
+    const bool pass_on = st->pass_on != 0;
+    const int n_active = pass_on ? st->A : 0;  // a pass that is gated off has no rows; its blocks still take a ticket
     const int lane = threadIdx.x & 63;
-    unsigned long long ev = 0;
-    bool removed = false;
-    int my_block = -1;
-    int64_t first = 0, delta = 0;
-    if (r < n_active) {
-        const int b = best[r];
-        if (b != INT_MAX) {
-            const int64_t i = act_idx[r], j = act_idx[b];
-            int64_t last;
-            chunk_of(g, i, first, last);
-            mask[i] = 0;
-            my_block = int(i / block_items);
-            delta = j - i;
-            removed = true;
-            ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
-        } else {
-            ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
+    unsigned long long ev_total = 0, rm_total = 0;
+    // a capped grid walks the rows tile by tile (block-uniform bounds: every wavefront keeps all its lanes for the ballots)
+    for (int row0 = blockIdx.x * 256; row0 < n_active; row0 += gridDim.x * 256) {
+        const int r = row0 + threadIdx.x;
+        unsigned long long ev = 0;
+        bool removed = false;
+        int my_block = -1;
+        int64_t first = 0, delta = 0;
+        if (r < n_active) {
+            const int b = best[r];
+            if (b != INT_MAX) {
+                const int64_t i = act_idx[r], j = act_idx[b];
+                int64_t last;
+                chunk_of(g, i, first, last);
+                mask[i] = 0;
+                my_block = int(i / block_items);
+                delta = j - i;
+                removed = true;
+                ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
+            } else {
+                ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
+            }
         }
-    }
-    // the scan's per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a
-    // wavefront fall into one or two blocks, and thousands of single decrements of two cache lines would serialise
-    for (unsigned long long left = __ballot(removed); left;) {
-        const int l = __ffsll((long long)left) - 1;
-        const int blk = __shfl(my_block, l);
-        const unsigned long long same = __ballot(removed && my_block == blk);
-        if (lane == l) atomicSub(&bsum[blk], __popcll(same));
-        left &= ~same;
-    }
-    // one slot reservation per wavefront for the keys of its removed rows (order inside the cache is irrelevant)
-    const unsigned long long rm = __ballot(removed);
-    const int n_rm = __popcll(rm);
-    int base = 0;
-    if (n_rm) {
-        if (lane == 0) base = atomicAdd(n_keys, n_rm);
-        base = __shfl(base, 0);
-        if (removed) {
-            const int slot = base + __popcll(rm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            key_a[slot] = int32_t(first);
-            key_b[slot] = int32_t(first + delta);
+        // the scan's per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a
+        // wavefront fall into one or two blocks, and thousands of single decrements of two cache lines would serialise
+        for (unsigned long long left = __ballot(removed); left;) {
+            const int l = __ffsll((long long)left) - 1;
+            const int blk = __shfl(my_block, l);
+            const unsigned long long same = __ballot(removed && my_block == blk);
+            if (lane == l) atomicSub(&bsum[blk], __popcll(same));
+            left &= ~same;
         }
+        // one slot reservation per wavefront for the keys of its removed rows (order inside the cache is irrelevant)
+        const unsigned long long rm = __ballot(removed);
+        const int n_rm = __popcll(rm);
+        int base = 0;
+        if (n_rm) {
+            if (lane == 0) base = atomicAdd(n_keys, n_rm);
+            base = __shfl(base, 0);
+            if (removed) {
+                const int slot = base + __popcll(rm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                key_a[slot] = int32_t(first);
+                key_b[slot] = int32_t(first + delta);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+        ev_total += ev, rm_total += (unsigned long long)n_rm;
     }
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
     if (lane == 0) {
         const unsigned bucket = blockIdx.x * 4 + (threadIdx.x >> 6);
-        count_add(cnt, bucket, CNT_EVALUATED, ev);
-        count_add(cnt, bucket, CNT_REMOVED, (unsigned long long)n_rm);
+        count_add(cnt, bucket, CNT_EVALUATED, ev_total);
+        count_add(cnt, bucket, CNT_REMOVED, rm_total);
     }
+    // The last block to get here closes this pass and opens the next one (what a separate one-block launch would do).
+    // The only data handed from block to block are the statistics buckets, and those are written by agent-scope
+    // atomics and read with agent-scope (sc1) loads -- so no cache fence is needed (a __threadfence() per block costs
+    // an L2 write-back each: measured 14 us per pass): every wave drains its atomics, the block's barrier, ONE lane's
+    // ticket add, and the block whose add came last reads (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(&st->ticket, 1u);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    pass_step_block(st, cnt, rec, next, dbit, s_sum);
+    if (threadIdx.x == 0) st->ticket = 0;
 }
 
 __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {

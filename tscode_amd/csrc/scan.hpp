@@ -44,13 +44,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t 
 
 // pass 2: pos[i] = number of non-zero mask bytes before i (pos[n] = total); optionally the list of
 // kept indices (act_idx[pos[i]] = i) and the mask as a bit array (bit i of mbit = mask[i] != 0).
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
-                                                              const int32_t *__restrict__ bsum, int32_t *__restrict__ pos,
-                                                              int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
-                                                              int32_t *__restrict__ total_out, const int *__restrict__ gate) {
-    __shared__ int s_w[SCAN_THREADS / WAVE];
-    __shared__ int s_o[SCAN_THREADS / WAVE];
-    if (gate && *gate == 0) return;
+// (the work of one block; s_w, s_o: SCAN_THREADS / WAVE ints of LDS each)
+__device__ inline void scan_write_block(const uint8_t *__restrict__ mask, int64_t n, const int32_t *__restrict__ bsum,
+                                        int32_t *__restrict__ pos, int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
+                                        int32_t *__restrict__ total_out, int *s_w, int *s_o) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // exclusive offset of this block = sum of the counts of the blocks before it (a few hundred values at most)
     int part = 0;
@@ -90,10 +87,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__re
     }
 }
 
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
+                                                              const int32_t *__restrict__ bsum, int32_t *__restrict__ pos,
+                                                              int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
+                                                              int32_t *__restrict__ total_out, const int *__restrict__ gate) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    __shared__ int s_o[SCAN_THREADS / WAVE];
+    if (gate && *gate == 0) return;
+    scan_write_block(mask, n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o);
+}
+
 // Enqueue the two passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
 // act_idx / mbit are produced); total_dev (optional) receives count_nonzero(mask).
 // bsum_current: the caller keeps bsum up to date itself (the prune run does, through k_apply_pass), so the
 // counting pass is skipped.
+inline int scan_grid_blocks(int64_t n) { return int(ceil_div<int64_t>(n + 1, SCAN_TILE)); }
+
 inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
                      uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr, bool bsum_current = false) {
     int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])

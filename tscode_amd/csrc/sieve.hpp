@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
 #pragma unroll
         for (int k = 0; k < DW; ++k) {
             const float v = float(d[k]);
-            D[i * DW + k] = v;
+            D[i * DW + (k % KD) * 2 + k / KD] = v;  // the two families interleaved: (family 0, family 1) of component k side by side
             mx = fmaxf(mx, fabsf(v));
         }
         G[i] = g;
@@ -298,26 +298,28 @@ __global__ void k_descriptor_limit(const unsigned *__restrict__ dmax_bits, doubl
     *limit32 = (l32 < 3.0e38) ? f : 3.4e38f;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct SieveArgs {
-    long long ld;
+    int n;   // upper bound of the active count the grid was sized for (structures of the run)
     int h;
     int tile_begin;
     int tile_stride;
     int seg_cols;
     double thr, maxdev_thr;
     double half_h_thr2;   // h * thr^2 / 2
+    double two_thr2;      // 2 thr^2 when the near-duplicate test applies (h >= 4), else -1
     int drain_min;        // queue length that triggers a drain between column tiles (1..64)
     const float *desc_limit32;  // device: fp32 squared descriptor distance above which a pair is certainly dissimilar
 };
 
-// H = p^T q and the sign test / exact path for one pair read from memory.  Returns true iff the pair is
-// similar in the reference's sense (rmsd < thr and maxdev < 2 thr, rmsd_pruning.py:75); exact_taken tells
-// whether the explicit-rotation path ran.  `lpp` consecutive lanes (power of two) share the pair: lane `sub`
-// takes atoms sub, sub + lpp, ... and the group sums H with a butterfly, so a batch of few pairs has a short
-// critical path (lpp = 64 / batch size) while a full batch runs one pair per lane (lpp = 1).
-__device__ inline bool pair_is_similar(const double *__restrict__ p, const double *__restrict__ q, int h, double Gp, double Gq,
-                                       double half_h_thr2, double thr, double maxdev_thr, bool &exact_taken, int sub, int lpp) {
-    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+// H = p^T q of one pair read from memory.  `lpp` consecutive lanes (a power of two) share the pair: lane `sub` takes
+// atoms sub, sub + lpp, ... and the group sums H with a butterfly, so a batch of few pairs has a short critical path
+// (lpp = 64 / batch size) while a full batch runs one pair per lane (lpp = 1).
+__device__ inline void pair_H(const double *__restrict__ p, const double *__restrict__ q, int h, int sub, int lpp, double H[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] = 0.0;
 #pragma unroll 2
     for (int a = sub; a < h; a += lpp) {
         const double px = p[3 * a], py = p[3 * a + 1], pz = p[3 * a + 2];
@@ -330,6 +332,14 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #pragma unroll
         for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], off);
     }
+}
+
+// One pair end to end: true iff it is similar in the reference's sense (rmsd < thr and maxdev < 2 thr,
+// rmsd_pruning.py:75); exact_taken tells whether the explicit-rotation path ran.
+__device__ inline bool pair_is_similar(const double *__restrict__ p, const double *__restrict__ q, int h, double Gp, double Gq,
+                                       double half_h_thr2, double thr, double maxdev_thr, bool &exact_taken, int sub, int lpp) {
+    double H[9];
+    pair_H(p, q, h, sub, lpp, H);
     exact_taken = false;
     if (certainly_dissimilar(H, 0.5 * (Gp + Gq) - half_h_thr2)) return false;
     exact_taken = true;
@@ -340,95 +350,176 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 
 template <int TI>
 __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                        const double *__restrict__ Gall, const float *__restrict__ Dr,
-                                                        const float *__restrict__ Dc, const int32_t *__restrict__ cend,
+                                                        const double *__restrict__ Gall, const float *__restrict__ D,
+                                                        const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
+    static_assert(DW == 2 * KD, "two families of KD components");
     constexpr int QCAP = TI * 256 + 64;  // one 256-column tile can add TI*256 pairs on top of a remainder below 64
+    constexpr int CPL = 4;               // columns per lane: a tile is 64 * CPL columns, so one LDS read of a row
+    constexpr int TILE_COLS = 64 * CPL;  // descriptor serves 4 x 64 pairs and the loop overhead is paid once per 256
     // an entry packs the row (4 bits) and the column offset inside the segment (12 bits: segments are <= 4096 columns)
     __shared__ unsigned short s_queue[4][QCAP];
+    __shared__ unsigned short s_exq[4][128];  // pairs that the sign test could not reject, waiting for the exact path
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (st->pass_on == 0) return;
-    const int n_active = st->A;
     const int slot = blockIdx.x * 4 + wid;
     const int tile = a.tile_begin + slot * a.tile_stride;
     const int r0 = tile * TI;
-    if (r0 >= n_active) return;
-    const int nrows = min(TI, n_active - r0);
     const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
     const int seg_hi = seg_lo + a.seg_cols;
+    if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
 
+    // ---- prologue in two memory round trips: (1) the state, this item's 16 stop columns / best columns (they decide
+    // whether it has work at all: most items of a late pass have none) and the structure indices of its rows and of its
+    // first column tile; (2) the descriptors of those rows and columns, gathered straight from the per-structure table
+    // D[N][DW] through act[] (active structures are in increasing index order, so the gather is nearly contiguous and
+    // no per-pass compacted copy of the descriptors is needed).  act[x] is a valid structure index for every x < n: the
+    // first pass of a run writes all n entries, later passes a prefix.
+    const int pass_on = st->pass_on, n_active = st->A;
     int my_cend = 0, my_best = 0;
-    if (lane < nrows) {
+    if (lane < TI && r0 + lane < a.n) {
         my_cend = cend[r0 + lane];
         my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    static_assert(DW == 16 && TI * DW == 256, "row staging: 4 rows x 16 components per 64 lanes");
+    int row_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_src[j] = act[min(r0 + 4 * j + (lane >> 4), a.n - 1)];
+    int col_src[CPL];
+    auto load_cols = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) col_src[u] = act[min(c0 + 64 * u + lane, a.n - 1)];
+    };
+    load_cols(seg_lo);
+    if (pass_on == 0 || r0 >= n_active) return;
+    const int nrows = min(TI, n_active - r0);
     const bool live0 = lane < nrows && my_cend > max(r0 + lane + 1, seg_lo) && my_best >= seg_lo;
     unsigned alive = unsigned(__ballot(live0));
     if (!alive) return;
+
+    const float limit32 = *a.desc_limit32;
+    float rd_stage[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
+    f32x2 dq[CPL][KD];  // .x = family 0, .y = family 1
+    auto load_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(D + int64_t(col_src[u]) * DW);
+#pragma unroll
+            for (int k = 0; k < KD / 2; ++k) {
+                const f32x4 v = src[k];
+                dq[u][2 * k] = f32x2{v.x, v.y};
+                dq[u][2 * k + 1] = f32x2{v.z, v.w};
+            }
+        }
+    };
+    load_tile();
+
     int cmax = live0 ? my_cend : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
     cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
 
-    // the row descriptors of this work item: nrows * DW consecutive doubles of Dr -> LDS
+    // the row descriptors of this work item -> LDS (rows beyond nrows are never read back)
     float *rowdesc = s_rowdesc[wid];
-    for (int e = lane; e < nrows * DW; e += 64) rowdesc[e] = Dr[int64_t(r0) * DW + e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
     __builtin_amdgcn_wave_barrier();
 
     const int h3 = a.h * 3;
-    const float limit32 = *a.desc_limit32;
     unsigned short *queue = s_queue[wid];
     int qn = 0;
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // evaluate queue entries [base, base + cnt), cnt <= 64: lpp = 64 / pow2ceil(cnt) lanes per pair
-    auto drain = [&](int base, int cnt) {
+    // Queue entries are evaluated in two stages, each over batches of up to 64 pairs with lpp = 64 / pow2ceil(batch) lanes
+    // per pair.  Stage 1 forms H and applies the sign test; the few pairs it cannot reject (a few per cent) go to a second
+    // queue.  Stage 2 -- the long explicit-rotation path -- runs when 64 of those have gathered (or at the end), so its
+    // cost is paid once per 64 candidates instead of once per stage-1 batch with a handful of lanes busy.
+    unsigned short *exq = s_exq[wid];
+    int qe = 0;
+    auto decode = [&](unsigned e, int &t, int &col, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
+        t = int(e >> 12);
+        col = seg_lo + int(e & 0xfffu);
+        const int64_t i = act[r0 + t], j = act[col];
+        pp = heavy + i * h3, pq = heavy + j * h3;
+        Gi = Gall[i], Gj = Gall[j];
+    };
+    auto sign_stage = [&](int base, int cnt) __attribute__((always_inline)) {
         int lpp = 64;
         while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
         const int g = lane / lpp, sub = lane - g * lpp;
-        const bool mine = g < cnt;
-        bool sim = false, exact = false;
-        int t = 0, r = r0, col = seg_lo;
-        const double *pp = heavy, *pq = heavy;
-        double Gi = 0.0, Gj = 0.0;
-        if (mine) {
-            const unsigned e = queue[base + g];
-            t = int(e >> 12);
-            col = seg_lo + int(e & 0xfffu);
-            r = r0 + t;
-            const int64_t i = act[r], j = act[col];
-            pp = heavy + i * h3, pq = heavy + j * h3;
-            Gi = Gall[i], Gj = Gall[j];
+        bool cand = false, sim = false;
+        unsigned e = 0;
+        int t = 0;
+        if (g < cnt) {  // a lane group is either wholly busy or wholly idle: the group shuffles only involve converged lanes
+            e = queue[base + g];
+            int col;
+            const double *pp, *pq;
+            double Gi, Gj, H[9];
+            decode(e, t, col, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, sub, lpp, H);
+            const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2);
+            cand = sub == 0 && verdict == PAIR_UNDECIDED;
+            sim = sub == 0 && verdict == PAIR_SIMILAR;
+            if (sim) atomicMin(&best[r0 + t], col);
         }
-        // a lane group is either wholly busy or wholly idle, so the group shuffles inside the evaluation only ever
-        // involve converged lanes
-        if (mine) sim = pair_is_similar(pp, pq, a.h, Gi, Gj, a.half_h_thr2, a.thr, a.maxdev_thr, exact, sub, lpp);
-        exact = exact && sub == 0;
-        if (sim && sub == 0) atomicMin(&best[r], col);
-        n_eval += cnt;
-        n_exact += __popcll(__ballot(exact));
-        unsigned long long sm = __ballot(sim && sub == 0);
+        unsigned long long sm = __builtin_amdgcn_ballot_w64(sim);
         while (sm) {  // rows that found a similar column stop being screened (the reference returns there, :75-77)
             const int l = __ffsll((long long)sm) - 1;
             sm &= sm - 1;
             alive &= ~(1u << __builtin_amdgcn_readlane(t, l));
         }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (m) {
+            if (cand) exq[qe + __popcll(m & lt_mask)] = (unsigned short)e;
+            qe += __popcll(m);
+        }
+        n_eval += cnt;
+        n_exact += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int g = lane / lpp, sub = lane - g * lpp;
+        bool sim = false;
+        int t = 0;
+        if (g < cnt) {
+            int col;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], rm, md;
+            decode(exq[base + g], t, col, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, sub, lpp, H);
+            exact_rmsd_maxdev(pp, pq, a.h, H, Gi, Gj, rm, md, sub, lpp);
+            sim = sub == 0 && rm < a.thr && md < a.maxdev_thr;  // rmsd_pruning.py:75
+            if (sim) atomicMin(&best[r0 + t], col);
+        }
+        unsigned long long sm = __builtin_amdgcn_ballot_w64(sim);
+        while (sm) {  // rows that found a similar column stop being screened (the reference returns there, :75-77)
+            const int l = __ffsll((long long)sm) - 1;
+            sm &= sm - 1;
+            alive &= ~(1u << __builtin_amdgcn_readlane(t, l));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto drain = [&](int base, int cnt) __attribute__((always_inline)) {
+        sign_stage(base, cnt);
+#ifdef TSC_DBG_NOEXACT
+        qe = 0;
+#endif
+        if (qe >= 64) {
+            exact_stage(qe - 64, 64);
+            qe -= 64;
+        }
     };
 
-    constexpr int CPL = 4;            // columns per lane: a tile is 64 * CPL columns, so one LDS read of a row
-    constexpr int TILE_COLS = 64 * CPL;  // descriptor serves 4 x 64 pairs and the loop overhead is paid once per 256
-    for (int c0 = seg_lo; c0 < cmax && alive; c0 += TILE_COLS) {
-        {   // ---- screen one tile against every live row (the column descriptors die with this block)
-            float dq[CPL][DW];
-#pragma unroll
-            for (int u = 0; u < CPL; ++u)
-#pragma unroll
-                for (int k = 0; k < DW; ++k) dq[u][k] = Dc[int64_t(k) * a.ld + c0 + 64 * u + lane];
+    for (int c0 = seg_lo; c0 < cmax;) {  // (alive != 0 here)
+        {   // ---- screen one tile against every live row
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
             while (rows) {
@@ -436,40 +527,73 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
                 rows &= rows - 1;
                 const int r = r0 + t;
                 const int ce = __builtin_amdgcn_readlane(my_cend, t);
-                const float *dr = rowdesc + t * DW;
-                float rd[DW];
+                const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
+                f32x2 rd[KD];
 #pragma unroll
-                for (int k = 0; k < DW; ++k) rd[k] = dr[k];
+                for (int k = 0; k < KD; ++k) rd[k] = dr[k];
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
                 n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
+                // larger of the two family distances for the lane's CPL columns: packed fp32 (v_pk_add_f32 / v_pk_fma_f32
+                // handle both families in one instruction), four independent chains
+                float mx[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL; ++u) {
-                    const int col = c0 + 64 * u + lane;
-                    float s0 = 0.0f, s1 = 0.0f;
+                    f32x2 s2 = {0.0f, 0.0f};
 #pragma unroll
                     for (int k = 0; k < KD; ++k) {
-                        const float d0 = rd[k] - dq[u][k], d1 = rd[KD + k] - dq[u][KD + k];
-                        s0 = fmaf(d0, d0, s0);
-                        s1 = fmaf(d1, d1, s1);
+                        const f32x2 d = rd[k] - dq[u][k];
+                        s2 = __builtin_elementwise_fma(d, d, s2);
                     }
-                    const bool pass = col > r && col < ce && !(s0 > limit32) && !(s1 > limit32);
-                    const unsigned long long m = __ballot(pass);
-                    if (m) {
-                        if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(col - seg_lo));
-                        qn += __popcll(m);
+                    mx[u] = fmaxf(s2.x, s2.y);
+                }
+                if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: mask the columns outside
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        const int col = c0 + 64 * u + lane;
+                        mx[u] = (col > r && col < ce) ? mx[u] : __builtin_inff();
+                    }
+                }
+                // most rows of a tile have no column within the limit: one test for all CPL * 64 pairs (a NaN distance --
+                // NaN coordinates -- is ignored by the minimum; such a pair is not similar for the reference either, :75)
+                const float mn = fminf(fminf(mx[0], mx[1]), fminf(mx[2], mx[3]));
+                static_assert(CPL == 4, "the minimum above covers four columns per lane");
+                if (__builtin_amdgcn_ballot_w64(!(mn > limit32))) {
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        const bool pass = !(mx[u] > limit32);
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                        if (m) {
+                            if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
+                            qn += __popcll(m);
+                        }
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
         // ---- drain full batches between tiles; a remainder below 64 waits for the next tile
+#ifdef TSC_DBG_NODRAIN
+        qn = 0;
+#endif
         while (qn >= a.drain_min) {
             const int cnt = min(qn, 64);
             drain(qn - cnt, cnt);
             qn -= cnt;
         }
+        // the next tile's columns (loaded here, after the drain, so that they do not occupy registers during it)
+        c0 += TILE_COLS;
+        if (!(c0 < cmax && alive)) break;
+        load_cols(c0);
+        load_tile();
     }
+#ifdef TSC_DBG_NODRAIN
+    qn = 0;
+#endif
     if (qn > 0) drain(0, qn);
+#ifdef TSC_DBG_NOEXACT
+    qe = 0;
+#endif
+    if (qe > 0) exact_stage(0, qe);
     if (lane == 0) {
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);

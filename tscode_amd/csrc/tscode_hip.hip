@@ -1,5 +1,6 @@
 // tscode_hip.hip -- the C ABI of include/tscode_hip.h on top of the kernels in this directory.
 // gfx950 only.  There is deliberately no CPU implementation behind these entry points.
+#include <hip/hip_ext.h>
 #include "common.hpp"
 #include "embed_clash.hpp"
 #include "rmsd.hpp"
@@ -478,7 +479,7 @@ struct tsc_prune {
     unsigned long long *mbit = nullptr, *dbit = nullptr;
     size_t bit_words = 0;
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
-    float *Dall = nullptr, *Dr = nullptr, *Dc = nullptr;   // sieve kernel: fp32 descriptors
+    float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     double *Gall = nullptr;
     float *desc_limit32 = nullptr;  // device scalar
     PassCounters *counters = nullptr;
@@ -489,6 +490,7 @@ struct tsc_prune {
     int next_ks = 0;       // next index into KS to consider
     int cur_slot = -1;     // schedule slot of the pass in flight (-1 = none)
     int last_slot = -1;    // slot of the last pass that was enqueued and not yet closed on the device
+    int opened_slot = -1;  // slot that the device has already opened (done by the apply kernel of the pass before it)
     int64_t cur_k = 0;
     bool local_done = false;
     bool slot_used[TSC_MAX_PASSES] = {false};
@@ -577,7 +579,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     p->ctx = c;
     p->heavy = heavy_dev;
     p->n = n;
-    p->npad = (n + 63) / 64 * 64 + 64;
+    p->npad = (n + 63) / 64 * 64 + 320;  // the last column tile of a segment reads up to 255 columns past the active count
     p->h = h;
     p->hp = (h + 3) / 4 * 4;
     p->thr = rmsd_thr;
@@ -603,8 +605,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc && p->algo == ALGO_SIEVE) {
         rc = palloc(p, size_t(n) * DW, &p->Dall);
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
-        if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dr);
-        if (!rc) rc = palloc(p, size_t(p->npad) * DW, &p->Dc);
         if (!rc) rc = palloc(p, 4, &p->desc_limit32);
     }
     if (!rc && p->algo == ALGO_TILE) {
@@ -664,9 +664,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_estimate(ts
 }
 
 template <int HP>
-static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const TileArgs &a) {
-    hipLaunchKernelGGL((k_rmsd_tile<HP, TILE_ROWS>), grid, dim3(256), 0, st, (const double *)p->Xr, (const double *)p->Xc,
-                       (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a);
+static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const TileArgs &a, hipEvent_t e0, hipEvent_t e1) {
+    hipExtLaunchKernelGGL((k_rmsd_tile<HP, TILE_ROWS>), grid, dim3(256), 0, st, e0, e1, 0, (const double *)p->Xr, (const double *)p->Xc,
+                          (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
@@ -680,24 +680,25 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int slot = p->cur_slot;
     const int A = int(n);  // grids are sized for the upper bound; kernels read the true count from the state block
     PassGeom g{int(n), int(k), int(n / k)};
-    const int *gate = &p->state->pass_on;
     for (int i = 0; i < 4; ++i)
         if (!p->ev[slot][i]) TSC_TRY(get_event(c, &p->ev[slot][i]));
-    TSC_HIP(hipEventRecord(p->ev[slot][0], st));
-    // 0. close the previous pass, open this one: gate (:192), counters, cache-view bitmap
-    hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, p->last_slot, slot, (long long)k, p->algo, p->dbit,
-                       int(p->bit_words));
+    if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[slot][0], st));
+    // 0. open this pass: gate (:192), counters, cache-view bitmap -- already done by the apply kernel of the pass before
+    //    it (its last block), by a one-block launch for the first pass of a run
+    if (p->opened_slot != slot) {
+        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words)};
+        hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
+    }
     p->last_slot = slot;
     p->slot_used[slot] = true;
-    // 1. ranks of the active structures, their index list and the mask as bits
-    TSC_TRY(scan_mask(st, p->mask, n, p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total, gate, true));
-    // 2. cache view of this pass; stop column, best[] and compacted descriptor of every row
+    // 1. ranks of the active structures, their index list, the mask as bits, the cache view of this pass
     const int use_cache = (p->mode == 0);
-    if (use_cache)
-        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, p->key_a, p->key_b, p->n_keys, p->dbit,
-                           (const PruneState *)p->state);
+    hipLaunchKernelGGL(k_open_pass, dim3(scan_grid_blocks(n)), dim3(SCAN_THREADS), 0, st, g, use_cache, (const PruneState *)p->state,
+                       (const uint8_t *)p->mask, (const int32_t *)p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total,
+                       (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit);
+    // 2. stop column, best[] and compacted descriptor of every row
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, p->cend, p->best, (const float *)p->Dall, DW, p->Dr, p->Dc, p->npad);
+                       p->dbit, p->cend, p->best);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
@@ -716,7 +717,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
-    TSC_HIP(hipEventRecord(p->ev[slot][1], st));
+    // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
+    // hipEventRecord before and after it costs about 4 us each on MI355X)
+    hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
     if (p->algo == ALGO_TILE) {
         TileArgs a;
         a.ld = p->npad, a.h = p->h;
@@ -724,30 +727,30 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         switch (p->hp) {
-            case 4: launch_tile<4>(st, grid, p, a); break;
-            case 8: launch_tile<8>(st, grid, p, a); break;
-            case 12: launch_tile<12>(st, grid, p, a); break;
-            case 16: launch_tile<16>(st, grid, p, a); break;
-            case 20: launch_tile<20>(st, grid, p, a); break;
-            case 24: launch_tile<24>(st, grid, p, a); break;
-            case 28: launch_tile<28>(st, grid, p, a); break;
-            case 32: launch_tile<32>(st, grid, p, a); break;
+            case 4: launch_tile<4>(st, grid, p, a, e0, e1); break;
+            case 8: launch_tile<8>(st, grid, p, a, e0, e1); break;
+            case 12: launch_tile<12>(st, grid, p, a, e0, e1); break;
+            case 16: launch_tile<16>(st, grid, p, a, e0, e1); break;
+            case 20: launch_tile<20>(st, grid, p, a, e0, e1); break;
+            case 24: launch_tile<24>(st, grid, p, a, e0, e1); break;
+            case 28: launch_tile<28>(st, grid, p, a, e0, e1); break;
+            case 32: launch_tile<32>(st, grid, p, a, e0, e1); break;
             default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
         }
     } else {
         SieveArgs a;
-        a.ld = p->npad, a.h = p->h;
+        a.n = int(n), a.h = p->h;
         a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
         a.desc_limit32 = p->desc_limit32;
         a.drain_min = c->drain_min;
-        hipLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                           (const float *)p->Dr, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                           (const PruneState *)p->state, a);
+        hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                              (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
+                              (const PruneState *)p->state, a);
     }
     TSC_HIP(hipGetLastError());
-    TSC_HIP(hipEventRecord(p->ev[slot][2], st));
     p->local_done = true;
     return 0;
 }
@@ -762,7 +765,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_pru
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev) {
     TSC_REQUIRE(p && best_dev, "null argument");
-    if (p->cur_k != 0 || p->last_slot >= 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
+    if (p->cur_k != 0 || p->next_ks != 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
     p->best = static_cast<int32_t *>(best_dev);
     return 0;
 }
@@ -773,10 +776,24 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
     PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
-    hipLaunchKernelGGL(k_apply_pass, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), 0, c->stream, g, (const PruneState *)p->state, p->act, p->cend,
-                       p->best, p->mask, p->key_a, p->key_b, p->n_keys, p->counters, p->bsum, SCAN_TILE);
+    // the slot tsc_prune_next_pass will hand out next (same rule, not consumed here): the last block of the apply
+    // kernel closes this pass and opens that one
+    int nxt = -1;
+    for (int s = p->next_ks; s < TSC_MAX_PASSES; ++s) {
+        const int64_t k = int64_t(KS[s]);
+        if (k == 1 || 20 * k < p->n) {
+            nxt = s;
+            break;
+        }
+    }
+    StepArgs sa{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words) : 0};
+    const int blocks = int(std::min<int64_t>(ceil_div<int64_t>(p->n, 256), 512));
+    hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, c->stream, g, p->state, p->act, p->cend, p->best, p->mask, p->key_a, p->key_b,
+                       p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit);
+    p->opened_slot = nxt;
+    p->last_slot = -1;  // closed on the device
     TSC_HIP(hipGetLastError());
-    TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
+    if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
     p->cur_k = 0;
     p->cur_slot = -1;
     p->collected = false;
@@ -806,7 +823,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     if (!p->collected) {
         hipStream_t st = c->stream;
         if (p->last_slot >= 0) {
-            hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, p->last_slot, -1, 0ll, 0, p->dbit, 0);
+            StepArgs sa{p->last_slot, -1, 0ll, 0, 0};
+            hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
             p->last_slot = -1;
         }
         static_assert(sizeof(PassRecord) * TSC_MAX_PASSES <= 4096, "records fit the pinned staging buffer");
@@ -822,8 +840,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             s.pairs_evaluated = rec[slot].evaluated, s.pairs_computed = rec[slot].formed, s.candidates = rec[slot].exact;
             s.pairs_screened = rec[slot].screened, s.new_keys = rec[slot].removed, s.algo = rec[slot].algo;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
-            if (hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
+            if (c->pass_timing >= 2 && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
+            if (c->pass_timing >= 1 && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
         }
         p->collected = true;
     }
@@ -900,6 +918,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->drain_min = int(value);
         return 0;
     }
+    if (strcmp(name, "pass_timing") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
+        c->pass_timing = int(value);
+        return 0;
+    }
     if (strcmp(name, "seg_cols") == 0) {
         TSC_REQUIRE(value == 0 || (value >= 256 && value <= 4096 && int(value) % 256 == 0), "seg_cols must be 0 (automatic) or a multiple of 256 in [256, 4096]");
         c->seg_cols = int(value);
@@ -967,14 +990,19 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     DeviceGuard guard(c->device);
     hipStream_t st = c->stream;
     Scratch s(c);
-    hipEvent_t ev[4];
-    for (auto &e : ev) TSC_HIP(hipEventCreate(&e));
+    // stage timings only on request ("pass_timing" = 2): four events in the stream cost about 4 us each
+    const bool timed = timings_ms && c->pass_timing >= 2;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     struct EvGuard {
+        tsc_ctx *c;
         hipEvent_t *e;
         ~EvGuard() {
-            for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]);
+            for (int i = 0; i < 4; ++i)
+                if (e[i]) c->event_pool.push_back(e[i]);
         }
-    } evg{ev};
+    } evg{c, ev};
+    if (timed)
+        for (auto &e : ev) TSC_TRY(get_event(c, &e));
     // heavy_slot[a] = rank of atom a among the heavy atoms, -1 for the others
     std::vector<int32_t> slot(size_t(ft.n_total), -1);
     for (int a = 0; a < n_heavy; ++a) {
@@ -988,11 +1016,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
     TSC_TRY(s.get(size_t(n_poses), &act));
     TSC_TRY(s.get(1, &total));
-    TSC_HIP(hipEventRecord(ev[0], st));
+    if (timed) TSC_HIP(hipEventRecord(ev[0], st));
     // K1+K2 fused verdicts
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
                                      clash_mask, nullptr));
-    TSC_HIP(hipEventRecord(ev[1], st));
+    if (timed) TSC_HIP(hipEventRecord(ev[1], st));
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     int32_t n_pass = 0;
@@ -1005,7 +1033,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         hipLaunchKernelGGL(k_transform, dim3(grid_for(int64_t(n_pass) * ft.n_total, 256)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos,
                            (const int32_t *)act, int64_t(n_pass), structures, (const int32_t *)d_slot, n_heavy, d_heavy);
         TSC_HIP(hipGetLastError());
-        TSC_HIP(hipEventRecord(ev[2], st));
+        if (timed) TSC_HIP(hipEventRecord(ev[2], st));
         TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
         if (!stats) {  // count survivors without the stats array
@@ -1014,14 +1042,19 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(read_i32(c, total, &t));
             n_keep = t;
         }
-    } else {
+    } else if (timed) {
         TSC_HIP(hipEventRecord(ev[2], st));
     }
-    TSC_HIP(hipEventRecord(ev[3], st));
-    TSC_HIP(hipEventSynchronize(ev[3]));
+    if (timed) {
+        TSC_HIP(hipEventRecord(ev[3], st));
+        TSC_HIP(hipEventSynchronize(ev[3]));
+    } else {
+        TSC_HIP(hipStreamSynchronize(st));
+    }
     if (n_passes) *n_passes = np;
     if (n_keep_host) *n_keep_host = n_keep;
-    if (timings_ms) {
+    if (timings_ms && !timed) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.0f;
+    if (timed) {
         TSC_HIP(hipEventElapsedTime(&timings_ms[0], ev[0], ev[1]));
         TSC_HIP(hipEventElapsedTime(&timings_ms[1], ev[1], ev[2]));
         TSC_HIP(hipEventElapsedTime(&timings_ms[2], ev[2], ev[3]));
