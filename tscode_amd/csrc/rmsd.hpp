@@ -248,7 +248,8 @@ struct PassRecord {  // one per schedule slot, read back once at the end of the 
 __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit,
                                                    unsigned long long *__restrict__ dbit, int bit_words, int32_t *__restrict__ n_keys,
                                                    PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
-                                                   PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items) {
+                                                   PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items,
+                                                   unsigned *__restrict__ dmax_bits) {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
     for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
     }
     if (tid == 0) {
         n_keys[0] = 0;
+        if (dmax_bits) *dmax_bits = 0;  // running maximum of the descriptor build (sieve.hpp)
         st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0;
     }
 }

@@ -33,6 +33,9 @@
 
 namespace tsc {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int KD = 8;              // descriptor dimensions per family
 constexpr int NFAM = 2;            // feature families
 constexpr int DW = KD * NFAM;      // doubles per structure descriptor
@@ -75,23 +78,61 @@ __global__ __launch_bounds__(256) void k_feature_moments(const double *__restric
     }
 }
 
-// D[i][fam*KD + k] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space; the bias is the
-// projection of the mean feature vector and cancels in every difference),  G[i] = sum_a |x_ia|^2,
-// *dmax_bits = max |D| over everything, as the bit pattern of a non-negative float (atomicMax on the integer view).
+// fp32 limit of the screen for an exact limit `limit` = h thr^2, from the largest descriptor magnitude dmax: every computed
+// difference of two components is within eta = 3 * 2^-24 * 2 dmax of the exact one, the 8-term sum of squares carries at most
+// 2^-20 relative error, so s_exact >= s32 (1 - 2^-20) - 2 eta sqrt(KD s32); the limit returned is the smallest s32 above which
+// that lower bound certainly exceeds `limit`.  A NaN / inf dmax gives a limit that drops nothing.
+__device__ inline float screen_limit32(float dmaxf, double limit) {
+    const double dmax = (dmaxf >= 0.0f && dmaxf < 3.0e38f) ? double(dmaxf) : 3.0e38;
+    const double eta = 3.0 * 5.9604644775390625e-08 * 2.0 * dmax;               // 3 * 2^-24 * 2 dmax
+    const double a = 1.0 - 9.5367431640625e-07, b = 2.0 * eta * sqrt(double(KD));  // 1 - 2^-20
+    const double x = (b + sqrt(b * b + 4.0 * a * limit)) / (2.0 * a);
+    const double l32 = x * x * (1.0 + 1e-6) + 1e-30;
+    float f = float(l32);
+    if (double(f) < l32) f = __uint_as_float(__float_as_uint(f) + 1u);  // next float up (f > 0)
+    return (l32 < 3.0e38) ? f : 3.4e38f;
+}
+
+// D[i][2k + fam] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space, the two families
+// interleaved; the bias is the projection of the mean feature vector and cancels in every difference),
+// G[i] = sum_a |x_ia|^2; *dmax_bits = max |D| over everything as the bit pattern of a non-negative float (atomicMax on the
+// integer view; zero on entry) -- the pair kernel turns it into the fp32 limit of the screen (screen_limit32).
+// A block stages S structures in LDS with coalesced loads (a thread-per-structure walk reads 64 lines per instruction and
+// thrashes the L1); T = 256 / S consecutive lanes share a structure (atoms sub, sub + T, ...) and reduce with shuffles.
 __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
                                                       const double *__restrict__ Q, const double *__restrict__ bias, float *__restrict__ D,
-                                                      double *__restrict__ G, unsigned *__restrict__ dmax_bits) {
-    extern __shared__ __attribute__((aligned(16))) double s_q[];  // [KD][nf0] then [KD][nf1]
-    for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += blockDim.x) s_q[e] = Q[e];
-    __syncthreads();
-    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    float mx = 0.0f;
-    if (i < n) {
-        const double *x = heavy + i * h * 3;
-        double d[DW], g = 0.0;
+                                                      double *__restrict__ G, unsigned *__restrict__ dmax_bits, int S) {
+    extern __shared__ __attribute__((aligned(16))) double s_mem[];  // [KD][nf0], [KD][nf1], then S rows of pitch doubles
+    const int h3 = h * 3, pitch = h3 | 1, T = 256 / S;
+    double *s_q = s_mem, *s_x = s_mem + KD * (nf0 + nf1);
+    for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += 256) s_q[e] = Q[e];
+    const int64_t i0 = int64_t(blockIdx.x) * S;
+    const int ns = int(min<int64_t>(S, n - i0));
+    const double *src = heavy + i0 * h3;
+    // eight loads in flight per thread before the first LDS store (a plain copy loop waits for every load in turn)
+    for (int base = threadIdx.x; base < ns * h3; base += 256 * 8) {
+        double v[8];
 #pragma unroll
-        for (int k = 0; k < DW; ++k) d[k] = -bias[k];
-        for (int a = 0; a < h; ++a) {
+        for (int j = 0; j < 8; ++j) v[j] = (base + 256 * j < ns * h3) ? src[base + 256 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + 256 * j;
+            if (e < ns * h3) {
+                const int row = e / h3;
+                s_x[row * pitch + (e - row * h3)] = v[j];
+            }
+        }
+    }
+    __syncthreads();
+    const int sidx = threadIdx.x / T, sub = threadIdx.x - sidx * T;
+    const bool mine = sidx < ns;
+    double d[DW], g = 0.0;
+#pragma unroll
+    for (int k = 0; k < DW; ++k) d[k] = 0.0;
+    if (mine) {
+        const double *x = s_x + sidx * pitch;
+        const double *q1 = s_q + KD * nf0;
+        for (int a = sub; a < h; a += T) {
             const double n2 = x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2];
             g += n2;
             if (a < nf0) {
@@ -101,46 +142,48 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
             }
             if (a < nf1) {
                 const double f = feature(x, h, 1, a);
-                const double *q1 = s_q + KD * nf0;
 #pragma unroll
                 for (int k = 0; k < KD; ++k) d[KD + k] = fma(q1[k * nf1 + a], f, d[KD + k]);
             }
         }
+    }
+    for (int off = T >> 1; off > 0; off >>= 1) {  // T <= 64 consecutive lanes of one wavefront
+#pragma unroll
+        for (int k = 0; k < DW; ++k) d[k] += __shfl_xor(d[k], off);
+        g += __shfl_xor(g, off);
+    }
+    float mx = 0.0f;
+    if (mine && sub == 0) {
+        float v[DW];
 #pragma unroll
         for (int k = 0; k < DW; ++k) {
-            const float v = float(d[k]);
-            D[i * DW + (k % KD) * 2 + k / KD] = v;  // the two families interleaved: (family 0, family 1) of component k side by side
-            mx = fmaxf(mx, fabsf(v));
+            v[(k % KD) * 2 + k / KD] = float(d[k] - bias[k]);
+            mx = fmaxf(mx, fabsf(float(d[k] - bias[k])));
         }
-        G[i] = g;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(D + (i0 + sidx) * DW);
+#pragma unroll
+        for (int k = 0; k < DW / 4; ++k) dst[k] = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        G[i0 + sidx] = g;
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(dmax_bits, __float_as_uint(mx));
-}
-
-// fp32 limit for the squared descriptor distance: any s32 above it certainly means an exact distance above `limit`.
-// dmax = largest |component|; differences of two components are within eta of exact, the 8-term sum of squares
-// carries at most 2^-20 relative error.
-inline float descriptor_limit32(double limit, double dmax) {
-    const double eta = 3.0 * std::ldexp(1.0, -24) * 2.0 * dmax;
-    const double a = 1.0 - std::ldexp(1.0, -20), b = 2.0 * eta * std::sqrt(double(KD));
-    const double x = (b + std::sqrt(b * b + 4.0 * a * limit)) / (2.0 * a);
-    const double l32 = x * x * (1.0 + 1e-6) + 1e-30;
-    float f = float(l32);
-    if (double(f) < l32) f = std::nextafter(f, INFINITY);
-    return f;
+    // same-address atomics serialise (about 12 ns each): only a wavefront that would raise the maximum sends one
+    if ((threadIdx.x & 63) == 0 && mx > __uint_as_float(__hip_atomic_load(dmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        atomicMax(dmax_bits, __float_as_uint(mx));
 }
 
 // Device-side descriptor basis: one wavefront per feature family.  Orthonormal rows spanning the leading principal
 // axes of the feature covariance by a few steps of block power iteration (the spectrum of these features decays
-// fast: one step already gives the full screening power, three are run).  Rows are re-orthonormalised by
+// fast: one step gives the screening power of three to within 3 % of the pairs that reach H).  Rows are re-orthonormalised by
 // CholeskyQR2: lane (i, j) accumulates the Gram entry <W_i, W_j>, lane 0 factors the 8x8 Gram matrix, every lane
 // applies L^-1 to its columns -- no cross-lane reduction on the critical path.  Whatever the iteration produced,
 // the rows are finally divided by sqrt of a Gershgorin bound of |V V^T|_2, so |V x| <= |x| holds rigorously and
 // the screen can never drop a similar pair.
 //   M      second moments of the family, (nf+1)^2, upper triangle filled, index nf = the constant 1
 //   Qout   [KD][nf] rows of the basis;  bias[k] = V_k . mean
-constexpr int BASIS_ITERS = 3;
+#ifndef TSC_BASIS_ITERS
+#define TSC_BASIS_ITERS 1
+#endif
+constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
 __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
                                                           int n_samples, double *__restrict__ Q, double *__restrict__ bias) {
@@ -285,21 +328,6 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
     }
 }
 
-// fp32 limit of the screen from the largest descriptor magnitude (see descriptor_limit32 for the derivation)
-__global__ void k_descriptor_limit(const unsigned *__restrict__ dmax_bits, double limit, float *__restrict__ limit32) {
-    float dmaxf = __uint_as_float(*dmax_bits);
-    double dmax = (dmaxf >= 0.0f && dmaxf < 3.0e38f) ? double(dmaxf) : 3.0e38;  // NaN / inf: the screen drops nothing
-    const double eta = 3.0 * 5.9604644775390625e-08 * 2.0 * dmax;               // 3 * 2^-24 * 2 dmax
-    const double a = 1.0 - 9.5367431640625e-07, b = 2.0 * eta * sqrt(double(KD));  // 1 - 2^-20
-    const double x = (b + sqrt(b * b + 4.0 * a * limit)) / (2.0 * a);
-    const double l32 = x * x * (1.0 + 1e-6) + 1e-30;
-    float f = float(l32);
-    if (double(f) < l32) f = __uint_as_float(__float_as_uint(f) + 1u);  // next float up (f > 0)
-    *limit32 = (l32 < 3.0e38) ? f : 3.4e38f;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SieveArgs {
     int n;   // upper bound of the active count the grid was sized for (structures of the run)
@@ -311,7 +339,8 @@ struct SieveArgs {
     double half_h_thr2;   // h * thr^2 / 2
     double two_thr2;      // 2 thr^2 when the near-duplicate test applies (h >= 4), else -1
     int drain_min;        // queue length that triggers a drain between column tiles (1..64)
-    const float *desc_limit32;  // device: fp32 squared descriptor distance above which a pair is certainly dissimilar
+    const unsigned *dmax_bits;  // device: largest |descriptor component| of the run (bit pattern of a float), see screen_limit32
+    double desc_limit;          // h thr^2: exact squared descriptor distance above which a pair is certainly dissimilar
 };
 
 // H = p^T q of one pair read from memory.  `lpp` consecutive lanes (a power of two) share the pair: lane `sub` takes
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     unsigned alive = unsigned(__ballot(live0));
     if (!alive) return;
 
-    const float limit32 = *a.desc_limit32;
+    const float limit32 = screen_limit32(__uint_as_float(*a.dmax_bits), a.desc_limit);
     float rd_stage[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
@@ -599,73 +628,6 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
         count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
     }
-}
-
-// Orthonormal basis (KD x nf, row-major) of the dominant subspace of the covariance of the feature vectors:
-// block power iteration with modified Gram-Schmidt.  Any orthonormal Q is valid for the bound; this one is
-// merely good.  M is the (nf+1) x (nf+1) second-moment matrix of k_feature_moments (upper triangle filled).
-inline void descriptor_basis(const double *M, int nf, int n_samples, double *Q) {
-    const int h = nf, m = nf + 1, kd = KD;
-    for (int e = 0; e < kd * h; ++e) Q[e] = 0.0;
-    if (h == 0) return;
-    std::vector<double> C(size_t(h) * h);
-    const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
-    for (int a = 0; a < h; ++a)
-        for (int b = a; b < h; ++b) {
-            double mu_a = M[size_t(a) * m + h] * inv, mu_b = M[size_t(b) * m + h] * inv;
-            double c = M[size_t(a) * m + b] * inv - mu_a * mu_b;
-            C[size_t(a) * h + b] = C[size_t(b) * h + a] = c;
-        }
-    std::vector<double> V(size_t(kd) * h), Z(size_t(kd) * h);
-    // deterministic start: spread unit vectors + a small ramp so that no start vector is orthogonal to everything
-    for (int k = 0; k < kd; ++k)
-        for (int a = 0; a < h; ++a) V[size_t(k) * h + a] = ((a % kd) == k ? 1.0 : 0.0) + 1e-3 * ((a * 7 + k * 13) % 11 - 5);
-    auto orthonormalise = [&](std::vector<double> &W) {
-        for (int k = 0; k < kd; ++k) {
-            double *v = &W[size_t(k) * h];
-            auto project_out = [&]() {
-                for (int rep = 0; rep < 2; ++rep)
-                    for (int j = 0; j < k; ++j) {
-                        const double *u = &W[size_t(j) * h];
-                        double d = 0;
-                        for (int a = 0; a < h; ++a) d += u[a] * v[a];
-                        for (int a = 0; a < h; ++a) v[a] -= d * u[a];
-                    }
-                double nn = 0;
-                for (int a = 0; a < h; ++a) nn += v[a] * v[a];
-                return std::sqrt(nn);
-            };
-            double nn = project_out();
-            for (int trial = 0; !(nn > 1e-150) && trial < h; ++trial) {  // degenerate: try the unit vectors in turn
-                for (int a = 0; a < h; ++a) v[a] = (a == trial) ? 1.0 : 0.0;
-                nn = project_out();
-            }
-            if (!(nn > 1e-150)) {  // nf < KD: no direction left; a zero row keeps the bound valid
-                for (int a = 0; a < h; ++a) v[a] = 0.0;
-                continue;
-            }
-            for (int a = 0; a < h; ++a) v[a] /= nn;
-        }
-    };
-    orthonormalise(V);
-    for (int it = 0; it < 24; ++it) {
-        for (int k = 0; k < kd; ++k) {
-            const double *q = &V[size_t(k) * h];
-            double nz = 0;
-            for (int a = 0; a < h; ++a) {
-                double acc = 0;
-                const double *crow = &C[size_t(a) * h];
-                for (int b = 0; b < h; ++b) acc += crow[b] * q[b];
-                Z[size_t(k) * h + a] = acc;
-                nz += acc * acc;
-            }
-            if (!(nz > 1e-280))  // C annihilates this direction (no variance there): keep it, the bound stays valid
-                for (int a = 0; a < h; ++a) Z[size_t(k) * h + a] = q[a];
-        }
-        orthonormalise(Z);
-        V.swap(Z);
-    }
-    for (int e = 0; e < kd * h; ++e) Q[e] = V[e];
 }
 
 }  // namespace tsc

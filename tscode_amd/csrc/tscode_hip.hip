@@ -481,7 +481,7 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     double *Gall = nullptr;
-    float *desc_limit32 = nullptr;  // device scalar
+    unsigned *dmax_bits = nullptr;  // device scalar: largest |descriptor component| as float bits (zeroed by k_init_run)
     PassCounters *counters = nullptr;
     PruneState *state = nullptr;
     PassRecord *records = nullptr;  // [TSC_MAX_PASSES]
@@ -530,16 +530,16 @@ static int build_descriptors(tsc_prune *p) {
     const int n_samples = int(std::min<int64_t>(p->n, DESC_SAMPLE));
     const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
     Scratch s(c);
-    double *d_M[NFAM], *d_Q;
-    unsigned *d_dmax;
+    double *d_M[NFAM], *d_Q, *d_zero;
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
     TSC_TRY(s.get(q_doubles + DW + 1, &d_Q));
-    TSC_TRY(s.get(4, &d_dmax));
-    TSC_HIP(hipMemsetAsync(d_dmax, 0, 4 * sizeof(unsigned), st));
+    // the moment matrices of both families in one block (one memset)
+    const size_t m0 = size_t(nf[0] + 1) * (nf[0] + 1), m1 = size_t(nf[1] + 1) * (nf[1] + 1);
+    TSC_TRY(s.get(m0 + m1, &d_zero));
+    TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1) * sizeof(double), st));
+    d_M[0] = d_zero, d_M[1] = d_zero + m0;
     for (int f = 0; f < NFAM; ++f) {
         const int m = nf[f] + 1;
-        TSC_TRY(s.get(size_t(m) * m, &d_M[f]));
-        TSC_HIP(hipMemsetAsync(d_M[f], 0, size_t(m) * m * sizeof(double), st));
         if (nf[f] == 0) continue;
         size_t lds = size_t(32) * m * sizeof(double);
         if (lds > 64 * 1024)
@@ -548,9 +548,17 @@ static int build_descriptors(tsc_prune *p) {
     }
     hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
                        d_Q + q_doubles);
-    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, 256)), dim3(256), q_doubles * sizeof(double), st, p->heavy, p->n, h, nf[0], nf[1],
-                       (const double *)d_Q, (const double *)(d_Q + q_doubles), p->Dall, p->Gall, d_dmax);
-    hipLaunchKernelGGL(k_descriptor_limit, dim3(1), dim3(1), 0, st, (const unsigned *)d_dmax, double(p->h) * p->thr * p->thr, p->desc_limit32);
+    // structures per block of k_descriptors: as many as fit 48 KB of LDS next to the basis (a power of two, 4..64: the
+    // 256 / S lanes that share a structure must be one wavefront at most)
+    const size_t pitch = size_t(h * 3) | 1;
+    int S = 64;
+    while (S > 4 && (q_doubles + size_t(S) * pitch) * sizeof(double) > 48 * 1024) S >>= 1;
+    const size_t lds_desc = (q_doubles + size_t(S) * pitch) * sizeof(double);
+    TSC_REQUIRE(lds_desc <= 150 * 1024, "%d heavy atoms per structure exceed what the descriptor kernel can stage in LDS", h);
+    if (lds_desc > 64 * 1024)
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_descriptors), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_desc)));
+    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, S)), dim3(256), lds_desc, st, p->heavy, p->n, h, nf[0], nf[1], (const double *)d_Q,
+                       (const double *)(d_Q + q_doubles), p->Dall, p->Gall, p->dmax_bits, S);
     TSC_HIP(hipGetLastError());
     return 0;  // the scratch blocks go back to the stream-ordered cache: later users run after these kernels
 }
@@ -605,7 +613,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc && p->algo == ALGO_SIEVE) {
         rc = palloc(p, size_t(n) * DW, &p->Dall);
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
-        if (!rc) rc = palloc(p, 4, &p->desc_limit32);
+        if (!rc) rc = palloc(p, 4, &p->dmax_bits);
     }
     if (!rc && p->algo == ALGO_TILE) {
         const size_t hp3 = size_t(p->hp) * 3;
@@ -616,7 +624,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) {
         hipStream_t st = c->stream;
         hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
-                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE);
+                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE, p->dmax_bits);
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
         // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
@@ -744,7 +752,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
-        a.desc_limit32 = p->desc_limit32;
+        a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
         a.drain_min = c->drain_min;
         hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
                               (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
