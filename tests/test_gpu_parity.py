@@ -481,3 +481,30 @@ def test_prune_when_descriptors_cannot_separate(eng, oracle):
         assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
         assert sum(s["pairs_computed"] for s in stats) >= 0.9 * sum(s["pairs_screened"] for s in stats)   # nothing screened out
     assert 30 < ref["mask"].sum() < 400
+
+
+def test_clash_fp32_band_falls_back_to_fp64(eng, oracle):
+    """Verdict-only clash masks use a packed-fp32 minimum with a rigorous band; poses whose closest inter-fragment
+    distance sits within 1e-9 .. 1e-4 of the threshold must come out exactly like the fp64 reference."""
+    rng = np.random.default_rng(77)
+    n_a, n_b = 9, 7
+    poses, expect = [], []
+    for eps in (0.0, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3):
+        for rep in range(8):
+            a = rng.normal(size=(n_a, 3)) * 2.0
+            b = rng.normal(size=(n_b, 3)) * 2.0 + np.array([30.0, 0.0, 0.0])        # far away: no clash
+            # move fragment b so that its atom 0 sits at distance 1.5 + eps from atom 3 of a, along a random direction
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            b = b - b[0] + a[3] + d * (1.5 + eps)
+            shift = rng.normal(size=3) * 20.0                                         # large coordinates widen the band
+            poses.append(np.concatenate([a, b]) + shift)
+    poses = np.ascontiguousarray(np.array(poses))
+    ids = np.array([n_a, n_b], dtype=np.int32)
+    ref = oracle.compenetration_mask(poses, ids, 1.5, 0)
+    for fp32 in (1, 0):
+        eng.set_option("clash_fp32", fp32)
+        got = eng.clash_mask(poses, ids, 1.5, 0)
+        assert np.array_equal(got.astype(bool), ref.astype(bool)), fp32
+    eng.set_option("clash_fp32", 1)
+    assert 0 < ref.sum() < len(ref)

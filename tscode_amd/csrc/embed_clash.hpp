@@ -101,7 +101,22 @@ inline double clash_sq_bound(double thresh) {
     return x;
 }
 
-template <bool FUSED, bool SELF>
+typedef float clash_f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS bytes one wavefront of k_clash needs: the fp64 pose(s) and, for MINMODE, an fp32 copy as three arrays
+inline size_t clash_lds_per_wave(int n, int lp, bool minmode) {
+    const int ppw = 64 / lp, npad = (n + 1) & ~1;
+    return size_t(ppw) * n * 3 * sizeof(double) + (minmode ? size_t(ppw) * 3 * npad * sizeof(float) : 0);
+}
+
+// MINMODE (max_clashes == 0, no counts wanted -- the pipeline's case): the verdict is "no inter-fragment distance
+// below thresh", i.e. min d^2 >= sq_bound.  The minimum is taken in packed fp32 (two partner atoms per instruction,
+// v_pk_add_f32 / v_pk_fma_f32 / v_min3_f32: 3.5 instructions per pair against 8 in fp64) on an fp32 copy of the pose,
+// and decided with a rigorous error bound: with C = max |coordinate| of the pose, u = 2^-24 and e = 4 u C (1 + u) the
+// computed s32 differs from the exact d^2 by at most 4 u s32 + 2 sqrt(3) e d + 3 e^2, so s32 >= hi = x0 + M means
+// d^2 >= x0 and s32 < lo = x0 - M means d^2 < x0 (M below).  A pose whose minimum falls between lo and hi (a few in
+// 10^4) is decided by the fp64 count like everything else.
+template <bool FUSED, bool SELF, bool MINMODE>
 __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
                                                 const double *__restrict__ frags, FragTable ft,
                                                 const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
@@ -109,13 +124,16 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
                                                 int32_t *__restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) double s_xyz[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n = a.n, lp = a.lp, ppw = 64 / lp;
-    double *w_xyz = s_xyz + size_t(wid) * ppw * n * 3;
+    const int n = a.n, lp = a.lp, ppw = 64 / lp, npad = (n + 1) & ~1;
+    const size_t wave_doubles = (size_t(ppw) * n * 3 * sizeof(double) + (MINMODE ? size_t(ppw) * 3 * npad * sizeof(float) : 0)) / sizeof(double);
+    double *w_xyz = s_xyz + size_t(wid) * wave_doubles;
+    float *w_f32 = reinterpret_cast<float *>(w_xyz + size_t(ppw) * n * 3);  // [ppw][3][npad]
     const int64_t waves_total = int64_t(gridDim.x) * 4;
     for (int64_t wv = int64_t(blockIdx.x) * 4 + wid; wv * ppw < a.n_poses; wv += waves_total) {
         const int64_t pose0 = wv * ppw;
         const int np = int(min<int64_t>(ppw, a.n_poses - pose0));
         // ---- stage np poses in LDS
+        double cmax = 0.0;
         if (FUSED) {
             for (int e = lane; e < np * n; e += 64) {
                 int sub = e / n, at = e - sub * n;
@@ -124,39 +142,102 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
                 w_xyz[e * 3 + 0] = v[0];
                 w_xyz[e * 3 + 1] = v[1];
                 w_xyz[e * 3 + 2] = v[2];
+                if (MINMODE) {
+                    float *f = w_f32 + size_t(sub) * 3 * npad;
+                    f[at] = float(v[0]), f[npad + at] = float(v[1]), f[2 * npad + at] = float(v[2]);
+                    cmax = fmax(cmax, fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))));
+                }
             }
         } else {
             const double *src = coords + pose0 * n * 3;
-            for (int e = lane; e < np * n * 3; e += 64) w_xyz[e] = src[e];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- count close pairs: lane owns atom ia of pose `sub`, walks earlier-fragment atoms j
-        const int sub = lane / lp, li = lane - sub * lp;
-        const double *p = w_xyz + size_t(sub) * n * 3;
-        int cnt = 0;
-        if (sub < np) {
-            for (int ia = a.first_row + li; ia < n; ia += lp) {
-                const double x = p[ia * 3], y = p[ia * 3 + 1], z = p[ia * 3 + 2];
-                int jend = n;
-                if (!SELF) {
-                    jend = 0;
-#pragma unroll
-                    for (int k = 1; k < MAX_MOLS; ++k)
-                        if (k < a.n_mols && ia >= a.atom_off[k]) jend = a.atom_off[k];
-                }
-                // four independent partner atoms per trip: their LDS reads are issued together
-#pragma unroll 4
-                for (int j = 0; j < jend; ++j) {
-                    const double dx = x - p[j * 3], dy = y - p[j * 3 + 1], dz = z - p[j * 3 + 2];
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    const bool hit = SELF ? (d2 < a.sq_bound && d2 > 0.0) : (d2 < a.sq_bound);
-                    cnt += hit ? 1 : 0;
+            for (int e = lane; e < np * n * 3; e += 64) {
+                const double v = src[e];
+                w_xyz[e] = v;
+                if (MINMODE) {
+                    const int sub = e / (n * 3), r = e - sub * n * 3, at = r / 3, k = r - at * 3;
+                    w_f32[size_t(sub) * 3 * npad + k * npad + at] = float(v);
+                    cmax = fmax(cmax, fabs(v));
                 }
             }
         }
-        for (int off = lp >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        __builtin_amdgcn_wave_barrier();
+        const int sub = lane / lp, li = lane - sub * lp;
+        const double *p = w_xyz + size_t(sub) * n * 3;
+        bool decided = false;
+        int verdict = 0;
+        if (MINMODE) {
+            // one bound for the whole wavefront (the largest coordinate of any of its poses): simple and still tiny
+            for (int off = 32; off > 0; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+            constexpr double U = 5.9604644775390625e-08;  // 2^-24
+            const double e = 4.0 * U * cmax * (1.0 + U), x0 = a.sq_bound;
+            const double M = 1.01 * (8.0 * U * x0 + (2.0 * 1.7320508075688774 * e * sqrt(x0) + 3.0 * e * e) * (1.0 + 4.0 * U));
+            float lo = float(x0 - M), hi = float(x0 + M);
+            if (double(lo) > x0 - M) lo = __uint_as_float(__float_as_uint(lo) - 1u);  // round towards the safe side (both > 0)
+            if (double(hi) < x0 + M) hi = __uint_as_float(__float_as_uint(hi) + 1u);
+            const float *X = w_f32 + size_t(sub) * 3 * npad, *Y = X + npad, *Z = Y + npad;
+            float m = __builtin_inff();
+            if (sub < np && cmax < 1.0e15 && x0 - M > 0.0) {
+                for (int ia = a.first_row + li; ia < n; ia += lp) {
+                    const float xi = X[ia], yi = Y[ia], zi = Z[ia];
+                    int jend = 0;
+#pragma unroll
+                    for (int k = 1; k < MAX_MOLS; ++k)
+                        if (k < a.n_mols && ia >= a.atom_off[k]) jend = a.atom_off[k];
+                    const clash_f32x2 x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+                    const int j2 = jend & ~1;
+#pragma unroll 4
+                    for (int j = 0; j < j2; j += 2) {
+                        const clash_f32x2 dx = x2 - *reinterpret_cast<const clash_f32x2 *>(X + j);
+                        const clash_f32x2 dy = y2 - *reinterpret_cast<const clash_f32x2 *>(Y + j);
+                        const clash_f32x2 dz = z2 - *reinterpret_cast<const clash_f32x2 *>(Z + j);
+                        clash_f32x2 s2 = dx * dx;
+                        s2 = __builtin_elementwise_fma(dy, dy, s2);
+                        s2 = __builtin_elementwise_fma(dz, dz, s2);
+                        m = fminf(m, fminf(s2.x, s2.y));
+                    }
+                    if (jend & 1) {
+                        const float dx = xi - X[j2], dy = yi - Y[j2], dz = zi - Z[j2];
+                        m = fminf(m, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                    }
+                    // a pose that owns the whole wavefront stops at its first certain clash (most poses of a dense embed clash)
+                    if (lp == 64 && __any(m < lo)) break;
+                }
+                for (int off = lp >> 1; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+                if (m >= hi) decided = true, verdict = 1;       // every distance certainly >= thresh (NaN: undecided)
+                else if (m < lo) decided = true, verdict = 0;   // some distance certainly < thresh
+            } else {
+                for (int off = lp >> 1; off > 0; off >>= 1) (void)__shfl_xor(m, off);  // keep the shuffles convergent
+            }
+            if (sub >= np) decided = true;
+        }
+        // ---- count close pairs in fp64: lane owns atom ia of pose `sub`, walks earlier-fragment atoms j
+        int cnt = 0;
+        if (!MINMODE || __any(!decided)) {
+            if (sub < np && !decided) {
+                for (int ia = a.first_row + li; ia < n; ia += lp) {
+                    const double x = p[ia * 3], y = p[ia * 3 + 1], z = p[ia * 3 + 2];
+                    int jend = n;
+                    if (!SELF) {
+                        jend = 0;
+#pragma unroll
+                        for (int k = 1; k < MAX_MOLS; ++k)
+                            if (k < a.n_mols && ia >= a.atom_off[k]) jend = a.atom_off[k];
+                    }
+                    // four independent partner atoms per trip: their LDS reads are issued together
+#pragma unroll 4
+                    for (int j = 0; j < jend; ++j) {
+                        const double dx = x - p[j * 3], dy = y - p[j * 3 + 1], dz = z - p[j * 3 + 2];
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        const bool hit = SELF ? (d2 < a.sq_bound && d2 > 0.0) : (d2 < a.sq_bound);
+                        cnt += hit ? 1 : 0;
+                    }
+                }
+            }
+            for (int off = lp >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (!decided) verdict = (long long)cnt <= a.max_clashes ? 1 : 0;
+        }
         if (sub < np && li == 0) {
-            mask[pose0 + sub] = (long long)cnt <= a.max_clashes ? 1 : 0;
+            mask[pose0 + sub] = uint8_t(verdict);
             if (counts) counts[pose0 + sub] = cnt;
         }
         __builtin_amdgcn_wave_barrier();

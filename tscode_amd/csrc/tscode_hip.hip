@@ -262,17 +262,17 @@ static int make_clash_args(int64_t n_poses, int n_atoms, const int32_t *ids, int
     return 0;
 }
 
-template <bool FUSED, bool SELF>
+template <bool FUSED, bool SELF, bool MINMODE>
 static int launch_clash_impl(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
                              const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
     const int ppw = 64 / a.lp;
-    size_t lds = size_t(4) * ppw * a.n * 3 * sizeof(double);
+    size_t lds = size_t(4) * clash_lds_per_wave(a.n, a.lp, MINMODE);
     TSC_REQUIRE(lds <= 160 * 1024, "pose too large for the LDS staging of the clash kernel (%d atoms)", a.n);
     int64_t waves = ceil_div<int64_t>(a.n_poses, ppw);
     int blocks = grid_for(waves, 4, 256 * 8);
     if (lds > 64 * 1024)
-        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clash<FUSED, SELF>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL((k_clash<FUSED, SELF>), dim3(blocks), dim3(256), lds, c->stream, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clash<FUSED, SELF, MINMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL((k_clash<FUSED, SELF, MINMODE>), dim3(blocks), dim3(256), lds, c->stream, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -281,8 +281,11 @@ template <bool FUSED>
 static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, const double *frags, const FragTable &ft,
                         const int32_t *conf_idx, const double *rot, const double *pos, uint8_t *mask, int32_t *counts) {
     if (a.n_poses == 0) return 0;
-    if (a.self_mode) return launch_clash_impl<FUSED, true>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
-    return launch_clash_impl<FUSED, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+    if (a.self_mode) return launch_clash_impl<FUSED, true, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+    // verdict only and no clash allowed: the packed-fp32 minimum with its fp64 fallback (embed_clash.hpp)
+    const bool minmode = !counts && a.max_clashes == 0 && c->clash_fp32 != 0 && 4 * clash_lds_per_wave(a.n, a.lp, true) <= 160 * 1024;
+    if (minmode) return launch_clash_impl<FUSED, false, true>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
+    return launch_clash_impl<FUSED, false, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_clash_mask_dev(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
@@ -929,6 +932,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
+        return 0;
+    }
+    if (strcmp(name, "clash_fp32") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "clash_fp32 must be 0 or 1");
+        c->clash_fp32 = int(value);
         return 0;
     }
     if (strcmp(name, "seg_cols") == 0) {
