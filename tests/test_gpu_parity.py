@@ -176,12 +176,15 @@ def test_prune_golden(eng, algo):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["algo-auto", "algo-tile", "algo-sieve"])
+@pytest.fixture(params=[(0, 1), (1, 1), (2, 0)], ids=["algo-auto", "algo-tile", "algo-sieve-global"])
 def algo(request, eng):
-    """Runs a test once per pair kernel: automatic choice, register-tiled all-pairs, descriptor sieve."""
-    eng.set_option("prune_algo", request.param)
-    yield request.param
+    """Runs a test once per pair kernel: automatic choice (descriptor sieve; passes with short chunks in the chunk-local
+    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path."""
+    eng.set_option("prune_algo", request.param[0])
+    eng.set_option("local_pass", request.param[1])
+    yield request.param[0]
     eng.set_option("prune_algo", 0)
+    eng.set_option("local_pass", 1)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -202,7 +205,7 @@ def test_prune_c2_vs_oracle(eng, oracle, mode, algo):
         assert s["pairs_evaluated"] == r["pairs_evaluated"]      # the reference's sequential work, reproduced exactly
         assert s["new_keys"] == r["new_keys"]
         assert max(s["pairs_computed"], s["pairs_screened"]) >= s["pairs_evaluated"]   # the GPU looks at a superset
-        assert s["algo"] in (1, 2) and (algo == 0 or s["algo"] == algo)
+        assert s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo)      # 3 = chunk-local kernel (automatic choice only)
     print(f"C2 mode {mode}: {len(heavy)} -> {mask.sum()}; margins rmsd {mr:.2e} maxdev {mm:.2e}")
 
 

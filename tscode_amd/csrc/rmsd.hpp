@@ -249,14 +249,19 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
                                                    unsigned long long *__restrict__ dbit, int bit_words, int32_t *__restrict__ n_keys,
                                                    PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
                                                    PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items,
-                                                   unsigned *__restrict__ dmax_bits) {
+                                                   unsigned *__restrict__ dmax_bits, unsigned *__restrict__ zero_words, int n_zero_words,
+                                                   int32_t *__restrict__ act) {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
     for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
     for (int64_t e = (n / 8) * 8 + tid; e < n; e += stride) mask[e] = 1;
+    // every entry of the active list is a valid structure index from the start: the pair kernel gathers through
+    // act[x] for x up to n without knowing the active count, and the first global pass may come after chunk-local ones
+    for (int64_t e = tid; e < n; e += stride) act[e] = int32_t(e);
     for (int64_t e = tid; e < bit_words; e += stride) mbit[e] = 0, dbit[e] = 0;
     unsigned long long *c = &cnt->w[0][0];
     for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
+    for (int64_t e = tid; e < n_zero_words; e += stride) zero_words[e] = 0;  // tickets of the chunk-local pass kernel
     char *r = reinterpret_cast<char *>(rec);
     for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride) r[e] = 0;
     // per-block counts of the mask for the exclusive scan of every pass; k_apply_pass keeps them current
@@ -279,6 +284,7 @@ struct StepArgs {
     long long k_cur;
     int algo_cur;
     int bit_words;
+    int prev_algo;  // >= 0: the kernel that really ran the closing pass (recorded in its PassRecord), -1: as opened
 };
 
 __device__ inline void pass_step_block(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec, const StepArgs &sa,
@@ -303,6 +309,7 @@ __device__ inline void pass_step_block(PruneState *__restrict__ st, PassCounters
             r.evaluated = (long long)s_sum[CNT_EVALUATED], r.removed = (long long)s_sum[CNT_REMOVED];
             st->n_active -= int(s_sum[CNT_REMOVED]);
             r.n_after = st->n_active;
+            if (sa.prev_algo >= 0) r.algo = sa.prev_algo;
         }
         int on = 0;
         if (sa.cur >= 0) {
@@ -345,6 +352,22 @@ __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, in
 
 // Cache view of one pass: a key (a, b) = (first, first + (j - i)) (:65) can be hit only where a is a chunk
 // start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
+// Cache view of a pass on its own (the chunk-local pass kernel, local_pass.hpp, needs nothing else from k_open_pass):
+// key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
+__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
+                                                     const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
+                                                     const PruneState *__restrict__ st) {
+    if (st->pass_on == 0) return;
+    const int nk = *n_keys;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
+        const int a = key_a[q], b = key_b[q];
+        const int c = a / g.cs;
+        if (c * g.cs != a || c >= g.k) continue;
+        const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
+        if (b < last) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
+    }
+}
+
 // Opens the data of a pass in one launch: ranks of the active structures, their index list and the mask as bits
 // (the second phase of the exclusive scan, scan.hpp; k_apply_pass keeps the per-block counts current), and the
 // cache view of the pass: key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.

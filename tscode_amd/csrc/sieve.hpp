@@ -405,8 +405,8 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     // whether it has work at all: most items of a late pass have none) and the structure indices of its rows and of its
     // first column tile; (2) the descriptors of those rows and columns, gathered straight from the per-structure table
     // D[N][DW] through act[] (active structures are in increasing index order, so the gather is nearly contiguous and
-    // no per-pass compacted copy of the descriptors is needed).  act[x] is a valid structure index for every x < n: the
-    // first pass of a run writes all n entries, later passes a prefix.
+    // no per-pass compacted copy of the descriptors is needed).  act[x] is a valid structure index for every x < n:
+    // k_init_run fills it with the identity, every pass rewrites a prefix.
     const int pass_on = st->pass_on, n_active = st->A;
     int my_cend = 0, my_best = 0;
     if (lane < TI && r0 + lane < a.n) {

@@ -6,6 +6,7 @@
 #include "rmsd.hpp"
 #include "scan.hpp"
 #include "sieve.hpp"
+#include "local_pass.hpp"
 #include "group_filter.hpp"
 
 #include <algorithm>
@@ -465,7 +466,7 @@ static const double KS[TSC_MAX_PASSES] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 20
 constexpr int TILE_ROWS = 16;
 constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel takes any h
 
-enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2 };
+enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2, ALGO_LOCAL = 3 /* reported only: a pass run by the chunk-local kernel */ };
 
 struct tsc_prune {
     tsc_ctx *ctx = nullptr;
@@ -484,6 +485,8 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     double *Gall = nullptr;
+    LocalTickets *tickets = nullptr;  // chunk-local pass kernel
+    bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
     unsigned *dmax_bits = nullptr;  // device scalar: largest |descriptor component| as float bits (zeroed by k_init_run)
     PassCounters *counters = nullptr;
     PruneState *state = nullptr;
@@ -617,6 +620,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         rc = palloc(p, size_t(n) * DW, &p->Dall);
         if (!rc) rc = palloc(p, size_t(n), &p->Gall);
         if (!rc) rc = palloc(p, 4, &p->dmax_bits);
+        if (!rc) rc = palloc(p, 1, &p->tickets);
     }
     if (!rc && p->algo == ALGO_TILE) {
         const size_t hp3 = size_t(p->hp) * 3;
@@ -627,7 +631,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) {
         hipStream_t st = c->stream;
         hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
-                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE, p->dmax_bits);
+                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE, p->dmax_bits,
+                           reinterpret_cast<unsigned *>(p->tickets), p->tickets ? int(sizeof(LocalTickets) / sizeof(unsigned)) : 0, p->act);
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
         // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
@@ -680,6 +685,21 @@ static void launch_tile(hipStream_t st, dim3 grid, const tsc_prune *p, const Til
                           (const double *)p->G, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a);
 }
 
+// The pass that follows the open one (what tsc_prune_next_pass will hand out next; not consumed here): the kernel that
+// finishes a pass also closes it and opens this one on the device.
+static StepArgs next_step_args(const tsc_prune *p, int *next_slot) {
+    int nxt = -1;
+    for (int s = p->next_ks; s < TSC_MAX_PASSES; ++s) {
+        const int64_t k = int64_t(KS[s]);
+        if (k == 1 || 20 * k < p->n) {
+            nxt = s;
+            break;
+        }
+    }
+    *next_slot = nxt;
+    return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words) : 0, p->cur_local ? ALGO_LOCAL : -1};
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
     TSC_REQUIRE(p != nullptr, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
@@ -697,13 +717,46 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // 0. open this pass: gate (:192), counters, cache-view bitmap -- already done by the apply kernel of the pass before
     //    it (its last block), by a one-block launch for the first pass of a run
     if (p->opened_slot != slot) {
-        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words)};
+        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words), -1};
         hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
     }
     p->last_slot = slot;
     p->slot_used[slot] = true;
-    // 1. ranks of the active structures, their index list, the mask as bits, the cache view of this pass
     const int use_cache = (p->mode == 0);
+    const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
+    // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
+    // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
+    // chunks are a few tiles long -- at 57k structures the passes k = 1000 and 500 drop from 47 to 29 us -- and for small
+    // ensembles, where every pass fits and a run is all launch latency; long chunks keep the four-launch path)
+    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= LP_MAX_ROWS &&
+                   (longest_chunk <= 256 || n <= 4096);
+    if (p->cur_local) {
+        if (use_cache)
+            hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
+                               (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state);
+        LocalPassArgs a;
+        a.h = p->h, a.use_cache = use_cache;
+        a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
+        a.nb_last = std::max(1, ceil_div(ceil_div(int(longest_chunk), LP_TI), LP_TILES_PER_BLOCK));
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
+        a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.dmax_bits = p->dmax_bits;
+        int nxt = -1;
+        const StepArgs sa = next_step_args(p, &nxt);
+        const int64_t blocks = (k - 1) * a.nb_regular + a.nb_last;
+        hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
+        hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask,
+                              (const unsigned long long *)p->dbit, p->heavy, (const double *)p->Gall, (const float *)p->Dall, p->key_a, p->key_b,
+                              p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit, p->tickets);
+        TSC_HIP(hipGetLastError());
+        p->opened_slot = nxt;
+        p->last_slot = -1;  // closed on the device
+        p->local_done = true;
+        return 0;
+    }
+    // 1. ranks of the active structures, their index list, the mask as bits, the cache view of this pass
     hipLaunchKernelGGL(k_open_pass, dim3(scan_grid_blocks(n)), dim3(SCAN_THREADS), 0, st, g, use_cache, (const PruneState *)p->state,
                        (const uint8_t *)p->mask, (const int32_t *)p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total,
                        (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit);
@@ -718,7 +771,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     }
     // 3. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
     const int n_tiles = ceil_div(A, TILE_ROWS);
-    const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
     // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
     // work (many small chunks), long ones amortise the per-item setup when it has a lot
@@ -786,24 +838,17 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
-    PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
-    // the slot tsc_prune_next_pass will hand out next (same rule, not consumed here): the last block of the apply
-    // kernel closes this pass and opens that one
-    int nxt = -1;
-    for (int s = p->next_ks; s < TSC_MAX_PASSES; ++s) {
-        const int64_t k = int64_t(KS[s]);
-        if (k == 1 || 20 * k < p->n) {
-            nxt = s;
-            break;
-        }
+    if (!p->cur_local) {  // (a chunk-local pass has applied its verdicts already)
+        PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
+        int nxt = -1;
+        const StepArgs sa = next_step_args(p, &nxt);
+        const int blocks = int(std::min<int64_t>(ceil_div<int64_t>(p->n, 256), 512));
+        hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, c->stream, g, p->state, p->act, p->cend, p->best, p->mask, p->key_a, p->key_b,
+                           p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit);
+        p->opened_slot = nxt;
+        p->last_slot = -1;  // closed on the device
+        TSC_HIP(hipGetLastError());
     }
-    StepArgs sa{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words) : 0};
-    const int blocks = int(std::min<int64_t>(ceil_div<int64_t>(p->n, 256), 512));
-    hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, c->stream, g, p->state, p->act, p->cend, p->best, p->mask, p->key_a, p->key_b,
-                       p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit);
-    p->opened_slot = nxt;
-    p->last_slot = -1;  // closed on the device
-    TSC_HIP(hipGetLastError());
     if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
     p->cur_k = 0;
     p->cur_slot = -1;
@@ -834,7 +879,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     if (!p->collected) {
         hipStream_t st = c->stream;
         if (p->last_slot >= 0) {
-            StepArgs sa{p->last_slot, -1, 0ll, 0, 0};
+            StepArgs sa{p->last_slot, -1, 0ll, 0, 0, -1};
             hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
             p->last_slot = -1;
         }
@@ -932,6 +977,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
+        return 0;
+    }
+    if (strcmp(name, "local_pass") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "local_pass must be 0 or 1");
+        c->local_pass = int(value);
         return 0;
     }
     if (strcmp(name, "clash_fp32") == 0) {
