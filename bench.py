@@ -102,6 +102,10 @@ def main():
     pg = None
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                       # --force-sharded without a launcher: a one-rank group
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
@@ -134,7 +138,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             res = pipe.step()
-            acc["tile_ms"] += sum(s["tile_ms"] for s in res["stats"])
+            acc["tile_ms"] += sum(s["tile_ms"] for s in res["stats"] if s["algo"] in (1, 2))     # the pair kernel's own launches
             acc["evals"] += sum(s["pairs_evaluated"] for s in res["stats"])
             acc["computed"] += sum(s["pairs_computed"] for s in res["stats"])
             acc["screened"] += sum(s["pairs_screened"] for s in res["stats"])
@@ -179,12 +183,14 @@ def main():
         n = ens.n_poses
         flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
         tile_s = tile_ms / 1e3
-        n_launch = len(res["stats"])                        # pair-kernel launches per step (one per pass)
+        big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: chunk-local kernel)
+        n_launch = len(big)                                 # pair-kernel launches per step
         launches = n_launch * args.steps
         avg_launch_s = tile_s / launches if launches and tile_s > 0 else None
         # algorithmic bytes of the prune: sum over passes (A_p * h * 24 + 2 N)  (SURVEY.md 8d), per launch: the mean
         b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
-        b_launch = b_k3 / n_launch if n_launch else None
+        b_big = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in big)
+        b_launch = b_big / n_launch if n_launch else None
         b_k12 = n * ens.frag_coords.__len__() * 96 + n_pass * ens.n_atoms * 24 + n
         ms_per_step = dt / args.steps * 1e3
         kernel = "k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile"
@@ -205,13 +211,15 @@ def main():
         # figure exceeds the FP64 peak; `executed` is what the instructions really do: the fp32 screen (2 families x 8
         # components x (sub + fma) = 48 flop per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per
         # pair that reaches them; register-tiled kernel: every computed pair, h padded to a multiple of 4)
-        achieved_alg = (evals / args.steps) * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
-        if screened:
-            f32_flops = (screened / args.steps) * 48
-            f64_flops = (computed / args.steps) * (18 * h + 110)
+        evals_big = sum(s["pairs_evaluated"] for s in big)
+        screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
+        achieved_alg = evals_big * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
+        if screened_big:
+            f32_flops = screened_big * 48
+            f64_flops = computed_big * (18 * h + 110)
         else:
             f32_flops = 0.0
-            f64_flops = (computed / args.steps) * (18 * ((h + 3) // 4 * 4) + 110)
+            f64_flops = computed_big * (18 * ((h + 3) // 4 * 4) + 110)
         per_s = (lambda x: x / (tile_s / args.steps) / 1e12) if tile_s > 0 else (lambda x: None)
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
@@ -246,10 +254,11 @@ def main():
                 "launches_per_step": n_launch,
                 "kernel_ms_per_step": tile_ms / args.steps,
                 "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
-                "fp64_valu": {"algorithmic_pair_evals_per_step": evals / args.steps, "flops_per_eval": flops_per_eval,
+                "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
+                "fp64_valu": {"algorithmic_pair_evals_per_step": evals_big, "flops_per_eval": flops_per_eval,
                               "achieved_algorithmic_TFLOPs": achieved_alg, "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
                               "frac_algorithmic": (achieved_alg / FP64_VALU_PEAK_TFLOPS) if achieved_alg else None,
-                              "pairs_screened_per_step": screened / args.steps, "pairs_with_H_formed_per_step": computed / args.steps,
+                              "pairs_screened_per_step": screened_big, "pairs_with_H_formed_per_step": computed_big,
                               "executed_fp32_TFLOPs": per_s(f32_flops), "executed_fp64_TFLOPs": per_s(f64_flops),
                               "peak_fp32_TFLOPs": FP32_VALU_PEAK_TFLOPS},
             },
@@ -258,7 +267,8 @@ def main():
             "events_off": events_off,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
-                        "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4)} for s in res["stats"]],
+                        "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4),
+                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for s in res["stats"]],
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, n), args.mode)
