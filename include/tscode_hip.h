@@ -125,6 +125,23 @@ int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, 
 int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                        double *rmsd, double *maxdev);
 
+/* Conformational-search rotations.  tsc_csearch_rotate builds every candidate of
+ * tscode/torsion_module.py:463-500 from one start structure: for each torsion t with angles[m][t] != 0 the atoms of
+ * masks[t] turn about the bond torsions[t][1]-torsions[t][2] (tscode/utils.py:389-414 rotate_dihedral, in place, in
+ * torsion order), a rotation that fails tscode/numba_functions.py:26-47 torsion_comp_check is walked back in 5-degree
+ * steps (angle // 5 of them, Python floor division) until it passes.  coords f64[n_atoms, 3]; torsions i32[n_tors, 4];
+ * masks u8[n_tors, n_atoms] (tscode/torsion_module.py:301-325 _get_rotation_mask, computed by the caller);
+ * angles i32[n_cand, n_tors] degrees; out f64[n_cand, n_atoms, 3]; rotated_bonds i32[n_cand] (the reference keeps a
+ * candidate iff this is non-zero, :505).  tsc_torsion_comp_check: ok i32[n_structs] = 1 / 0 for structures sharing one
+ * torsion and mask.  Host-pointer and device-pointer (_dev) forms. */
+int tsc_csearch_rotate(tsc_ctx *ctx, const double *coords, int n_atoms, const int32_t *torsions, const uint8_t *masks, int n_tors,
+                       const int32_t *angles, int64_t n_cand, double thresh, int64_t max_clashes, double *out, int32_t *rotated_bonds);
+int tsc_csearch_rotate_dev(tsc_ctx *ctx, const double *coords, int n_atoms, const int32_t *torsions, const uint8_t *masks, int n_tors,
+                           const int32_t *angles, int64_t n_cand, double thresh, int64_t max_clashes, double *out,
+                           int32_t *rotated_bonds);
+int tsc_torsion_comp_check(tsc_ctx *ctx, const double *coords, int64_t n_structs, int n_atoms, const int32_t *torsion,
+                           const uint8_t *mask, double thresh, int64_t max_clashes, int32_t *ok);
+
 /* Greedy per-group filter of the embed loops (tscode/embeds.py:715, :843): inside each group a pose is accepted iff
  * it is not similar (tscode/rmsd_pruning.py:208-224, all atoms, rmsd < thr and maxdev < 2 thr) to any pose accepted
  * before it in that group.  poses f64[n_poses, n_atoms, 3]; group g is poses[group_off[g] : group_off[g+1]]

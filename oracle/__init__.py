@@ -235,3 +235,36 @@ def prune_pass_rows(heavy, mask, keys, k, rank, world, tile_rows, best, rmsd_thr
                               _p(mask, _u8p), _p(keys, _i64p), C.c_int64(len(keys)), C.c_int64(k), C.c_int(rank), C.c_int(world),
                               C.c_int(tile_rows), best.ctypes.data_as(C.POINTER(C.c_int32)))
     return best
+
+
+# ---- csearch dihedral rotations --------------------------------------------------
+def rotate_dihedral(coords, torsion, angle, mask):
+    """utils.py:389-414 (returns a rotated copy; the reference works in place)."""
+    c = _f64(coords).copy()
+    tor = np.ascontiguousarray(torsion, dtype=np.int32)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_rotate_dihedral(_p(c), C.c_int(len(c)), _p(tor), C.c_double(angle), _p(m))
+    return c
+
+
+def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0):
+    c = _f64(coords)
+    tor = np.ascontiguousarray(torsion, dtype=np.int32)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_torsion_comp_check.restype = C.c_int
+    return int(lib().orc_torsion_comp_check(_p(c), C.c_int(len(c)), _p(tor), _p(m), C.c_double(thresh), C.c_int64(max_clashes), None))
+
+
+def csearch_rotate(coords, torsions, masks, angles, thresh=1.5, max_clashes=0, return_margin=False):
+    """Every candidate of torsion_module.py:463-500: (new_coords [M, n, 3], rotated_bonds [M])."""
+    c = _f64(coords)
+    tor = np.ascontiguousarray(torsions, dtype=np.int32).reshape(-1, 4)
+    m = np.ascontiguousarray(masks, dtype=np.uint8).reshape(len(tor), len(c))
+    ang = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, len(tor))
+    out = np.empty((len(ang), len(c), 3))
+    rb = np.zeros(len(ang), dtype=np.int32)
+    margin = C.c_double(np.inf)
+    lib().orc_csearch_rotate.restype = None
+    lib().orc_csearch_rotate(_p(c), C.c_int(len(c)), _p(tor), _p(m), C.c_int(len(tor)), _p(ang), C.c_int64(len(ang)), C.c_double(thresh),
+                             C.c_int64(max_clashes), _p(out), _p(rb), C.byref(margin) if return_margin else None)
+    return (out, rb, margin.value) if return_margin else (out, rb)

@@ -691,3 +691,86 @@ ORC_API int orc_prune_pass_rows(const double *heavy, int64_t N, int h, double rm
     free(pos);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* csearch dihedral rotations (torsion_module.py:463-500)                  */
+
+/* utils.py:389-414  rotate_dihedral(coords, dihedral, angle, mask): IN PLACE.
+ * axis = coords[i2] - coords[i3]; mat = rot_mat_from_pointer(axis, angle); center = coords[i3];
+ * coords[mask] = (mat @ (coords[mask] - center).T).T + center */
+ORC_API void orc_rotate_dihedral(double *coords, int n, const int32_t torsion[4], double angle_deg, const uint8_t *mask) {
+    const int i2 = torsion[1], i3 = torsion[2];
+    double axis[3], center[3], R[9];
+    for (int k = 0; k < 3; ++k) axis[k] = coords[3 * i2 + k] - coords[3 * i3 + k], center[k] = coords[3 * i3 + k];
+    orc_rot_mat_from_pointer(axis, angle_deg, R);
+    for (int a = 0; a < n; ++a) {
+        if (!mask[a]) continue;
+        double v[3] = {coords[3 * a] - center[0], coords[3 * a + 1] - center[1], coords[3 * a + 2] - center[2]};
+        for (int i = 0; i < 3; ++i) coords[3 * a + i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2] + center[i];
+    }
+}
+
+/* numba_functions.py:26-47  torsion_comp_check(coords, torsion, mask, thresh, max_clashes) -> 1 / 0:
+ * m1 = coords[mask]; m2 = coords[~mask minus {i2, i3}]; 0 if count(all_dists(m2, m1) < thresh) > max_clashes else 1.
+ * min_margin (optional): smallest |d - thresh| met (guard band of the tests). */
+ORC_API int orc_torsion_comp_check(const double *coords, int n, const int32_t torsion[4], const uint8_t *mask, double thresh,
+                                   int64_t max_clashes, double *min_margin) {
+    const int i2 = torsion[1], i3 = torsion[2];
+    int64_t count = 0;
+    for (int b = 0; b < n; ++b) {
+        if (mask[b] || b == i2 || b == i3) continue;
+        for (int a = 0; a < n; ++a) {
+            if (!mask[a]) continue;
+            double dx = coords[3 * b] - coords[3 * a], dy = coords[3 * b + 1] - coords[3 * a + 1], dz = coords[3 * b + 2] - coords[3 * a + 2];
+            double d = sqrt(dx * dx + dy * dy + dz * dz); /* algebra.py:133-155 */
+            if (d < thresh) ++count;
+            if (min_margin && fabs(d - thresh) < *min_margin) *min_margin = fabs(d - thresh);
+        }
+    }
+    return count > max_clashes ? 0 : 1;
+}
+
+/* torsion_module.py:463-500, the body of the loop over angle sets, for every candidate (the reference stops at n_out
+ * accepted candidates; the caller takes the first n_out rows with rotated_bonds != 0):
+ *   new_coords = copy(coords); rotated_bonds = 0
+ *   for t, angle in enumerate(angle_set):
+ *     if angle != 0:
+ *        rotate_dihedral(new_coords, torsion, angle, mask)            (in place: temp_coords IS new_coords)
+ *        if not torsion_comp_check(...):  for _ in range(angle // 5): rotate by -5; if check passes: rotated_bonds += 1; break
+ *        else: rotated_bonds += 1
+ * angle // 5 is Python floor division; a negative count runs no back-off step (and the clashing rotation stays).
+ * out [m][n][3], rotated_bonds [m]; min_margin (optional, in/out) over every check made. */
+ORC_API void orc_csearch_rotate(const double *coords, int n, const int32_t *torsions, const uint8_t *masks, int n_tors,
+                                const int32_t *angles, int64_t n_cand, double thresh, int64_t max_clashes, double *out,
+                                int32_t *rotated_bonds, double *min_margin) {
+    double margin = min_margin ? *min_margin : 0.0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(min : margin)
+    for (int64_t m = 0; m < n_cand; ++m) {
+        double *c = out + (size_t)m * n * 3;
+        memcpy(c, coords, sizeof(double) * (size_t)n * 3);
+        int rotated = 0;
+        double mm = margin;
+        for (int t = 0; t < n_tors; ++t) {
+            const int angle = angles[m * n_tors + t];
+            if (angle == 0) continue;
+            const int32_t *tor = torsions + 4 * t;
+            const uint8_t *mask = masks + (size_t)t * n;
+            orc_rotate_dihedral(c, n, tor, (double)angle, mask);
+            if (!orc_torsion_comp_check(c, n, tor, mask, thresh, max_clashes, min_margin ? &mm : NULL)) {
+                int steps = angle >= 0 ? angle / 5 : -((-angle + 4) / 5); /* floor division */
+                for (int rep = 0; rep < steps; ++rep) {
+                    orc_rotate_dihedral(c, n, tor, -5.0, mask);
+                    if (orc_torsion_comp_check(c, n, tor, mask, thresh, max_clashes, min_margin ? &mm : NULL)) {
+                        ++rotated;
+                        break;
+                    }
+                }
+            } else {
+                ++rotated;
+            }
+        }
+        rotated_bonds[m] = rotated;
+        if (mm < margin) margin = mm;
+    }
+    if (min_margin) *min_margin = margin;
+}

@@ -278,7 +278,111 @@ def gen_g6():
     _save("G6_tfd", seed=9106, coords=coords, quadruplets=quads, fingerprints=fp, similarity=sim)
 
 
+# --------------------------------------------------------------------------- G7
+def _chain_molecule(rng, n_backbone, branches):
+    """A branched chain: backbone atoms 0..n_backbone-1 bonded in sequence (1.5 A steps, self-avoiding), plus `branches`
+    extra atoms each bonded to a random backbone atom.  Returns coords and the bond list."""
+    coords = [np.zeros(3)]
+    bonds = []
+    while len(coords) < n_backbone:
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        cand = coords[-1] + 1.5 * d
+        if all(np.linalg.norm(cand - c) > 1.3 for c in coords[:-1]):
+            bonds.append((len(coords) - 1, len(coords)))
+            coords.append(cand)
+    for _ in range(branches):
+        while True:
+            root = int(rng.integers(1, n_backbone - 1))
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            cand = coords[root] + 1.1 * d
+            if all(np.linalg.norm(cand - c) > 1.0 for i, c in enumerate(coords) if i != root):
+                bonds.append((root, len(coords)))
+                coords.append(cand)
+                break
+    return np.array(coords), bonds
+
+
+def _rotation_mask(n, bonds, torsion):
+    """What torsion_module.py:301-325 (_get_rotation_mask) computes, on the bond list: atoms reachable from i1 without
+    crossing i2-i3, inverted if more than half, i2 cleared."""
+    i1, i2, i3, _ = torsion
+    adj = {a: set() for a in range(n)}
+    for a, b in bonds:
+        if {a, b} != {i2, i3}:
+            adj[a].add(b), adj[b].add(a)
+    seen, todo = {i1}, [i1]
+    while todo:
+        for b in adj[todo.pop()]:
+            if b not in seen:
+                seen.add(b), todo.append(b)
+    mask = np.array([a in seen for a in range(n)])
+    if np.count_nonzero(mask) > int(n / 2):
+        mask = ~mask
+    mask[i2] = False
+    return mask
+
+
+def gen_g7():
+    """csearch rotations (next-row N3).  tscode.utils / tscode.torsion_module do not import here (cclib, _tkinter,
+    periodictable are absent), so rotate_dihedral (utils.py:389-414) and the candidate loop (torsion_module.py:463-500)
+    are written out below around the REFERENCE's own rot_mat_from_pointer (tscode.algebra) and torsion_comp_check
+    (tscode.numba_functions); every verdict and every matrix in the fixture comes from those two."""
+    print("G7 csearch dihedral rotations (next-row N3)")
+    rng = np.random.default_rng(9107)
+
+    def rotate_dihedral(coords, dihedral, angle, mask):                 # utils.py:389-414 (in place)
+        i1, i2, i3, _ = dihedral
+        axis = coords[i2] - coords[i3]
+        mat = ref_alg.rot_mat_from_pointer(axis, angle)
+        center = coords[i3]
+        coords[mask] = (mat @ (coords[mask] - center).T).T + center
+        return coords
+
+    cases = []
+    for case, (nb, br, n_tors, n_cand) in enumerate(((10, 4, 3, 60), (24, 12, 5, 80), (40, 30, 6, 60))):
+        coords, bonds = _chain_molecule(rng, nb, br)
+        n = len(coords)
+        centres = rng.choice(np.arange(1, nb - 2), size=n_tors, replace=False)
+        torsions = np.array([(c - 1, c, c + 1, c + 2) for c in centres], dtype=np.int32)
+        masks = np.array([_rotation_mask(n, bonds, t) for t in torsions])
+        angles = rng.choice(np.array([0, 60, 120, 180, 240, 300, -60, -120, 30, 7]), size=(n_cand, n_tors)).astype(np.int32)
+        out = np.empty((n_cand, n, 3))
+        rb = np.zeros(n_cand, dtype=np.int32)
+        checks = []
+        for a, angle_set in enumerate(angles):                           # torsion_module.py:463-500
+            new_coords = np.copy(coords)
+            rotated_bonds = 0
+            for t, torsion in enumerate(torsions):
+                angle = int(angle_set[t])
+                if angle != 0:
+                    mask = masks[t]
+                    temp_coords = rotate_dihedral(new_coords, torsion, angle, mask=mask)
+                    ok = ref_nf.torsion_comp_check(temp_coords, torsion=torsion, mask=mask, thresh=1.5)
+                    checks.append(int(ok))
+                    if not ok:
+                        for _ in range(angle // 5):
+                            temp_coords = rotate_dihedral(temp_coords, torsion, -5, mask=mask)
+                            if ref_nf.torsion_comp_check(temp_coords, torsion=torsion, mask=mask, thresh=1.5):
+                                rotated_bonds += 1
+                                break
+                    else:
+                        rotated_bonds += 1
+                    new_coords = temp_coords
+            out[a], rb[a] = new_coords, rotated_bonds
+        cases.append(dict(coords=coords, torsions=torsions, masks=masks, angles=angles, out=out, rotated_bonds=rb,
+                          first_checks=np.array(checks, dtype=np.int8)))
+        print(f"  case {case}: n = {n}, {n_tors} torsions, {n_cand} candidates, rotated_bonds histogram {np.bincount(rb)}, "
+              f"{np.mean(checks):.2f} of the first checks pass")
+    flat = {"n_cases": len(cases), "seed": 9107}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat[f"{k}{i}"] = v
+    _save("G7_csearch", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
     for g in which:
         globals()["gen_" + g.lower()]()

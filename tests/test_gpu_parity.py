@@ -511,3 +511,47 @@ def test_clash_fp32_band_falls_back_to_fp64(eng, oracle):
         assert np.array_equal(got.astype(bool), ref.astype(bool)), fp32
     eng.set_option("clash_fp32", 1)
     assert 0 < ref.sum() < len(ref)
+
+
+# ----------------------------------------------------------------------------- N3: csearch rotations
+def test_csearch_rotations_golden(eng, oracle):
+    """tscode/torsion_module.py:463-500 candidates against the reference-derived fixture G7 and the oracle."""
+    import tscode_amd
+    g = load_golden("G7_csearch")
+    for c in range(int(g["n_cases"])):
+        coords, torsions, masks, angles = g[f"coords{c}"], g[f"torsions{c}"], g[f"masks{c}"], g[f"angles{c}"]
+        out, rb = eng.csearch_rotate(coords, torsions, masks, angles, 1.5, 0)
+        assert np.array_equal(rb, g[f"rotated_bonds{c}"])                 # every verdict of every walk-back step
+        assert np.abs(out - g[f"out{c}"]).max() < VAL_TOL
+        # drop-in single calls
+        t0 = next(t for t in range(len(torsions)) if angles[0][t] != 0)
+        one = tscode_amd.rotate_dihedral(coords.copy(), torsions[t0], int(angles[0][t0]), mask=masks[t0].astype(bool))
+        assert np.abs(one - oracle.rotate_dihedral(coords, torsions[t0], float(angles[0][t0]), masks[t0])).max() < VAL_TOL
+        assert tscode_amd.torsion_comp_check(one, torsions[t0], masks[t0].astype(bool), 1.5) == int(g[f"first_checks{c}"][0])
+        kept = tscode_amd.csearch_candidates(coords, torsions, masks, angles, n_out=7)
+        assert kept.shape == (7, len(coords), 3) and np.abs(kept - g[f"out{c}"][np.flatnonzero(g[f"rotated_bonds{c}"])[:7]]).max() < VAL_TOL
+
+
+def test_csearch_rotations_vs_oracle_large(eng, oracle):
+    """A 200-atom trimolecular complex (the size of BASELINE config 5), 8 torsions, 3000 candidates."""
+    rng = np.random.default_rng(21)
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C5", 4)
+    coords = ens.poses()[0]
+    n = len(coords)
+    # torsions along consecutive atoms of the first fragment; masks: everything after the bond inside that fragment
+    n0 = ens.frag_coords[0].shape[1]
+    centres = rng.choice(np.arange(2, n0 - 3), size=8, replace=False)
+    torsions = np.array([(c - 1, c, c + 1, c + 2) for c in centres], dtype=np.int32)
+    masks = np.zeros((8, n), dtype=np.uint8)
+    for t, c in enumerate(centres):
+        masks[t, c + 1:n0] = 1
+    angles = rng.choice(np.array([0, 0, 60, 120, 180, -60, 25]), size=(3000, 8)).astype(np.int32)
+    # (threshold 1.4: the synthetic fragments are walks of exactly 1.5 A steps, so 1.5 would sit on bonded distances)
+    ref_out, ref_rb, margin = oracle.csearch_rotate(coords, torsions, masks, angles, 1.4, 0, return_margin=True)
+    assert margin > 1e-9
+    out, rb = eng.csearch_rotate(coords, torsions, masks, angles, 1.4, 0)
+    assert np.array_equal(rb, ref_rb) and np.abs(out - ref_out).max() < VAL_TOL
+    ok = eng.torsion_comp_check(out[:500], torsions[0], masks[0], 1.4, 0)
+    assert ok.tolist() == [oracle.torsion_comp_check(o, torsions[0], masks[0], 1.4) for o in out[:500]]
+    assert 0 < (rb == 0).sum() + (rb > 0).sum() and len(np.unique(rb)) > 2

@@ -121,3 +121,18 @@ def test_g5_rotations(oracle):
         assert abs(oracle.vec_angle(a, b) - ref) < 1e-6   # acos near +-1 amplifies last-bit differences
     out = oracle.transform_coords(g["tc_coords"], g["tc_rot"], g["tc_pos"])
     assert np.allclose(out, g["transform_coords"], atol=1e-13, rtol=0)
+
+
+def test_g7_csearch_rotations(oracle):
+    """rotate_dihedral / torsion_comp_check / the candidate loop of torsion_module.py:463-500."""
+    g = load_golden("G7_csearch")
+    for c in range(int(g["n_cases"])):
+        coords, torsions, masks, angles = g[f"coords{c}"], g[f"torsions{c}"], g[f"masks{c}"], g[f"angles{c}"]
+        out, rb, margin = oracle.csearch_rotate(coords, torsions, masks, angles, 1.5, 0, return_margin=True)
+        assert margin > 1e-9                                      # guard band: no distance sits on the threshold
+        assert np.array_equal(rb, g[f"rotated_bonds{c}"])
+        assert np.abs(out - g[f"out{c}"]).max() < 1e-9
+        # single calls
+        t0 = next(t for t in range(len(torsions)) if angles[0][t] != 0)
+        one = oracle.rotate_dihedral(coords, torsions[t0], float(angles[0][t0]), masks[t0])
+        assert oracle.torsion_comp_check(one, torsions[t0], masks[t0], 1.5) == int(g[f"first_checks{c}"][0])

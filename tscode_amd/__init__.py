@@ -15,6 +15,7 @@ from .embeds import embed_batch, filter_angular_groups, get_embed, string_embed_
 from .engine import Engine, FragmentSet, device_count, get_engine  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .numba_functions import compenetration_check, compenetration_mask, count_clashes  # noqa: F401
+from .torsion_module import csearch_candidates, csearch_rotate, rotate_dihedral, torsion_comp_check  # noqa: F401
 from .rmsd_pruning import _rmsd_similarity, last_prune_stats, prune_conformers_rmsd, rmsd_and_max_numba  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,124 @@
+// csearch.hpp -- SURVEY.md 8(f) N3: the dihedral rotations of the conformational search, batched.
+//
+// tscode/torsion_module.py:463-500 builds every candidate conformer from the same start structure: for each torsion with
+// a non-zero angle, rotate_dihedral (utils.py:389-414: the masked atoms turn about the i2-i3 bond) followed by
+// torsion_comp_check (numba_functions.py:26-47: no atom of the moved side within `thresh` of an atom of the other side,
+// the bond atoms i2, i3 aside); a clashing rotation is walked back in 5-degree steps until it stops clashing
+// (`for _ in range(angle // 5)`, Python floor division, so a negative angle is never walked back).  Candidates are
+// independent; the torsions of one candidate are not.  One wavefront owns one candidate: its coordinates live in LDS,
+// lanes are atoms, the torsions run in order with the data-dependent back-off loop inside.
+#pragma once
+#include "common.hpp"
+
+namespace tsc {
+
+struct CsearchArgs {
+    int n;       // atoms
+    int n_tors;
+    long long n_cand;
+    double sq_bound;  // d < thresh  <=>  d2 < sq_bound  (clash_sq_bound, embed_clash.hpp)
+    long long max_clashes;
+};
+
+// algebra.py:325-344 rot_mat_from_pointer(axis, angle_deg) via algebra.py:284-323 (quaternion, scalar last)
+__device__ inline void rot_mat_from_pointer_dev(const double ax[3], double angle_deg, double R[9]) {
+    const double nrm = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);  // algebra.py:89-96
+    const double u0 = ax[0] / nrm, u1 = ax[1] / nrm, u2 = ax[2] / nrm;
+    const double half = angle_deg * (3.14159265358979323846 / 180) / 2;
+    const double s = sin(half), q0 = cos(half);
+    const double q1 = s * u0, q2 = s * u1, q3 = s * u2;
+    R[0] = 2 * (q0 * q0 + q1 * q1) - 1, R[1] = 2 * (q1 * q2 - q0 * q3), R[2] = 2 * (q1 * q3 + q0 * q2);
+    R[3] = 2 * (q1 * q2 + q0 * q3), R[4] = 2 * (q0 * q0 + q2 * q2) - 1, R[5] = 2 * (q2 * q3 - q0 * q1);
+    R[6] = 2 * (q1 * q3 - q0 * q2), R[7] = 2 * (q2 * q3 + q0 * q1), R[8] = 2 * (q0 * q0 + q3 * q3) - 1;
+}
+
+// utils.py:389-414 on a structure in LDS: every lane forms the (wave-uniform) matrix, lanes with a masked atom apply it.
+// If i3 itself is masked it maps onto itself exactly (its offset from the centre is zero), so no lane reads a value that
+// another lane is changing.
+__device__ inline void rotate_dihedral_lds(double *c, int n, int i2, int i3, double angle_deg, const uint8_t *__restrict__ mask, int lane) {
+    const double ax[3] = {c[3 * i2] - c[3 * i3], c[3 * i2 + 1] - c[3 * i3 + 1], c[3 * i2 + 2] - c[3 * i3 + 2]};
+    const double cen[3] = {c[3 * i3], c[3 * i3 + 1], c[3 * i3 + 2]};
+    double R[9];
+    rot_mat_from_pointer_dev(ax, angle_deg, R);
+    __builtin_amdgcn_wave_barrier();
+    for (int a = lane; a < n; a += 64) {
+        if (!mask[a]) continue;
+        const double v0 = c[3 * a] - cen[0], v1 = c[3 * a + 1] - cen[1], v2 = c[3 * a + 2] - cen[2];
+        c[3 * a] = R[0] * v0 + R[1] * v1 + R[2] * v2 + cen[0];
+        c[3 * a + 1] = R[3] * v0 + R[4] * v1 + R[5] * v2 + cen[1];
+        c[3 * a + 2] = R[6] * v0 + R[7] * v1 + R[8] * v2 + cen[2];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// numba_functions.py:26-47 on a structure in LDS (wave-uniform result): 1 = passes
+__device__ inline int torsion_comp_check_lds(const double *c, int n, int i2, int i3, const uint8_t *__restrict__ mask, double sq_bound,
+                                             long long max_clashes, int lane) {
+    int cnt = 0;
+    for (int a = lane; a < n; a += 64) {
+        if (!mask[a]) continue;
+        const double x = c[3 * a], y = c[3 * a + 1], z = c[3 * a + 2];
+        for (int b = 0; b < n; ++b) {
+            if (mask[b] || b == i2 || b == i3) continue;
+            const double dx = c[3 * b] - x, dy = c[3 * b + 1] - y, dz = c[3 * b + 2] - z;
+            cnt += (dx * dx + dy * dy + dz * dz < sq_bound) ? 1 : 0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    return (long long)cnt > max_clashes ? 0 : 1;
+}
+
+// out [n_cand][n][3], rotated_bonds [n_cand]; angles [n_cand][n_tors] int32 degrees; masks [n_tors][n]; torsions [n_tors][4]
+__global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,
+                                                         const uint8_t *__restrict__ masks, const int32_t *__restrict__ angles,
+                                                         double *__restrict__ out, int32_t *__restrict__ rotated_bonds) {
+    extern __shared__ __attribute__((aligned(16))) double s_c[];  // [4][n * 3]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = a.n;
+    double *c = s_c + size_t(wid) * n * 3;
+    for (int64_t m = int64_t(blockIdx.x) * 4 + wid; m < a.n_cand; m += int64_t(gridDim.x) * 4) {
+        for (int e = lane; e < n * 3; e += 64) c[e] = base[e];  // new_coords = np.copy(coords), :473
+        __builtin_amdgcn_wave_barrier();
+        int rotated = 0;
+        for (int t = 0; t < a.n_tors; ++t) {
+            const int angle = angles[m * a.n_tors + t];
+            if (angle == 0) continue;  // :482
+            const int i2 = tors[4 * t + 1], i3 = tors[4 * t + 2];
+            const uint8_t *mask = masks + size_t(t) * n;
+            rotate_dihedral_lds(c, n, i2, i3, double(angle), mask, lane);  // :484
+            if (!torsion_comp_check_lds(c, n, i2, i3, mask, a.sq_bound, a.max_clashes, lane)) {  // :487
+                const int steps = angle >= 0 ? angle / 5 : -((-angle + 4) / 5);  // angle // 5
+                for (int rep = 0; rep < steps; ++rep) {  // :490-498
+                    rotate_dihedral_lds(c, n, i2, i3, -5.0, mask, lane);
+                    if (torsion_comp_check_lds(c, n, i2, i3, mask, a.sq_bound, a.max_clashes, lane)) {
+                        ++rotated;
+                        break;
+                    }
+                }
+            } else {
+                ++rotated;  // :501
+            }
+        }
+        double *o = out + m * n * 3;
+        for (int e = lane; e < n * 3; e += 64) o[e] = c[e];
+        if (lane == 0) rotated_bonds[m] = rotated;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// torsion_comp_check for a batch of structures sharing torsion and mask: ok[s] = 1 / 0
+__global__ __launch_bounds__(256) void k_torsion_comp_check(CsearchArgs a, const double *__restrict__ coords, const int32_t *__restrict__ tors,
+                                                             const uint8_t *__restrict__ mask, int32_t *__restrict__ ok) {
+    extern __shared__ __attribute__((aligned(16))) double s_c[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = a.n;
+    double *c = s_c + size_t(wid) * n * 3;
+    for (int64_t m = int64_t(blockIdx.x) * 4 + wid; m < a.n_cand; m += int64_t(gridDim.x) * 4) {
+        const double *src = coords + m * n * 3;
+        for (int e = lane; e < n * 3; e += 64) c[e] = src[e];
+        __builtin_amdgcn_wave_barrier();
+        const int r = torsion_comp_check_lds(c, n, tors[1], tors[2], mask, a.sq_bound, a.max_clashes, lane);
+        if (lane == 0) ok[m] = r;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace tsc

@@ -8,6 +8,7 @@
 #include "sieve.hpp"
 #include "local_pass.hpp"
 #include "group_filter.hpp"
+#include "csearch.hpp"
 
 #include <algorithm>
 
@@ -1036,6 +1037,93 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(ts
     TSC_TRY(s.get(size_t(n_poses), &d_acc));
     TSC_TRY(tsc_greedy_group_filter_dev(c, d_poses, d_off, n_groups, n_poses, n_atoms, rmsd_thr, d_acc));
     TSC_HIP(hipMemcpyAsync(accepted, d_acc, size_t(n_poses), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// conformational-search rotations
+
+static int csearch_args(int n_atoms, int n_tors, int64_t n_cand, double thresh, int64_t max_clashes, CsearchArgs *a) {
+    TSC_REQUIRE(n_atoms > 0 && n_tors >= 0 && n_cand >= 0, "bad sizes (%d atoms, %d torsions, %lld candidates)", n_atoms, n_tors, (long long)n_cand);
+    TSC_REQUIRE(size_t(4) * n_atoms * 3 * sizeof(double) <= 150 * 1024, "%d atoms exceed the LDS staging of the csearch kernels", n_atoms);
+    a->n = n_atoms, a->n_tors = n_tors, a->n_cand = n_cand;
+    a->sq_bound = clash_sq_bound(thresh), a->max_clashes = max_clashes;
+    return 0;
+}
+
+static int check_torsions(const int32_t *torsions, int n_tors, int n_atoms) {
+    for (int t = 0; t < n_tors; ++t)
+        for (int q = 0; q < 4; ++q)
+            TSC_REQUIRE(torsions[4 * t + q] >= 0 && torsions[4 * t + q] < n_atoms, "torsion %d: atom index %d out of range", t, torsions[4 * t + q]);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate_dev(tsc_ctx *c, const double *coords, int n_atoms, const int32_t *torsions,
+                                                                             const uint8_t *masks, int n_tors, const int32_t *angles, int64_t n_cand,
+                                                                             double thresh, int64_t max_clashes, double *out, int32_t *rotated_bonds) {
+    TSC_REQUIRE(c && coords && out && rotated_bonds && torsions && masks && angles, "tsc_csearch_rotate_dev: null argument");
+    CsearchArgs a;
+    TSC_TRY(csearch_args(n_atoms, n_tors, n_cand, thresh, max_clashes, &a));
+    if (n_cand == 0) return 0;
+    DeviceGuard guard(c->device);
+    const size_t lds = size_t(4) * n_atoms * 3 * sizeof(double);
+    if (lds > 64 * 1024)
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csearch_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_csearch_rotate, dim3(grid_for(n_cand, 4, 256 * 8)), dim3(256), lds, c->stream, a, coords, torsions, masks, angles, out, rotated_bonds);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate(tsc_ctx *c, const double *coords, int n_atoms, const int32_t *torsions,
+                                                                         const uint8_t *masks, int n_tors, const int32_t *angles, int64_t n_cand,
+                                                                         double thresh, int64_t max_clashes, double *out, int32_t *rotated_bonds) {
+    TSC_REQUIRE(c && coords && out && rotated_bonds && (n_tors == 0 || (torsions && masks && angles)), "tsc_csearch_rotate: null argument");
+    TSC_REQUIRE(n_atoms > 0 && n_tors >= 0 && n_cand >= 0, "bad sizes");
+    TSC_TRY(check_torsions(torsions, n_tors, n_atoms));
+    if (n_cand == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_coords, *d_out;
+    int32_t *d_tors, *d_angles, *d_rb;
+    uint8_t *d_masks;
+    TSC_TRY(upload(c, s, coords, size_t(n_atoms) * 3, &d_coords));
+    TSC_TRY(upload(c, s, torsions, size_t(n_tors) * 4, &d_tors));
+    TSC_TRY(upload(c, s, masks, size_t(n_tors) * n_atoms, &d_masks));
+    TSC_TRY(upload(c, s, angles, size_t(n_cand) * n_tors, &d_angles));
+    TSC_TRY(s.get(size_t(n_cand) * n_atoms * 3, &d_out));
+    TSC_TRY(s.get(size_t(n_cand), &d_rb));
+    TSC_TRY(tsc_csearch_rotate_dev(c, d_coords, n_atoms, d_tors, d_masks, n_tors, d_angles, n_cand, thresh, max_clashes, d_out, d_rb));
+    TSC_HIP(hipMemcpyAsync(out, d_out, size_t(n_cand) * n_atoms * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(rotated_bonds, d_rb, size_t(n_cand) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc_ctx *c, const double *coords, int64_t n_structs, int n_atoms,
+                                                                             const int32_t *torsion, const uint8_t *mask, double thresh,
+                                                                             int64_t max_clashes, int32_t *ok) {
+    TSC_REQUIRE(c && coords && torsion && mask && ok, "tsc_torsion_comp_check: null argument");
+    CsearchArgs a;
+    TSC_TRY(csearch_args(n_atoms, 1, n_structs, thresh, max_clashes, &a));
+    TSC_TRY(check_torsions(torsion, 1, n_atoms));
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_coords;
+    int32_t *d_tors, *d_ok;
+    uint8_t *d_mask;
+    TSC_TRY(upload(c, s, coords, size_t(n_structs) * n_atoms * 3, &d_coords));
+    TSC_TRY(upload(c, s, torsion, size_t(4), &d_tors));
+    TSC_TRY(upload(c, s, mask, size_t(n_atoms), &d_mask));
+    TSC_TRY(s.get(size_t(n_structs), &d_ok));
+    const size_t lds = size_t(4) * n_atoms * 3 * sizeof(double);
+    if (lds > 64 * 1024)
+        TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_torsion_comp_check), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_torsion_comp_check, dim3(grid_for(n_structs, 4, 256 * 8)), dim3(256), lds, c->stream, a, (const double *)d_coords,
+                       (const int32_t *)d_tors, (const uint8_t *)d_mask, d_ok);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(ok, d_ok, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -185,6 +185,34 @@ class Engine:
                                                C.c_double(rmsd_thr), ptr(acc)))
         return acc.astype(bool)
 
+    # ---- N3: conformational-search rotations ---------------------------------------------------
+    def csearch_rotate(self, coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
+        """Every candidate of tscode/torsion_module.py:463-500: (new_coords f64[M, n, 3], rotated_bonds i32[M])."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        torsions = np.ascontiguousarray(torsions, dtype=np.int32).reshape(-1, 4)
+        n, nt = len(coords), len(torsions)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8).reshape(nt, n)
+        angles = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, nt)
+        if coords.ndim != 2 or coords.shape[1] != 3:
+            raise ValueError("coords must be (n_atoms, 3)")
+        out = np.empty((len(angles), n, 3))
+        rb = np.zeros(len(angles), dtype=np.int32)
+        check(self.lib.tsc_csearch_rotate(self._h, ptr(coords), C.c_int(n), ptr(torsions), ptr(masks), C.c_int(nt), ptr(angles),
+                                          C.c_int64(len(angles)), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(out), ptr(rb)))
+        return out, rb
+
+    def torsion_comp_check(self, coords, torsion, mask, thresh=1.5, max_clashes=0):
+        """ok i32[M] for structures f64[M, n, 3] sharing one torsion and mask (tscode/numba_functions.py:26-47)."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.ndim != 3 or coords.shape[2] != 3:
+            raise ValueError("coords must be (n_structs, n_atoms, 3)")
+        torsion = np.ascontiguousarray(torsion, dtype=np.int32).reshape(4)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(coords.shape[1])
+        ok = np.zeros(len(coords), dtype=np.int32)
+        check(self.lib.tsc_torsion_comp_check(self._h, ptr(coords), C.c_int64(len(coords)), C.c_int(coords.shape[1]), ptr(torsion), ptr(mask),
+                                              C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(ok)))
+        return ok
+
     def prune_heavy(self, heavy, rmsd_thr=0.5, mode=0):
         """prune_conformers_rmsd on the heavy-atom array f64[N, h, 3]. Returns (mask bool[N], per-pass stats)."""
         heavy = np.ascontiguousarray(heavy, dtype=np.float64)

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import sys
 
-from . import algebra, embeds, numba_functions, rmsd_pruning
+from . import algebra, embeds, numba_functions, rmsd_pruning, torsion_module
 
 # attribute -> (replacement, modules that bind it)
 _PATCHES = {
@@ -25,6 +25,9 @@ _PATCHES = {
     "get_embed": (embeds.get_embed, ("tscode.embeds",)),
     "all_dists": (algebra.all_dists, ("tscode.algebra", "tscode.numba_functions", "tscode.graph_manipulations")),
     "transform_coords": (algebra.transform_coords, ("tscode.algebra",)),
+    # (rotate_dihedral is NOT patched: tscode/torsion_module.py:984-1005 calls it with fractional angles, the batched
+    # kernel takes the integer tables of the conformational search; use tscode_amd.csearch_rotate for those loops)
+    "torsion_comp_check": (torsion_module.torsion_comp_check, ("tscode.numba_functions", "tscode.torsion_module")),
 }
 
 _saved = {}

@@ -1,0 +1,62 @@
+"""Drop-in names of the conformational-search rotations and their batched form.
+
+Reference: ``tscode/utils.py:389-414`` (rotate_dihedral), ``tscode/numba_functions.py:26-47`` (torsion_comp_check),
+``tscode/torsion_module.py:463-509`` (the loop over angle sets of random_csearch / csearch).  The rotation masks
+(``_get_rotation_mask``, a graph walk) and the shuffled angle table stay with the caller; everything per candidate
+runs on the GPU, one wavefront per candidate.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import get_engine
+
+__all__ = ["rotate_dihedral", "torsion_comp_check", "csearch_rotate", "csearch_candidates"]
+
+
+def csearch_rotate(coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
+    """All candidates at once: ``(new_coords [M, n, 3], rotated_bonds [M])`` for ``angles [M, n_torsions]`` (degrees, ints)."""
+    return get_engine().csearch_rotate(coords, torsions, masks, angles, thresh, max_clashes)
+
+
+def csearch_candidates(coords, torsions, masks, angles, n_out=100, max_tries=10000, thresh=1.5):
+    """The ``new_structures`` array of tscode/torsion_module.py:463-509: candidates in the order of ``angles`` (shuffle it
+    first, :459), kept iff at least one bond really rotated (:505), until ``n_out`` are kept or row ``max_tries`` is reached."""
+    angles = np.asarray(angles)
+    new_coords, rotated = csearch_rotate(coords, torsions, masks, angles, thresh)
+    kept = []
+    for a in range(len(angles)):
+        if rotated[a] != 0:
+            kept.append(a)
+            if len(kept) == n_out or a == max_tries:
+                break
+    return new_coords[kept]
+
+
+def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None):
+    """tscode/utils.py:389-414.  Like the reference it changes ``coords`` in place and returns it."""
+    coords_arr = np.asarray(coords)
+    n = len(coords_arr)
+    if indices_to_be_moved is not None:
+        mask = np.array([i in indices_to_be_moved for i in range(n)])
+    if mask is None:
+        m = np.zeros(n, dtype=bool)
+        m[dihedral[0]] = True
+        mask = m
+    mask = np.asarray(mask, dtype=bool)
+    if float(angle) != int(angle):
+        raise ValueError("the batched kernel takes whole degrees (the reference's angle tables are integers)")
+    if int(angle) == 0:
+        return coords                                    # (the candidate loop never rotates by zero, :482)
+    # one candidate, one torsion; a clash budget nothing can exceed switches the walk-back off
+    out, _ = get_engine().csearch_rotate(coords_arr, [tuple(int(i) for i in dihedral)], [mask], [[int(angle)]], 1.5, 2 ** 62)
+    coords_arr[...] = out[0]
+    return coords
+
+
+def torsion_comp_check(coords, torsion, mask, thresh=1.5, max_clashes=0) -> int:
+    """tscode/numba_functions.py:26-47: 1 if at most ``max_clashes`` distances between the moved side and the rest (the bond
+    atoms aside) are below ``thresh``, else 0."""
+    coords = np.asarray(coords, dtype=np.float64)
+    return int(get_engine().torsion_comp_check(coords[None], torsion, mask, thresh, max_clashes)[0])
