@@ -6,10 +6,16 @@
 
 A "step" is one pass of the hot path over one synthetic ensemble that is already resident in HBM:
 fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_conformers_rmsd
-(reference-exact mode), verdict masks left on the device.  With N > 1 (one process per GPU) the SAME
-ensemble is sharded over the ranks (strong scaling): pose blocks for embed/clash, one RCCL all-gather of
-the surviving heavy-atom coordinates, row tiles of every prune pass dealt round-robin with an
-all-reduce(MIN) per pass.
+(reference-exact mode), verdict masks left on the device and copied to pinned host memory.
+
+N > 1 (one process per GPU).  The 100k x 50 pipeline is a 1.1 ms job on one MI355X, a chain of ~50 dependent
+launches, so the two ways the path shards behave very differently and the line reports both:
+  * `value` (scaling "weak", --multi ensembles, the default): every GPU runs the whole pipeline on its own 100k x 50
+    ensemble -- ensembles are independent, no data-path collective; this is how a batch of embeds uses a node;
+  * `sharded_single_ensemble` (scaling "strong"; --multi sharded makes it the line's value): ONE ensemble sharded over
+    the ranks -- pose blocks for embed/clash, one RCCL all-gather of the surviving heavy-atom coordinates, row tiles of
+    every large prune pass dealt round-robin with an all-reduce(MIN) per pass (tscode_amd/pipeline.py::sharded_step).
+    It is what an ensemble too large for one GPU's patience (C4: 1M x 50) needs.
 
 Rank 0 prints ONE JSON line (see the keys below).  The CPU baseline leg (rank 0, N = 1 only) times the
 oracle -- this repo's C restatement of the reference algorithm, "port" -- on a bounded sample of the same
@@ -45,6 +51,12 @@ def parse():
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
     ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (seg_cols, drain_min), repeatable")
+    ap.add_argument("--multi", choices=["ensembles", "sharded"], default="ensembles",
+                    help="N > 1: 'ensembles' = one whole ensemble per GPU, no data-path collective (weak scaling; the line's value), "
+                         "'sharded' = ONE ensemble sharded over the ranks (strong scaling; all-gather + per-pass all-reduce). "
+                         "With 'ensembles' the sharded protocol is timed too and reported beside it.")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one GPU to rehearse "
+                                                      "the 'ensembles' mode (the sharded protocol needs nccl = RCCL)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--pass-timing", type=int, default=1,
@@ -106,16 +118,26 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
+    red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"      # where the small timing / parity reductions live
 
     from tscode_amd.pipeline import DevicePipeline
     from tscode_amd.synthetic import make_config
 
-    ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble, keeps only its block
-    pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
-                          force_sharded=args.force_sharded)
+    ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble
+    sharded_mode = (world > 1 and args.multi == "sharded") or args.force_sharded
+    if sharded_mode:                                        # ONE ensemble, every rank keeps only its block of the pose axis
+        pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
+                              force_sharded=args.force_sharded)
+    else:                                                   # one whole ensemble per GPU: the single-GPU pipeline on every rank
+        pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
+    units_per_step = ens.n_poses * (1 if sharded_mode else world)     # conformers all ranks process in one step
     from tscode_amd import get_engine
     get_engine(local_rank).set_option("prune_algo", args.algo)
     get_engine(local_rank).set_option("pass_timing", args.pass_timing)
@@ -129,7 +151,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_loop(steps):
+    def timed_loop(steps, pipe=pipe):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks. Returns (seconds, last result, sums)."""
         acc = {"tile_ms": 0.0, "evals": 0, "computed": 0, "screened": 0,
                "stage_ms": {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}}
@@ -147,7 +169,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, res, acc
@@ -164,7 +186,23 @@ def main():
         get_engine(local_rank).set_option("pass_timing", 0)
         dt0, _, _ = timed_loop(args.steps)
         get_engine(local_rank).set_option("pass_timing", args.pass_timing)
-        events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": ens.n_poses * args.steps / dt0, "unit": "conformers/s"}
+        events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": units_per_step * args.steps / dt0, "unit": "conformers/s"}
+    # N > 1 in 'ensembles' mode: the sharded single-ensemble protocol (strong scaling) timed beside it, same K steps
+    sharded_beside = None
+    if world > 1 and not sharded_mode and args.backend == "nccl":
+        try:
+            spipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
+            for _ in range(args.warmup):
+                spipe.step()
+            dts, sres, _ = timed_loop(args.steps, spipe)
+            skeep = spipe.h_keep[:sres["n_pass"]].numpy().copy()
+            sharded_beside = {"ms_per_step": dts / args.steps * 1e3, "value": ens.n_poses * args.steps / dts, "unit": "conformers/s",
+                              "scaling": "strong", "n_survivors": int(sres["n_keep"]),
+                              "keep_sha256_16": hashlib.sha256(np.packbits(skeep.astype(bool)).tobytes()).hexdigest()[:16],
+                              "what": "ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom "
+                                      "shards, all-reduce(MIN) per large pass"}
+        except Exception as exc:                             # the line's value above is already measured
+            sharded_beside = {"error": f"{type(exc).__name__}: {exc}"}
 
     # verdict fingerprint (after the timed region)
     n_pass, n_keep = res["n_pass"], res["n_keep"]
@@ -177,6 +215,10 @@ def main():
     parity = None
     if expected is not None:
         parity = bool(expected["n_pass"] == n_pass and expected["n_keep"] == n_keep and expected["keep_sha256_16"] == digest)
+        if world > 1:                                       # every rank checks its own result
+            flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            parity = bool(flag.item())
 
     if rank == 0:
         h = ens.n_heavy
@@ -223,14 +265,14 @@ def main():
         per_s = (lambda x: x / (tile_s / args.steps) / 1e12) if tile_s > 0 else (lambda x: None)
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
-            "value": n * args.steps / dt,
+            "value": units_per_step * args.steps / dt,
             "unit": "conformers/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if sharded_mode else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -238,7 +280,10 @@ def main():
                                    f"10 children per parent, seed {ens.seed}; clash_thresh 1.5, max_clashes 0, rmsd_thr 0.5, "
                                    f"mode {args.mode} ({'reference-exact' if args.mode == 0 else 'cache-free'})",
                        "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": digest,
-                       "parity_vs_recorded_oracle": parity, "parallelism": f"conformer-axis shards x{world}",
+                       "parity_vs_recorded_oracle": parity,
+                       "parallelism": (f"one ensemble sharded over {world} rank(s): pose blocks, all-gather, per-pass all-reduce" if sharded_mode else
+                                       f"{world} x (one whole ensemble per GPU), no data-path collective"),
+                       "conformers_per_step_all_ranks": units_per_step,
                        "library_events_in_timed_region": args.pass_timing},
             "roofline": {
                 "kernel": kernel + " (all-pairs Kabsch RMSD of one pass; one launch per pass)",
@@ -262,9 +307,12 @@ def main():
                               "executed_fp32_TFLOPs": per_s(f32_flops), "executed_fp64_TFLOPs": per_s(f64_flops),
                               "peak_fp32_TFLOPs": FP32_VALU_PEAK_TFLOPS},
             },
-            "pipeline_hbm": {"algorithmic_bytes": b_k12 + b_k3, "achieved_GBs": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9,
-                             "peak_GBs": HBM_PEAK_GBS, "frac": (b_k12 + b_k3) / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS},
+            "pipeline_hbm": {"algorithmic_bytes": (b_k12 + b_k3) * (units_per_step // n),
+                             "achieved_GBs": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9,
+                             "peak_GBs": HBM_PEAK_GBS * world,
+                             "frac": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9 / (HBM_PEAK_GBS * world)},
             "events_off": events_off,
+            "sharded_single_ensemble": sharded_beside,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4),
