@@ -187,23 +187,6 @@ def main():
         dt0, _, _ = timed_loop(args.steps)
         get_engine(local_rank).set_option("pass_timing", args.pass_timing)
         events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": units_per_step * args.steps / dt0, "unit": "conformers/s"}
-    # N > 1 in 'ensembles' mode: the sharded single-ensemble protocol (strong scaling) timed beside it, same K steps
-    sharded_beside = None
-    if world > 1 and not sharded_mode and args.backend == "nccl":
-        try:
-            spipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
-            for _ in range(args.warmup):
-                spipe.step()
-            dts, sres, _ = timed_loop(args.steps, spipe)
-            skeep = spipe.h_keep[:sres["n_pass"]].numpy().copy()
-            sharded_beside = {"ms_per_step": dts / args.steps * 1e3, "value": ens.n_poses * args.steps / dts, "unit": "conformers/s",
-                              "scaling": "strong", "n_survivors": int(sres["n_keep"]),
-                              "keep_sha256_16": hashlib.sha256(np.packbits(skeep.astype(bool)).tobytes()).hexdigest()[:16],
-                              "what": "ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom "
-                                      "shards, all-reduce(MIN) per large pass"}
-        except Exception as exc:                             # the line's value above is already measured
-            sharded_beside = {"error": f"{type(exc).__name__}: {exc}"}
-
     # verdict fingerprint (after the timed region)
     n_pass, n_keep = res["n_pass"], res["n_keep"]
     keep = pipe.h_keep[:n_pass].numpy().copy()             # the host copy every step produces
@@ -312,14 +295,47 @@ def main():
                              "peak_GBs": HBM_PEAK_GBS * world,
                              "frac": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9 / (HBM_PEAK_GBS * world)},
             "events_off": events_off,
-            "sharded_single_ensemble": sharded_beside,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(s["gpu_ms"], 4), "tile_ms": round(s["tile_ms"], 4),
                         "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for s in res["stats"]],
         }
+    else:
+        out = None
+    # N > 1 in 'ensembles' mode: the sharded single-ensemble protocol (strong scaling) timed beside it, same K steps.
+    # The line's value is already measured; a watchdog makes sure it is printed even if a collective of this extra
+    # leg should hang on some node (this leg runs under RCCL with N > 1 only on the driver's hardware).
+    sharded_beside = None
+    if world > 1 and not sharded_mode and args.backend == "nccl":
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["sharded_single_ensemble"] = {"error": "timed out after 120 s"}
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(120.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            spipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
+            for _ in range(args.warmup):
+                spipe.step()
+            dts, sres, _ = timed_loop(args.steps, spipe)
+            skeep = spipe.h_keep[:sres["n_pass"]].numpy().copy()
+            sharded_beside = {"ms_per_step": dts / args.steps * 1e3, "value": ens.n_poses * args.steps / dts, "unit": "conformers/s",
+                              "scaling": "strong", "n_survivors": int(sres["n_keep"]),
+                              "keep_sha256_16": hashlib.sha256(np.packbits(skeep.astype(bool)).tobytes()).hexdigest()[:16],
+                              "what": "ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom "
+                                      "shards, all-reduce(MIN) per large pass"}
+        except Exception as exc:                             # the line's value above is already measured
+            sharded_beside = {"error": f"{type(exc).__name__}: {exc}"}
+        watchdog.cancel()
+    if rank == 0:
+        out["sharded_single_ensemble"] = sharded_beside
+    if rank == 0:
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, n), args.mode)
+            out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, ens.n_poses), args.mode)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_sharded:
