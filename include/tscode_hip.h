@@ -125,6 +125,20 @@ int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, 
 int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                        double *rmsd, double *maxdev);
 
+/* Pose parameters of the string embed (tscode/embeds.py:98-116), for n_sites (conformer pair, reactive-
+ * centre pair) combinations x n_angles angles, pose = site * n_angles + angle index:
+ *   R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec) (:108, tscode/utils.py:183-208);
+ *   R = rot_mat_from_pointer(ref_vec, angle) @ R0 when angle != 0 (:110-112);  t = p1 - R @ p2 (:114);
+ * molecule 0 keeps identity / origin.  p1, p2, ref_vec, mol_vec f64[n_sites, 3]; conf_pair i32[n_sites, 2];
+ * angles f64[n_angles] degrees; rot f64[N, 2, 9], pos f64[N, 2, 3], conf_idx i32[N, 2] -- the inputs of
+ * tsc_transform_batch / tsc_embed_clash_mask_dev / tsc_pipeline_dev.  Host-pointer and device-pointer (_dev) forms. */
+int tsc_string_embed_params(tsc_ctx *ctx, const double *p1, const double *p2, const double *ref_vec, const double *mol_vec,
+                            const int32_t *conf_pair, int64_t n_sites, const double *angles, int n_angles, double *rot, double *pos,
+                            int32_t *conf_idx);
+int tsc_string_embed_params_dev(tsc_ctx *ctx, const double *p1, const double *p2, const double *ref_vec, const double *mol_vec,
+                                const int32_t *conf_pair, int64_t n_sites, const double *angles, int n_angles, double *rot,
+                                double *pos, int32_t *conf_idx);
+
 /* Conformational-search rotations.  tsc_csearch_rotate builds every candidate of
  * tscode/torsion_module.py:463-500 from one start structure: for each torsion t with angles[m][t] != 0 the atoms of
  * masks[t] turn about the bond torsions[t][1]-torsions[t][2] (tscode/utils.py:389-414 rotate_dihedral, in place, in

@@ -268,3 +268,15 @@ def csearch_rotate(coords, torsions, masks, angles, thresh=1.5, max_clashes=0, r
     lib().orc_csearch_rotate(_p(c), C.c_int(len(c)), _p(tor), _p(m), C.c_int(len(tor)), _p(ang), C.c_int64(len(ang)), C.c_double(thresh),
                              C.c_int64(max_clashes), _p(out), _p(rb), C.byref(margin) if return_margin else None)
     return (out, rb, margin.value) if return_margin else (out, rb)
+
+
+def string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles):
+    """embeds.py:98-116 for every (site, angle): (rot [S*A, 2, 3, 3], pos [S*A, 2, 3], conf_idx [S*A, 2])."""
+    p1, p2, ref_vec, mol_vec = (_f64(np.atleast_2d(x)) for x in (p1, p2, ref_vec, mol_vec))
+    cp = np.ascontiguousarray(np.atleast_2d(conf_pair), dtype=np.int32)
+    ang = _f64(angles)
+    S, A = len(p1), len(ang)
+    rot, pos, ci = np.empty((S * A, 2, 3, 3)), np.empty((S * A, 2, 3)), np.empty((S * A, 2), dtype=np.int32)
+    lib().orc_string_embed_params.restype = None
+    lib().orc_string_embed_params(_p(p1), _p(p2), _p(ref_vec), _p(mol_vec), _p(cp), C.c_int64(S), _p(ang), C.c_int(A), _p(rot), _p(pos), _p(ci))
+    return rot, pos, ci

@@ -774,3 +774,39 @@ ORC_API void orc_csearch_rotate(const double *coords, int n, const int32_t *tors
     }
     if (min_margin) *min_margin = margin;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* pose parameters of the string embed (embeds.py:98-116)                   */
+/* For site s (one conformer pair x one reactive-centre pair) and angle a:
+ *   R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec)              (:108)
+ *   R  = rot_mat_from_pointer(ref_vec, angle) @ R0  if angle != 0     (:110-112)
+ *   t  = p1 - R @ p2                                                  (:114)
+ * pose index = s * n_angles + a; molecule 0 stays at identity / origin.
+ * rot [n_sites * n_angles][2][9], pos [..][2][3], conf_idx [..][2]. */
+ORC_API void orc_string_embed_params(const double *p1, const double *p2, const double *ref_vec, const double *mol_vec,
+                                     const int32_t *conf_pair, int64_t n_sites, const double *angles, int n_angles, double *rot,
+                                     double *pos, int32_t *conf_idx) {
+    for (int64_t s = 0; s < n_sites; ++s) {
+        const double neg_ref[3] = {-ref_vec[3 * s], -ref_vec[3 * s + 1], -ref_vec[3 * s + 2]};
+        double R0[9];
+        orc_rotation_matrix_from_vectors(mol_vec + 3 * s, neg_ref, R0);
+        for (int a = 0; a < n_angles; ++a) {
+            const int64_t q = s * n_angles + a;
+            double R[9];
+            if (angles[a] != 0) {
+                double dR[9];
+                orc_rot_mat_from_pointer(ref_vec + 3 * s, angles[a], dR);
+                matmul3(dR, R0, R);
+            } else {
+                memcpy(R, R0, sizeof(R));
+            }
+            double *ro = rot + q * 18, *po = pos + q * 6;
+            for (int i = 0; i < 9; ++i) ro[i] = (i % 4 == 0) ? 1.0 : 0.0, ro[9 + i] = R[i];
+            for (int i = 0; i < 3; ++i) {
+                po[i] = 0.0;
+                po[3 + i] = p1[3 * s + i] - (R[3 * i] * p2[3 * s] + R[3 * i + 1] * p2[3 * s + 1] + R[3 * i + 2] * p2[3 * s + 2]);
+            }
+            conf_idx[2 * q] = conf_pair[2 * s], conf_idx[2 * q + 1] = conf_pair[2 * s + 1];
+        }
+    }
+}

@@ -555,3 +555,36 @@ def test_csearch_rotations_vs_oracle_large(eng, oracle):
     ok = eng.torsion_comp_check(out[:500], torsions[0], masks[0], 1.4, 0)
     assert ok.tolist() == [oracle.torsion_comp_check(o, torsions[0], masks[0], 1.4) for o in out[:500]]
     assert 0 < (rb == 0).sum() + (rb > 0).sum() and len(np.unique(rb)) > 2
+
+
+# ----------------------------------------------------------------------------- N1: string-embed pose parameters
+def test_string_embed_params_vs_oracle(eng, oracle):
+    """tscode/embeds.py:98-116 for a whole embed in one launch: against the oracle, against the reference-derived
+    matrices of G5, and by the invariant of :114 (the reactive centres coincide)."""
+    import tscode_amd
+    rng = np.random.default_rng(31)
+    S = 257
+    p1, p2, rv, mv = rng.normal(size=(4, S, 3)) * 2
+    mv[0] = rv[0] * 1.7            # mol_vec parallel to ref_vec   -> antiparallel to -ref_vec: the 180-degree-about-z branch
+    mv[1] = -rv[1] * 0.3           # mol_vec parallel to -ref_vec  -> identity branch
+    cp = rng.integers(0, 5, size=(S, 2)).astype(np.int32)
+    angles = np.arange(0, 360, 10).astype(np.float64)
+    rot, pos, ci = eng.string_embed_params(p1, p2, rv, mv, cp, angles)
+    ro, po, co = oracle.string_embed_params(p1, p2, rv, mv, cp, angles)
+    assert np.array_equal(ci, co) and np.abs(rot - ro).max() < 1e-12 and np.abs(pos - po).max() < 1e-11
+    A = len(angles)
+    for s in (0, 1, 2, 100):
+        for a in (0, 1, 17):
+            R, t = rot[s * A + a, 1], pos[s * A + a, 1]
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and np.abs(R @ p2[s] + t - p1[s]).max() < 1e-11      # :114
+            assert np.array_equal(rot[s * A + a, 0], np.eye(3)) and not pos[s * A + a, 0].any()
+    # reference matrices: G5 holds rot_mat_from_pointer(ptr, ang) from the reference; with mol_vec = -ref_vec R0 is the identity
+    g = load_golden("G5_rotations")
+    ptr_, ang_ = g["ptr"], g["ang"]
+    k = [i for i in range(len(ang_)) if ang_[i] != 0][:8]
+    r2, _, _ = eng.string_embed_params(np.zeros((len(k), 3)), np.zeros((len(k), 3)), ptr_[k], -ptr_[k], np.zeros((len(k), 2), np.int32), ang_[k])
+    for q, i in enumerate(k):
+        assert np.abs(r2[q * len(k) + q, 1] - g["rot_mat_from_pointer"][i]).max() < 1e-12
+    # the single-site drop-in still places the reactive centres on top of each other
+    poses, r, t = tscode_amd.string_embed_poses(rng.normal(size=(6, 3)), rng.normal(size=(4, 3)), p1[5], p2[5], rv[5], mv[5], range(0, 360, 30))
+    assert poses.shape == (12, 10, 3) and np.abs(np.einsum("nij,j->ni", r[:, 1], p2[5]) + t[:, 1] - p1[5]).max() < 1e-11

@@ -121,4 +121,80 @@ __global__ __launch_bounds__(256) void k_torsion_comp_check(CsearchArgs a, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// pose parameters of the string embed (tscode/embeds.py:98-116), one thread per pose.
+//   R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec)   (utils.py:183-208: Rodrigues, exact-zero tests kept)
+//   R  = rot_mat_from_pointer(ref_vec, angle) @ R0 for angle != 0;   t = p1 - R @ p2
+// pose = site * n_angles + a; molecule 0 stays at identity.  rot [N][2][9], pos [N][2][3], conf_idx [N][2].
+__device__ inline void rotation_matrix_from_vectors_dev(const double v1[3], const double v2[3], double out[9]) {
+    // no fused multiply-add here: the reference tests the cross product of the normalised vectors against exact zero, and
+    // for (anti)parallel inputs whether that test fires depends on the last bit of each product (NumPy multiplies, then
+    // subtracts)
+#pragma clang fp contract(off)
+    const double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]), n2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+    const double a[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1}, b[3] = {v2[0] / n2, v2[1] / n2, v2[2] / n2};
+    const double v[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double s = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (s != 0) {
+        const double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+        const double k[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+        const double f = (1 - c) / (s * s);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double kk = k[3 * i] * k[j] + k[3 * i + 1] * k[3 + j] + k[3 * i + 2] * k[6 + j];
+                out[3 * i + j] = ((i == j) ? 1.0 : 0.0) + k[3 * i + j] + kk * f;
+            }
+        return;
+    }
+    const double ab[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
+    if (sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]) == 0) {  // antiparallel: half a turn about z
+        const double z[3] = {0, 0, 1};
+        rot_mat_from_pointer_dev(z, 180.0, out);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = (i % 4 == 0) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_string_embed_params(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                              const double *__restrict__ ref_vec, const double *__restrict__ mol_vec,
+                                                              const int32_t *__restrict__ conf_pair, int64_t n_sites,
+                                                              const double *__restrict__ angles, int n_angles, double *__restrict__ rot,
+                                                              double *__restrict__ pos, int32_t *__restrict__ conf_idx) {
+    const int64_t total = n_sites * n_angles;
+    for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < total; q += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t s = q / n_angles;
+        const double angle = angles[q - s * n_angles];
+        const double rv[3] = {ref_vec[3 * s], ref_vec[3 * s + 1], ref_vec[3 * s + 2]};
+        const double neg[3] = {-rv[0], -rv[1], -rv[2]};
+        const double mv[3] = {mol_vec[3 * s], mol_vec[3 * s + 1], mol_vec[3 * s + 2]};
+        double R0[9], R[9];
+        rotation_matrix_from_vectors_dev(mv, neg, R0);
+        if (angle != 0) {
+            double dR[9];
+            rot_mat_from_pointer_dev(rv, angle, dR);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) R[3 * i + j] = dR[3 * i] * R0[j] + dR[3 * i + 1] * R0[3 + j] + dR[3 * i + 2] * R0[6 + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = R0[i];
+        }
+        double *ro = rot + q * 18, *po = pos + q * 6;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ro[i] = (i % 4 == 0) ? 1.0 : 0.0, ro[9 + i] = R[i];
+        const double x = p2[3 * s], y = p2[3 * s + 1], z = p2[3 * s + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            po[i] = 0.0;
+            po[3 + i] = p1[3 * s + i] - (R[3 * i] * x + R[3 * i + 1] * y + R[3 * i + 2] * z);
+        }
+        conf_idx[2 * q] = conf_pair[2 * s], conf_idx[2 * q + 1] = conf_pair[2 * s + 1];
+    }
+}
+
 }  // namespace tsc

@@ -1129,6 +1129,52 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc
 }
 
 // --------------------------------------------------------------------------------------------------
+// string-embed pose parameters
+
+extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params_dev(tsc_ctx *c, const double *p1, const double *p2, const double *ref_vec,
+                                                                                  const double *mol_vec, const int32_t *conf_pair, int64_t n_sites,
+                                                                                  const double *angles, int n_angles, double *rot, double *pos,
+                                                                                  int32_t *conf_idx) {
+    TSC_REQUIRE(c && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && rot && pos && conf_idx, "tsc_string_embed_params_dev: null argument");
+    TSC_REQUIRE(n_sites >= 0 && n_angles >= 0, "bad sizes");
+    if (n_sites == 0 || n_angles == 0) return 0;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_string_embed_params, dim3(grid_for(n_sites * n_angles, 256, 256 * 8)), dim3(256), 0, c->stream, p1, p2, ref_vec, mol_vec,
+                       conf_pair, n_sites, angles, n_angles, rot, pos, conf_idx);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params(tsc_ctx *c, const double *p1, const double *p2, const double *ref_vec,
+                                                                              const double *mol_vec, const int32_t *conf_pair, int64_t n_sites,
+                                                                              const double *angles, int n_angles, double *rot, double *pos,
+                                                                              int32_t *conf_idx) {
+    TSC_REQUIRE(c && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && rot && pos && conf_idx, "tsc_string_embed_params: null argument");
+    TSC_REQUIRE(n_sites >= 0 && n_angles >= 0, "bad sizes");
+    if (n_sites == 0 || n_angles == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_p1, *d_p2, *d_rv, *d_mv, *d_ang, *d_rot, *d_pos;
+    int32_t *d_cp, *d_ci;
+    const size_t N = size_t(n_sites) * n_angles;
+    TSC_TRY(upload(c, s, p1, size_t(n_sites) * 3, &d_p1));
+    TSC_TRY(upload(c, s, p2, size_t(n_sites) * 3, &d_p2));
+    TSC_TRY(upload(c, s, ref_vec, size_t(n_sites) * 3, &d_rv));
+    TSC_TRY(upload(c, s, mol_vec, size_t(n_sites) * 3, &d_mv));
+    TSC_TRY(upload(c, s, conf_pair, size_t(n_sites) * 2, &d_cp));
+    TSC_TRY(upload(c, s, angles, size_t(n_angles), &d_ang));
+    TSC_TRY(s.get(N * 18, &d_rot));
+    TSC_TRY(s.get(N * 6, &d_pos));
+    TSC_TRY(s.get(N * 2, &d_ci));
+    TSC_TRY(tsc_string_embed_params_dev(c, d_p1, d_p2, d_rv, d_mv, d_cp, n_sites, d_ang, n_angles, d_rot, d_pos, d_ci));
+    TSC_HIP(hipMemcpyAsync(rot, d_rot, N * 18 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(pos, d_pos, N * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(conf_idx, d_ci, N * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
 // pipeline
 
 extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,

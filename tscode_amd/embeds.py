@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors
+from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors  # noqa: F401  (host-side singles, re-exported)
 from .engine import FragmentSet, get_engine
 
 __all__ = ["get_embed", "embed_batch", "string_embed_poses", "filter_angular_groups"]
@@ -43,19 +43,17 @@ def string_embed_poses(coords1, coords2, p1, p2, ref_vec, mol_vec, angles):
     """
     coords1 = np.asarray(coords1, dtype=np.float64)
     coords2 = np.asarray(coords2, dtype=np.float64)
-    p1, p2 = np.asarray(p1, dtype=np.float64), np.asarray(p2, dtype=np.float64)
-    ref_vec, mol_vec = np.asarray(ref_vec, dtype=np.float64), np.asarray(mol_vec, dtype=np.float64)
-    r0 = rotation_matrix_from_vectors(mol_vec, -ref_vec)
-    n = len(angles)
-    rot = np.zeros((n, 2, 3, 3))
-    pos = np.zeros((n, 2, 3))
-    rot[:, 0] = np.eye(3)
-    for i, angle in enumerate(angles):
-        r = r0 if angle == 0 else rot_mat_from_pointer(ref_vec, angle) @ r0
-        rot[i, 1] = r
-        pos[i, 1] = p1 - r @ p2
-    poses = embed_batch([coords1[None], coords2[None]], np.zeros((n, 2), np.int32), rot, pos)
+    rot, pos, conf_idx = string_embed_params([p1], [p2], [ref_vec], [mol_vec], [[0, 0]], angles)
+    poses = embed_batch([coords1[None], coords2[None]], conf_idx, rot, pos)
     return poses, rot, pos
+
+
+def string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles):
+    """Pose parameters of the whole string embed (tscode/embeds.py:91-116) in one launch: for every site (a conformer pair
+    ``conf_pair[s] = (c1, c2)`` with one reactive-centre pair ``p1[s], p2[s], ref_vec[s], mol_vec[s]``) and every angle,
+    ``rot [S*A, 2, 3, 3]``, ``pos [S*A, 2, 3]``, ``conf_idx [S*A, 2]`` in the reference's loop order (site-major) -- the
+    inputs of ``embed_batch`` / ``compenetration_mask`` / ``pipeline.DevicePipeline``."""
+    return get_engine().string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles)
 
 
 def filter_angular_groups(poses, group_sizes, rmsd_thr=1.0):

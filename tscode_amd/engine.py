@@ -185,6 +185,20 @@ class Engine:
                                                C.c_double(rmsd_thr), ptr(acc)))
         return acc.astype(bool)
 
+    # ---- N1: string-embed pose parameters -------------------------------------------------------
+    def string_embed_params(self, p1, p2, ref_vec, mol_vec, conf_pair, angles):
+        """tscode/embeds.py:98-116 for every (site, angle): rot f64[S*A, 2, 3, 3], pos f64[S*A, 2, 3], conf_idx i32[S*A, 2]."""
+        p1, p2, ref_vec, mol_vec = (np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64) for x in (p1, p2, ref_vec, mol_vec))
+        conf_pair = np.ascontiguousarray(np.atleast_2d(conf_pair), dtype=np.int32)
+        angles = np.ascontiguousarray(angles, dtype=np.float64)
+        S, A = len(p1), len(angles)
+        if not (p1.shape == p2.shape == ref_vec.shape == mol_vec.shape == (S, 3)) or conf_pair.shape != (S, 2):
+            raise ValueError("p1, p2, ref_vec, mol_vec must be (n_sites, 3) and conf_pair (n_sites, 2)")
+        rot, pos, ci = np.empty((S * A, 2, 3, 3)), np.empty((S * A, 2, 3)), np.empty((S * A, 2), dtype=np.int32)
+        check(self.lib.tsc_string_embed_params(self._h, ptr(p1), ptr(p2), ptr(ref_vec), ptr(mol_vec), ptr(conf_pair), C.c_int64(S), ptr(angles),
+                                               C.c_int(A), ptr(rot), ptr(pos), ptr(ci)))
+        return rot, pos, ci
+
     # ---- N3: conformational-search rotations ---------------------------------------------------
     def csearch_rotate(self, coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
         """Every candidate of tscode/torsion_module.py:463-500: (new_coords f64[M, n, 3], rotated_bonds i32[M])."""
