@@ -125,6 +125,18 @@ int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, 
 int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                        double *rmsd, double *maxdev);
 
+/* Torsion-fingerprint pruning (tscode/numba_functions.py:142-264).
+ * tsc_torsion_fingerprints: _get_tf_mat -- out f32[n_structs, n_quads] of dihedral angles in degrees (tscode/algebra.py:24-55)
+ * over quads i32[n_quads, 4]; coords f64[n_structs, n_atoms, 3].
+ * tsc_tfd_first_similar: the pair search of one pass (:171-199) over fingerprints tf f32[n_structs, n_quads]: chunk `step`
+ * is [d*step, d*(step+1)), the last one [d*(k-1), num_active); first i32[n_structs] = absolute index of the first j > i of
+ * i's chunk with tfd_similarity(tf[i], tf[j], thresh) (:242-253), or -1.  The graph step that turns the matches into
+ * rejects (:201-226) is the caller's (tscode_amd/numba_functions.py keeps the reference's networkx objects). */
+int tsc_torsion_fingerprints(tsc_ctx *ctx, const double *coords, int64_t n_structs, int n_atoms, const int32_t *quads, int n_quads,
+                             float *out);
+int tsc_tfd_first_similar(tsc_ctx *ctx, const float *tf, int64_t n_structs, int n_quads, int64_t d, int64_t k, int64_t num_active,
+                          double thresh, int32_t *first);
+
 /* Pose parameters of the string embed (tscode/embeds.py:98-116), for n_sites (conformer pair, reactive-
  * centre pair) combinations x n_angles angles, pose = site * n_angles + angle index:
  *   R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec) (:108, tscode/utils.py:183-208);

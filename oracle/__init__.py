@@ -280,3 +280,29 @@ def string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles):
     lib().orc_string_embed_params.restype = None
     lib().orc_string_embed_params(_p(p1), _p(p2), _p(ref_vec), _p(mol_vec), _p(cp), C.c_int64(S), _p(ang), C.c_int(A), _p(rot), _p(pos), _p(ci))
     return rot, pos, ci
+
+
+# ---- torsion fingerprints / TFD pair search ---------------------------------------
+def torsion_fingerprints(structures, quadruplets):
+    s = _f64(structures)
+    q = np.ascontiguousarray(quadruplets, dtype=np.int32).reshape(-1, 4)
+    out = np.empty((len(s), len(q)), dtype=np.float32)
+    lib().orc_torsion_fingerprints.restype = None
+    lib().orc_torsion_fingerprints(_p(s), C.c_int64(len(s)), C.c_int(s.shape[1]), _p(q), C.c_int(len(q)), _p(out))
+    return out
+
+
+def tfd_similarity(a, b, thresh=10):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    lib().orc_tfd_similarity.restype = C.c_int
+    return bool(lib().orc_tfd_similarity(_p(a), _p(b), C.c_int(len(a)), C.c_double(thresh), None))
+
+
+def tfd_first_similar(tf_mat, d, k, num_active, thresh=10, return_margin=False):
+    tf = np.ascontiguousarray(tf_mat, dtype=np.float32)
+    first = np.empty(len(tf), dtype=np.int32)
+    margin = C.c_double(np.inf)
+    lib().orc_tfd_first_similar.restype = None
+    lib().orc_tfd_first_similar(_p(tf), C.c_int64(len(tf)), C.c_int(tf.shape[1]), C.c_int64(int(d)), C.c_int64(int(k)), C.c_int64(int(num_active)),
+                                C.c_double(thresh), _p(first), C.byref(margin) if return_margin else None)
+    return (first, margin.value) if return_margin else first

@@ -810,3 +810,75 @@ ORC_API void orc_string_embed_params(const double *p1, const double *p2, const d
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* torsion fingerprints and the pair search of prune_conformers_tfd         */
+
+/* algebra.py:24-55 dihedral(p) in degrees (Praxeolitic formula) */
+static double dihedral_deg(const double *p0, const double *p1, const double *p2, const double *p3) {
+    double b0[3], b1[3], b2[3];
+    for (int k = 0; k < 3; ++k) b0[k] = -1.0 * (p1[k] - p0[k]), b1[k] = p2[k] - p1[k], b2[k] = p3[k] - p2[k];
+    const double n1 = norm_of3(b1);
+    for (int k = 0; k < 3; ++k) b1[k] /= n1;
+    const double d0 = b0[0] * b1[0] + b0[1] * b1[1] + b0[2] * b1[2], d2 = b2[0] * b1[0] + b2[1] * b1[1] + b2[2] * b1[2];
+    double v[3], w[3];
+    for (int k = 0; k < 3; ++k) v[k] = b0[k] - d0 * b1[k], w[k] = b2[k] - d2 * b1[k];
+    const double x = v[0] * w[0] + v[1] * w[1] + v[2] * w[2];
+    const double c[3] = {b1[1] * v[2] - b1[2] * v[1], b1[2] * v[0] - b1[0] * v[2], b1[0] * v[1] - b1[1] * v[0]};
+    const double y = c[0] * w[0] + c[1] * w[1] + c[2] * w[2];
+    return atan2(y, x) * (180.0 / M_PI);
+}
+
+/* numba_functions.py:233-240, :255-264  _get_tf_mat: float32 [N][T] */
+ORC_API void orc_torsion_fingerprints(const double *coords, int64_t N, int n, const int32_t *quads, int T, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < N; ++s) {
+        const double *c = coords + (size_t)s * n * 3;
+        for (int t = 0; t < T; ++t) {
+            const int32_t *q = quads + 4 * t;
+            out[s * T + t] = (float)dihedral_deg(c + 3 * q[0], c + 3 * q[1], c + 3 * q[2], c + 3 * q[3]);
+        }
+    }
+}
+
+/* numba_functions.py:242-253 tfd_similarity: deltas = |tfp1 - tfp2| (float32); deltas = |deltas - (deltas > 180) * 360|
+ * (float64 after the integer term); True iff sum(deltas) < thresh.  *sum_out (optional) = the sum. */
+ORC_API int orc_tfd_similarity(const float *a, const float *b, int T, double thresh, double *sum_out) {
+    double sum = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const float d32 = fabsf(a[t] - b[t]);
+        double d = (double)d32;
+        if (d32 > 180.0f) d -= 360.0;
+        sum += fabs(d);
+    }
+    if (sum_out) *sum_out = sum;
+    return sum < thresh;
+}
+
+/* numba_functions.py:171-199, the pair search of one pass: chunk `step` covers [d*step, d*(step+1)), the last one
+ * [d*(k-1), num_active) (:175-178 -- yes, the count of active structures as an index); inside a chunk row i scans j > i
+ * (removed structures included: the mask is never consulted) and stops at the first similar one.  The reference's cache
+ * only skips pairs it already found dissimilar, so it cannot change a verdict and is not needed here.
+ * first[i] = absolute index of the first similar j, -1 if none or if i lies in no chunk.  min_margin (optional, in/out). */
+ORC_API void orc_tfd_first_similar(const float *tf, int64_t N, int T, int64_t d, int64_t k, int64_t num_active, double thresh,
+                                   int32_t *first, double *min_margin) {
+    double margin = min_margin ? *min_margin : 0.0;
+    for (int64_t i = 0; i < N; ++i) first[i] = -1;
+#pragma omp parallel for schedule(dynamic, 1) reduction(min : margin)
+    for (int64_t step = 0; step < k; ++step) {
+        const int64_t start = d * step;
+        int64_t len = (step == k - 1) ? num_active - start : d;
+        if (len < 0) len = 0;
+        for (int64_t i = 0; i < len; ++i)
+            for (int64_t j = i + 1; j < len; ++j) {
+                double sum;
+                const int sim = orc_tfd_similarity(tf + (start + i) * T, tf + (start + j) * T, T, thresh, &sum);
+                if (min_margin && fabs(sum - thresh) < margin) margin = fabs(sum - thresh);
+                if (sim) {
+                    first[start + i] = (int32_t)(start + j);
+                    break;
+                }
+            }
+    }
+    if (min_margin) *min_margin = margin;
+}

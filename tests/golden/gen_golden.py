@@ -382,7 +382,36 @@ def gen_g7():
     _save("G7_csearch", **flat)
 
 
+# --------------------------------------------------------------------------- G8
+def gen_g8():
+    """prune_conformers_tfd (next-row N2) on clustered ensembles: the reference's own function, networkx 3.x and all.
+    Which member of a cluster survives is `tuple(graph.nodes)[0]` of a networkx subgraph view (numba_functions.py:221-226),
+    i.e. it depends on CPython's set iteration order; the fixture records what THIS interpreter + networkx give, and the
+    product reproduces it by building the same Python set / graph objects on the host from the GPU's matches."""
+    import networkx
+    print(f"G8 prune_conformers_tfd (next-row N2), networkx {networkx.__version__}, python {sys.version.split()[0]}")
+    rng = np.random.default_rng(9108)
+    quads = np.array([[0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 5], [4, 5, 6, 7], [6, 7, 8, 9], [0, 4, 8, 11]])
+    flat = {"n_cases": 0, "seed": 9108, "networkx": networkx.__version__, "python": sys.version.split()[0]}
+    for case, (n_par, n_child, noise, thresh) in enumerate(((12, 5, 0.01, 10), (140, 5, 0.02, 10), (400, 6, 0.03, 20), (30, 4, 0.02, 10))):
+        parents = rng.normal(size=(n_par, 12, 3)) * 2
+        structures = (parents[:, None] + rng.normal(size=(n_par, n_child, 12, 3)) * noise).reshape(-1, 12, 3)
+        structures = np.ascontiguousarray(structures[rng.permutation(len(structures))])
+        if case == 3:                                         # exact duplicates and a wrap-around pair
+            structures[7] = structures[3]
+            structures[11] = structures[3]
+        t0 = time.time()
+        tf_mat = ref_nf._get_tf_mat(structures, quads)
+        pruned, mask = ref_nf.prune_conformers_tfd(structures, quads, thresh=thresh)
+        assert np.array_equal(pruned, structures[mask])
+        flat[f"structures{case}"], flat[f"tf_mat{case}"], flat[f"mask{case}"], flat[f"thresh{case}"] = structures, tf_mat, mask, thresh
+        flat["n_cases"] = case + 1
+        print(f"  case {case}: N = {len(structures)}, thresh {thresh}: {mask.sum()} survive ({time.time() - t0:.1f} s)")
+    flat["quadruplets"] = quads
+    _save("G8_tfd_prune", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     for g in which:
         globals()["gen_" + g.lower()]()

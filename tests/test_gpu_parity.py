@@ -588,3 +588,33 @@ def test_string_embed_params_vs_oracle(eng, oracle):
     # the single-site drop-in still places the reactive centres on top of each other
     poses, r, t = tscode_amd.string_embed_poses(rng.normal(size=(6, 3)), rng.normal(size=(4, 3)), p1[5], p2[5], rv[5], mv[5], range(0, 360, 30))
     assert poses.shape == (12, 10, 3) and np.abs(np.einsum("nij,j->ni", r[:, 1], p2[5]) + t[:, 1] - p1[5]).max() < 1e-11
+
+
+# ----------------------------------------------------------------------------- N2: torsion-fingerprint pruning
+def test_tfd_pruning_golden(eng, oracle):
+    """prune_conformers_tfd on the GPU against the reference's own results (G8: its function, networkx and all), plus the
+    fingerprints and tfd_similarity against G6."""
+    pytest.importorskip("networkx")
+    import tscode_amd
+    g6 = load_golden("G6_tfd")
+    fp = tscode_amd._get_tf_mat(g6["coords"], g6["quadruplets"])
+    assert fp.dtype == np.float32 and fp.shape == g6["fingerprints"].shape
+    assert np.abs(fp - g6["fingerprints"]).max() < 2e-5 and (fp != g6["fingerprints"]).mean() < 0.01     # float32 of an fp64 angle
+    assert np.array_equal(tscode_amd.get_torsion_fingerprint(g6["coords"][3], g6["quadruplets"]), fp[3])
+    sims = [[tscode_amd.tfd_similarity(g6["fingerprints"][i], g6["fingerprints"][j], thresh=t) for j in range(10)] for i in range(4) for t in (10, 90, 300)]
+    assert np.array_equal(np.array(sims), g6["similarity"][:12].astype(bool))
+    g = load_golden("G8_tfd_prune")
+    for c in range(int(g["n_cases"])):
+        structures, thresh = g[f"structures{c}"], float(g[f"thresh{c}"])
+        tf = eng.torsion_fingerprints(structures, g["quadruplets"])
+        assert np.abs(tf - g[f"tf_mat{c}"]).max() < 2e-5
+        # every pass of the pair search against the oracle on the reference's fingerprints
+        n = len(structures)
+        for k in (1, 2, 5, 10):
+            if k == 1 or 5 * k < n:
+                first_o, margin = oracle.tfd_first_similar(g[f"tf_mat{c}"], n // k, k, n - 3, thresh, return_margin=True)
+                assert margin > 1e-6
+                assert np.array_equal(eng.tfd_first_similar(g[f"tf_mat{c}"], n // k, k, n - 3, thresh), first_o), (c, k)
+        pruned, mask = tscode_amd.prune_conformers_tfd(structures, g["quadruplets"], thresh=thresh)
+        assert np.array_equal(mask, g[f"mask{c}"]), (c, mask.sum(), g[f"mask{c}"].sum())
+        assert np.array_equal(pruned, structures[mask])

@@ -136,3 +136,39 @@ def test_g7_csearch_rotations(oracle):
         t0 = next(t for t in range(len(torsions)) if angles[0][t] != 0)
         one = oracle.rotate_dihedral(coords, torsions[t0], float(angles[0][t0]), masks[t0])
         assert oracle.torsion_comp_check(one, torsions[t0], masks[t0], 1.5) == int(g[f"first_checks{c}"][0])
+
+
+class _OraclePairSearch:
+    """prune_conformers_tfd's GPU calls answered by the CPU oracle (the product's host logic under test on CPU)."""
+    def __init__(self, oracle):
+        self.o, self.margin = oracle, np.inf
+
+    def fingerprints(self, structures, quads):
+        return self.o.torsion_fingerprints(structures, quads)
+
+    def first_similar(self, tf, d, k, num_active, thresh):
+        first, m = self.o.tfd_first_similar(tf, d, k, num_active, thresh, return_margin=True)
+        self.margin = min(self.margin, m)
+        return first
+
+
+def test_g6_g8_torsion_fingerprint_pruning(oracle):
+    """fingerprints / tfd_similarity (G6) and prune_conformers_tfd end to end (G8, the reference's own
+    function with networkx): the oracle's pair search + the product's host-side graph step give the reference's mask."""
+    pytest.importorskip("networkx")
+    from tscode_amd.numba_functions import prune_conformers_tfd
+    g6 = load_golden("G6_tfd")
+    fp = oracle.torsion_fingerprints(g6["coords"], g6["quadruplets"])
+    assert fp.dtype == np.float32 and np.abs(fp - g6["fingerprints"]).max() < 2e-5
+    sims = [[oracle.tfd_similarity(g6["fingerprints"][i], g6["fingerprints"][j], t) for j in range(10)] for i in range(10) for t in (10, 90, 300)]
+    assert np.array_equal(np.array(sims), g6["similarity"].astype(bool))
+    g = load_golden("G8_tfd_prune")
+    for c in range(int(g["n_cases"])):
+        structures, thresh = g[f"structures{c}"], float(g[f"thresh{c}"])
+        tf = oracle.torsion_fingerprints(structures, g["quadruplets"])
+        assert np.abs(tf - g[f"tf_mat{c}"]).max() < 2e-5
+        ps = _OraclePairSearch(oracle)
+        pruned, mask = prune_conformers_tfd(structures, g["quadruplets"], thresh=thresh, _pair_search=ps)
+        assert ps.margin > 1e-6                                   # no fingerprint sum sits on the threshold
+        assert np.array_equal(mask, g[f"mask{c}"]), (c, mask.sum(), g[f"mask{c}"].sum())
+        assert np.array_equal(pruned, structures[mask])

@@ -14,7 +14,8 @@ from .algebra import (align_vec_pair, all_dists, norm, norm_of, quaternion_to_ro
 from .embeds import embed_batch, filter_angular_groups, get_embed, string_embed_params, string_embed_poses  # noqa: F401
 from .engine import Engine, FragmentSet, device_count, get_engine  # noqa: F401
 from .install import install, uninstall  # noqa: F401
-from .numba_functions import compenetration_check, compenetration_mask, count_clashes  # noqa: F401
+from .numba_functions import (_get_tf_mat, compenetration_check, compenetration_mask, count_clashes, get_torsion_fingerprint,  # noqa: F401
+                              prune_conformers_tfd, tfd_similarity)
 from .torsion_module import csearch_candidates, csearch_rotate, rotate_dihedral, torsion_comp_check  # noqa: F401
 from .rmsd_pruning import _rmsd_similarity, last_prune_stats, prune_conformers_rmsd, rmsd_and_max_numba  # noqa: F401
 

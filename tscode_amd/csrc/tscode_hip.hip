@@ -9,6 +9,7 @@
 #include "local_pass.hpp"
 #include "group_filter.hpp"
 #include "csearch.hpp"
+#include "tfd.hpp"
 
 #include <algorithm>
 
@@ -1124,6 +1125,52 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc
                        (const int32_t *)d_tors, (const uint8_t *)d_mask, d_ok);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipMemcpyAsync(ok, d_ok, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// torsion-fingerprint pruning
+
+extern "C" __attribute__((visibility("default"))) int tsc_torsion_fingerprints(tsc_ctx *c, const double *coords, int64_t n_structs, int n_atoms,
+                                                                               const int32_t *quads, int n_quads, float *out) {
+    TSC_REQUIRE(c && coords && quads && out, "tsc_torsion_fingerprints: null argument");
+    TSC_REQUIRE(n_structs >= 0 && n_atoms > 0 && n_quads >= 0, "bad sizes");
+    for (int q = 0; q < 4 * n_quads; ++q) TSC_REQUIRE(quads[q] >= 0 && quads[q] < n_atoms, "quadruplet atom index %d out of range", quads[q]);
+    if (n_structs == 0 || n_quads == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_coords;
+    int32_t *d_quads;
+    float *d_out;
+    TSC_TRY(upload(c, s, coords, size_t(n_structs) * n_atoms * 3, &d_coords));
+    TSC_TRY(upload(c, s, quads, size_t(n_quads) * 4, &d_quads));
+    TSC_TRY(s.get(size_t(n_structs) * n_quads, &d_out));
+    hipLaunchKernelGGL(k_torsion_fingerprints, dim3(grid_for(n_structs * n_quads, 256, 256 * 8)), dim3(256), 0, c->stream, (const double *)d_coords,
+                       n_structs, n_atoms, (const int32_t *)d_quads, n_quads, d_out);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(out, d_out, size_t(n_structs) * n_quads * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, int64_t d,
+                                                                            int64_t k, int64_t num_active, double thresh, int32_t *first) {
+    TSC_REQUIRE(c && tf && first, "tsc_tfd_first_similar: null argument");
+    TSC_REQUIRE(n_structs >= 0 && n_quads >= 0 && d > 0 && k > 0 && num_active >= 0 && num_active <= n_structs && d * k <= n_structs,
+                "bad pass geometry (n = %lld, d = %lld, k = %lld, active = %lld)", (long long)n_structs, (long long)d, (long long)k, (long long)num_active);
+    TSC_REQUIRE(n_structs < INT32_MAX, "too many structures");
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    float *d_tf;
+    int32_t *d_first;
+    TSC_TRY(upload(c, s, tf, size_t(n_structs) * n_quads, &d_tf));
+    TSC_TRY(s.get(size_t(n_structs), &d_first));
+    hipLaunchKernelGGL(k_tfd_first_similar, dim3(grid_for(n_structs, 4, 256 * 16)), dim3(256), 0, c->stream, (const float *)d_tf, n_structs, n_quads, d, k,
+                       num_active, thresh, d_first);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(first, d_first, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -185,6 +185,26 @@ class Engine:
                                                C.c_double(rmsd_thr), ptr(acc)))
         return acc.astype(bool)
 
+    # ---- N2: torsion fingerprints / TFD pair search -----------------------------------------------
+    def torsion_fingerprints(self, structures, quadruplets):
+        """_get_tf_mat (tscode/numba_functions.py:233-240): f32[N, T] dihedral angles in degrees."""
+        structures = np.ascontiguousarray(structures, dtype=np.float64)
+        if structures.ndim != 3 or structures.shape[2] != 3:
+            raise ValueError("structures must be (N, n_atoms, 3)")
+        quads = np.ascontiguousarray(quadruplets, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((len(structures), len(quads)), dtype=np.float32)
+        check(self.lib.tsc_torsion_fingerprints(self._h, ptr(structures), C.c_int64(len(structures)), C.c_int(structures.shape[1]), ptr(quads),
+                                                C.c_int(len(quads)), ptr(out)))
+        return out
+
+    def tfd_first_similar(self, tf_mat, d, k, num_active, thresh=10.0):
+        """The pair search of one pass of prune_conformers_tfd (tscode/numba_functions.py:171-199): i32[N], -1 = none."""
+        tf = np.ascontiguousarray(tf_mat, dtype=np.float32)
+        first = np.full(len(tf), -1, dtype=np.int32)
+        check(self.lib.tsc_tfd_first_similar(self._h, ptr(tf), C.c_int64(len(tf)), C.c_int(tf.shape[1]), C.c_int64(int(d)), C.c_int64(int(k)),
+                                             C.c_int64(int(num_active)), C.c_double(float(thresh)), ptr(first)))
+        return first
+
     # ---- N1: string-embed pose parameters -------------------------------------------------------
     def string_embed_params(self, p1, p2, ref_vec, mol_vec, conf_pair, angles):
         """tscode/embeds.py:98-116 for every (site, angle): rot f64[S*A, 2, 3, 3], pos f64[S*A, 2, 3], conf_idx i32[S*A, 2]."""

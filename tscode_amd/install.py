@@ -28,6 +28,8 @@ _PATCHES = {
     # (rotate_dihedral is NOT patched: tscode/torsion_module.py:984-1005 calls it with fractional angles, the batched
     # kernel takes the integer tables of the conformational search; use tscode_amd.csearch_rotate for those loops)
     "torsion_comp_check": (torsion_module.torsion_comp_check, ("tscode.numba_functions", "tscode.torsion_module")),
+    "prune_conformers_tfd": (numba_functions.prune_conformers_tfd,
+                             ("tscode.numba_functions", "tscode.embedder", "tscode.operators", "tscode.torsion_module")),
 }
 
 _saved = {}

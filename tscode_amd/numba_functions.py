@@ -6,7 +6,10 @@ import numpy as np
 
 from .engine import get_engine
 
-__all__ = ["compenetration_check", "count_clashes", "compenetration_mask"]
+__all__ = ["compenetration_check", "count_clashes", "compenetration_mask", "prune_conformers_tfd", "_get_tf_mat",
+           "get_torsion_fingerprint", "tfd_similarity"]
+
+TFD_KS = (5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1)      # numba_functions.py:160-162
 
 
 def compenetration_mask(coords, ids=None, thresh=1.5, max_clashes=0, return_counts=False):
@@ -27,3 +30,70 @@ def count_clashes(coords) -> int:
     coords = np.asarray(coords, dtype=np.float64)
     _, counts = get_engine().clash_mask(coords[None], None, 0.5, 0, return_counts=True)
     return int(counts[0])
+
+
+# ---- torsion-fingerprint pruning (tscode/numba_functions.py:142-264) --------------------------
+def _get_tf_mat(structures, quadruplets):
+    """tscode/numba_functions.py:233-240: float32 [N, n_quadruplets] dihedral angles in degrees."""
+    return get_engine().torsion_fingerprints(structures, quadruplets)
+
+
+def get_torsion_fingerprint(coords, quadruplets):
+    """tscode/numba_functions.py:255-264 for one structure."""
+    return get_engine().torsion_fingerprints(np.asarray(coords, dtype=np.float64)[None], quadruplets)[0]
+
+
+def tfd_similarity(tfp1, tfp2, thresh=10) -> bool:
+    """tscode/numba_functions.py:242-253: True iff the wrapped absolute differences of the two fingerprints sum to < thresh."""
+    tf = np.stack([np.asarray(tfp1, dtype=np.float32), np.asarray(tfp2, dtype=np.float32)])
+    return bool(get_engine().tfd_first_similar(tf, 2, 1, 2, thresh)[0] == 1)
+
+
+def _tfd_reject_matches(first, d, k, final_mask):
+    """tscode/numba_functions.py:181-226 after the pair search: `first[i]` = absolute index of the first similar j of row i
+    (-1: none).  Per chunk the matches go into the same Python objects the reference builds -- a set filled in row order,
+    nx.Graph(matches), connected components, `tuple(graph.nodes)[0]` as the member kept -- so that the choice, which
+    depends on CPython's set order inside networkx, comes out the same as the reference's in the same interpreter."""
+    rows = np.flatnonzero(first >= 0)
+    if len(rows) == 0:
+        return
+    import networkx as nx
+    steps = np.minimum(rows // d, int(k) - 1)
+    bounds = np.flatnonzero(np.diff(steps)) + 1
+    for sel in np.split(rows, bounds):                       # rows of one chunk, ascending
+        off = d * int(min(sel[0] // d, int(k) - 1))
+        matches = set()
+        for i_abs in sel.tolist():
+            matches.add((i_abs - off, int(first[i_abs]) - off))          # :190
+        g = nx.Graph(matches)                                            # :209
+        subgraphs = [g.subgraph(c) for c in nx.connected_components(g)]
+        groups = [tuple(graph.nodes) for graph in subgraphs]
+        best_of_cluster = [group[0] for group in groups]                 # :214, "keep the first structure"
+        rejects_sets = [set(a) - {b} for a, b in zip(groups, best_of_cluster)]
+        for s in rejects_sets:
+            for i in s:
+                final_mask[i + off] = 0                                  # :222-224
+
+
+def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False, _pair_search=None):
+    """tscode/numba_functions.py:142-231.  Fingerprints and the O(N^2 / k) pair search of every pass run on the GPU (one
+    launch each); the schedule, the gate `k == 1 or 5 k < active` (:166) and the graph step stay in Python.  The reference's
+    cache_set only skips pairs it already found dissimilar, so it changes no result and is not kept.
+    Returns (structures[mask], mask)."""
+    structures = np.asarray(structures)
+    n = structures.shape[0]
+    eng = None if _pair_search else get_engine()
+    tf_mat = _pair_search.fingerprints(structures, quadruplets) if _pair_search else eng.torsion_fingerprints(structures, quadruplets)
+    final_mask = np.ones(n, dtype=bool)
+    for k in TFD_KS:
+        num_active_str = int(np.count_nonzero(final_mask))
+        if k == 1 or 5 * k < num_active_str:                              # :166
+            d = int(n // k)                                               # :173
+            if d == 0:
+                continue
+            if verbose:
+                print(f"Working on subgroups with k={k} ({num_active_str} candidates left) {' ' * 10}", end="\r")
+            search = _pair_search.first_similar if _pair_search else eng.tfd_first_similar
+            first = search(tf_mat, d, int(k), num_active_str, thresh)
+            _tfd_reject_matches(first, d, int(k), final_mask)
+    return structures[final_mask], final_mask
