@@ -151,6 +151,16 @@ int tsc_string_embed_params_dev(tsc_ctx *ctx, const double *p1, const double *p2
                                 const int32_t *conf_pair, int64_t n_sites, const double *angles, int n_angles, double *rot,
                                 double *pos, int32_t *conf_idx);
 
+/* Pose parameters of the cyclical embed (tscode/embeds.py:676-713), one row per (pose, molecule):
+ * alignment = align_vec_pair([end - start, direction], [pivot, meanpoint - mean(reactive atoms)]) (tscode/algebra.py:258-282),
+ * step = rot_mat_from_pointer(alignment @ (r0 - r1) or alignment @ pivot, angle), rotation = step @ alignment,
+ * position = centre - step @ centre + mean(start, end) - alignment @ meanpoint with centre = alignment @ mean(reactive atoms).
+ * start, end, direction, pivot, meanpoint, r0, r1 f64[n, 3] (r1 ignored where n_reactive is 1); n_reactive i32[n] (1 or 2);
+ * angle f64[n] degrees; rot f64[n, 9], pos f64[n, 3].  Host pointers. */
+int tsc_cyclical_embed_params(tsc_ctx *ctx, const double *start, const double *end, const double *direction, const double *pivot,
+                              const double *meanpoint, const double *r0, const double *r1, const int32_t *n_reactive,
+                              const double *angle, int64_t n, double *rot, double *pos);
+
 /* Conformational-search rotations.  tsc_csearch_rotate builds every candidate of
  * tscode/torsion_module.py:463-500 from one start structure: for each torsion t with angles[m][t] != 0 the atoms of
  * masks[t] turn about the bond torsions[t][1]-torsions[t][2] (tscode/utils.py:389-414 rotate_dihedral, in place, in

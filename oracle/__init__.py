@@ -306,3 +306,15 @@ def tfd_first_similar(tf_mat, d, k, num_active, thresh=10, return_margin=False):
     lib().orc_tfd_first_similar(_p(tf), C.c_int64(len(tf)), C.c_int(tf.shape[1]), C.c_int64(int(d)), C.c_int64(int(k)), C.c_int64(int(num_active)),
                                 C.c_double(thresh), _p(first), C.byref(margin) if return_margin else None)
     return (first, margin.value) if return_margin else first
+
+
+def cyclical_embed_params(start, end, direction, pivot, meanpoint, r0, r1, n_reactive, angle):
+    """embeds.py:676-713 per (pose, molecule) row: (rot [n, 3, 3], pos [n, 3])."""
+    arrs = [_f64(np.atleast_2d(x)) for x in (start, end, direction, pivot, meanpoint, r0, r1)]
+    nr = np.ascontiguousarray(n_reactive, dtype=np.int32)
+    ang = _f64(angle)
+    n = len(ang)
+    rot, pos = np.empty((n, 3, 3)), np.empty((n, 3))
+    lib().orc_cyclical_embed_params.restype = None
+    lib().orc_cyclical_embed_params(*[_p(a) for a in arrs], _p(nr), _p(ang), C.c_int64(n), _p(rot), _p(pos))
+    return rot, pos

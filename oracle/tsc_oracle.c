@@ -882,3 +882,44 @@ ORC_API void orc_tfd_first_similar(const float *tf, int64_t N, int T, int64_t d,
     }
     if (min_margin) *min_margin = margin;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* pose parameters of the cyclical embed (embeds.py:676-713), one (pose, molecule) per row:
+ *   atomic_pivot_mean = mean(reactive_coords)                                   (1 or 2 reactive atoms)
+ *   mol_direction = meanpoint - atomic_pivot_mean, or meanpoint if that is exactly zero   (:678-681)
+ *   A = align_vec_pair([end - start, direction], [pivot, mol_direction])        (:691-692)
+ *   axis = A @ (r0 - r1) for two reactive atoms, else A @ pivot                 (:697-700)
+ *   S = rot_mat_from_pointer(axis, angle); centre = A @ atomic_pivot_mean       (:704-708)
+ *   rotation = S @ A; position = centre - S @ centre + mean(start, end) - A @ meanpoint   (:711-714)
+ * in: start, end, direction, pivot, meanpoint, r0, r1 f64[n][3]; n_reactive i32[n]; angle f64[n]; out rot [n][9], pos [n][3]. */
+ORC_API void orc_cyclical_embed_params(const double *start, const double *end, const double *direction, const double *pivot,
+                                       const double *meanpoint, const double *r0, const double *r1, const int32_t *n_reactive,
+                                       const double *angle, int64_t n, double *rot, double *pos) {
+    for (int64_t q = 0; q < n; ++q) {
+        const double *st = start + 3 * q, *en = end + 3 * q, *dir = direction + 3 * q, *pv = pivot + 3 * q, *mp = meanpoint + 3 * q;
+        const double *a0 = r0 + 3 * q, *a1 = r1 + 3 * q;
+        double apm[3], md[3], ref[6], tgt[6], A[9], axis_in[3], axis[3], S[9], centre[3];
+        int zero = 1;
+        for (int i = 0; i < 3; ++i) {
+            apm[i] = n_reactive[q] == 2 ? (a0[i] + a1[i]) / 2.0 : a0[i];
+            md[i] = mp[i] - apm[i];
+            if (md[i] != 0.) zero = 0;
+        }
+        if (zero)
+            for (int i = 0; i < 3; ++i) md[i] = mp[i];
+        for (int i = 0; i < 3; ++i) ref[i] = en[i] - st[i], ref[3 + i] = dir[i], tgt[i] = pv[i], tgt[3 + i] = md[i];
+        orc_align_vec_pair(ref, tgt, A);
+        for (int i = 0; i < 3; ++i) axis_in[i] = n_reactive[q] == 2 ? a0[i] - a1[i] : pv[i];
+        for (int i = 0; i < 3; ++i) {
+            axis[i] = A[3 * i] * axis_in[0] + A[3 * i + 1] * axis_in[1] + A[3 * i + 2] * axis_in[2];
+            centre[i] = A[3 * i] * apm[0] + A[3 * i + 1] * apm[1] + A[3 * i + 2] * apm[2];
+        }
+        orc_rot_mat_from_pointer(axis, angle[q], S);
+        matmul3(S, A, rot + 9 * q);
+        for (int i = 0; i < 3; ++i) {
+            const double s_c = S[3 * i] * centre[0] + S[3 * i + 1] * centre[1] + S[3 * i + 2] * centre[2];
+            const double a_m = A[3 * i] * mp[0] + A[3 * i + 1] * mp[1] + A[3 * i + 2] * mp[2];
+            pos[3 * q + i] = centre[i] - s_c + ((st[i] + en[i]) / 2.0 - a_m);
+        }
+    }
+}

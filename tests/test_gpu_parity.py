@@ -618,3 +618,31 @@ def test_tfd_pruning_golden(eng, oracle):
         pruned, mask = tscode_amd.prune_conformers_tfd(structures, g["quadruplets"], thresh=thresh)
         assert np.array_equal(mask, g[f"mask{c}"]), (c, mask.sum(), g[f"mask{c}"].sum())
         assert np.array_equal(pruned, structures[mask])
+
+
+def test_cyclical_embed_params_vs_oracle(eng, oracle):
+    """tscode/embeds.py:676-713 per (pose, molecule): against the oracle (align_vec_pair pinned by G5) and by the invariants
+    of the construction."""
+    import tscode_amd
+    rng = np.random.default_rng(41)
+    n = 3000
+    st, en, di, pv, mp, r0, r1 = rng.normal(size=(7, n, 3)) * 2
+    nr = rng.integers(1, 3, size=n).astype(np.int32)
+    ang = rng.choice(np.arange(0, 360, 10), size=n).astype(np.float64)
+    mp[5] = r0[5]; nr[5] = 1                                  # meanpoint == the reactive atom: the :677 fallback
+    rot, pos = eng.cyclical_embed_params(st, en, di, pv, mp, r0, r1, nr, ang)
+    ro, po = oracle.cyclical_embed_params(st, en, di, pv, mp, r0, r1, nr, ang)
+    assert np.abs(rot - ro).max() < 1e-9 and np.abs(pos - po).max() < 1e-8
+    assert np.abs(np.einsum("nij,nkj->nik", rot, rot) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(rot) - 1).max() < 1e-12
+    apm = np.where((nr == 2)[:, None], (r0 + r1) / 2, r0)
+    fixed = np.einsum("nij,nj->ni", rot, apm) + pos           # the reactive atoms' mean point does not depend on the angle ...
+    rot0, pos0 = tscode_amd.cyclical_embed_params(st, en, di, pv, mp, r0, r1, nr, np.zeros(n))
+    assert np.abs(fixed - (np.einsum("nij,nj->ni", rot0, apm) + pos0)).max() < 1e-9
+    assert np.abs(np.einsum("nij,nj->ni", rot0, mp) + pos0 - (st + en) / 2).max() < 1e-9      # ... and at angle 0 the pivot's mean point sits on the side's
+    # G5: align_vec_pair of the reference itself (angle 0, one reactive atom at the origin => rotation == align_vec_pair(ref, tgt))
+    g = load_golden("G5_rotations")
+    ref_v, tgt_v, avp = g["avp_ref"][2:], g["avp_tgt"][2:], g["align_vec_pair"][2:]
+    m = len(ref_v)
+    z = np.zeros((m, 3))
+    r5, _ = eng.cyclical_embed_params(z, ref_v[:, 0], ref_v[:, 1], tgt_v[:, 0], tgt_v[:, 1], z, z, np.ones(m, np.int32), np.zeros(m))
+    assert np.abs(r5 - avp).max() < 1e-9

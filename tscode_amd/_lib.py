@@ -72,6 +72,7 @@ _SIGNATURES = {
     "tsc_tfd_first_similar": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp]),
     "tsc_string_embed_params": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp, _vp]),
     "tsc_string_embed_params_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp, _vp]),
+    "tsc_cyclical_embed_params": (C.c_int, [_vp] * 10 + [C.c_int64, _vp, _vp]),
     "tsc_csearch_rotate": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_double, C.c_int64, _vp, _vp]),
     "tsc_csearch_rotate_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_double, C.c_int64, _vp, _vp]),
     "tsc_torsion_comp_check": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_double, C.c_int64, _vp]),

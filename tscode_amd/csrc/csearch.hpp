@@ -9,6 +9,7 @@
 // lanes are atoms, the torsions run in order with the data-dependent back-off loop inside.
 #pragma once
 #include "common.hpp"
+#include "rmsd.hpp"
 
 namespace tsc {
 
@@ -194,6 +195,80 @@ __global__ __launch_bounds__(256) void k_string_embed_params(const double *__res
             po[3 + i] = p1[3 * s + i] - (R[3 * i] * x + R[3 * i + 1] * y + R[3 * i + 2] * z);
         }
         conf_idx[2 * q] = conf_pair[2 * s], conf_idx[2 * q + 1] = conf_pair[2 * s + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pose parameters of the cyclical embed (tscode/embeds.py:676-713), one thread per (pose, molecule).
+// align_vec_pair (algebra.py:258-282: SVD of B = sum_j ref_j tgt_j^T, improper-rotation fix, U V^T) is the proper rotation
+// R that best maps tgt_j onto ref_j; here it is taken as the top eigenvector of Horn's quaternion matrix of
+// S = sum_j tgt_j ref_j^T (cyclic Jacobi, top_eigvec4 of rmsd.hpp) -- the same rotation wherever it is unique.
+__device__ inline void align_vec_pair_dev(const double ref0[3], const double ref1[3], const double tgt0[3], const double tgt1[3], double R[9]) {
+    double S[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[3 * a + b] = tgt0[a] * ref0[b] + tgt1[a] * ref1[b];
+    double N[4][4];
+    N[0][0] = S[0] + S[4] + S[8];
+    N[1][1] = S[0] - S[4] - S[8];
+    N[2][2] = -S[0] + S[4] - S[8];
+    N[3][3] = -S[0] - S[4] + S[8];
+    N[0][1] = N[1][0] = S[5] - S[7];
+    N[0][2] = N[2][0] = S[6] - S[2];
+    N[0][3] = N[3][0] = S[1] - S[3];
+    N[1][2] = N[2][1] = S[1] + S[3];
+    N[1][3] = N[3][1] = S[6] + S[2];
+    N[2][3] = N[3][2] = S[5] + S[7];
+    double e[4];
+    top_eigvec4(N, e);
+    const double nn = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double w = e[0] * nn, x = e[1] * nn, y = e[2] * nn, z = e[3] * nn;
+    R[0] = w * w + x * x - y * y - z * z, R[1] = 2 * (x * y - w * z), R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z), R[4] = w * w - x * x + y * y - z * z, R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y), R[7] = 2 * (y * z + w * x), R[8] = w * w - x * x - y * y + z * z;
+}
+
+__global__ __launch_bounds__(256) void k_cyclical_embed_params(const double *__restrict__ start, const double *__restrict__ end,
+                                                                const double *__restrict__ direction, const double *__restrict__ pivot,
+                                                                const double *__restrict__ meanpoint, const double *__restrict__ r0,
+                                                                const double *__restrict__ r1, const int32_t *__restrict__ n_reactive,
+                                                                const double *__restrict__ angle, int64_t n, double *__restrict__ rot,
+                                                                double *__restrict__ pos) {
+    for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += int64_t(gridDim.x) * blockDim.x) {
+        double st[3], en[3], dir[3], pv[3], mp[3], a0[3], a1[3], apm[3], md[3], ref0[3];
+        const bool two = n_reactive[q] == 2;
+        bool zero = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            st[i] = start[3 * q + i], en[i] = end[3 * q + i], dir[i] = direction[3 * q + i], pv[i] = pivot[3 * q + i], mp[i] = meanpoint[3 * q + i];
+            a0[i] = r0[3 * q + i], a1[i] = r1[3 * q + i];
+            apm[i] = two ? (a0[i] + a1[i]) / 2.0 : a0[i];  // np.mean(reactive_coords, axis=0), :673
+            md[i] = mp[i] - apm[i];                         // :676
+            zero = zero && md[i] == 0.0;
+            ref0[i] = en[i] - st[i];
+        }
+        if (zero) {  // :677-678
+#pragma unroll
+            for (int i = 0; i < 3; ++i) md[i] = mp[i];
+        }
+        double A[9], S[9], axis[3], centre[3];
+        align_vec_pair_dev(ref0, dir, pv, md, A);  // :691-692
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double v0 = two ? a0[0] - a1[0] : pv[0], v1 = two ? a0[1] - a1[1] : pv[1], v2 = two ? a0[2] - a1[2] : pv[2];
+            axis[i] = A[3 * i] * v0 + A[3 * i + 1] * v1 + A[3 * i + 2] * v2;                  // :697-700
+            centre[i] = A[3 * i] * apm[0] + A[3 * i + 1] * apm[1] + A[3 * i + 2] * apm[2];    // :708
+        }
+        rot_mat_from_pointer_dev(axis, angle[q], S);  // :704
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rot[9 * q + 3 * i + j] = S[3 * i] * A[j] + S[3 * i + 1] * A[3 + j] + S[3 * i + 2] * A[6 + j];  // :711
+            const double s_c = S[3 * i] * centre[0] + S[3 * i + 1] * centre[1] + S[3 * i + 2] * centre[2];
+            const double a_m = A[3 * i] * mp[0] + A[3 * i + 1] * mp[1] + A[3 * i + 2] * mp[2];
+            pos[3 * q + i] = centre[i] - s_c + ((st[i] + en[i]) / 2.0 - a_m);  // :713-714
+        }
     }
 }
 

@@ -1221,6 +1221,34 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params(ts
     return 0;
 }
 
+extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(tsc_ctx *c, const double *start, const double *end,
+                                                                                const double *direction, const double *pivot, const double *meanpoint,
+                                                                                const double *r0, const double *r1, const int32_t *n_reactive,
+                                                                                const double *angle, int64_t n, double *rot, double *pos) {
+    TSC_REQUIRE(c && start && end && direction && pivot && meanpoint && r0 && r1 && n_reactive && angle && rot && pos, "tsc_cyclical_embed_params: null argument");
+    TSC_REQUIRE(n >= 0, "bad size");
+    for (int64_t q = 0; q < n; ++q) TSC_REQUIRE(n_reactive[q] == 1 || n_reactive[q] == 2, "row %lld: n_reactive must be 1 or 2", (long long)q);
+    if (n == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    const double *host[7] = {start, end, direction, pivot, meanpoint, r0, r1};
+    double *dev[7], *d_angle, *d_rot, *d_pos;
+    int32_t *d_nr;
+    for (int i = 0; i < 7; ++i) TSC_TRY(upload(c, s, host[i], size_t(n) * 3, &dev[i]));
+    TSC_TRY(upload(c, s, n_reactive, size_t(n), &d_nr));
+    TSC_TRY(upload(c, s, angle, size_t(n), &d_angle));
+    TSC_TRY(s.get(size_t(n) * 9, &d_rot));
+    TSC_TRY(s.get(size_t(n) * 3, &d_pos));
+    hipLaunchKernelGGL(k_cyclical_embed_params, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, c->stream, (const double *)dev[0], (const double *)dev[1],
+                       (const double *)dev[2], (const double *)dev[3], (const double *)dev[4], (const double *)dev[5], (const double *)dev[6],
+                       (const int32_t *)d_nr, (const double *)d_angle, n, d_rot, d_pos);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(rot, d_rot, size_t(n) * 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(pos, d_pos, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------------------
 // pipeline
 

@@ -56,6 +56,14 @@ def string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles):
     return get_engine().string_embed_params(p1, p2, ref_vec, mol_vec, conf_pair, angles)
 
 
+def cyclical_embed_params(start, end, direction, pivot, meanpoint, r0, r1, n_reactive, angle):
+    """Rotation and position of every (pose, molecule) of the cyclical embed (tscode/embeds.py:676-713) in one launch.  One
+    row per (pose, molecule): ``start, end`` = the polygon side (``vec_pair``), ``direction`` = ``directions[i]``, ``pivot`` /
+    ``meanpoint`` = the active pivot's vector and mean point, ``r0, r1`` = the reactive atoms (``n_reactive`` 1 or 2),
+    ``angle`` in degrees.  Returns ``(rot [n, 3, 3], pos [n, 3])`` -- ``mol.rotation`` / ``mol.position`` of :711-714."""
+    return get_engine().cyclical_embed_params(start, end, direction, pivot, meanpoint, r0, r1, n_reactive, angle)
+
+
 def filter_angular_groups(poses, group_sizes, rmsd_thr=1.0):
     """The per-group greedy filter of the cyclical embed loops (tscode/embeds.py:713-717, :841-845), batched:
 

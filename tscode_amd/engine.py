@@ -219,6 +219,18 @@ class Engine:
                                                C.c_int(A), ptr(rot), ptr(pos), ptr(ci)))
         return rot, pos, ci
 
+    def cyclical_embed_params(self, start, end, direction, pivot, meanpoint, r0, r1, n_reactive, angle):
+        """tscode/embeds.py:676-713 per (pose, molecule) row: rot f64[n, 3, 3], pos f64[n, 3]."""
+        arrs = [np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64) for x in (start, end, direction, pivot, meanpoint, r0, r1)]
+        n_reactive = np.ascontiguousarray(n_reactive, dtype=np.int32)
+        angle = np.ascontiguousarray(angle, dtype=np.float64)
+        n = len(angle)
+        if any(a.shape != (n, 3) for a in arrs) or n_reactive.shape != (n,):
+            raise ValueError("all vector inputs must be (n, 3), n_reactive and angle (n,)")
+        rot, pos = np.empty((n, 3, 3)), np.empty((n, 3))
+        check(self.lib.tsc_cyclical_embed_params(self._h, *[ptr(a) for a in arrs], ptr(n_reactive), ptr(angle), C.c_int64(n), ptr(rot), ptr(pos)))
+        return rot, pos
+
     # ---- N3: conformational-search rotations ---------------------------------------------------
     def csearch_rotate(self, coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
         """Every candidate of tscode/torsion_module.py:463-500: (new_coords f64[M, n, 3], rotated_bonds i32[M])."""
