@@ -137,6 +137,20 @@ int tsc_torsion_fingerprints(tsc_ctx *ctx, const double *coords, int64_t n_struc
 int tsc_tfd_first_similar(tsc_ctx *ctx, const float *tf, int64_t n_structs, int n_quads, int64_t d, int64_t k, int64_t num_active,
                           double thresh, int32_t *first);
 
+/* Moments of inertia and embed scores.
+ * tsc_inertia_moments: tscode/algebra.py:165-186 get_inertia_moments for every structure -- out f64[n_structs, 3], the
+ * eigenvalues of the inertia tensor about the centre of mass ordered by absolute value; masses f64[n_atoms].
+ * tsc_moi_first_similar: the pair search of tscode/algebra.py:188-205 -- first i32[n_structs] = first j > i whose three moments
+ * all differ by less than max_deviation relative to structure i's, or -1 (the graph step of prune_by_moment_of_inertia,
+ * tscode/optimization_methods.py:341-358, is the caller's).
+ * tsc_embed_scores: tscode/numba_functions.py:273-288 _score_embed_poses (scores f32[n_structs], float32 accumulation) and the
+ * signed error of fitness_check (tscode/optimization_methods.py:544-557; fitness_error f64[n_structs]); indices i32[n_structs,
+ * n_c, 2], distances f64[n_structs, n_c] (NaN = no target).  Host pointers. */
+int tsc_inertia_moments(tsc_ctx *ctx, const double *structures, int64_t n_structs, int n_atoms, const double *masses, double *out);
+int tsc_moi_first_similar(tsc_ctx *ctx, const double *moments, int64_t n_structs, double max_deviation, int32_t *first);
+int tsc_embed_scores(tsc_ctx *ctx, const double *structures, int64_t n_structs, int n_atoms, const int32_t *indices,
+                     const double *distances, int n_c, float *scores, double *fitness_error);
+
 /* Pose parameters of the string embed (tscode/embeds.py:98-116), for n_sites (conformer pair, reactive-
  * centre pair) combinations x n_angles angles, pose = site * n_angles + angle index:
  *   R0 = rotation_matrix_from_vectors(mol_vec, -ref_vec) (:108, tscode/utils.py:183-208);

@@ -318,3 +318,31 @@ def cyclical_embed_params(start, end, direction, pivot, meanpoint, r0, r1, n_rea
     lib().orc_cyclical_embed_params.restype = None
     lib().orc_cyclical_embed_params(*[_p(a) for a in arrs], _p(nr), _p(ang), C.c_int64(n), _p(rot), _p(pos))
     return rot, pos
+
+
+# ---- moments of inertia / embed scores ----------------------------------------------
+def inertia_moments(structures, masses):
+    s, m = _f64(structures), _f64(masses)
+    out = np.empty((len(s), 3))
+    lib().orc_inertia_moments.restype = None
+    lib().orc_inertia_moments(_p(s), C.c_int64(len(s)), C.c_int(s.shape[1]), _p(m), _p(out))
+    return out
+
+
+def moi_first_similar(moments, max_deviation=1e-2, return_margin=False):
+    mo = _f64(moments)
+    first = np.empty(len(mo), dtype=np.int32)
+    margin = C.c_double(np.inf)
+    lib().orc_moi_first_similar.restype = None
+    lib().orc_moi_first_similar(_p(mo), C.c_int64(len(mo)), C.c_double(max_deviation), _p(first), C.byref(margin) if return_margin else None)
+    return (first, margin.value) if return_margin else first
+
+
+def embed_scores(structures, indices, distances):
+    s = _f64(structures)
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    dist = _f64(distances)
+    sc, err = np.empty(len(s), dtype=np.float32), np.empty(len(s))
+    lib().orc_embed_scores.restype = None
+    lib().orc_embed_scores(_p(s), C.c_int64(len(s)), C.c_int(s.shape[1]), _p(idx), _p(dist), C.c_int(idx.shape[1]), _p(sc), _p(err))
+    return sc, err

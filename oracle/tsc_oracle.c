@@ -923,3 +923,105 @@ ORC_API void orc_cyclical_embed_params(const double *start, const double *end, c
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* moments of inertia (algebra.py:165-213) and embed scores                 */
+
+/* eigenvalues of a symmetric 3x3 by cyclic Jacobi, sorted by absolute value (algebra.py:207-212 diagonalize:
+ * np.linalg.eig, columns ordered by |eigenvalue|, diag(B^-1 A B)) */
+static void sym3_eigvals_by_abs(double A[9], double out[3]) {
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5], dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+        if (!(off > 1e-32 * dia)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = A[3 * p + q];
+                if (apq == 0.0) continue;
+                double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+                double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    double akp = A[3 * k + p], akq = A[3 * k + q];
+                    A[3 * k + p] = c * akp - s * akq, A[3 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double apk = A[3 * p + k], aqk = A[3 * q + k];
+                    A[3 * p + k] = c * apk - s * aqk, A[3 * q + k] = s * apk + c * aqk;
+                }
+            }
+    }
+    double e[3] = {A[0], A[4], A[8]};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (fabs(e[j]) > fabs(e[j + 1])) {
+                double t = e[j];
+                e[j] = e[j + 1], e[j + 1] = t;
+            }
+    out[0] = e[0], out[1] = e[1], out[2] = e[2];
+}
+
+/* algebra.py:165-186 get_inertia_moments for every structure: out [N][3] */
+ORC_API void orc_inertia_moments(const double *structures, int64_t N, int n, const double *masses, double *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < N; ++s) {
+        const double *c = structures + (size_t)s * n * 3;
+        double tot = 0, com[3] = {0, 0, 0}, I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < n; ++a) {
+            tot += masses[a];
+            for (int k = 0; k < 3; ++k) com[k] += c[3 * a + k] * masses[a];
+        }
+        for (int k = 0; k < 3; ++k) com[k] /= tot;
+        for (int a = 0; a < n; ++a) {
+            double x[3] = {c[3 * a] - com[0], c[3 * a + 1] - com[1], c[3 * a + 2] - com[2]};
+            double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) I[3 * i + j] += masses[a] * ((i == j ? r2 : 0.0) - x[i] * x[j]);
+        }
+        sym3_eigvals_by_abs(I, out + 3 * s);
+    }
+}
+
+/* algebra.py:188-205 get_moi_similarity_matches: first[i] = first j > i with all(|im_i - im_j| / im_i < max_deviation), -1 */
+ORC_API void orc_moi_first_similar(const double *moments, int64_t N, double max_deviation, int32_t *first, double *min_margin) {
+    double margin = min_margin ? *min_margin : 0.0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(min : margin)
+    for (int64_t i = 0; i < N; ++i) {
+        first[i] = -1;
+        for (int64_t j = i + 1; j < N; ++j) {
+            int all = 1;
+            for (int k = 0; k < 3; ++k) {
+                double rel = fabs(moments[3 * i + k] - moments[3 * j + k]) / moments[3 * i + k];
+                if (min_margin && fabs(rel - max_deviation) < margin) margin = fabs(rel - max_deviation);
+                if (!(rel < max_deviation)) all = 0;
+            }
+            if (all) {
+                first[i] = (int32_t)j;
+                break;
+            }
+        }
+    }
+    if (min_margin) *min_margin = margin;
+}
+
+/* numba_functions.py:273-288 _score_embed_poses (float32 accumulator) and optimization_methods.py:544-557 fitness_check's
+ * signed error (float64; a NaN target = None is skipped): indices i32[N][n_c][2], distances f64[N][n_c] */
+ORC_API void orc_embed_scores(const double *structures, int64_t N, int n, const int32_t *indices, const double *distances, int n_c,
+                              float *scores, double *fitness_error) {
+    for (int64_t s = 0; s < N; ++s) {
+        const double *c = structures + (size_t)s * n * 3;
+        float sc = 0.0f;
+        double err = 0.0;
+        for (int i = 0; i < n_c; ++i) {
+            const int a = indices[(s * n_c + i) * 2], b = indices[(s * n_c + i) * 2 + 1];
+            const double d[3] = {c[3 * a] - c[3 * b], c[3 * a + 1] - c[3 * b + 1], c[3 * a + 2] - c[3 * b + 2]};
+            const double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), target = distances[s * n_c + i];
+            if (target == target) {
+                sc = (float)((double)sc + fabs(dist - target));
+                err += dist - target;
+            }
+        }
+        if (scores) scores[s] = sc;
+        if (fitness_error) fitness_error[s] = err;
+    }
+}

@@ -411,7 +411,60 @@ def gen_g8():
     _save("G8_tfd_prune", **flat)
 
 
+# --------------------------------------------------------------------------- G9
+def gen_g9():
+    """Moment-of-inertia matches and embed scores (next-row N4): the reference's get_inertia_moments /
+    get_moi_similarity_matches (tscode.algebra) and _score_embed_poses (tscode.numba_functions); the graph step of
+    prune_by_moment_of_inertia (optimization_methods.py:341-358) and fitness_check (:544-557) are written out here because
+    tscode.optimization_methods does not import in this image (ase, periodictable, ...)."""
+    import networkx as nx
+    print("G9 moments of inertia / embed scores (next-row N4)")
+    rng = np.random.default_rng(9109)
+    flat = {"n_cases": 0, "seed": 9109}
+    for case, (n_par, n_child, n_atoms) in enumerate(((10, 4, 9), (60, 5, 14))):
+        masses = rng.choice(np.array([12.0107, 14.0067, 15.9994, 32.065, 35.453]), size=n_atoms)
+        parents = rng.normal(size=(n_par, n_atoms, 3)) * 2
+        structures = (parents[:, None] + rng.normal(size=(n_par, n_child, n_atoms, 3)) * 0.004).reshape(-1, n_atoms, 3)
+        # rigid motions and mirror images keep the moments: rotamer / enantiomer duplicates
+        for s in range(0, len(structures), 3):
+            q = rng.normal(size=4)
+            R = ref_alg.quaternion_to_rotation_matrix(q / np.linalg.norm(q))
+            structures[s] = structures[s] @ R.T + rng.normal(size=3)
+        structures[1] = structures[0] * np.array([1.0, 1.0, -1.0])
+        structures = np.ascontiguousarray(structures[rng.permutation(len(structures))])
+        moments = np.array([ref_alg.get_inertia_moments(s.copy(), masses) for s in structures])
+        matches = ref_alg.get_moi_similarity_matches(structures.copy(), masses, max_deviation=1e-2)
+        G = nx.Graph(matches)                                             # optimization_methods.py:341-358
+        subgraphs = [G.subgraph(c) for c in nx.connected_components(G)]
+        groups = [tuple(graph.nodes) for graph in subgraphs]
+        best_of_cluster = [group[0] for group in groups]
+        rejects_sets = [set(a) - {b} for a, b in zip(groups, best_of_cluster)]
+        mask = np.ones(structures.shape[0], dtype=bool)
+        for _s in rejects_sets:
+            for i in _s:
+                mask[i] = False
+        flat[f"structures{case}"], flat[f"masses{case}"], flat[f"moments{case}"] = structures, masses, moments
+        flat[f"matches{case}"], flat[f"mask{case}"] = np.array(matches, dtype=np.int64).reshape(-1, 2), mask
+        flat["n_cases"] = case + 1
+        print(f"  case {case}: N = {len(structures)}, {len(matches)} matches, {mask.sum()} survive")
+    # embed scores and fitness
+    structures = rng.normal(size=(40, 12, 3)) * 2
+    ci = rng.integers(0, 12, size=(40, 3, 2))
+    ci[:, :, 1] = (ci[:, :, 0] + 1 + rng.integers(0, 10, size=(40, 3))) % 12
+    cd = rng.uniform(1.0, 4.0, size=(40, 3))
+    scores = ref_nf._score_embed_poses(structures, ci, cd)
+    fit = []
+    for s in range(40):                                                   # optimization_methods.py:544-557
+        error = 0
+        for (a, b), target in zip(ci[s], cd[s]):
+            if target is not None:
+                error += (ref_alg.norm_of(structures[s][a] - structures[s][b]) - target)
+        fit.append(error)
+    flat.update(sc_structures=structures, sc_indices=ci, sc_distances=cd, scores=scores, fitness_error=np.array(fit))
+    _save("G9_moi_scores", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
     for g in which:
         globals()["gen_" + g.lower()]()

@@ -646,3 +646,33 @@ def test_cyclical_embed_params_vs_oracle(eng, oracle):
     z = np.zeros((m, 3))
     r5, _ = eng.cyclical_embed_params(z, ref_v[:, 0], ref_v[:, 1], tgt_v[:, 0], tgt_v[:, 1], z, z, np.ones(m, np.int32), np.zeros(m))
     assert np.abs(r5 - avp).max() < 1e-9
+
+
+# ----------------------------------------------------------------------------- N4: moments of inertia, embed scores
+def test_moi_and_scores_golden(eng, oracle):
+    """get_inertia_moments / get_moi_similarity_matches / the graph step of prune_by_moment_of_inertia / _score_embed_poses /
+    fitness_check against the reference-derived fixture G9."""
+    pytest.importorskip("networkx")
+    import tscode_amd
+    g = load_golden("G9_moi_scores")
+    for c in range(int(g["n_cases"])):
+        structures, masses = g[f"structures{c}"], g[f"masses{c}"]
+        mo = eng.inertia_moments(structures, masses)
+        assert (np.abs(mo - g[f"moments{c}"]) / np.abs(g[f"moments{c}"])).max() < 1e-12
+        _, margin = oracle.moi_first_similar(g[f"moments{c}"], 1e-2, return_margin=True)
+        assert margin > 1e-9
+        matches = tscode_amd.get_moi_similarity_matches(structures, masses, max_deviation=1e-2)
+        assert matches == [tuple(m) for m in g[f"matches{c}"].tolist()]
+        # prune_by_moment_of_inertia: no hydrogens here, masses given per atom
+        atomnos = np.full(structures.shape[1], 6)
+        pruned, mask = tscode_amd.prune_by_moment_of_inertia(structures, atomnos, max_deviation=1e-2, masses=masses)
+        assert np.array_equal(mask, g[f"mask{c}"]) and np.array_equal(pruned, structures[mask])
+        assert np.abs(tscode_amd.get_inertia_moments(structures[2], masses) - g[f"moments{c}"][2]).max() < 1e-9 * np.abs(g[f"moments{c}"][2]).max()
+    sc = tscode_amd._score_embed_poses(g["sc_structures"], g["sc_indices"], g["sc_distances"])
+    assert sc.dtype == np.float32 and np.abs(sc - g["scores"]).max() < 1e-5
+    so, eo = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
+    _, err = eng.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
+    assert np.abs(err - g["fitness_error"]).max() < 1e-12 and np.array_equal(sc, so)
+    thr = float(np.median(g["fitness_error"]))
+    assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], g["sc_distances"], thr), g["fitness_error"] < thr)
+    assert tscode_amd.fitness_check(g["sc_structures"][0], g["sc_indices"][0], list(g["sc_distances"][0]), thr) == bool(g["fitness_error"][0] < thr)

@@ -172,3 +172,18 @@ def test_g6_g8_torsion_fingerprint_pruning(oracle):
         assert ps.margin > 1e-6                                   # no fingerprint sum sits on the threshold
         assert np.array_equal(mask, g[f"mask{c}"]), (c, mask.sum(), g[f"mask{c}"].sum())
         assert np.array_equal(pruned, structures[mask])
+
+
+def test_g9_moments_and_scores(oracle):
+    """the oracle against the reference's get_inertia_moments / get_moi_similarity_matches /
+    _score_embed_poses (G9)."""
+    g = load_golden("G9_moi_scores")
+    for c in range(int(g["n_cases"])):
+        mo = oracle.inertia_moments(g[f"structures{c}"], g[f"masses{c}"])
+        assert (np.abs(mo - g[f"moments{c}"]) / np.abs(g[f"moments{c}"])).max() < 1e-12
+        first, margin = oracle.moi_first_similar(g[f"moments{c}"], 1e-2, return_margin=True)
+        ref = np.full(len(mo), -1)
+        ref[g[f"matches{c}"][:, 0]] = g[f"matches{c}"][:, 1]
+        assert margin > 1e-9 and np.array_equal(first, ref)
+    sc, err = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
+    assert np.abs(sc - g["scores"]).max() < 1e-6 and np.abs(err - g["fitness_error"]).max() < 1e-12

@@ -16,6 +16,8 @@ from .engine import Engine, FragmentSet, device_count, get_engine  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .numba_functions import (_get_tf_mat, compenetration_check, compenetration_mask, count_clashes, get_torsion_fingerprint,  # noqa: F401
                               prune_conformers_tfd, tfd_similarity)
+from .optimization_methods import (_score_embed_poses, fitness_check, fitness_mask, get_inertia_moments,  # noqa: F401
+                                   get_moi_similarity_matches, prune_by_moment_of_inertia)
 from .torsion_module import csearch_candidates, csearch_rotate, rotate_dihedral, torsion_comp_check  # noqa: F401
 from .rmsd_pruning import _rmsd_similarity, last_prune_stats, prune_conformers_rmsd, rmsd_and_max_numba  # noqa: F401
 

@@ -10,6 +10,7 @@
 #include "group_filter.hpp"
 #include "csearch.hpp"
 #include "tfd.hpp"
+#include "moi.hpp"
 
 #include <algorithm>
 
@@ -1171,6 +1172,69 @@ extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_
                        num_active, thresh, d_first);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipMemcpyAsync(first, d_first, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// moments of inertia, embed scores
+
+extern "C" __attribute__((visibility("default"))) int tsc_inertia_moments(tsc_ctx *c, const double *structures, int64_t n_structs, int n_atoms,
+                                                                          const double *masses, double *out) {
+    TSC_REQUIRE(c && structures && masses && out && n_structs >= 0 && n_atoms > 0, "tsc_inertia_moments: bad argument");
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_s, *d_m, *d_o;
+    TSC_TRY(upload(c, s, structures, size_t(n_structs) * n_atoms * 3, &d_s));
+    TSC_TRY(upload(c, s, masses, size_t(n_atoms), &d_m));
+    TSC_TRY(s.get(size_t(n_structs) * 3, &d_o));
+    hipLaunchKernelGGL(k_inertia_moments, dim3(grid_for(n_structs, 256, 256 * 8)), dim3(256), 0, c->stream, (const double *)d_s, n_structs, n_atoms,
+                       (const double *)d_m, d_o);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(out, d_o, size_t(n_structs) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_moi_first_similar(tsc_ctx *c, const double *moments, int64_t n_structs, double max_deviation,
+                                                                            int32_t *first) {
+    TSC_REQUIRE(c && moments && first && n_structs >= 0 && n_structs < INT32_MAX, "tsc_moi_first_similar: bad argument");
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_m;
+    int32_t *d_f;
+    TSC_TRY(upload(c, s, moments, size_t(n_structs) * 3, &d_m));
+    TSC_TRY(s.get(size_t(n_structs), &d_f));
+    hipLaunchKernelGGL(k_moi_first_similar, dim3(grid_for(n_structs, 4, 256 * 16)), dim3(256), 0, c->stream, (const double *)d_m, n_structs, max_deviation, d_f);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(first, d_f, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_embed_scores(tsc_ctx *c, const double *structures, int64_t n_structs, int n_atoms,
+                                                                       const int32_t *indices, const double *distances, int n_c, float *scores,
+                                                                       double *fitness_error) {
+    TSC_REQUIRE(c && structures && indices && distances && scores && fitness_error && n_structs >= 0 && n_atoms > 0 && n_c >= 0, "tsc_embed_scores: bad argument");
+    for (int64_t q = 0; q < n_structs * n_c * 2; ++q) TSC_REQUIRE(indices[q] >= 0 && indices[q] < n_atoms, "constrained index %d out of range", indices[q]);
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_s, *d_d, *d_e;
+    int32_t *d_i;
+    float *d_sc;
+    TSC_TRY(upload(c, s, structures, size_t(n_structs) * n_atoms * 3, &d_s));
+    TSC_TRY(upload(c, s, indices, size_t(n_structs) * n_c * 2, &d_i));
+    TSC_TRY(upload(c, s, distances, size_t(n_structs) * n_c, &d_d));
+    TSC_TRY(s.get(size_t(n_structs), &d_sc));
+    TSC_TRY(s.get(size_t(n_structs), &d_e));
+    hipLaunchKernelGGL(k_embed_scores, dim3(grid_for(n_structs, 256, 256 * 8)), dim3(256), 0, c->stream, (const double *)d_s, n_structs, n_atoms,
+                       (const int32_t *)d_i, (const double *)d_d, n_c, d_sc, d_e);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(scores, d_sc, size_t(n_structs) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(fitness_error, d_e, size_t(n_structs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -205,6 +205,34 @@ class Engine:
                                              C.c_int64(int(num_active)), C.c_double(float(thresh)), ptr(first)))
         return first
 
+    # ---- N4: moments of inertia, embed scores -------------------------------------------------------
+    def inertia_moments(self, structures, masses):
+        structures = np.ascontiguousarray(structures, dtype=np.float64)
+        masses = np.ascontiguousarray(masses, dtype=np.float64)
+        if structures.ndim != 3 or structures.shape[2] != 3 or masses.shape != (structures.shape[1],):
+            raise ValueError("structures must be (N, n_atoms, 3) and masses (n_atoms,)")
+        out = np.empty((len(structures), 3))
+        check(self.lib.tsc_inertia_moments(self._h, ptr(structures), C.c_int64(len(structures)), C.c_int(structures.shape[1]), ptr(masses), ptr(out)))
+        return out
+
+    def moi_first_similar(self, moments, max_deviation=1e-2):
+        moments = np.ascontiguousarray(moments, dtype=np.float64).reshape(-1, 3)
+        first = np.full(len(moments), -1, dtype=np.int32)
+        check(self.lib.tsc_moi_first_similar(self._h, ptr(moments), C.c_int64(len(moments)), C.c_double(float(max_deviation)), ptr(first)))
+        return first
+
+    def embed_scores(self, structures, indices, distances):
+        structures = np.ascontiguousarray(structures, dtype=np.float64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        distances = np.ascontiguousarray(distances, dtype=np.float64)
+        n = len(structures)
+        if indices.ndim != 3 or indices.shape[0] != n or indices.shape[2] != 2 or distances.shape != indices.shape[:2]:
+            raise ValueError("indices must be (N, n_c, 2) and distances (N, n_c)")
+        sc, err = np.zeros(n, dtype=np.float32), np.zeros(n)
+        check(self.lib.tsc_embed_scores(self._h, ptr(structures), C.c_int64(n), C.c_int(structures.shape[1]), ptr(indices), ptr(distances),
+                                        C.c_int(indices.shape[1]), ptr(sc), ptr(err)))
+        return sc, err
+
     # ---- N1: string-embed pose parameters -------------------------------------------------------
     def string_embed_params(self, p1, p2, ref_vec, mol_vec, conf_pair, angles):
         """tscode/embeds.py:98-116 for every (site, angle): rot f64[S*A, 2, 3, 3], pos f64[S*A, 2, 3], conf_idx i32[S*A, 2]."""

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import sys
 
-from . import algebra, embeds, numba_functions, rmsd_pruning, torsion_module
+from . import algebra, embeds, numba_functions, optimization_methods, rmsd_pruning, torsion_module
 
 # attribute -> (replacement, modules that bind it)
 _PATCHES = {
@@ -28,6 +28,9 @@ _PATCHES = {
     # (rotate_dihedral is NOT patched: tscode/torsion_module.py:984-1005 calls it with fractional angles, the batched
     # kernel takes the integer tables of the conformational search; use tscode_amd.csearch_rotate for those loops)
     "torsion_comp_check": (torsion_module.torsion_comp_check, ("tscode.numba_functions", "tscode.torsion_module")),
+    "get_moi_similarity_matches": (optimization_methods.get_moi_similarity_matches, ("tscode.algebra", "tscode.optimization_methods")),
+    "_score_embed_poses": (optimization_methods._score_embed_poses, ("tscode.numba_functions",)),
+    "fitness_check": (optimization_methods.fitness_check, ("tscode.optimization_methods", "tscode.embedder")),
     "prune_conformers_tfd": (numba_functions.prune_conformers_tfd,
                              ("tscode.numba_functions", "tscode.embedder", "tscode.operators", "tscode.torsion_module")),
 }
