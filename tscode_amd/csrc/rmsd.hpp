@@ -409,7 +409,7 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
-                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best) {
+                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax) {
     // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
     if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
@@ -444,10 +444,19 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
             }
         }
     }
+    int my_c = 0;
     if (mine && sl == 0) {
-        cend[r] = pos[found];
+        my_c = pos[found];
+        cend[r] = my_c;
         best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
     }
+    // largest stop column of the 16 rows of this block = one row tile of the pair kernel: lets a work item whose column
+    // segment lies beyond it leave after two scalar loads
+    __shared__ int s_cmax[4];
+    for (int off = 32; off > 0; off >>= 1) my_c = max(my_c, __shfl_xor(my_c, off));
+    if (lane == 0) s_cmax[threadIdx.x >> 6] = my_c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cmax[blockIdx.x] = max(max(s_cmax[0], s_cmax[1]), max(s_cmax[2], s_cmax[3]));
 }
 
 // Gather the active structures into the two layouts the tile kernel reads:

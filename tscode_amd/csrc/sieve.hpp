@@ -339,6 +339,7 @@ struct SieveArgs {
     double half_h_thr2;   // h * thr^2 / 2
     double two_thr2;      // 2 thr^2 when the near-duplicate test applies (h >= 4), else -1
     int drain_min;        // queue length that triggers a drain between column tiles (1..64)
+    const int32_t *tile_cmax;   // device: per row tile, the largest stop column of its 16 rows (k_stop_scan)
     const unsigned *dmax_bits;  // device: largest |descriptor component| of the run (bit pattern of a float), see screen_limit32
     double desc_limit;          // h thr^2: exact squared descriptor distance above which a pair is certainly dissimilar
 };
@@ -400,6 +401,8 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
     const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
     const int seg_hi = seg_lo + a.seg_cols;
     if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
+    // most items of a pass with long chunks start beyond every stop column of their row tile: two scalar loads and out
+    if (st->pass_on == 0 || a.tile_cmax[tile] <= seg_lo) return;
 
     // ---- prologue in two memory round trips: (1) the state, this item's 16 stop columns / best columns (they decide
     // whether it has work at all: most items of a late pass have none) and the structure indices of its rows and of its

@@ -482,7 +482,7 @@ struct tsc_prune {
     // device state
     uint8_t *mask = nullptr;
     int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
-    int32_t *bsum = nullptr, *total = nullptr;
+    int32_t *bsum = nullptr, *total = nullptr, *tile_cmax = nullptr;
     unsigned long long *mbit = nullptr, *dbit = nullptr;
     size_t bit_words = 0;
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
@@ -614,6 +614,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) rc = palloc(p, 4, &p->n_keys);
     if (!rc) rc = palloc(p, scan_bsum_count(n), &p->bsum);
     if (!rc) rc = palloc(p, 4, &p->total);
+    if (!rc) rc = palloc(p, size_t(n) / 16 + 2, &p->tile_cmax);
     if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
     if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
     if (!rc) rc = palloc(p, 1, &p->counters);
@@ -765,7 +766,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
                        (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit);
     // 2. stop column, best[] and compacted descriptor of every row
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, p->cend, p->best);
+                       p->dbit, p->cend, p->best, p->tile_cmax);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
@@ -811,6 +812,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.tile_cmax = p->tile_cmax;
         a.drain_min = c->drain_min;
         hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
                               (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
