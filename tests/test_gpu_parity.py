@@ -676,3 +676,38 @@ def test_moi_and_scores_golden(eng, oracle):
     thr = float(np.median(g["fitness_error"]))
     assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], g["sc_distances"], thr), g["fitness_error"] < thr)
     assert tscode_amd.fitness_check(g["sc_structures"][0], g["sc_indices"][0], list(g["sc_distances"][0]), thr) == bool(g["fitness_error"][0] < thr)
+
+
+def test_adjacent_rows_edge_cases(eng, oracle):
+    """Empty and degenerate inputs of the next-row entry points (they must not fault and must mirror the reference's shapes)."""
+    import tscode_amd
+    quads = np.array([[0, 1, 2, 3]])
+    # N2: one structure, two identical structures, no quadruplets
+    one = np.random.default_rng(0).normal(size=(1, 5, 3))
+    kept, mask = tscode_amd.prune_conformers_tfd(one, quads)
+    assert mask.tolist() == [True] and kept.shape == (1, 5, 3)
+    two = np.concatenate([one, one])
+    _, mask = tscode_amd.prune_conformers_tfd(two, quads)
+    assert mask.sum() == 1                                        # one of two identical structures goes
+    assert eng.tfd_first_similar(np.zeros((0, 3), np.float32), 1, 1, 0, 10.0).shape == (0,)
+    assert tscode_amd._get_tf_mat(one, np.zeros((0, 4), np.int32)).shape == (1, 0)
+    # N3: no candidates; all-zero angle sets leave the structure untouched and rotate nothing
+    coords = one[0]
+    mask5 = np.array([0, 0, 0, 1, 1], dtype=np.uint8)
+    out, rb = eng.csearch_rotate(coords, [(0, 1, 2, 3)], [mask5], np.zeros((0, 1), np.int32))
+    assert out.shape == (0, 5, 3) and rb.shape == (0,)
+    out, rb = eng.csearch_rotate(coords, [(0, 1, 2, 3)], [mask5], np.zeros((3, 1), np.int32))
+    assert np.array_equal(out, np.broadcast_to(coords, (3, 5, 3))) and rb.tolist() == [0, 0, 0]
+    assert tscode_amd.csearch_candidates(coords, [(0, 1, 2, 3)], [mask5], np.zeros((3, 1), np.int32)).shape[0] == 0
+    # a negative angle that clashes is never walked back (angle // 5 < 0) and does not count as rotated
+    clash = np.array([[0.0, 0, 0], [1.5, 0, 0], [2.2, 1.2, 0], [3.5, 1.4, 0.3], [0.3, 0.9, 0.2]])
+    for ang in (-170, 170, -40, 40):
+        o_ref, rb_ref = oracle.csearch_rotate(clash, [(0, 1, 2, 3)], [mask5], [[ang]], 1.5, 0)
+        o_gpu, rb_gpu = eng.csearch_rotate(clash, [(0, 1, 2, 3)], [mask5], [[ang]], 1.5, 0)
+        assert np.array_equal(rb_ref, rb_gpu) and np.abs(o_ref - o_gpu).max() < VAL_TOL
+    # N4: a single structure has no match; constraints with a missing target are skipped
+    assert tscode_amd.get_moi_similarity_matches(one, np.ones(5)) == []
+    assert tscode_amd.fitness_check(coords, [(0, 1), (2, 3)], [None, float(np.linalg.norm(coords[2] - coords[3]))], 1e-9)
+    # N1: no sites
+    r, p, c = eng.string_embed_params(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2), np.int32), [0.0, 10.0])
+    assert r.shape == (0, 2, 3, 3) and p.shape == (0, 2, 3) and c.shape == (0, 2)

@@ -1160,6 +1160,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_fingerprints(t
 extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, int64_t d,
                                                                             int64_t k, int64_t num_active, double thresh, int32_t *first) {
     TSC_REQUIRE(c && tf && first, "tsc_tfd_first_similar: null argument");
+    if (n_structs == 0) return 0;
     TSC_REQUIRE(n_structs >= 0 && n_quads >= 0 && d > 0 && k > 0 && num_active >= 0 && num_active <= n_structs && d * k <= n_structs,
                 "bad pass geometry (n = %lld, d = %lld, k = %lld, active = %lld)", (long long)n_structs, (long long)d, (long long)k, (long long)num_active);
     TSC_REQUIRE(n_structs < INT32_MAX, "too many structures");
