@@ -244,7 +244,10 @@ int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the 
                                                                       device, a pass whose gate is closed does nothing */
 int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs);        /* upper bound of the pairs of the open pass: lets every
                                                                       rank decide alike whether sharding it pays */
-int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous */
+int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous.  With world_size == 1 a pass whose chunks
+                                                                      are short runs whole in here (chunk-local kernel, option
+                                                                      "local_pass"): best[] is then not produced and
+                                                                      tsc_prune_pass_finish only does the bookkeeping */
 int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i32[n_entries], valid until finish */
 /* Make the run keep best[] in a caller-owned device buffer of n int32 (e.g. a torch tensor that
  * torch.distributed can all-reduce); call right after tsc_prune_create. */
