@@ -378,16 +378,22 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
     return rm < thr && md < maxdev_thr;
 }
 
-template <int TI>
-__global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+#ifndef TSC_SIEVE_OCC2
+#define TSC_SIEVE_OCC2 6
+#endif
+#ifndef TSC_SIEVE_OCC1
+#define TSC_SIEVE_OCC1 6
+#endif
+template <int TI, int CPL>
+__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
                                                         const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
     static_assert(DW == 2 * KD, "two families of KD components");
-    constexpr int QCAP = TI * 256 + 64;  // one 256-column tile can add TI*256 pairs on top of a remainder below 64
-    constexpr int CPL = 4;               // columns per lane: a tile is 64 * CPL columns, so one LDS read of a row
+    constexpr int QCAP = TI * 64 * CPL + 64;  // one column tile can add TI * 64 * CPL pairs on top of a remainder below 64
+    // CPL columns per lane: a tile is 64 * CPL columns, so one LDS read of a row
     constexpr int TILE_COLS = 64 * CPL;  // descriptor serves 4 x 64 pairs and the loop overhead is paid once per 256
     // an entry packs the row (4 bits) and the column offset inside the segment (12 bits: segments are <= 4096 columns)
     __shared__ unsigned short s_queue[4][QCAP];
@@ -587,8 +593,9 @@ __global__ __launch_bounds__(256, 4) void k_rmsd_sieve(const double *__restrict_
                 }
                 // most rows of a tile have no column within the limit: one test for all CPL * 64 pairs (a NaN distance --
                 // NaN coordinates -- is ignored by the minimum; such a pair is not similar for the reference either, :75)
-                const float mn = fminf(fminf(mx[0], mx[1]), fminf(mx[2], mx[3]));
-                static_assert(CPL == 4, "the minimum above covers four columns per lane");
+                float mn = mx[0];
+#pragma unroll
+                for (int u = 1; u < CPL; ++u) mn = fminf(mn, mx[u]);
                 if (__builtin_amdgcn_ballot_w64(!(mn > limit32))) {
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {

@@ -814,9 +814,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
         a.tile_cmax = p->tile_cmax;
         a.drain_min = c->drain_min;
-        hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                              (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
-                              (const PruneState *)p->state, a);
+        if (c->sieve_cpl == 1)
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
+        else if (c->sieve_cpl == 2)
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
+        else
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 4>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dall, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
     }
     TSC_HIP(hipGetLastError());
     p->local_done = true;
@@ -982,6 +991,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
+        return 0;
+    }
+    if (strcmp(name, "sieve_cpl") == 0) {
+        TSC_REQUIRE(value == 1 || value == 2 || value == 4, "sieve_cpl must be 1, 2 or 4");
+        c->sieve_cpl = int(value);
         return 0;
     }
     if (strcmp(name, "local_pass") == 0) {
