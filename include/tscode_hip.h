@@ -57,7 +57,8 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 256, at most 4096; 0 = automatic);
  * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64);
  * "sieve_cpl": columns per lane of the sieve kernel's screen, 1, 2 (default) or 4 -- register footprint against occupancy;
- * "local_pass": 1 (default) lets passes with short chunks run in the one-launch chunk-local kernel; "clash_fp32": 1 (default)
+ * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 256, up to 2048) structures
+ * run in the one-launch chunk-local kernel; "clash_fp32": 1 (default)
  * decides verdict-only clash masks by a packed-fp32 minimum with fp64 fallback;
  * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
  * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms),

@@ -25,6 +25,10 @@ constexpr int LP_TILES_PER_BLOCK = 2 * LP_WAVES;  // row tiles one block is size
 constexpr int LP_QCAP = LP_TI * 64 + 64;
 constexpr int LP_WORDS = LP_MAX_ROWS / 64;
 constexpr int LP_TICKET_GROUPS = 16;  // two-level ticket: same-address atomics serialise (~12 ns each)
+#ifndef TSC_LP_OCC
+#define TSC_LP_OCC 4
+#endif
+constexpr int LP_OCCUPANCY = TSC_LP_OCC;  // workgroups per CU the register allocation aims at (unbounded, the kernel takes 255 VGPRs: one)
 
 struct LocalPassArgs {
     int h;
@@ -47,7 +51,7 @@ __device__ inline unsigned long long lds_extract64(const unsigned long long *bit
     return lo | hi;
 }
 
-__global__ __launch_bounds__(LP_THREADS) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
+__global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
                                                              const unsigned long long *__restrict__ dbit, const double *__restrict__ heavy,
                                                              const double *__restrict__ Gall, const float *__restrict__ D,
                                                              int32_t *__restrict__ key_a, int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,

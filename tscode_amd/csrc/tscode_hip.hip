@@ -730,10 +730,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
     // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
-    // chunks are a few tiles long -- at 57k structures the passes k = 1000 and 500 drop from 47 to 29 us -- and for small
-    // ensembles, where every pass fits and a run is all launch latency; long chunks keep the four-launch path)
-    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= LP_MAX_ROWS &&
-                   (longest_chunk <= 256 || n <= 4096);
+    // chunks are a few row tiles long -- at 57k structures the passes k = 1000 and 500 take 33 and 39 us instead of about
+    // 50 -- and is no better than the four-launch path beyond; "local_max_chunk" moves the limit)
+    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= std::min(LP_MAX_ROWS, c->local_max_chunk);
     if (p->cur_local) {
         if (use_cache)
             hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
@@ -996,6 +995,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "sieve_cpl") == 0) {
         TSC_REQUIRE(value == 1 || value == 2 || value == 4, "sieve_cpl must be 1, 2 or 4");
         c->sieve_cpl = int(value);
+        return 0;
+    }
+    if (strcmp(name, "local_max_chunk") == 0) {
+        TSC_REQUIRE(value >= 16 && value <= LP_MAX_ROWS, "local_max_chunk must be in [16, %d]", LP_MAX_ROWS);
+        c->local_max_chunk = int(value);
         return 0;
     }
     if (strcmp(name, "local_pass") == 0) {
