@@ -60,8 +60,10 @@ __host__ __device__ inline T ceil_div(T a, T b) {
 struct tsc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;     // scalar read-backs that should not wait for work enqueued after their producer
     bool own_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_sync = nullptr;         // orders the auxiliary stream behind the main one (no timing)
     std::multimap<size_t, void *> cache;  // free scratch blocks by size
     std::map<void *, size_t> live;        // blocks handed out
     void *pinned = nullptr;               // small pinned host buffer for scalar read-backs

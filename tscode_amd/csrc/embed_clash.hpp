@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ fr
                                                     const double *__restrict__ pos, const int32_t *__restrict__ idx,
                                                     int64_t n_out, double *__restrict__ out,
                                                     const int32_t *__restrict__ heavy_slot, int n_heavy,
-                                                    double *__restrict__ heavy_out) {
+                                                    double *__restrict__ heavy_out, const int32_t *__restrict__ n_out_dev) {
+    // n_out_dev (optional): the row count lives on the device (the total of the scan that made idx); the grid is then
+    // sized for an upper bound and the host need not wait for the count before launching
     const int n = ft.n_total;
+    if (n_out_dev) n_out = *n_out_dev;
     const int64_t total = n_out * n;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
         int64_t r = e / n;

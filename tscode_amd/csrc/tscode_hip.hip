@@ -48,7 +48,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
     if (!c) return fail(TSC_ERR_NOMEM, "out of host memory");
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) {
         c->pinned_bytes = 16384;
@@ -71,7 +73,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -193,7 +197,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_transform_batch_dev(ts
     if (n_poses == 0) return 0;
     DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256)), dim3(256), 0, c->stream, frags, ft, conf_idx, rot,
-                       pos, (const int32_t *)nullptr, n_poses, out, (const int32_t *)nullptr, 0, (double *)nullptr);
+                       pos, (const int32_t *)nullptr, n_poses, out, (const int32_t *)nullptr, 0, (double *)nullptr, (const int32_t *)nullptr);
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -356,6 +360,20 @@ extern "C" __attribute__((visibility("default"))) int tsc_all_dists(tsc_ctx *c, 
 
 // --------------------------------------------------------------------------------------------------
 // ordered compaction
+
+// Fetch a device scalar that the work enqueued so far has produced WITHOUT waiting for what is enqueued after this call:
+// the copy goes to the auxiliary stream behind an event; read_i32_finish waits for that stream only.
+static int read_i32_begin(tsc_ctx *c, const int32_t *dev) {
+    TSC_HIP(hipEventRecord(c->ev_sync, c->stream));
+    TSC_HIP(hipStreamWaitEvent(c->aux_stream, c->ev_sync, 0));
+    TSC_HIP(hipMemcpyAsync(c->pinned, dev, sizeof(int32_t), hipMemcpyDeviceToHost, c->aux_stream));
+    return 0;
+}
+static int read_i32_finish(tsc_ctx *c, int32_t *host_out) {
+    TSC_HIP(hipStreamSynchronize(c->aux_stream));
+    *host_out = *static_cast<int32_t *>(c->pinned);
+    return 0;
+}
 
 static int read_i32(tsc_ctx *c, const int32_t *dev, int32_t *host_out) {
     TSC_HIP(hipMemcpyAsync(c->pinned, dev, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1383,16 +1401,19 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     if (timed) TSC_HIP(hipEventRecord(ev[1], st));
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
+    // the passing poses are embedded (all atoms + heavy atoms) by a launch sized for every pose that reads the count on the
+    // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
+    TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
+    TSC_TRY(read_i32_begin(c, total));
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
+                       int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
+    TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
-    TSC_TRY(read_i32(c, total, &n_pass));  // also makes the stack-local `slot` upload safe
+    TSC_TRY(read_i32_finish(c, &n_pass));  // (the copy waited for the scan, hence for the upload of the stack-local `slot` too)
     if (n_pass_host) *n_pass_host = n_pass;
     int64_t n_keep = 0;
     int np = 0;
     if (n_pass > 0) {
-        TSC_TRY(s.get(size_t(n_pass) * n_heavy * 3, &d_heavy));
-        hipLaunchKernelGGL(k_transform, dim3(grid_for(int64_t(n_pass) * ft.n_total, 256)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos,
-                           (const int32_t *)act, int64_t(n_pass), structures, (const int32_t *)d_slot, n_heavy, d_heavy);
-        TSC_HIP(hipGetLastError());
         if (timed) TSC_HIP(hipEventRecord(ev[2], st));
         TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
