@@ -138,25 +138,11 @@ def test_g7_csearch_rotations(oracle):
         assert oracle.torsion_comp_check(one, torsions[t0], masks[t0], 1.5) == int(g[f"first_checks{c}"][0])
 
 
-class _OraclePairSearch:
-    """prune_conformers_tfd's GPU calls answered by the CPU oracle (the product's host logic under test on CPU)."""
-    def __init__(self, oracle):
-        self.o, self.margin = oracle, np.inf
-
-    def fingerprints(self, structures, quads):
-        return self.o.torsion_fingerprints(structures, quads)
-
-    def first_similar(self, tf, d, k, num_active, thresh):
-        first, m = self.o.tfd_first_similar(tf, d, k, num_active, thresh, return_margin=True)
-        self.margin = min(self.margin, m)
-        return first
-
-
 def test_g6_g8_torsion_fingerprint_pruning(oracle):
     """fingerprints / tfd_similarity (G6) and prune_conformers_tfd end to end (G8, the reference's own
     function with networkx): the oracle's pair search + the product's host-side graph step give the reference's mask."""
     pytest.importorskip("networkx")
-    from tscode_amd.numba_functions import prune_conformers_tfd
+    from tscode_amd.numba_functions import _tfd_schedule          # the product's host-side schedule + graph step (pure Python)
     g6 = load_golden("G6_tfd")
     fp = oracle.torsion_fingerprints(g6["coords"], g6["quadruplets"])
     assert fp.dtype == np.float32 and np.abs(fp - g6["fingerprints"]).max() < 2e-5
@@ -167,9 +153,14 @@ def test_g6_g8_torsion_fingerprint_pruning(oracle):
         structures, thresh = g[f"structures{c}"], float(g[f"thresh{c}"])
         tf = oracle.torsion_fingerprints(structures, g["quadruplets"])
         assert np.abs(tf - g[f"tf_mat{c}"]).max() < 2e-5
-        ps = _OraclePairSearch(oracle)
-        pruned, mask = prune_conformers_tfd(structures, g["quadruplets"], thresh=thresh, _pair_search=ps)
-        assert ps.margin > 1e-6                                   # no fingerprint sum sits on the threshold
+        margins = []
+
+        def first_similar(tf_mat, d, k, num_active, th):         # the pair search answered by the CPU oracle
+            first, m = oracle.tfd_first_similar(tf_mat, d, k, num_active, th, return_margin=True)
+            margins.append(m)
+            return first
+        pruned, mask = _tfd_schedule(structures, tf, thresh, False, first_similar)
+        assert min(margins) > 1e-6                                # no fingerprint sum sits on the threshold
         assert np.array_equal(mask, g[f"mask{c}"]), (c, mask.sum(), g[f"mask{c}"].sum())
         assert np.array_equal(pruned, structures[mask])
 

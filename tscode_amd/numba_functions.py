@@ -75,15 +75,10 @@ def _tfd_reject_matches(first, d, k, final_mask):
                 final_mask[i + off] = 0                                  # :222-224
 
 
-def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False, _pair_search=None):
-    """tscode/numba_functions.py:142-231.  Fingerprints and the O(N^2 / k) pair search of every pass run on the GPU (one
-    launch each); the schedule, the gate `k == 1 or 5 k < active` (:166) and the graph step stay in Python.  The reference's
-    cache_set only skips pairs it already found dissimilar, so it changes no result and is not kept.
-    Returns (structures[mask], mask)."""
-    structures = np.asarray(structures)
+def _tfd_schedule(structures, tf_mat, thresh, verbose, first_similar):
+    """The pass schedule of tscode/numba_functions.py:160-226 around a pair search `first_similar(tf_mat, d, k, num_active,
+    thresh) -> int32[N]` (the engine's kernel in the product; the tests also drive it with the CPU oracle's)."""
     n = structures.shape[0]
-    eng = None if _pair_search else get_engine()
-    tf_mat = _pair_search.fingerprints(structures, quadruplets) if _pair_search else eng.torsion_fingerprints(structures, quadruplets)
     final_mask = np.ones(n, dtype=bool)
     for k in TFD_KS:
         num_active_str = int(np.count_nonzero(final_mask))
@@ -93,7 +88,17 @@ def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False, _pai
                 continue
             if verbose:
                 print(f"Working on subgroups with k={k} ({num_active_str} candidates left) {' ' * 10}", end="\r")
-            search = _pair_search.first_similar if _pair_search else eng.tfd_first_similar
-            first = search(tf_mat, d, int(k), num_active_str, thresh)
+            first = first_similar(tf_mat, d, int(k), num_active_str, thresh)
             _tfd_reject_matches(first, d, int(k), final_mask)
     return structures[final_mask], final_mask
+
+
+def prune_conformers_tfd(structures, quadruplets, thresh=10, verbose=False):
+    """tscode/numba_functions.py:142-231.  Fingerprints and the O(N^2 / k) pair search of every pass run on the GPU (one
+    launch each); the schedule, the gate `k == 1 or 5 k < active` (:166) and the graph step stay in Python.  The reference's
+    cache_set only skips pairs it already found dissimilar, so it changes no result and is not kept.
+    Returns (structures[mask], mask)."""
+    structures = np.asarray(structures)
+    eng = get_engine()
+    tf_mat = eng.torsion_fingerprints(structures, quadruplets)
+    return _tfd_schedule(structures, tf_mat, thresh, verbose, eng.tfd_first_similar)
