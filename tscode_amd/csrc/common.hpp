@@ -71,7 +71,7 @@ struct tsc_ctx {
     int prune_algo = 0;                   // tsc_ctx_set_option("prune_algo"): 0 auto, 1 register-tiled, 2 sieve
     int seg_cols = 0;                     // columns per pair-kernel work item (0 = chosen from the problem size)
     int drain_min = 64;                   // sieve: queued pairs that trigger an evaluation batch
-    int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 6 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64 at 8
+    int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
     int local_max_chunk = 256;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback

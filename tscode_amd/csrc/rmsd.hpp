@@ -85,6 +85,57 @@ __device__ inline void top_eigvec4(double A[4][4], double q[4]) {
     }
 }
 
+// The same cyclic Jacobi on matrices that live in memory (LDS): A[16], V[16] row-major, dynamic indices.  The register
+// version above costs 64 VGPRs for its two matrices; a kernel that wants a small register footprint runs this one for
+// the (rare) degenerate pairs, one lane at a time on a 256-byte area per wavefront.
+__device__ inline void top_eigvec4_mem(double *A, double *V, double q[4]) {
+#pragma nounroll
+    for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+#pragma nounroll
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma nounroll
+        for (int i = 0; i < 4; ++i) {
+            dia += A[5 * i] * A[5 * i];
+#pragma nounroll
+            for (int j = i + 1; j < 4; ++j) off += A[4 * i + j] * A[4 * i + j];
+        }
+        if (!(off > 1e-30 * dia)) break;
+#pragma nounroll
+        for (int p = 0; p < 3; ++p)
+#pragma nounroll
+            for (int r = p + 1; r < 4; ++r) {
+                const double apq = A[4 * p + r];
+                if (apq != 0.0) {
+                    const double theta = (A[5 * r] - A[5 * p]) / (2.0 * apq);
+                    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    t = theta < 0.0 ? -t : t;
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma nounroll
+                    for (int k = 0; k < 4; ++k) {  // columns p, r of A and V
+                        const double akp = A[4 * k + p], akr = A[4 * k + r];
+                        A[4 * k + p] = c * akp - s * akr;
+                        A[4 * k + r] = s * akp + c * akr;
+                        const double vkp = V[4 * k + p], vkr = V[4 * k + r];
+                        V[4 * k + p] = c * vkp - s * vkr;
+                        V[4 * k + r] = s * vkp + c * vkr;
+                    }
+#pragma nounroll
+                    for (int k = 0; k < 4; ++k) {  // rows p, r of A
+                        const double apk = A[4 * p + k], ark = A[4 * r + k];
+                        A[4 * p + k] = c * apk - s * ark;
+                        A[4 * r + k] = s * apk + c * ark;
+                    }
+                }
+            }
+    }
+    int kb = 0;
+#pragma nounroll
+    for (int k = 1; k < 4; ++k)
+        if (A[5 * k] > A[5 * kb]) kb = k;
+    for (int i = 0; i < 4; ++i) q[i] = V[4 * i + kb];
+}
+
 // 3x3 determinant of the minor of the symmetric 4x4 A that drops row I and column J, with the cofactor sign.
 template <int I, int J>
 __device__ inline double cofactor4(const double (&A)[4][4]) {
@@ -104,19 +155,17 @@ __device__ inline double cofactor4(const double (&A)[4][4]) {
 //               (collinear / planar-through-origin / mirror-symmetric cases).
 // A group of `lpp` consecutive lanes (a power of two, all converged, all holding the same S) may share one pair:
 // lane `sub` of the group then takes atoms sub, sub + lpp, ... of the residual loop and the group reduces.
-__device__ inline void exact_rmsd_maxdev(const double *__restrict__ p, const double *__restrict__ q, int h, const double S[9],
-                                         double Gp, double Gq, double &rmsd, double &maxdev, int sub = 0, int lpp = 1) {
-    double N[4][4];
-    N[0][0] = S[0] + S[4] + S[8];
-    N[1][1] = S[0] - S[4] - S[8];
-    N[2][2] = -S[0] + S[4] - S[8];
-    N[3][3] = -S[0] - S[4] + S[8];
-    N[0][1] = N[1][0] = S[5] - S[7];
-    N[0][2] = N[2][0] = S[6] - S[2];
-    N[0][3] = N[3][0] = S[1] - S[3];
-    N[1][2] = N[2][1] = S[1] + S[3];
-    N[1][3] = N[3][1] = S[6] + S[2];
-    N[2][3] = N[3][2] = S[5] + S[7];
+// Horn's matrix N(S), row-major into 16 doubles
+__device__ inline void horn_matrix(const double S[9], double *M) {
+    M[0] = S[0] + S[4] + S[8], M[5] = S[0] - S[4] - S[8], M[10] = -S[0] + S[4] - S[8], M[15] = -S[0] - S[4] + S[8];
+    M[1] = M[4] = S[5] - S[7], M[2] = M[8] = S[6] - S[2], M[3] = M[12] = S[1] - S[3];
+    M[6] = M[9] = S[1] + S[3], M[7] = M[13] = S[6] + S[2], M[11] = M[14] = S[5] + S[7];
+}
+
+// Fast way to the rotation quaternion e (not normalised): Newton for the top eigenvalue, then the best-conditioned column
+// of adj(N - l I).  Returns false when the top eigenvalue is (nearly) degenerate and the adjugate collapses (collinear /
+// planar-through-origin / mirror-symmetric cases): the caller then runs a Jacobi eigen-solver (top_eigvec4 / _mem).
+__device__ inline bool rotation_quaternion_fast(const double S[9], double Gp, double Gq, double e[4]) {
     // characteristic quartic l^4 + c2 l^2 + c1 l + c0 (see the sign test below)
     const double F = S[0] * S[0] + S[1] * S[1] + S[2] * S[2] + S[3] * S[3] + S[4] * S[4] + S[5] * S[5] + S[6] * S[6] + S[7] * S[7] + S[8] * S[8];
     const double C0 = S[4] * S[8] - S[5] * S[7], C1 = S[5] * S[6] - S[3] * S[8], C2 = S[3] * S[7] - S[4] * S[6];
@@ -126,48 +175,49 @@ __device__ inline void exact_rmsd_maxdev(const double *__restrict__ p, const dou
     const double CF = C0 * C0 + C1 * C1 + C2 * C2 + C3 * C3 + C4 * C4 + C5 * C5 + C6 * C6 + C7 * C7 + C8 * C8;
     const double c2 = -2.0 * F, c1 = -8.0 * det, c0 = F * F - 4.0 * CF;
     double lam = 0.5 * (Gp + Gq);
-    bool newton_ok = lam > 0.0;
-    for (int it = 0; it < 40 && newton_ok; ++it) {
+    if (!(lam > 0.0)) return false;
+    for (int it = 0; it < 40; ++it) {
         const double l2 = lam * lam;
         const double P = l2 * l2 + c2 * l2 + c1 * lam + c0, P1 = 4.0 * l2 * lam + 2.0 * c2 * lam + c1;
-        if (!(P1 > 0.0)) {
-            newton_ok = false;
-            break;
-        }
+        if (!(P1 > 0.0)) return false;
         const double dl = P / P1;
         lam -= dl;
         if (fabs(dl) <= 1e-15 * fabs(lam)) break;
     }
-    double e[4];
-    bool have = false;
-    if (newton_ok) {
-        double A[4][4];
+    double A[4][4];
+    {
+        double M[16];
+        horn_matrix(S, M);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) A[i][j] = N[i][j] - (i == j ? lam : 0.0);
-        const double d0 = cofactor4<0, 0>(A), d1 = cofactor4<1, 1>(A), d2 = cofactor4<2, 2>(A), d3 = cofactor4<3, 3>(A);
-        double scale = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = i; j < 4; ++j) scale = fmax(scale, fabs(A[i][j]));
-        const double a0 = fabs(d0), a1 = fabs(d1), a2 = fabs(d2), a3 = fabs(d3);
-        const double best = fmax(fmax(a0, a1), fmax(a2, a3));
-        if (best > 1e-4 * scale * scale * scale) {  // adj(A) = c v v^T with |c| large enough: any big column is v
-            have = true;
-            if (a0 == best) {
-                e[0] = d0, e[1] = cofactor4<0, 1>(A), e[2] = cofactor4<0, 2>(A), e[3] = cofactor4<0, 3>(A);
-            } else if (a1 == best) {
-                e[0] = cofactor4<1, 0>(A), e[1] = d1, e[2] = cofactor4<1, 2>(A), e[3] = cofactor4<1, 3>(A);
-            } else if (a2 == best) {
-                e[0] = cofactor4<2, 0>(A), e[1] = cofactor4<2, 1>(A), e[2] = d2, e[3] = cofactor4<2, 3>(A);
-            } else {
-                e[0] = cofactor4<3, 0>(A), e[1] = cofactor4<3, 1>(A), e[2] = cofactor4<3, 2>(A), e[3] = d3;
-            }
-        }
+            for (int j = 0; j < 4; ++j) A[i][j] = M[4 * i + j] - (i == j ? lam : 0.0);
     }
-    if (!have) top_eigvec4(N, e);
+    const double d0 = cofactor4<0, 0>(A), d1 = cofactor4<1, 1>(A), d2 = cofactor4<2, 2>(A), d3 = cofactor4<3, 3>(A);
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) scale = fmax(scale, fabs(A[i][j]));
+    const double a0 = fabs(d0), a1 = fabs(d1), a2 = fabs(d2), a3 = fabs(d3);
+    const double best = fmax(fmax(a0, a1), fmax(a2, a3));
+    if (!(best > 1e-4 * scale * scale * scale)) return false;  // adj(A) = c v v^T with |c| large enough: any big column is v
+    if (a0 == best) {
+        e[0] = d0, e[1] = cofactor4<0, 1>(A), e[2] = cofactor4<0, 2>(A), e[3] = cofactor4<0, 3>(A);
+    } else if (a1 == best) {
+        e[0] = cofactor4<1, 0>(A), e[1] = d1, e[2] = cofactor4<1, 2>(A), e[3] = cofactor4<1, 3>(A);
+    } else if (a2 == best) {
+        e[0] = cofactor4<2, 0>(A), e[1] = cofactor4<2, 1>(A), e[2] = d2, e[3] = cofactor4<2, 3>(A);
+    } else {
+        e[0] = cofactor4<3, 0>(A), e[1] = cofactor4<3, 1>(A), e[2] = cofactor4<3, 2>(A), e[3] = d3;
+    }
+    return true;
+}
+
+// rmsd and max deviation of p rotated by the quaternion e (w, x, y, z; any length) against q (rmsd_pruning.py:29-39); lpp
+// lanes share the pair (atoms sub, sub + lpp, ...) and reduce with a butterfly
+__device__ inline void residual_rmsd_maxdev(const double *__restrict__ p, const double *__restrict__ q, int h, const double e[4], double &rmsd,
+                                            double &maxdev, int sub = 0, int lpp = 1) {
     const double nn = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
     const double w = e[0] * nn, x = e[1] * nn, y = e[2] * nn, z = e[3] * nn;
     const double R00 = w * w + x * x - y * y - z * z, R01 = 2 * (x * y - w * z), R02 = 2 * (x * z + w * y);
@@ -190,6 +240,21 @@ __device__ inline void exact_rmsd_maxdev(const double *__restrict__ p, const dou
     }
     rmsd = sqrt(ss / double(h));
     maxdev = sqrt(mx);  // max_a sqrt(d2_a) == sqrt(max_a d2_a): sqrt is monotone
+}
+
+__device__ inline void exact_rmsd_maxdev(const double *__restrict__ p, const double *__restrict__ q, int h, const double S[9],
+                                         double Gp, double Gq, double &rmsd, double &maxdev, int sub = 0, int lpp = 1) {
+    double e[4];
+    if (!rotation_quaternion_fast(S, Gp, Gq, e)) {
+        double N[4][4], M[16];
+        horn_matrix(S, M);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) N[i][j] = M[4 * i + j];
+        top_eigvec4(N, e);
+    }
+    residual_rmsd_maxdev(p, q, h, e, rmsd, maxdev, sub, lpp);
 }
 
 // rmsd_and_max_numba (rmsd_pruning.py:6-41) for one pair; p, q point at h consecutive xyz triples.

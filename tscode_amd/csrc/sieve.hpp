@@ -379,7 +379,7 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 }
 
 #ifndef TSC_SIEVE_OCC2
-#define TSC_SIEVE_OCC2 6
+#define TSC_SIEVE_OCC2 5
 #endif
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     // an entry packs the row (4 bits) and the column offset inside the segment (12 bits: segments are <= 4096 columns)
     __shared__ unsigned short s_queue[4][QCAP];
     __shared__ unsigned short s_exq[4][128];  // pairs that the sign test could not reject, waiting for the exact path
+    __shared__ double s_jacobi[4][32];        // scratch of the Jacobi fallback of the exact path (rmsd.hpp), per wavefront
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -525,23 +526,56 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         int lpp = 64;
         while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
         const int g = lane / lpp, sub = lane - g * lpp;
-        bool sim = false;
+        bool sim = false, degenerate = false;
         int t = 0;
+        unsigned ent = 0;
         if (g < cnt) {
             int col;
             const double *pp, *pq;
-            double Gi, Gj, H[9], rm, md;
-            decode(exq[base + g], t, col, pp, pq, Gi, Gj);
+            double Gi, Gj, H[9], e[4];
+            ent = exq[base + g];
+            decode(ent, t, col, pp, pq, Gi, Gj);
             pair_H(pp, pq, a.h, sub, lpp, H);
-            exact_rmsd_maxdev(pp, pq, a.h, H, Gi, Gj, rm, md, sub, lpp);
-            sim = sub == 0 && rm < a.thr && md < a.maxdev_thr;  // rmsd_pruning.py:75
-            if (sim) atomicMin(&best[r0 + t], col);
+            if (rotation_quaternion_fast(H, Gi, Gj, e)) {  // (the lanes of a group hold the same H: they branch together)
+                double rm, md;
+                residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, sub, lpp);
+                sim = sub == 0 && rm < a.thr && md < a.maxdev_thr;  // rmsd_pruning.py:75
+                if (sim) atomicMin(&best[r0 + t], col);
+            } else {
+                degenerate = sub == 0;
+            }
         }
         unsigned long long sm = __builtin_amdgcn_ballot_w64(sim);
         while (sm) {  // rows that found a similar column stop being screened (the reference returns there, :75-77)
             const int l = __ffsll((long long)sm) - 1;
             sm &= sm - 1;
             alive &= ~(1u << __builtin_amdgcn_readlane(t, l));
+        }
+        // Pairs whose top eigenvalue is degenerate (collinear, planar through the origin, mirror-symmetric structures) need
+        // the Jacobi eigen-solver.  Its two 4x4 matrices would cost every work item 64 registers, so the whole wavefront
+        // takes such a pair on, one at a time: H by all 64 lanes, the solver by lane 0 on a 256-byte LDS area, the residual
+        // by all lanes again.
+        for (unsigned long long dm = __builtin_amdgcn_ballot_w64(degenerate); dm; dm &= dm - 1) {
+            const unsigned e1 = unsigned(__builtin_amdgcn_readlane(int(ent), __ffsll((long long)dm) - 1));
+            int t2, col2;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], e[4], rm, md;
+            decode(e1, t2, col2, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, lane, 64, H);
+            double *jac = s_jacobi[wid];
+            if (lane == 0) {
+                horn_matrix(H, jac);
+                top_eigvec4_mem(jac, jac + 16, e);
+                jac[0] = e[0], jac[1] = e[1], jac[2] = e[2], jac[3] = e[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+            e[0] = jac[0], e[1] = jac[1], e[2] = jac[2], e[3] = jac[3];
+            __builtin_amdgcn_wave_barrier();
+            residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, lane, 64);
+            if (rm < a.thr && md < a.maxdev_thr) {  // wave-uniform
+                if (lane == 0) atomicMin(&best[r0 + t2], col2);
+                alive &= ~(1u << t2);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     };
