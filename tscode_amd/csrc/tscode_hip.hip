@@ -1405,7 +1405,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
     TSC_TRY(read_i32_begin(c, total));
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256, 256 * 64)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
                        int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
     TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
