@@ -417,20 +417,47 @@ __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, in
 
 // Cache view of one pass: a key (a, b) = (first, first + (j - i)) (:65) can be hit only where a is a chunk
 // start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
+// Cache view of a pass from the key list, shared by k_dbit_build and k_open_pass: key (a, b) sets bit b of dbit when a is a
+// chunk start of this pass and b lies in that chunk, and the bit of b's 1024-bit block in the summary dsum (k_stop_scan
+// walks only the non-empty blocks).  The summary of a run of 57k structures is ONE word: its bits are OR-ed across the
+// wavefront first and sent by one lane, or every applicable key would queue on the same address.
+__device__ inline void build_cache_view(const PassGeom &g, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b, int nk,
+                                        unsigned long long *__restrict__ dbit, unsigned long long *__restrict__ dsum) {
+    const int lane = threadIdx.x & 63;
+    const int stride = gridDim.x * blockDim.x;
+    for (int q0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; q0 < nk; q0 += stride) {  // wave-uniform bounds
+        const int q = q0 + lane;
+        bool ok = false;
+        int b = 0;
+        if (q < nk) {
+            const int a = key_a[q];
+            b = key_b[q];
+            const int c = a / g.cs;
+            if (c * g.cs == a && c < g.k) {
+                const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
+                ok = b < last;
+            }
+        }
+        if (ok) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
+        for (unsigned long long left = __ballot(ok); left;) {
+            const int word = __shfl(b >> 16, __ffsll((long long)left) - 1);
+            const bool same = ok && (b >> 16) == word;
+            unsigned long long bits = same ? 1ull << ((b >> 10) & 63) : 0ull;
+            for (int off = 32; off > 0; off >>= 1) bits |= __shfl_xor(bits, off);
+            const unsigned long long grp = __ballot(same);
+            if (lane == __ffsll((long long)grp) - 1) atomicOr(&dsum[word], bits);
+            left &= ~grp;
+        }
+    }
+}
+
 // Cache view of a pass on its own (the chunk-local pass kernel, local_pass.hpp, needs nothing else from k_open_pass):
 // key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
 __global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
                                                      const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
-                                                     const PruneState *__restrict__ st) {
+                                                     const PruneState *__restrict__ st, unsigned long long *__restrict__ dsum) {
     if (st->pass_on == 0) return;
-    const int nk = *n_keys;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
-        const int a = key_a[q], b = key_b[q];
-        const int c = a / g.cs;
-        if (c * g.cs != a || c >= g.k) continue;
-        const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
-        if (b < last) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
-    }
+    build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
 }
 
 // Opens the data of a pass in one launch: ranks of the active structures, their index list and the mask as bits
@@ -442,20 +469,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_open_pass(PassGeom g, int use_
                                                              int32_t *__restrict__ pos, int32_t *__restrict__ act_idx,
                                                              uint8_t *__restrict__ mbit_bytes, int32_t *__restrict__ total_out,
                                                              const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
-                                                             const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit) {
+                                                             const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
+                                                             unsigned long long *__restrict__ dsum) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
     __shared__ int s_o[SCAN_THREADS / WAVE];
     if (st->pass_on == 0) return;
     scan_write_block(mask, g.n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o);
     if (!use_cache) return;
-    const int nk = *n_keys;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nk; q += gridDim.x * blockDim.x) {
-        const int a = key_a[q], b = key_b[q];
-        const int c = a / g.cs;
-        if (c * g.cs != a || c >= g.k) continue;
-        const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
-        if (b < last) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
-    }
+    build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
 }
 
 __device__ inline unsigned long long extract64(const unsigned long long *__restrict__ bits, int64_t start) {
@@ -474,7 +495,8 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
-                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax) {
+                                                    const unsigned long long *__restrict__ dsum, int32_t *__restrict__ cend,
+                                                    int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax) {
     // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
     if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
@@ -487,25 +509,45 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
     }
     int64_t found = last;
     if (use_cache) {
-        const int64_t len = mine ? last - i - 1 : 0;  // candidate deltas d = 1 .. len
+        // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
+        // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
+        // blocks of it, found through the summary bitmap dsum, instead of every block of its chunk
+        const int64_t len = mine ? last - i - 1 : 0;
+        const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
+        int64_t B = p_lo >> 10;
+        const int64_t B_hi = p_hi >> 10;
         bool scanning = len > 0;
-        for (int64_t base = 0; __ballot(scanning) != 0; base += 16 * 64) {
+        while (__ballot(scanning) != 0) {
+            if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
+                bool any = false;
+                while (B <= B_hi) {
+                    const unsigned long long sw = dsum[B >> 6] >> (B & 63);
+                    if (sw) {
+                        B += __ffsll((long long)sw) - 1;
+                        any = B <= B_hi;
+                        break;
+                    }
+                    B = ((B >> 6) + 1) << 6;
+                }
+                scanning = any;
+            }
             unsigned long long w = 0;
-            const int64_t d0 = 1 + base + int64_t(sl) * 64;
-            if (scanning && d0 <= len) {
-                w = extract64(mbit, i + d0) & extract64(dbit, first + d0);
-                const int64_t rem = len - d0 + 1;
-                if (rem < 64) w &= (1ull << rem) - 1ull;
+            const int64_t p0 = (B * 16 + sl) * 64;  // first position of this lane's word of the block
+            if (scanning && p0 <= p_hi && p0 + 63 >= p_lo) {
+                w = dbit[B * 16 + sl] & extract64(mbit, p0 + shift);
+                if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
+                if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
             }
             const unsigned hit = unsigned(__ballot(w != 0) >> (16 * sub)) & 0xffffu;  // this row's 16 lanes
             if (scanning && hit) {
                 const int fl = __ffs(hit) - 1;
                 const unsigned long long wl = __shfl(w, 16 * sub + fl);
-                found = i + 1 + base + int64_t(fl) * 64 + (__ffsll((long long)wl) - 1);
+                found = (B * 16 + fl) * 64 + (__ffsll((long long)wl) - 1) + shift;  // mask position of the first cached column
                 scanning = false;
             } else {
                 (void)__shfl(w, 16 * sub);  // keep the shuffle convergent for every lane
-                if (base + 16 * 64 >= len) scanning = false;
+                ++B;
+                if (B > B_hi) scanning = false;
             }
         }
     }

@@ -502,7 +502,7 @@ struct tsc_prune {
     int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
     int32_t *bsum = nullptr, *total = nullptr, *tile_cmax = nullptr;
     unsigned long long *mbit = nullptr, *dbit = nullptr;
-    size_t bit_words = 0;
+    size_t bit_words = 0, dsum_words = 0;
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     double *Gall = nullptr;
@@ -634,7 +634,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (!rc) rc = palloc(p, 4, &p->total);
     if (!rc) rc = palloc(p, size_t(n) / 16 + 2, &p->tile_cmax);
     if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
-    if (!rc) rc = palloc(p, p->bit_words, &p->dbit);
+    p->dsum_words = p->bit_words / 1024 + 4;  // one summary bit per 1024 cache-view bits, kept right behind dbit
+    if (!rc) rc = palloc(p, p->bit_words + p->dsum_words, &p->dbit);
     if (!rc) rc = palloc(p, 1, &p->counters);
     if (!rc) rc = palloc(p, 1, &p->state);
     if (!rc) rc = palloc(p, TSC_MAX_PASSES, &p->records);
@@ -719,7 +720,7 @@ static StepArgs next_step_args(const tsc_prune *p, int *next_slot) {
         }
     }
     *next_slot = nxt;
-    return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words) : 0, p->cur_local ? ALGO_LOCAL : -1};
+    return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words + p->dsum_words) : 0, p->cur_local ? ALGO_LOCAL : -1};
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
@@ -739,7 +740,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // 0. open this pass: gate (:192), counters, cache-view bitmap -- already done by the apply kernel of the pass before
     //    it (its last block), by a one-block launch for the first pass of a run
     if (p->opened_slot != slot) {
-        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words), -1};
+        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words + p->dsum_words), -1};  // (zeroes dbit and its summary)
         hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
     }
     p->last_slot = slot;
@@ -754,7 +755,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     if (p->cur_local) {
         if (use_cache)
             hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
-                               (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state);
+                               (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state, p->dbit + p->bit_words);
         LocalPassArgs a;
         a.h = p->h, a.use_cache = use_cache;
         a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
@@ -780,10 +781,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // 1. ranks of the active structures, their index list, the mask as bits, the cache view of this pass
     hipLaunchKernelGGL(k_open_pass, dim3(scan_grid_blocks(n)), dim3(SCAN_THREADS), 0, st, g, use_cache, (const PruneState *)p->state,
                        (const uint8_t *)p->mask, (const int32_t *)p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total,
-                       (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit);
+                       (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit, p->dbit + p->bit_words);
     // 2. stop column, best[] and compacted descriptor of every row
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, p->cend, p->best, p->tile_cmax);
+                       p->dbit, (const unsigned long long *)(p->dbit + p->bit_words), p->cend, p->best, p->tile_cmax);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
