@@ -217,7 +217,7 @@ typedef struct {
     int64_t new_keys;        /* cache keys appended (:76, :204) */
     double gpu_ms;           /* HIP-event time of the whole pass on this device (0 unless "pass_timing" is 2) */
     double tile_ms;          /* HIP-event time of the pass's pair kernel alone (0 unless "pass_timing" >= 1) */
-    int32_t algo;            /* pair kernel used: 1 = register-tiled all-pairs, 2 = descriptor sieve */
+    int32_t algo;            /* kernel that ran the pass: 1 = register-tiled all-pairs, 2 = descriptor sieve, 3 = chunk-local kernel */
     int32_t reserved;
 } tsc_pass_stats;
 
