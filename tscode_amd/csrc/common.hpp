@@ -76,6 +76,8 @@ struct tsc_ctx {
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback
     int pass_timing = 0;                  // HIP events per pass: 0 none, 1 on the pair kernel's dispatch, 2 also around the whole pass
+    std::vector<int32_t> slot_host;       // heavy-atom slot table of the last tsc_pipeline_dev call and its device copy
+    int32_t *slot_dev = nullptr;
     std::vector<hipEvent_t> event_pool;   // recycled timing events of prune runs
 
     int alloc(size_t bytes, void **out) {

@@ -600,7 +600,7 @@ static int get_event(tsc_ctx *c, hipEvent_t *e) {
     return 0;
 }
 
-extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
+static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask_buffer, tsc_prune **out) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
     TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
@@ -622,7 +622,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
     p->bit_words = size_t(n / 64 + 4);
     int rc = 0;
-    if (!rc) rc = palloc(p, size_t(n), &p->mask);
+    if (mask_buffer)
+        p->mask = mask_buffer;  // the caller's verdict buffer serves as the working mask (8-byte aligned, n bytes)
+    else if (!rc)
+        rc = palloc(p, size_t(n), &p->mask);
     if (!rc) rc = palloc(p, size_t(n) + 1, &p->pos);
     if (!rc) rc = palloc(p, size_t(n), &p->act);
     if (!rc) rc = palloc(p, size_t(n), &p->cend);
@@ -671,6 +674,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     }
     *out = p;
     return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
+    return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out) {
@@ -943,7 +950,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
 static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
                      tsc_pass_stats *stats, int *n_passes) {
     tsc_prune *p = nullptr;
-    TSC_TRY(tsc_prune_create(c, heavy, n, h, rmsd_thr, mode, &p));
+    const bool in_place = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;  // run on the caller's buffer: no copy at the end
+    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p));
     int rc = 0;
     for (;;) {
         int64_t k = 0;
@@ -953,7 +961,7 @@ static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double r
     }
     if (!rc) {
         DeviceGuard guard(c->device);
-        hipError_t e = hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
+        hipError_t e = in_place ? hipSuccess : hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
         if (e == hipSuccess && mask_host) e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
     }
@@ -1391,7 +1399,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     }
     int32_t *d_slot, *bsum, *act, *total;
     double *d_heavy;
-    TSC_TRY(upload(c, s, slot.data(), slot.size(), &d_slot));
+    if (c->slot_dev && c->slot_host == slot) {  // same heavy-atom pattern as the last call (a run of steps): no upload
+        d_slot = c->slot_dev;
+    } else {
+        if (c->slot_dev) c->release(c->slot_dev);
+        c->slot_dev = nullptr;
+        void *q = nullptr;
+        TSC_TRY(c->alloc(slot.size() * sizeof(int32_t), &q));
+        c->slot_dev = static_cast<int32_t *>(q);
+        c->slot_host = slot;
+        TSC_HIP(hipMemcpyAsync(c->slot_dev, c->slot_host.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        d_slot = c->slot_dev;
+    }
     TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
     TSC_TRY(s.get(size_t(n_poses), &act));
     TSC_TRY(s.get(1, &total));
@@ -1410,7 +1429,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
                        int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
     TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
-    TSC_TRY(read_i32_finish(c, &n_pass));  // (the copy waited for the scan, hence for the upload of the stack-local `slot` too)
+    TSC_TRY(read_i32_finish(c, &n_pass));
     if (n_pass_host) *n_pass_host = n_pass;
     int64_t n_keep = 0;
     int np = 0;
