@@ -11,10 +11,12 @@
 //    four roots are real, L > lmax  <=>  P(L) > 0, P'(L) > 0, P''(L) > 0 (for L > 0).  A pair is REJECTED
 //    only when the three values exceed a rounding-error bound, so a rejection is always right; every
 //    other pair goes to
+//    (a second test of the same quartic ACCEPTS near-duplicates outright, see pair_verdict)
 //  * the EXACT path (explicit rotation): the quaternion of the optimal rotation is the top eigenvector of
-//    Horn's matrix (cyclic Jacobi, fp64); p is rotated, the residual is formed atom by atom and
-//    rmsd = sqrt(sum |d|^2 / h), maxdev = max |d| are compared with the thresholds exactly as the
-//    reference does (:75).  Values agree with the reference's LAPACK path to ~1e-13.
+//    Horn's matrix (Newton for the eigenvalue + adjugate column, cyclic Jacobi when that degenerates, fp64);
+//    p is rotated, the residual is formed atom by atom and rmsd = sqrt(sum |d|^2 / h), maxdev = max |d| are
+//    compared with the thresholds exactly as the reference does (:75).  Values agree with the reference's
+//    LAPACK path to ~1e-13.
 //
 // No MFMA, no LDS tiles for q: a lane owns one column structure q_j in registers (<= 32 heavy atoms after
 // padding), the row structure p_i is wavefront-uniform and is read through the scalar cache, so the
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// per-pass helper kernels (see prune.hpp for the pass sequence)
+// per-pass helper kernels (the pass sequence is in tscode_hip.hip, tsc_prune_pass_local / tsc_prune_pass_finish)
 
 struct PassGeom {
     int n;   // structures (< 2^31)
@@ -490,8 +492,8 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
 // One 16-lane group per active row i (4 rows per wavefront): cend[r] = rank of the first active column j in (i, last) with
 // (first + (j - i)) in the cache view (the row returns "not similar" there, :66-67), else rank of `last`.
 // Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
-// The same wavefront also initialises best[r] and, for the sieve, copies the row's descriptor (dw doubles of D, original
-// index space) into the two compacted layouts Dr[r][dw] / Dc[k][ld].
+// The same group also initialises best[r]; the block (16 rows = one row tile of the pair kernel) records the tile's largest
+// stop column.
 __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,

@@ -16,16 +16,19 @@
 // explicit-rotation path as the register-tiled kernel (rmsd.hpp).
 //
 // The screen runs in fp32 on mean-centred descriptors.  With M the largest |component| of the ensemble, every computed
-// difference is within eta = 3 * 2^-24 * 2M ... of the exact one (rounding of both operands and of the subtraction), so
-// s_exact >= s32 (1 - 2^-20) - 2 eta sqrt(KD s32); the host turns h thr^2 into the fp32 limit above which that lower
-// bound certainly exceeds h thr^2 (descriptor_limit32).  Pairs in the sliver between the two limits are simply not dropped.
+// difference is within eta = 3 * 2^-24 * 2M of the exact one (rounding of both operands and of the subtraction), so
+// s_exact >= s32 (1 - 2^-20) - 2 eta sqrt(KD s32); screen_limit32 turns h thr^2 into the fp32 limit above which that
+// lower bound certainly exceeds h thr^2.  Pairs in the sliver between the two limits are simply not dropped.
 //
-// Pass kernel: one wavefront = 16 rows x one column segment, lane = column.
-//   screen : the lane keeps its column's descriptor (2*KD doubles, coalesced load per 64-column tile); the 16 row
-//            descriptors sit in LDS and are read as broadcasts; 4*KD flops per pair; survivors go to a per-wavefront
-//            LDS queue (ballot + prefix popcount);
-//   drain  : whenever the queue holds 64 pairs, lane l takes pair l: H from the two structures in memory (L1/L2
-//            resident), sign test, exact path; atomicMin(best[row], column).
+// Pass kernel (k_rmsd_sieve): one wavefront = 16 rows x one column segment, lane = CPL columns of a tile.
+//   screen : descriptors are gathered straight from the per-structure table through the active list (no per-pass
+//            copy); the two families of a component sit side by side, so one v_pk_add_f32 + one v_pk_fma_f32 advance both
+//            distances; the 16 row descriptors sit in LDS and are read as broadcasts; ONE compare per (row, tile) decides
+//            whether any column is within the limit; survivors go to a per-wavefront LDS queue (ballot + prefix popcount);
+//   drain  : stage 1, whenever the queue holds 64 pairs (or at the end, spread over several lanes per pair): H from the
+//            two structures in memory, the quartic tests (reject / accept near-duplicates / undecided);
+//            stage 2, the explicit rotation for the undecided, when 64 have gathered or at the end;
+//            atomicMin(best[row], column).
 // Any number of heavy atoms is supported (no register-resident structure).
 #pragma once
 #include "common.hpp"
