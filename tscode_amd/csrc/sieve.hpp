@@ -96,6 +96,26 @@ __device__ inline float screen_limit32(float dmaxf, double limit) {
     return (l32 < 3.0e38) ? f : 3.4e38f;
 }
 
+// The same limit for the screen as the pair kernel computes it: S = fl(fl(|a|^2 + |b|^2) - 2 fl(a.b)) on the stored fp32
+// vectors a, b (8-term fma chains), which costs 10 packed instructions per column instead of 16 for sum (a_k - b_k)^2.  With
+// u = 2^-24 and g8 = 8u / (1 - 8u):  | |a|^2_fl - |a|^2 | <= g8 |a|^2,  | a.b_fl - a.b | <= g8 (|a|^2 + |b|^2) / 2,  so the
+// exact T = |a - b|^2 satisfies  T >= S (1 - 2u) - E,  E = (2 g8 + u (1 + g8)) (|a|^2 + |b|^2) <= (2 g8 + u (1 + g8)) 2 KD M^2.
+// The stored components are roundings of the exact descriptors, each difference within eta = 3 * 2^-24 * 2M of the exact
+// one as above, so s_exact >= T - 2 eta sqrt(KD T) (increasing in T beyond KD eta^2): a pair whose S exceeds the returned
+// value certainly has s_exact > limit.
+__device__ inline float screen_limit32_dot(float dmaxf, double limit) {
+    const double dmax = (dmaxf >= 0.0f && dmaxf < 3.0e38f) ? double(dmaxf) : 3.0e38;
+    constexpr double U = 5.9604644775390625e-08, G8 = 8.0 * U / (1.0 - 8.0 * U);
+    const double eta = 3.0 * U * 2.0 * dmax;
+    const double b = 2.0 * eta * sqrt(double(KD));
+    const double y = 0.5 * (b + sqrt(b * b + 4.0 * limit));   // sqrt of the smallest T with T - b sqrt(T) >= limit
+    const double E = (2.0 * G8 + U * (1.0 + G8)) * 2.0 * double(KD) * dmax * dmax;
+    const double l32 = (y * y + E) / (1.0 - 2.0 * U) * (1.0 + 1e-6) + 1e-30;
+    float f = float(l32);
+    if (double(f) < l32) f = __uint_as_float(__float_as_uint(f) + 1u);  // next float up (f > 0)
+    return (l32 < 3.0e38) ? f : 3.4e38f;
+}
+
 // D[i][2k + fam] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space, the two families
 // interleaved; the bias is the projection of the mean feature vector and cancels in every difference),
 // G[i] = sum_a |x_ia|^2; *dmax_bits = max |D| over everything as the bit pattern of a non-negative float (atomicMax on the
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     __shared__ unsigned short s_exq[4][128];  // pairs that the sign test could not reject, waiting for the exact path
     __shared__ double s_jacobi[4][32];        // scratch of the Jacobi fallback of the exact path (rmsd.hpp), per wavefront
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
+    __shared__ f32x2 s_rownorm[4][TI];  // |row descriptor|^2 per family
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * 4 + wid;
@@ -442,11 +463,12 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     unsigned alive = unsigned(__ballot(live0));
     if (!alive) return;
 
-    const float limit32 = screen_limit32(__uint_as_float(*a.dmax_bits), a.desc_limit);
+    const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
     float rd_stage[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
     f32x2 dq[CPL][KD];  // .x = family 0, .y = family 1
+    f32x2 cn[CPL];      // their squared norms
     auto load_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < CPL; ++u) {
@@ -457,6 +479,10 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
                 dq[u][2 * k] = f32x2{v.x, v.y};
                 dq[u][2 * k + 1] = f32x2{v.z, v.w};
             }
+            f32x2 nc = {0.0f, 0.0f};  // |column descriptor|^2 per family, once per tile (shared by its 16 rows)
+#pragma unroll
+            for (int k = 0; k < KD; ++k) nc = __builtin_elementwise_fma(dq[u][k], dq[u][k], nc);
+            cn[u] = nc;
         }
     };
     load_tile();
@@ -470,6 +496,14 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     float *rowdesc = s_rowdesc[wid];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < TI) {  // squared norms of the row descriptors, per family
+        const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
+        f32x2 nr = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
+        s_rownorm[wid][lane] = nr;
+    }
     __builtin_amdgcn_wave_barrier();
 
     const int h3 = a.h * 3;
@@ -608,17 +642,17 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
                 for (int k = 0; k < KD; ++k) rd[k] = dr[k];
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
                 n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
-                // larger of the two family distances for the lane's CPL columns: packed fp32 (v_pk_add_f32 / v_pk_fma_f32
-                // handle both families in one instruction), four independent chains
+                // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
+                // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
+                // the error bound)
+                const f32x2 nr = s_rownorm[wid][t];
                 float mx[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL; ++u) {
-                    f32x2 s2 = {0.0f, 0.0f};
+                    f32x2 dot = {0.0f, 0.0f};
 #pragma unroll
-                    for (int k = 0; k < KD; ++k) {
-                        const f32x2 d = rd[k] - dq[u][k];
-                        s2 = __builtin_elementwise_fma(d, d, s2);
-                    }
+                    for (int k = 0; k < KD; ++k) dot = __builtin_elementwise_fma(rd[k], dq[u][k], dot);
+                    const f32x2 s2 = __builtin_elementwise_fma(dot, f32x2{-2.0f, -2.0f}, nr + cn[u]);
                     mx[u] = fmaxf(s2.x, s2.y);
                 }
                 if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: mask the columns outside
