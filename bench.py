@@ -233,14 +233,14 @@ def main():
         hbm_achieved = b_launch / avg_launch_s / 1e9 if avg_launch_s else None
         # SURVEY.md 8(d) flop accounting beside it: the reference's own pair evaluations x (46 h + 500) flop each over the
         # kernel time.  The sieve reaches the reference's verdicts without forming H for most pairs, so this "algorithmic"
-        # figure exceeds the FP64 peak; `executed` is what the instructions really do: the fp32 screen (2 families x 8
-        # components x (sub + fma) = 48 flop per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per
+        # figure exceeds the FP64 peak; `executed` is what the instructions really do: the fp32 screen (2 families x (8 fma +
+        # add + fma) = 34 flop per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per
         # pair that reaches them; register-tiled kernel: every computed pair, h padded to a multiple of 4)
         evals_big = sum(s["pairs_evaluated"] for s in big)
         screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
         achieved_alg = evals_big * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
         if screened_big:
-            f32_flops = screened_big * 48
+            f32_flops = screened_big * 34        # dot-product form: 2 families x (8 fma + add + fma) per pair
             f64_flops = computed_big * (18 * h + 110)
         else:
             f32_flops = 0.0
