@@ -119,6 +119,14 @@ int tsc_compact_rows_dev(tsc_ctx *ctx, const void *src, const uint8_t *mask, int
                          int64_t *n_kept_host);
 int tsc_gather_heavy_dev(tsc_ctx *ctx, const double *coords, const uint8_t *mask, int64_t n_poses, int n_atoms,
                          const int32_t *heavy_idx_host, int n_heavy, double *heavy_out, int64_t *n_kept_host);
+/* The first half of tsc_pipeline_dev on its own (one rank's block of the pose axis in the sharded protocol): fused
+ * embed + clash verdicts, ordered compaction, then the passing poses embedded straight into `structures` (all atoms,
+ * may be NULL) and `heavy` (their heavy atoms, f64[n_pass, n_heavy, 3]) -- rejected poses are never materialised.
+ * n_pass_host receives the count (the call synchronises for it while the embed runs). */
+int tsc_embed_clash_compact_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
+                                int n_mols, const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses,
+                                const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, uint8_t *clash_mask,
+                                double *structures, double *heavy, int64_t *n_pass_host);
 
 /* ---- K3: Kabsch RMSD (no centring) ------------------------------------------------------------
  * Replaces rmsd_and_max_numba (tscode/rmsd_pruning.py:6-41) on listed pairs of one heavy-atom array:

@@ -1364,6 +1364,59 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(
 // --------------------------------------------------------------------------------------------------
 // pipeline
 
+// heavy_slot[a] = rank of atom a among the heavy atoms, -1 for the others; kept on the device between calls
+static int heavy_slot_table(tsc_ctx *c, const FragTable &ft, const int32_t *heavy_idx, int n_heavy, int32_t **d_slot) {
+    std::vector<int32_t> slot(size_t(ft.n_total), -1);
+    for (int a = 0; a < n_heavy; ++a) {
+        TSC_REQUIRE(heavy_idx[a] >= 0 && heavy_idx[a] < ft.n_total && (a == 0 || heavy_idx[a] > heavy_idx[a - 1]),
+                    "heavy_idx must be strictly increasing atom indices");
+        slot[size_t(heavy_idx[a])] = a;
+    }
+    if (!(c->slot_dev && c->slot_host == slot)) {  // (same heavy-atom pattern as the last call: no upload)
+        if (c->slot_dev) c->release(c->slot_dev);
+        c->slot_dev = nullptr;
+        void *q = nullptr;
+        TSC_TRY(c->alloc(slot.size() * sizeof(int32_t), &q));
+        c->slot_dev = static_cast<int32_t *>(q);
+        c->slot_host = slot;
+        TSC_HIP(hipMemcpyAsync(c->slot_dev, c->slot_host.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    *d_slot = c->slot_dev;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                                                                  const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                                                                  const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy,
+                                                                                  double clash_thresh, int64_t max_clashes, uint8_t *clash_mask,
+                                                                                  double *structures, double *heavy, int64_t *n_pass_host) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && clash_mask && heavy && n_pass_host, "tsc_embed_clash_compact_dev: null argument");
+    TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX, "bad n_poses");
+    *n_pass_host = 0;
+    if (n_poses == 0) return 0;
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    TSC_REQUIRE(n_heavy > 0 && n_heavy <= ft.n_total, "bad n_heavy");
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->stream;
+    Scratch s(c);
+    int32_t *d_slot, *bsum, *act, *total;
+    TSC_TRY(heavy_slot_table(c, ft, heavy_idx, n_heavy, &d_slot));
+    TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
+    TSC_TRY(s.get(size_t(n_poses), &act));
+    TSC_TRY(s.get(1, &total));
+    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes, clash_mask, nullptr));
+    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
+    TSC_TRY(read_i32_begin(c, total));
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256, 256 * 64)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
+                       int64_t(0), structures, (const int32_t *)d_slot, n_heavy, heavy, (const int32_t *)total);
+    TSC_HIP(hipGetLastError());
+    int32_t n_pass = 0;
+    TSC_TRY(read_i32_finish(c, &n_pass));
+    *n_pass_host = n_pass;
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
                                 int n_mols, const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses,
                                 const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, double rmsd_thr, int mode,
@@ -1390,27 +1443,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     } evg{c, ev};
     if (timed)
         for (auto &e : ev) TSC_TRY(get_event(c, &e));
-    // heavy_slot[a] = rank of atom a among the heavy atoms, -1 for the others
-    std::vector<int32_t> slot(size_t(ft.n_total), -1);
-    for (int a = 0; a < n_heavy; ++a) {
-        TSC_REQUIRE(heavy_idx[a] >= 0 && heavy_idx[a] < ft.n_total && (a == 0 || heavy_idx[a] > heavy_idx[a - 1]),
-                    "heavy_idx must be strictly increasing atom indices");
-        slot[size_t(heavy_idx[a])] = a;
-    }
     int32_t *d_slot, *bsum, *act, *total;
     double *d_heavy;
-    if (c->slot_dev && c->slot_host == slot) {  // same heavy-atom pattern as the last call (a run of steps): no upload
-        d_slot = c->slot_dev;
-    } else {
-        if (c->slot_dev) c->release(c->slot_dev);
-        c->slot_dev = nullptr;
-        void *q = nullptr;
-        TSC_TRY(c->alloc(slot.size() * sizeof(int32_t), &q));
-        c->slot_dev = static_cast<int32_t *>(q);
-        c->slot_host = slot;
-        TSC_HIP(hipMemcpyAsync(c->slot_dev, c->slot_host.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        d_slot = c->slot_dev;
-    }
+    TSC_TRY(heavy_slot_table(c, ft, heavy_idx, n_heavy, &d_slot));
     TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
     TSC_TRY(s.get(size_t(n_poses), &act));
     TSC_TRY(s.get(1, &total));

@@ -140,6 +140,18 @@ class Engine:
                                                 C.c_int64(n_poses), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(mask),
                                                 ptr(counts)))
 
+    def embed_clash_compact_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, heavy_idx, thresh, max_clashes, mask,
+                                structures, heavy) -> int:
+        """Fused embed + clash verdicts, then the passing poses embedded straight into ``structures`` (may be None) and ``heavy``.
+        Returns how many passed."""
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        n_pass = C.c_int64()
+        check(self.lib.tsc_embed_clash_compact_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos),
+                                                   C.c_int64(n_poses), heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)),
+                                                   C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(mask), ptr(structures), ptr(heavy),
+                                                   C.byref(n_pass)))
+        return n_pass.value
+
     def all_dists(self, a, b) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -53,7 +53,8 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
     dist.all_reduce(backend.counts, op=dist.ReduceOp.SUM, group=group)
     counts = [int(c) for c in backend.counts.cpu().tolist()]
     # the one exchange of coordinates: padded shards, one all-gather, then un-pad in block order
-    backend.heavy_pad[:n_pass_local].copy_(backend.heavy_local[:n_pass_local])
+    if backend.heavy_pad.data_ptr() != backend.heavy_local.data_ptr():
+        backend.heavy_pad[:n_pass_local].copy_(backend.heavy_local[:n_pass_local])
     dist.all_gather_into_tensor(backend.gather.view(-1), backend.heavy_pad.view(-1), group=group)
     off = 0
     for r, c in enumerate(counts):
@@ -137,11 +138,10 @@ class HipShardBackend:
         na, nl = ens.n_atoms, max(self.n_local, 1)
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.clash = torch.empty(nl, dtype=torch.uint8, device=self.dev)
-        self.all_poses = torch.empty((nl, na, 3), **f64)
         self.structures = torch.empty((nl, na, 3), **f64)
-        self.heavy_local = torch.empty((nl, h, 3), **f64)
         self.max_local = (n + world - 1) // world + 1
         self.heavy_pad = torch.zeros((self.max_local, h, 3), **f64)
+        self.heavy_local = self.heavy_pad[:nl]                     # this rank's survivors land in the send buffer directly
         self.gather = torch.empty((world * self.max_local, h, 3), **f64)
         self.heavy_all = torch.empty((n, h, 3), **f64)
         self.best = torch.empty(n, dtype=torch.int32, device=self.dev)
@@ -151,14 +151,10 @@ class HipShardBackend:
         torch.cuda.synchronize(self.dev)
 
     def embed_clash_block(self):
-        e = self.eng
-        e.embed_clash_mask_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.clash_thresh,
-                               self.max_clashes, self.clash)
-        e.transform_batch_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.all_poses)
-        n_pass = e.compact_rows_dev(self.all_poses, self.clash, self.n_local, self.ens.n_atoms * 24, self.structures)
-        if n_pass:
-            e.gather_heavy_dev(self.structures, None, n_pass, self.ens.n_atoms, self.heavy_idx, self.heavy_local)
-        return n_pass
+        # fused verdicts, then only the passing poses are embedded: straight into `structures` and into the padded send
+        # buffer of the all-gather (heavy_local is a view of it)
+        return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.heavy_idx,
+                                                self.clash_thresh, self.max_clashes, self.clash, self.structures, self.heavy_local)
 
     def make_stepper(self, n_pass):
         st = self.eng.prune_stepper(self.heavy_all, n_pass, self.h, self.rmsd_thr, self.mode)
