@@ -50,7 +50,9 @@ const char *tsc_last_error(void);
 int tsc_device_count(void); /* >= 0, or a negative tsc_status */
 int tsc_ctx_create(int device, tsc_ctx **out);
 int tsc_ctx_destroy(tsc_ctx *ctx);
-/* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Run on a caller-provided hipStream_t; NULL = the library's own (non-blocking) stream.  Note that PyTorch's DEFAULT stream has
+ * the handle 0 = NULL: to order this library's kernels with torch work (copies, RCCL collectives) make an explicit
+ * torch.cuda.Stream current and pass its .cuda_stream here (tscode_amd/pipeline.py does). */
 int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
 int tsc_ctx_synchronize(tsc_ctx *ctx);
 /* Tunables.  "prune_algo": 0 = automatic (default), 1 = register-tiled all-pairs kernel (<= 32 heavy atoms),

@@ -1,0 +1,45 @@
+"""Worker of tests/test_gpu_parity.py::test_sharded_protocol_on_gpu_ranks: one rank of the sharded pipeline on the HIP
+backend.  Launched by torch.distributed.run with the gloo backend, so that several ranks can share the box's one GPU
+(device tensors are staged over the host for the collectives; under nccl = RCCL nothing is staged).
+Rank 0 prints one JSON line."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    cfg, n_poses, min_pairs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    from tscode_amd.pipeline import DevicePipeline
+    from tscode_amd.synthetic import make_config
+    ens = make_config(cfg, n_poses if n_poses > 0 else None)
+    pipe = DevicePipeline(ens, device_index=0, rank=rank, world=world, mode=0, shard_min_pairs=min_pairs if min_pairs > 0 else None)
+    res = None
+    for _ in range(2):                                   # a second step on the same state: buffers are reused
+        res = pipe.step()
+    torch.cuda.synchronize()
+    keep = pipe.h_keep[:res["n_pass"]].numpy().copy()
+    digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
+    flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64)
+    gathered = [torch.zeros_like(flags) for _ in range(world)]
+    dist.all_gather(gathered, flags)
+    if rank == 0:
+        sharded_passes = [s["k"] for s in res["stats"] if s["algo"] in (1, 2)]
+        print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "keep_sha256_16": digest,
+                          "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"],
+                          "pairs_evaluated": [s["pairs_evaluated"] for s in res["stats"]], "global_path_passes": sharded_passes}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -383,6 +383,10 @@ class _SoloDist:
         SUM, MIN = "sum", "min"
 
     @staticmethod
+    def get_backend(group=None):
+        return "solo"
+
+    @staticmethod
     def all_reduce(t, op=None, group=None):
         return None
 
@@ -711,3 +715,38 @@ def test_adjacent_rows_edge_cases(eng, oracle):
     # N1: no sites
     r, p, c = eng.string_embed_params(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2), np.int32), [0.0, 10.0])
     assert r.shape == (0, 2, 3, 3) and p.shape == (0, 2, 3) and c.shape == (0, 2)
+
+
+@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000)])
+def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
+    """The multi-rank protocol on the product backend (HIP kernels), several ranks sharing this box's one GPU: gloo as the
+    transport (device tensors staged over the host), everything else as under RCCL -- pose blocks, all-gather of the
+    survivors' heavy atoms, row tiles of the large passes dealt round-robin with all-reduce(MIN), small passes replicated.
+    C3 with two ranks against the recorded oracle result; C2 with three ranks and the sharding threshold lowered so that
+    small passes are sharded too, against the oracle run here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "sharded_gpu_worker.py"), cfg, str(n_poses), str(min_pairs)]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got["world"] == world and got["ranks_agree"]
+    if cfg == "C3":
+        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))["C3:100000:mode0"]
+        assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
+        assert got["pairs_evaluated"] == [p["pairs_evaluated"] for p in exp["passes"]]
+    else:
+        from tscode_amd.synthetic import make_config
+        ens = make_config(cfg)
+        poses = ens.poses()
+        poses = poses[oracle.compenetration_mask(poses, ens.ids, 1.5, 0)]
+        ref = oracle.prune_heavy(np.ascontiguousarray(poses[:, ens.atomnos != 1]), 0.5, mode=0, row_parallel=True)
+        assert got["n_pass"] == len(poses) and got["n_keep"] == int(ref["mask"].sum())
+        assert got["pairs_evaluated"] == [s["pairs_evaluated"] for s in ref["stats"]]
+        assert len(got["global_path_passes"]) >= 3            # the lowered threshold really sharded passes

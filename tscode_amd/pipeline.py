@@ -37,8 +37,43 @@ def block_bounds(n: int, rank: int, world: int):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-def sharded_step(backend, rank: int, world: int, dist, group=None):
-    """One step of the hot path over an ensemble sharded across ``world`` ranks.
+def _staged(dist, t, group):
+    """gloo moves CUDA tensors only for a few collectives: with it (several ranks rehearsing on one GPU, tests) device tensors
+    take the detour over the host.  Under nccl (= RCCL) nothing is staged."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(dist, t, op, group):
+    if _staged(dist, t, group):
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather(dist, out, inp, group):
+    if _staged(dist, inp, group):
+        co, ci = out.cpu(), inp.cpu()
+        dist.all_gather_into_tensor(co, ci, group=group)
+        out.copy_(co)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=None):
+    """One step of the hot path over an ensemble sharded across ``world`` ranks, run inside ``backend.stream_context()`` when the
+    backend has one (the HIP backend makes its own torch stream current, so that its kernels, torch's copies and the
+    collectives are ordered on one stream)."""
+    enter = getattr(backend, "stream_context", None)
+    if enter is None:
+        return _sharded_step(backend, rank, world, dist, group, min_pairs)
+    with enter():
+        return _sharded_step(backend, rank, world, dist, group, min_pairs)
+
+
+def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
+    """The protocol itself.
 
     backend interface (all tensors live where the backend computes):
         embed_clash_block() -> n_pass_local      fills backend.heavy_local[:n_pass_local]  (h, 3 per row)
@@ -50,12 +85,12 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
     # how many poses of every block passed the clash check
     backend.counts.zero_()
     backend.counts[rank] = n_pass_local
-    dist.all_reduce(backend.counts, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(dist, backend.counts, dist.ReduceOp.SUM, group)
     counts = [int(c) for c in backend.counts.cpu().tolist()]
     # the one exchange of coordinates: padded shards, one all-gather, then un-pad in block order
     if backend.heavy_pad.data_ptr() != backend.heavy_local.data_ptr():
         backend.heavy_pad[:n_pass_local].copy_(backend.heavy_local[:n_pass_local])
-    dist.all_gather_into_tensor(backend.gather.view(-1), backend.heavy_pad.view(-1), group=group)
+    _all_gather(dist, backend.gather.view(-1), backend.heavy_pad.view(-1), group)
     off = 0
     for r, c in enumerate(counts):
         backend.heavy_all[off:off + c].copy_(backend.gather[r * backend.max_local:r * backend.max_local + c])
@@ -69,9 +104,9 @@ def sharded_step(backend, rank: int, world: int, dist, group=None):
                 k = st.next_pass()
                 if k == 0:
                     break
-                if world > 1 and st.pass_estimate() >= SHARD_MIN_PAIRS:
+                if world > 1 and st.pass_estimate() >= (SHARD_MIN_PAIRS if min_pairs is None else min_pairs):
                     st.pass_local(rank, world)          # this rank's row tiles only ...
-                    dist.all_reduce(backend.best[:st.n_active()], op=dist.ReduceOp.MIN, group=group)   # ... merged
+                    _all_reduce(dist, backend.best[:st.n_active()], dist.ReduceOp.MIN, group)   # ... merged
                 else:
                     st.pass_local(0, 1)                 # small pass: replicated, no exchange
                 st.pass_finish()
@@ -124,8 +159,11 @@ class HipShardBackend:
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
         self.eng = get_engine(device_index)
-        # this library's kernels, torch copies and RCCL collectives are all ordered on torch's current stream
-        self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        # This library's kernels, torch's copies and the collectives must be ordered on ONE stream.  torch's default stream
+        # has handle 0, which tsc_ctx_set_stream reads as "use the library's own stream": a dedicated torch stream is made
+        # current for every step instead (torch.distributed orders its collectives against the current stream).
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.eng.set_stream(self.stream.cuda_stream)
         self.fs = FragmentSet(ens.frag_coords)
         n = ens.n_poses
         self.lo, self.hi = block_bounds(n, rank, world)
@@ -150,6 +188,9 @@ class HipShardBackend:
         self.keep_host = torch.empty(n, dtype=torch.uint8).pin_memory()
         torch.cuda.synchronize(self.dev)
 
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
     def embed_clash_block(self):
         # fused verdicts, then only the passing poses are embedded: straight into `structures` and into the padded send
         # buffer of the all-gather (heavy_local is a view of it)
@@ -164,12 +205,13 @@ class HipShardBackend:
 
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
-                 process_group=None, force_sharded=False):
+                 process_group=None, force_sharded=False, shard_min_pairs=None):
         import torch
         self.torch, self.ens = torch, ens
         self.rank, self.world, self.pg = int(rank), int(world), process_group
         self.params = (clash_thresh, max_clashes, rmsd_thr, mode)
         self.sharded = self.world > 1 or force_sharded
+        self.shard_min_pairs = shard_min_pairs                  # None: SHARD_MIN_PAIRS (tests lower it to shard small passes too)
         if self.sharded:
             self.backend = HipShardBackend(ens, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
             self.d_keep, self.d_clash, self.d_structures = self.backend.keep, self.backend.clash, self.backend.structures
@@ -178,7 +220,7 @@ class DevicePipeline:
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
         self.eng = get_engine(device_index)
-        self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.eng.set_stream(None)                           # the library's own stream: a step makes no torch call
         self.fs = FragmentSet(ens.frag_coords)
         n = ens.n_poses
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -197,4 +239,4 @@ class DevicePipeline:
             c, m, r, mode = self.params
             return self.eng.pipeline_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx,
                                          c, m, r, mode, self.d_clash, self.d_structures, self.d_keep, self.h_keep)
-        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg)
+        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs)
