@@ -559,6 +559,30 @@ def test_csearch_rotations_vs_oracle_large(eng, oracle):
     ok = eng.torsion_comp_check(out[:500], torsions[0], masks[0], 1.4, 0)
     assert ok.tolist() == [oracle.torsion_comp_check(o, torsions[0], masks[0], 1.4) for o in out[:500]]
     assert 0 < (rb == 0).sum() + (rb > 0).sum() and len(np.unique(rb)) > 2
+    # a small rotating group (3 atoms: the wavefront is cut into slices of the fixed side), alone and next to a large one
+    masks2 = masks.copy()
+    masks2[0] = 0
+    masks2[0, centres[0] + 1:centres[0] + 4] = 1
+    masks2[3] = 0
+    masks2[3, centres[3] + 1] = 1
+    r2, rb2, margin = oracle.csearch_rotate(coords, torsions, masks2, angles[:1500], 1.4, 0, return_margin=True)
+    assert margin > 1e-9
+    o2, b2 = eng.csearch_rotate(coords, torsions, masks2, angles[:1500], 1.4, 0)
+    assert np.array_equal(b2, rb2) and np.abs(o2 - r2).max() < VAL_TOL
+    # clashes allowed (the fp64 count path)
+    r3, rb3 = oracle.csearch_rotate(coords, torsions, masks, angles[:800], 1.4, 3)
+    o3, b3 = eng.csearch_rotate(coords, torsions, masks, angles[:800], 1.4, 3)
+    assert np.array_equal(b3, rb3) and np.abs(o3 - r3).max() < VAL_TOL and not np.array_equal(rb3, ref_rb[:800])
+    ok3 = eng.torsion_comp_check(out[:300], torsions[2], masks[2], 1.4, 2)
+    assert ok3.tolist() == [oracle.torsion_comp_check(o, torsions[2], masks[2], 1.4, 2) for o in out[:300]]
+    # thresholds a hair above / below the smallest moved-fixed distance of a structure: inside the fp32 band, decided in fp64
+    x = out[7]
+    mv, fx = masks[1].astype(bool), ~masks[1].astype(bool)
+    fx[torsions[1][1]] = fx[torsions[1][2]] = False
+    dmin = np.sqrt(((x[mv][:, None] - x[fx][None]) ** 2).sum(-1)).min()
+    for thr, want in ((dmin * (1 + 1e-9), 0), (dmin * (1 - 1e-9), 1)):
+        assert oracle.torsion_comp_check(x, torsions[1], masks[1], thr) == want
+        assert eng.torsion_comp_check(x[None], torsions[1], masks[1], thr, 0).tolist() == [want]
 
 
 # ----------------------------------------------------------------------------- N1: string-embed pose parameters

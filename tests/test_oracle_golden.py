@@ -178,3 +178,22 @@ def test_g9_moments_and_scores(oracle):
         assert margin > 1e-9 and np.array_equal(first, ref)
     sc, err = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
     assert np.abs(sc - g["scores"]).max() < 1e-6 and np.abs(err - g["fitness_error"]).max() < 1e-12
+
+
+def test_tfd_single_match_chunks_need_no_graph():
+    """The shortcut of _tfd_reject_matches for chunks with one match against the graph step itself (networkx) on the same input."""
+    from tscode_amd.numba_functions import _tfd_reject_matches, _tfd_reject_graph
+    rng = np.random.default_rng(5)
+    n, d, k = 5000, 10, 500
+    first = np.full(n, -1, dtype=np.int32)
+    for c in rng.choice(k, size=300, replace=False):              # one match (i, j > i) in each of 300 chunks ...
+        i = c * d + rng.integers(0, d - 1)
+        first[i] = rng.integers(i + 1, (c + 1) * d)
+    for c in rng.choice(k, size=40, replace=False):               # ... and a few chunks with several
+        if np.all(first[c * d:(c + 1) * d] < 0):
+            first[c * d], first[c * d + 3] = c * d + 5, c * d + 7
+    a, b = np.ones(n, dtype=bool), np.ones(n, dtype=bool)
+    _tfd_reject_matches(first, d, k, a)
+    rows = np.flatnonzero(first >= 0)
+    _tfd_reject_graph(first, d, k, b, [rows[rows // d == c] for c in np.unique(rows // d)])
+    assert np.array_equal(a, b) and a.sum() < n - 300

@@ -9,6 +9,7 @@
 // lanes are atoms, the torsions run in order with the data-dependent back-off loop inside.
 #pragma once
 #include "common.hpp"
+#include "embed_clash.hpp"
 #include "rmsd.hpp"
 
 namespace tsc {
@@ -33,17 +34,60 @@ __device__ inline void rot_mat_from_pointer_dev(const double ax[3], double angle
     R[6] = 2 * (q1 * q3 - q0 * q2), R[7] = 2 * (q2 * q3 + q0 * q1), R[8] = 2 * (q0 * q0 + q3 * q3) - 1;
 }
 
-// utils.py:389-414 on a structure in LDS: every lane forms the (wave-uniform) matrix, lanes with a masked atom apply it.
+// Per torsion the atoms split into the side that turns (`moved`: mask set) and the side it is checked against (`fixed`:
+// mask clear, the bond atoms i2, i3 aside -- numba_functions.py:36-39).  A workgroup compacts both index lists of every
+// torsion into LDS once; the kernels then walk lists, not masks.
+struct TorsionLists {
+    uint16_t *moved, *fixed;  // [n_tors][n]
+    int *count;               // [n_tors][2] = (n_moved, n_fixed)
+};
+
+__host__ __device__ inline size_t torsion_lists_bytes(int n_tors, int n) {
+    return (size_t(n_tors) * n * 2 * sizeof(uint16_t) + size_t(n_tors) * 2 * sizeof(int) + 15) & ~size_t(15);
+}
+
+// LDS of one wavefront: the structure in fp64 and the fixed side of the current torsion as three packed fp32 arrays
+__host__ __device__ inline size_t csearch_wave_bytes(int n) { return size_t(n) * 3 * sizeof(double) + size_t(3) * ((n + 2) & ~1) * sizeof(float); }
+
+__device__ inline TorsionLists torsion_lists_at(void *lds, int n_tors, int n) {
+    TorsionLists L;
+    L.moved = static_cast<uint16_t *>(lds);
+    L.fixed = L.moved + size_t(n_tors) * n;
+    L.count = reinterpret_cast<int *>(L.fixed + size_t(n_tors) * n);
+    return L;
+}
+
+__device__ inline void build_torsion_lists(TorsionLists L, const uint8_t *__restrict__ masks, const int32_t *__restrict__ tors, int n_tors, int n) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int t = wid; t < n_tors; t += nw) {
+        const uint8_t *mask = masks + size_t(t) * n;
+        const int i2 = tors[4 * t + 1], i3 = tors[4 * t + 2];
+        int nm = 0, nf = 0;
+        for (int a0 = 0; a0 < n; a0 += 64) {
+            const int a = a0 + lane;
+            const bool mv = a < n && mask[a] != 0;
+            const bool fx = a < n && !mv && a != i2 && a != i3;
+            const unsigned long long bm = __ballot(mv), bf = __ballot(fx), below = (1ull << lane) - 1ull;
+            if (mv) L.moved[size_t(t) * n + nm + __popcll(bm & below)] = uint16_t(a);
+            if (fx) L.fixed[size_t(t) * n + nf + __popcll(bf & below)] = uint16_t(a);
+            nm += __popcll(bm), nf += __popcll(bf);
+        }
+        if (lane == 0) L.count[2 * t] = nm, L.count[2 * t + 1] = nf;
+    }
+    __syncthreads();
+}
+
+// utils.py:389-414 on a structure in LDS: every lane forms the (wave-uniform) matrix, lanes apply it to the moved atoms.
 // If i3 itself is masked it maps onto itself exactly (its offset from the centre is zero), so no lane reads a value that
 // another lane is changing.
-__device__ inline void rotate_dihedral_lds(double *c, int n, int i2, int i3, double angle_deg, const uint8_t *__restrict__ mask, int lane) {
+__device__ inline void rotate_dihedral_lds(double *c, int i2, int i3, double angle_deg, const uint16_t *moved, int nm, int lane) {
     const double ax[3] = {c[3 * i2] - c[3 * i3], c[3 * i2 + 1] - c[3 * i3 + 1], c[3 * i2 + 2] - c[3 * i3 + 2]};
     const double cen[3] = {c[3 * i3], c[3 * i3 + 1], c[3 * i3 + 2]};
     double R[9];
     rot_mat_from_pointer_dev(ax, angle_deg, R);
     __builtin_amdgcn_wave_barrier();
-    for (int a = lane; a < n; a += 64) {
-        if (!mask[a]) continue;
+    for (int r = lane; r < nm; r += 64) {
+        const int a = moved[r];
         const double v0 = c[3 * a] - cen[0], v1 = c[3 * a + 1] - cen[1], v2 = c[3 * a + 2] - cen[2];
         c[3 * a] = R[0] * v0 + R[1] * v1 + R[2] * v2 + cen[0];
         c[3 * a + 1] = R[3] * v0 + R[4] * v1 + R[5] * v2 + cen[1];
@@ -52,15 +96,71 @@ __device__ inline void rotate_dihedral_lds(double *c, int n, int i2, int i3, dou
     __builtin_amdgcn_wave_barrier();
 }
 
-// numba_functions.py:26-47 on a structure in LDS (wave-uniform result): 1 = passes
-__device__ inline int torsion_comp_check_lds(const double *c, int n, int i2, int i3, const uint8_t *__restrict__ mask, double sq_bound,
-                                             long long max_clashes, int lane) {
+// The fixed side of a torsion as packed fp32 (F = X[npad] Y[npad] Z[npad], an odd tail padded far away); returns the largest
+// |coordinate| among the fixed atoms (wave-uniform).  The fixed atoms do not move while the torsion is walked back.
+__device__ inline double stage_fixed_f32(const double *c, const uint16_t *fixed, int nf, float *F, int npad, int lane) {
+    double cmax = 0.0;
+    for (int j = lane; j < nf; j += 64) {
+        const int b = fixed[j];
+        const double x = c[3 * b], y = c[3 * b + 1], z = c[3 * b + 2];
+        F[j] = float(x), F[npad + j] = float(y), F[2 * npad + j] = float(z);
+        cmax = fmax(cmax, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+    }
+    if (lane == 0 && (nf & 1)) F[nf] = F[npad + nf] = F[2 * npad + nf] = 1.0e18f;
+    for (int off = 32; off > 0; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+    __builtin_amdgcn_wave_barrier();
+    return cmax;
+}
+
+// numba_functions.py:26-47 on a structure in LDS (wave-uniform result): 1 = passes.  Lanes are laid out as A moved atoms x
+// G slices of the fixed list (A the power of two covering min(n_moved, 64)), so that a small rotating group still fills
+// the wavefront.  With max_clashes == 0 (the reference's only use) the verdict is "no distance below thresh": the minimum
+// is taken in packed fp32 against the staged fixed side and decided with the rigorous band of k_clash (embed_clash.hpp:
+// fp32_min_band); a minimum inside the band, or max_clashes != 0, takes the fp64 count.
+__device__ inline int torsion_comp_check_lds(const double *c, const uint16_t *moved, int nm, const uint16_t *fixed, int nf, const float *F,
+                                             int npad, double cmax_fixed, double sq_bound, long long max_clashes, int lane) {
+    int A = 1;
+    while (A < nm && A < 64) A <<= 1;
+    const int G = 64 / A, ai = lane & (A - 1), g = lane / A;
+    const int per = (((nf + G - 1) / G) + 1) & ~1;  // even, so that packed pairs never straddle two slices
+    const int b0 = min(nf, g * per), b1 = min(nf, b0 + per);
+    if (max_clashes == 0 && nm > 0 && nf > 0) {
+        double cmax = cmax_fixed;
+        for (int r = ai; r < nm; r += A) {
+            const int a = moved[r];
+            cmax = fmax(cmax, fmax(fabs(c[3 * a]), fmax(fabs(c[3 * a + 1]), fabs(c[3 * a + 2]))));
+        }
+        for (int off = 32; off > 0; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+        float lo, hi;
+        if (fp32_min_band(sq_bound, cmax, &lo, &hi)) {
+            const float *X = F, *Y = F + npad, *Z = F + 2 * npad;
+            float m = __builtin_inff();
+            for (int r = ai; r < nm; r += A) {
+                const int a = moved[r];
+                const float xi = float(c[3 * a]), yi = float(c[3 * a + 1]), zi = float(c[3 * a + 2]);
+                const clash_f32x2 x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+#pragma unroll 4
+                for (int j = b0; j < b1; j += 2) {
+                    const clash_f32x2 dx = x2 - *reinterpret_cast<const clash_f32x2 *>(X + j);
+                    const clash_f32x2 dy = y2 - *reinterpret_cast<const clash_f32x2 *>(Y + j);
+                    const clash_f32x2 dz = z2 - *reinterpret_cast<const clash_f32x2 *>(Z + j);
+                    clash_f32x2 s2 = dx * dx;
+                    s2 = __builtin_elementwise_fma(dy, dy, s2);
+                    s2 = __builtin_elementwise_fma(dz, dz, s2);
+                    m = fminf(m, fminf(s2.x, s2.y));
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            if (m >= hi) return 1;  // every distance certainly >= thresh (NaN: falls through)
+            if (m < lo) return 0;   // some distance certainly < thresh
+        }
+    }
     int cnt = 0;
-    for (int a = lane; a < n; a += 64) {
-        if (!mask[a]) continue;
+    for (int r = ai; r < nm; r += A) {
+        const int a = moved[r];
         const double x = c[3 * a], y = c[3 * a + 1], z = c[3 * a + 2];
-        for (int b = 0; b < n; ++b) {
-            if (mask[b] || b == i2 || b == i3) continue;
+        for (int j = b0; j < b1; ++j) {
+            const int b = fixed[j];
             const double dx = c[3 * b] - x, dy = c[3 * b + 1] - y, dz = c[3 * b + 2] - z;
             cnt += (dx * dx + dy * dy + dz * dz < sq_bound) ? 1 : 0;
         }
@@ -70,13 +170,17 @@ __device__ inline int torsion_comp_check_lds(const double *c, int n, int i2, int
 }
 
 // out [n_cand][n][3], rotated_bonds [n_cand]; angles [n_cand][n_tors] int32 degrees; masks [n_tors][n]; torsions [n_tors][4]
+// dynamic LDS: torsion lists, then one csearch_wave_bytes(n) area per wavefront of the block
 __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,
                                                          const uint8_t *__restrict__ masks, const int32_t *__restrict__ angles,
                                                          double *__restrict__ out, int32_t *__restrict__ rotated_bonds) {
-    extern __shared__ __attribute__((aligned(16))) double s_c[];  // [4][n * 3]
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = a.n;
-    double *c = s_c + size_t(wid) * n * 3;
-    for (int64_t m = int64_t(blockIdx.x) * 4 + wid; m < a.n_cand; m += int64_t(gridDim.x) * 4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, n = a.n, npad = (n + 2) & ~1;
+    const TorsionLists L = torsion_lists_at(s_raw, a.n_tors, n);
+    build_torsion_lists(L, masks, tors, a.n_tors, n);
+    double *c = reinterpret_cast<double *>(s_raw + torsion_lists_bytes(a.n_tors, n) + size_t(wid) * csearch_wave_bytes(n));
+    float *F = reinterpret_cast<float *>(c + size_t(n) * 3);
+    for (int64_t m = int64_t(blockIdx.x) * nw + wid; m < a.n_cand; m += int64_t(gridDim.x) * nw) {
         for (int e = lane; e < n * 3; e += 64) c[e] = base[e];  // new_coords = np.copy(coords), :473
         __builtin_amdgcn_wave_barrier();
         int rotated = 0;
@@ -84,13 +188,15 @@ __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const dou
             const int angle = angles[m * a.n_tors + t];
             if (angle == 0) continue;  // :482
             const int i2 = tors[4 * t + 1], i3 = tors[4 * t + 2];
-            const uint8_t *mask = masks + size_t(t) * n;
-            rotate_dihedral_lds(c, n, i2, i3, double(angle), mask, lane);  // :484
-            if (!torsion_comp_check_lds(c, n, i2, i3, mask, a.sq_bound, a.max_clashes, lane)) {  // :487
+            const uint16_t *moved = L.moved + size_t(t) * n, *fixed = L.fixed + size_t(t) * n;
+            const int nm = L.count[2 * t], nf = L.count[2 * t + 1];
+            const double cmax_fixed = a.max_clashes == 0 ? stage_fixed_f32(c, fixed, nf, F, npad, lane) : 0.0;
+            rotate_dihedral_lds(c, i2, i3, double(angle), moved, nm, lane);  // :484
+            if (!torsion_comp_check_lds(c, moved, nm, fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane)) {  // :487
                 const int steps = angle >= 0 ? angle / 5 : -((-angle + 4) / 5);  // angle // 5
                 for (int rep = 0; rep < steps; ++rep) {  // :490-498
-                    rotate_dihedral_lds(c, n, i2, i3, -5.0, mask, lane);
-                    if (torsion_comp_check_lds(c, n, i2, i3, mask, a.sq_bound, a.max_clashes, lane)) {
+                    rotate_dihedral_lds(c, i2, i3, -5.0, moved, nm, lane);
+                    if (torsion_comp_check_lds(c, moved, nm, fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane)) {
                         ++rotated;
                         break;
                     }
@@ -109,14 +215,19 @@ __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const dou
 // torsion_comp_check for a batch of structures sharing torsion and mask: ok[s] = 1 / 0
 __global__ __launch_bounds__(256) void k_torsion_comp_check(CsearchArgs a, const double *__restrict__ coords, const int32_t *__restrict__ tors,
                                                              const uint8_t *__restrict__ mask, int32_t *__restrict__ ok) {
-    extern __shared__ __attribute__((aligned(16))) double s_c[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = a.n;
-    double *c = s_c + size_t(wid) * n * 3;
-    for (int64_t m = int64_t(blockIdx.x) * 4 + wid; m < a.n_cand; m += int64_t(gridDim.x) * 4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, n = a.n, npad = (n + 2) & ~1;
+    const TorsionLists L = torsion_lists_at(s_raw, 1, n);
+    build_torsion_lists(L, mask, tors, 1, n);
+    double *c = reinterpret_cast<double *>(s_raw + torsion_lists_bytes(1, n) + size_t(wid) * csearch_wave_bytes(n));
+    float *F = reinterpret_cast<float *>(c + size_t(n) * 3);
+    const int nm = L.count[0], nf = L.count[1];
+    for (int64_t m = int64_t(blockIdx.x) * nw + wid; m < a.n_cand; m += int64_t(gridDim.x) * nw) {
         const double *src = coords + m * n * 3;
         for (int e = lane; e < n * 3; e += 64) c[e] = src[e];
         __builtin_amdgcn_wave_barrier();
-        const int r = torsion_comp_check_lds(c, n, tors[1], tors[2], mask, a.sq_bound, a.max_clashes, lane);
+        const double cmax_fixed = a.max_clashes == 0 ? stage_fixed_f32(c, L.fixed, nf, F, npad, lane) : 0.0;
+        const int r = torsion_comp_check_lds(c, L.moved, nm, L.fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane);
         if (lane == 0) ok[m] = r;
         __builtin_amdgcn_wave_barrier();
     }

@@ -119,6 +119,18 @@ inline size_t clash_lds_per_wave(int n, int lp, bool minmode) {
 // computed s32 differs from the exact d^2 by at most 4 u s32 + 2 sqrt(3) e d + 3 e^2, so s32 >= hi = x0 + M means
 // d^2 >= x0 and s32 < lo = x0 - M means d^2 < x0 (M below).  A pose whose minimum falls between lo and hi (a few in
 // 10^4) is decided by the fp64 count like everything else.
+// lo / hi of the comment above for the squared bound x0 and the coordinate bound cmax; false = no usable band (take fp64)
+__device__ inline bool fp32_min_band(double x0, double cmax, float *lo_out, float *hi_out) {
+    constexpr double U = 5.9604644775390625e-08;  // 2^-24
+    const double e = 4.0 * U * cmax * (1.0 + U);
+    const double M = 1.01 * (8.0 * U * x0 + (2.0 * 1.7320508075688774 * e * sqrt(x0) + 3.0 * e * e) * (1.0 + 4.0 * U));
+    float lo = float(x0 - M), hi = float(x0 + M);
+    if (double(lo) > x0 - M) lo = __uint_as_float(__float_as_uint(lo) - 1u);  // round towards the safe side (both > 0)
+    if (double(hi) < x0 + M) hi = __uint_as_float(__float_as_uint(hi) + 1u);
+    *lo_out = lo, *hi_out = hi;
+    return cmax < 1.0e15 && x0 - M > 0.0;
+}
+
 template <bool FUSED, bool SELF, bool MINMODE>
 __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
                                                 const double *__restrict__ frags, FragTable ft,
@@ -171,15 +183,11 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
         if (MINMODE) {
             // one bound for the whole wavefront (the largest coordinate of any of its poses): simple and still tiny
             for (int off = 32; off > 0; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
-            constexpr double U = 5.9604644775390625e-08;  // 2^-24
-            const double e = 4.0 * U * cmax * (1.0 + U), x0 = a.sq_bound;
-            const double M = 1.01 * (8.0 * U * x0 + (2.0 * 1.7320508075688774 * e * sqrt(x0) + 3.0 * e * e) * (1.0 + 4.0 * U));
-            float lo = float(x0 - M), hi = float(x0 + M);
-            if (double(lo) > x0 - M) lo = __uint_as_float(__float_as_uint(lo) - 1u);  // round towards the safe side (both > 0)
-            if (double(hi) < x0 + M) hi = __uint_as_float(__float_as_uint(hi) + 1u);
+            float lo, hi;
+            const bool banded = fp32_min_band(a.sq_bound, cmax, &lo, &hi);
             const float *X = w_f32 + size_t(sub) * 3 * npad, *Y = X + npad, *Z = Y + npad;
             float m = __builtin_inff();
-            if (sub < np && cmax < 1.0e15 && x0 - M > 0.0) {
+            if (sub < np && banded) {
                 for (int ia = a.first_row + li; ia < n; ia += lp) {
                     const float xi = X[ia], yi = Y[ia], zi = Z[ia];
                     int jend = 0;

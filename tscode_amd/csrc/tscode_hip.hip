@@ -1095,10 +1095,19 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(ts
 
 static int csearch_args(int n_atoms, int n_tors, int64_t n_cand, double thresh, int64_t max_clashes, CsearchArgs *a) {
     TSC_REQUIRE(n_atoms > 0 && n_tors >= 0 && n_cand >= 0, "bad sizes (%d atoms, %d torsions, %lld candidates)", n_atoms, n_tors, (long long)n_cand);
-    TSC_REQUIRE(size_t(4) * n_atoms * 3 * sizeof(double) <= 150 * 1024, "%d atoms exceed the LDS staging of the csearch kernels", n_atoms);
+    TSC_REQUIRE(n_atoms <= 65535 && torsion_lists_bytes(n_tors, n_atoms) + csearch_wave_bytes(n_atoms) <= 150 * 1024,
+                "%d atoms x %d torsions exceed the LDS staging of the csearch kernels", n_atoms, n_tors);
     a->n = n_atoms, a->n_tors = n_tors, a->n_cand = n_cand;
     a->sq_bound = clash_sq_bound(thresh), a->max_clashes = max_clashes;
     return 0;
+}
+
+// wavefronts per workgroup (4, 2 or 1) that fit the LDS, and the dynamic LDS size of the launch
+static int csearch_waves(int n_atoms, int n_tors, size_t *lds) {
+    int w = 4;
+    while (w > 1 && torsion_lists_bytes(n_tors, n_atoms) + w * csearch_wave_bytes(n_atoms) > 150 * 1024) w >>= 1;
+    *lds = torsion_lists_bytes(n_tors, n_atoms) + w * csearch_wave_bytes(n_atoms);
+    return w;
 }
 
 static int check_torsions(const int32_t *torsions, int n_tors, int n_atoms) {
@@ -1116,10 +1125,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate_dev(tsc
     TSC_TRY(csearch_args(n_atoms, n_tors, n_cand, thresh, max_clashes, &a));
     if (n_cand == 0) return 0;
     DeviceGuard guard(c->device);
-    const size_t lds = size_t(4) * n_atoms * 3 * sizeof(double);
+    size_t lds;
+    const int waves = csearch_waves(n_atoms, n_tors, &lds);
     if (lds > 64 * 1024)
         TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csearch_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k_csearch_rotate, dim3(grid_for(n_cand, 4, 256 * 8)), dim3(256), lds, c->stream, a, coords, torsions, masks, angles, out, rotated_bonds);
+    hipLaunchKernelGGL(k_csearch_rotate, dim3(grid_for(n_cand, waves, 256 * 8)), dim3(64 * waves), lds, c->stream, a, coords, torsions, masks, angles, out,
+                       rotated_bonds);
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -1166,10 +1177,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc
     TSC_TRY(upload(c, s, torsion, size_t(4), &d_tors));
     TSC_TRY(upload(c, s, mask, size_t(n_atoms), &d_mask));
     TSC_TRY(s.get(size_t(n_structs), &d_ok));
-    const size_t lds = size_t(4) * n_atoms * 3 * sizeof(double);
+    size_t lds;
+    const int waves = csearch_waves(n_atoms, 1, &lds);
     if (lds > 64 * 1024)
         TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_torsion_comp_check), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k_torsion_comp_check, dim3(grid_for(n_structs, 4, 256 * 8)), dim3(256), lds, c->stream, a, (const double *)d_coords,
+    hipLaunchKernelGGL(k_torsion_comp_check, dim3(grid_for(n_structs, waves, 256 * 8)), dim3(64 * waves), lds, c->stream, a, (const double *)d_coords,
                        (const int32_t *)d_tors, (const uint8_t *)d_mask, d_ok);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipMemcpyAsync(ok, d_ok, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

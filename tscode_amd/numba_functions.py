@@ -57,10 +57,24 @@ def _tfd_reject_matches(first, d, k, final_mask):
     rows = np.flatnonzero(first >= 0)
     if len(rows) == 0:
         return
-    import networkx as nx
     steps = np.minimum(rows // d, int(k) - 1)
     bounds = np.flatnonzero(np.diff(steps)) + 1
-    for sel in np.split(rows, bounds):                       # rows of one chunk, ascending
+    # A chunk with ONE match (i, j) needs no graph: nx.Graph({(i, j)}) inserts i, then j, its only component is the whole
+    # graph, and tuple(graph.nodes)[0] is i -- j is rejected.  With many small chunks (the early passes) that is nearly
+    # every chunk, and building 10^4 two-node graphs was most of the call's time.
+    starts = np.concatenate(([0], bounds))
+    sizes = np.diff(np.concatenate((starts, [len(rows)])))
+    single = starts[sizes == 1]
+    final_mask[first[rows[single]]] = 0
+    if len(single) == len(starts):
+        return
+    _tfd_reject_graph(first, d, k, final_mask, [rows[a:a + n] for a, n in zip(starts.tolist(), sizes.tolist()) if n > 1])
+
+
+def _tfd_reject_graph(first, d, k, final_mask, chunks):
+    """The graph step of tscode/numba_functions.py:181-226 for the rows (ascending) of each chunk in ``chunks``."""
+    import networkx as nx
+    for sel in chunks:
         off = d * int(min(sel[0] // d, int(k) - 1))
         matches = set()
         for i_abs in sel.tolist():
