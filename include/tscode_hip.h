@@ -59,6 +59,9 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 256, at most 4096; 0 = automatic);
  * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64);
  * "sieve_cpl": columns per lane of the sieve kernel's screen, 1, 2 (default) or 4 -- register footprint against occupancy;
+ * "early_basis": 1 (default) lets tsc_pipeline_dev estimate the descriptor basis of the prune from a sample of the unfiltered
+ * poses on a side stream while the clash kernel runs (the choice of basis never changes a verdict); 0 = from the filtered
+ * structures, on the main stream.
  * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 256, up to 2048) structures
  * run in the one-launch chunk-local kernel; "clash_fp32": 1 (default)
  * decides verdict-only clash masks by a packed-fp32 minimum with fp64 fallback;

@@ -64,6 +64,8 @@ struct tsc_ctx {
     bool own_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_sync = nullptr;         // orders the auxiliary stream behind the main one (no timing)
+    hipStream_t basis_stream = nullptr;   // the descriptor basis of the pipeline, built beside the clash kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::multimap<size_t, void *> cache;  // free scratch blocks by size
     std::map<void *, size_t> live;        // blocks handed out
     void *pinned = nullptr;               // small pinned host buffer for scalar read-backs
@@ -72,10 +74,13 @@ struct tsc_ctx {
     int seg_cols = 0;                     // columns per pair-kernel work item (0 = chosen from the problem size)
     int drain_min = 64;                   // sieve: queued pairs that trigger an evaluation batch
     int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
+    int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int local_max_chunk = 256;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback
     int pass_timing = 0;                  // HIP events per pass: 0 none, 1 on the pair kernel's dispatch, 2 also around the whole pass
+    std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
+    int32_t *sample_dev = nullptr;
     std::vector<int32_t> slot_host;       // heavy-atom slot table of the last tsc_pipeline_dev call and its device copy
     int32_t *slot_dev = nullptr;
     std::vector<hipEvent_t> event_pool;   // recycled timing events of prune runs

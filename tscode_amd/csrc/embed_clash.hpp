@@ -44,9 +44,26 @@ __device__ inline void embed_atom(const double *__restrict__ frags, const FragTa
     for (int i = 0; i < 3; ++i) out[i] = R[3 * i] * x0 + R[3 * i + 1] * x1 + R[3 * i + 2] * x2 + t[i];
 }
 
-// K1: one thread per (pose, atom); consecutive threads write consecutive 24-byte triples.
+// one atom of one pose from pose parameters staged in LDS: R [entries][9], t [entries][3], conformer [entries],
+// entry l = local pose * n_mols + fragment.  (Fetching R and t per atom from global memory costs 12 vector loads per
+// atom, all hitting the same few lines: the address unit, not the bandwidth, then bounds the embedding kernels.)
+__device__ inline void embed_atom_staged(const double *__restrict__ frags, const FragTable &ft, const double *sR, const double *sT, const int *sC,
+                                         int local_pose, int a, double out[3]) {
+    const int m = frag_of_atom(ft, a), l = local_pose * ft.n_mols + m;
+    const double *X = frags + ft.frag_off[m] + (int64_t(sC[l]) * ft.n_atoms[m] + (a - ft.atom_off[m])) * 3;
+    const double *R = sR + l * 9, *t = sT + l * 3;
+    const double x0 = X[0], x1 = X[1], x2 = X[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = R[3 * i] * x0 + R[3 * i + 1] * x1 + R[3 * i + 2] * x2 + t[i];
+}
+
+// K1: a workgroup embeds TR_POSES poses at a time: their rotations, translations and conformer indices go to LDS first,
+// then one thread per (pose, atom); consecutive threads write consecutive 24-byte triples.
 // idx (optional): only the listed poses are embedded, out row r <- pose idx[r] (used after the clash
 // filter); heavy_sel/heavy_out (optional): additionally write the heavy-atom subset of each pose.
+constexpr int TR_POSES = 32;
+inline size_t transform_lds_bytes(int n_mols) { return size_t(TR_POSES) * n_mols * (12 * sizeof(double) + sizeof(int)) + TR_POSES * sizeof(int64_t); }
+
 __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ frags, FragTable ft,
                                                     const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
                                                     const double *__restrict__ pos, const int32_t *__restrict__ idx,
@@ -55,29 +72,51 @@ __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ fr
                                                     double *__restrict__ heavy_out, const int32_t *__restrict__ n_out_dev) {
     // n_out_dev (optional): the row count lives on the device (the total of the scan that made idx); the grid is then
     // sized for an upper bound and the host need not wait for the count before launching
-    const int n = ft.n_total;
+    extern __shared__ __attribute__((aligned(16))) double s_tr[];
+    const int n = ft.n_total, nm = ft.n_mols, tid = threadIdx.x;
     if (n_out_dev) n_out = *n_out_dev;
-    const int64_t total = n_out * n;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
-        int64_t r = e / n;
-        int a = int(e - r * n);
-        int64_t s = idx ? idx[r] : r;
-        double v[3];
-        embed_atom(frags, ft, conf_idx, rot, pos, s, a, v);
-        if (out) {
-            out[e * 3 + 0] = v[0];
-            out[e * 3 + 1] = v[1];
-            out[e * 3 + 2] = v[2];
+    int64_t *sP = reinterpret_cast<int64_t *>(s_tr);  // pose of every local row
+    double *sR = s_tr + TR_POSES, *sT = sR + TR_POSES * nm * 9;
+    int *sC = reinterpret_cast<int *>(sT + TR_POSES * nm * 3);
+    for (int64_t r0 = int64_t(blockIdx.x) * TR_POSES; r0 < n_out; r0 += int64_t(gridDim.x) * TR_POSES) {
+        const int np = int(min<int64_t>(TR_POSES, n_out - r0));
+        if (tid < np) sP[tid] = idx ? int64_t(idx[r0 + tid]) : r0 + tid;
+        __syncthreads();
+        for (int q = tid; q < np * nm * 9; q += 256) {
+            const int row = q / (nm * 9), w = q - row * nm * 9;
+            sR[q] = rot[sP[row] * nm * 9 + w];
         }
-        if (heavy_out) {
-            int hs = heavy_slot[a];  // position of atom a among the heavy atoms, or -1
-            if (hs >= 0) {
-                double *h = heavy_out + (r * n_heavy + hs) * 3;
-                h[0] = v[0];
-                h[1] = v[1];
-                h[2] = v[2];
+        for (int q = tid; q < np * nm * 3; q += 256) {
+            const int row = q / (nm * 3), w = q - row * nm * 3;
+            sT[q] = pos[sP[row] * nm * 3 + w];
+        }
+        for (int q = tid; q < np * nm; q += 256) {
+            const int row = q / nm, w = q - row * nm;
+            sC[q] = conf_idx[sP[row] * nm + w];
+        }
+        __syncthreads();
+        for (int e = tid; e < np * n; e += 256) {
+            const int row = e / n, a = e - row * n;
+            const int64_t r = r0 + row;
+            double v[3];
+            embed_atom_staged(frags, ft, sR, sT, sC, row, a, v);
+            if (out) {
+                double *o = out + (r * n + a) * 3;
+                o[0] = v[0];
+                o[1] = v[1];
+                o[2] = v[2];
+            }
+            if (heavy_out) {
+                const int hs = heavy_slot[a];  // position of atom a among the heavy atoms, or -1
+                if (hs >= 0) {
+                    double *h = heavy_out + (r * n_heavy + hs) * 3;
+                    h[0] = v[0];
+                    h[1] = v[1];
+                    h[2] = v[2];
+                }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -107,7 +146,7 @@ inline double clash_sq_bound(double thresh) {
 typedef float clash_f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS bytes one wavefront of k_clash needs: the fp64 pose(s) and, for MINMODE, an fp32 copy as three arrays
-inline size_t clash_lds_per_wave(int n, int lp, bool minmode) {
+__host__ __device__ inline size_t clash_lds_per_wave(int n, int lp, bool minmode) {
     const int ppw = 64 / lp, npad = (n + 1) & ~1;
     return size_t(ppw) * n * 3 * sizeof(double) + (minmode ? size_t(ppw) * 3 * npad * sizeof(float) : 0);
 }
@@ -140,7 +179,7 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
     extern __shared__ __attribute__((aligned(16))) double s_xyz[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = a.n, lp = a.lp, ppw = 64 / lp, npad = (n + 1) & ~1;
-    const size_t wave_doubles = (size_t(ppw) * n * 3 * sizeof(double) + (MINMODE ? size_t(ppw) * 3 * npad * sizeof(float) : 0)) / sizeof(double);
+    const size_t wave_doubles = clash_lds_per_wave(n, lp, MINMODE) / sizeof(double);
     double *w_xyz = s_xyz + size_t(wid) * wave_doubles;
     float *w_f32 = reinterpret_cast<float *>(w_xyz + size_t(ppw) * n * 3);  // [ppw][3][npad]
     const int64_t waves_total = int64_t(gridDim.x) * 4;
@@ -150,6 +189,8 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
         // ---- stage np poses in LDS
         double cmax = 0.0;
         if (FUSED) {
+            // (R, t and the conformer index come straight from global memory here: staging them in LDS first, as k_transform
+            // does, puts one more dependent round trip in front of a wavefront that is a chain of them -- measured 14 us slower)
             for (int e = lane; e < np * n; e += 64) {
                 int sub = e / n, at = e - sub * n;
                 double v[3];

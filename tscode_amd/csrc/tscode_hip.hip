@@ -49,6 +49,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->basis_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -75,6 +78,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->basis_stream) (void)hipStreamDestroy(c->basis_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -196,7 +202,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_transform_batch_dev(ts
     TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
     if (n_poses == 0) return 0;
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256)), dim3(256), 0, c->stream, frags, ft, conf_idx, rot,
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->stream, frags, ft, conf_idx, rot,
                        pos, (const int32_t *)nullptr, n_poses, out, (const int32_t *)nullptr, 0, (double *)nullptr, (const int32_t *)nullptr);
     TSC_HIP(hipGetLastError());
     return 0;
@@ -547,19 +553,15 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
     return 0;
 }
 
-// Descriptors of every structure for the sieve: leading principal axes of the two feature families (sieve.hpp).
-// Everything is enqueued; nothing waits for the host.
-static int build_descriptors(tsc_prune *p) {
-    tsc_ctx *c = p->ctx;
-    hipStream_t st = c->stream;
-    const int h = p->h;
+// Doubles of a descriptor basis: KD rows per feature family, then the DW projections of the mean feature vector (+ 1 spare)
+static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW + 1; }
+
+// Basis of the descriptors: leading principal axes of the two feature families (sieve.hpp) over `n_samples` structures
+// heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
+static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *heavy, int h, int n_samples, int64_t stride, double *d_Q) {
     const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
-    const int n_samples = int(std::min<int64_t>(p->n, DESC_SAMPLE));
-    const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
-    Scratch s(c);
-    double *d_M[NFAM], *d_Q, *d_zero;
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
-    TSC_TRY(s.get(q_doubles + DW + 1, &d_Q));
+    double *d_M[NFAM], *d_zero;
     // the moment matrices of both families in one block (one memset)
     const size_t m0 = size_t(nf[0] + 1) * (nf[0] + 1), m1 = size_t(nf[1] + 1) * (nf[1] + 1);
     TSC_TRY(s.get(m0 + m1, &d_zero));
@@ -571,10 +573,33 @@ static int build_descriptors(tsc_prune *p) {
         size_t lds = size_t(32) * m * sizeof(double);
         if (lds > 64 * 1024)
             TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, p->heavy, h, f, nf[f], stride, n_samples, d_M[f]);
+        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, heavy, h, f, nf[f], stride, n_samples, d_M[f]);
     }
     hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
                        d_Q + q_doubles);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+// Descriptors of every structure for the sieve.  `basis` (optional): a basis already enqueued elsewhere (any orthonormal
+// rows are valid: the choice only moves how many pairs the screen drops); otherwise it is estimated from the structures.
+// Everything is enqueued; nothing waits for the host.
+static int build_descriptors(tsc_prune *p, const double *basis) {
+    tsc_ctx *c = p->ctx;
+    hipStream_t st = c->stream;
+    const int h = p->h;
+    const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
+    const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
+    Scratch s(c);
+    const double *d_Q = basis;
+    if (!basis) {
+        const int n_samples = int(std::min<int64_t>(p->n, DESC_SAMPLE));
+        const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
+        double *q;
+        TSC_TRY(s.get(basis_doubles(h), &q));
+        TSC_TRY(build_basis(c, st, s, p->heavy, h, n_samples, stride, q));
+        d_Q = q;
+    }
     // structures per block of k_descriptors: as many as fit 48 KB of LDS next to the basis (a power of two, 4..64: the
     // 256 / S lanes that share a structure must be one wavefront at most)
     const size_t pitch = size_t(h * 3) | 1;
@@ -584,7 +609,7 @@ static int build_descriptors(tsc_prune *p) {
     TSC_REQUIRE(lds_desc <= 150 * 1024, "%d heavy atoms per structure exceed what the descriptor kernel can stage in LDS", h);
     if (lds_desc > 64 * 1024)
         TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_descriptors), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_desc)));
-    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, S)), dim3(256), lds_desc, st, p->heavy, p->n, h, nf[0], nf[1], (const double *)d_Q,
+    hipLaunchKernelGGL(k_descriptors, dim3(ceil_div<int64_t>(p->n, S)), dim3(256), lds_desc, st, p->heavy, p->n, h, nf[0], nf[1], d_Q,
                        (const double *)(d_Q + q_doubles), p->Dall, p->Gall, p->dmax_bits, S);
     TSC_HIP(hipGetLastError());
     return 0;  // the scratch blocks go back to the stream-ordered cache: later users run after these kernels
@@ -600,7 +625,8 @@ static int get_event(tsc_ctx *c, hipEvent_t *e) {
     return 0;
 }
 
-static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask_buffer, tsc_prune **out) {
+static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask_buffer, tsc_prune **out,
+                             const double *basis = nullptr) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
     TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
@@ -667,7 +693,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         if (e == hipSuccess && p->G) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
     }
-    if (!rc && p->Dall) rc = build_descriptors(p);
+    if (!rc && p->Dall) rc = build_descriptors(p, basis);
     if (rc) {
         tsc_prune_destroy(p);
         return rc;
@@ -948,10 +974,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
 // One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
 // synchronisation (the statistics read-back).
 static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
-                     tsc_pass_stats *stats, int *n_passes) {
+                     tsc_pass_stats *stats, int *n_passes, const double *basis = nullptr) {
     tsc_prune *p = nullptr;
     const bool in_place = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;  // run on the caller's buffer: no copy at the end
-    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p));
+    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis));
     int rc = 0;
     for (;;) {
         int64_t k = 0;
@@ -1022,6 +1048,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "sieve_cpl") == 0) {
         TSC_REQUIRE(value == 1 || value == 2 || value == 4, "sieve_cpl must be 1, 2 or 4");
         c->sieve_cpl = int(value);
+        return 0;
+    }
+    if (strcmp(name, "early_basis") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "early_basis must be 0 or 1");
+        c->early_basis = int(value);
         return 0;
     }
     if (strcmp(name, "local_max_chunk") == 0) {
@@ -1420,7 +1451,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_de
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes, clash_mask, nullptr));
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     TSC_TRY(read_i32_begin(c, total));
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256, 256 * 64)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
                        int64_t(0), structures, (const int32_t *)d_slot, n_heavy, heavy, (const int32_t *)total);
     TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
@@ -1462,6 +1493,42 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     TSC_TRY(s.get(size_t(n_poses), &act));
     TSC_TRY(s.get(1, &total));
     if (timed) TSC_HIP(hipEventRecord(ev[0], st));
+    // The descriptor basis of the prune (sieve.hpp) from a sample of the UNFILTERED poses, on its own stream beside the clash
+    // kernel: 3 small launches and a one-wavefront kernel (about 45 us of latency at C3) leave the critical path.  Any
+    // orthonormal basis gives the same verdicts; poses that fail the clash check are as good a sample of the geometry.
+    double *d_basis = nullptr;
+    struct BasisJoin {  // declared after the scratch: whatever path leaves this function, the side stream is idle before its blocks go back
+        tsc_ctx *c;
+        bool pending;
+        ~BasisJoin() {
+            if (pending) (void)hipStreamSynchronize(c->basis_stream);
+        }
+    } basis_join{c, false};
+    if (c->early_basis && c->prune_algo != ALGO_TILE) {
+        const int n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
+        const int64_t stride = std::max<int64_t>(1, n_poses / n_samples);
+        if (!(c->sample_dev && int(c->sample_host.size()) == n_samples && c->sample_host.back() == int32_t(stride * (n_samples - 1)))) {
+            if (c->sample_dev) c->release(c->sample_dev);
+            c->sample_dev = nullptr;
+            c->sample_host.resize(size_t(n_samples));
+            for (int i = 0; i < n_samples; ++i) c->sample_host[size_t(i)] = int32_t(stride * i);
+            void *q = nullptr;
+            TSC_TRY(c->alloc(size_t(n_samples) * sizeof(int32_t), &q));
+            c->sample_dev = static_cast<int32_t *>(q);
+            TSC_HIP(hipMemcpyAsync(c->sample_dev, c->sample_host.data(), size_t(n_samples) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        }
+        double *d_sample;
+        TSC_TRY(s.get(size_t(n_samples) * n_heavy * 3, &d_sample));
+        TSC_TRY(s.get(basis_doubles(n_heavy), &d_basis));
+        TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
+        TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
+        basis_join.pending = true;
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
+                           rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
+                           (const int32_t *)nullptr);
+        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis));
+        TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
+    }
     // K1+K2 fused verdicts
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
                                      clash_mask, nullptr));
@@ -1472,7 +1539,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
     TSC_TRY(read_i32_begin(c, total));
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses * ft.n_total, 256, 256 * 64)), dim3(256), 0, st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
                        int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
     TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
@@ -1480,9 +1547,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     if (n_pass_host) *n_pass_host = n_pass;
     int64_t n_keep = 0;
     int np = 0;
+    if (d_basis) TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
     if (n_pass > 0) {
         if (timed) TSC_HIP(hipEventRecord(ev[2], st));
-        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np));
+        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np, d_basis));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
         if (!stats) {  // count survivors without the stats array
             TSC_TRY(scan_mask(st, keep_mask, n_pass, bsum, nullptr, nullptr, nullptr, total));
