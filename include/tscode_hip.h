@@ -61,7 +61,8 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * "sieve_cpl": columns per lane of the sieve kernel's screen, 1, 2 (default) or 4 -- register footprint against occupancy;
  * "early_basis": 1 (default) lets tsc_pipeline_dev estimate the descriptor basis of the prune from a sample of the unfiltered
  * poses on a side stream while the clash kernel runs (the choice of basis never changes a verdict); 0 = from the filtered
- * structures, on the main stream.
+ * structures, on the main stream.  "fuse_descriptors": 1 (default) then lets the kernel that embeds the passing poses write their
+ * descriptors as well (poses of up to about 80 heavy atoms; otherwise and with 0 a separate launch reads the coordinates back).
  * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 256, up to 2048) structures
  * run in the one-launch chunk-local kernel; "clash_fp32": 1 (default)
  * decides verdict-only clash masks by a packed-fp32 minimum with fp64 fallback;

@@ -332,11 +332,13 @@ def test_pipeline_c2_vs_oracle(eng, oracle):
     print("C2 pipeline:", res["n_pass"], "pass the clash check,", res["n_keep"], "survive;", res["ms"])
     # the descriptor basis taken from the filtered structures (on the main stream) instead of the unfiltered sample built
     # beside the clash kernel: a different basis, the same verdicts
-    eng.set_option("early_basis", 0)
     keep2 = torch.empty(n, dtype=torch.uint8, device=dev)
-    res2 = eng.pipeline_dev(fs, d_frags, d_ci, d_rot, d_pos, n, heavy_idx, 1.5, 0, 0.5, 0, clash, structures, keep2)
-    eng.set_option("early_basis", 1)
-    assert res2["n_keep"] == res["n_keep"] and torch.equal(keep2[:res["n_pass"]], keep[:res["n_pass"]])
+    for opt in ("early_basis", "fuse_descriptors"):     # (the latter: descriptors by k_descriptors instead of the embedding kernel)
+        eng.set_option(opt, 0)
+        res2 = eng.pipeline_dev(fs, d_frags, d_ci, d_rot, d_pos, n, heavy_idx, 1.5, 0, 0.5, 0, clash, structures, keep2)
+        eng.set_option(opt, 1)
+        assert res2["n_keep"] == res["n_keep"] and torch.equal(keep2[:res["n_pass"]], keep[:res["n_pass"]]), opt
+        assert np.abs(structures[:res["n_pass"]].cpu().numpy() - poses[cm]).max() < 1e-12
     # every pose clashes: the side stream's work is joined although no prune follows
     res3 = eng.pipeline_dev(fs, d_frags, d_ci, d_rot, d_pos, n, heavy_idx, 50.0, 0, 0.5, 0, clash, structures, keep2)
     assert res3["n_pass"] == 0 and res3["n_keep"] == 0

@@ -62,7 +62,7 @@ __device__ inline void embed_atom_staged(const double *__restrict__ frags, const
 // idx (optional): only the listed poses are embedded, out row r <- pose idx[r] (used after the clash
 // filter); heavy_sel/heavy_out (optional): additionally write the heavy-atom subset of each pose.
 constexpr int TR_POSES = 32;
-inline size_t transform_lds_bytes(int n_mols) { return size_t(TR_POSES) * n_mols * (12 * sizeof(double) + sizeof(int)) + TR_POSES * sizeof(int64_t); }
+__host__ __device__ inline size_t transform_lds_bytes(int n_mols) { return size_t(TR_POSES) * n_mols * (12 * sizeof(double) + sizeof(int)) + TR_POSES * sizeof(int64_t); }
 
 __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ frags, FragTable ft,
                                                     const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,

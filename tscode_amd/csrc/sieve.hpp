@@ -32,6 +32,7 @@
 // Any number of heavy atoms is supported (no register-resident structure).
 #pragma once
 #include "common.hpp"
+#include "embed_clash.hpp"
 #include "rmsd.hpp"
 
 namespace tsc {
@@ -57,9 +58,13 @@ inline int n_features(int h, int fam) { return std::min(fam == 0 ? h : h / 2, DE
 
 // Second-moment matrix of the sampled feature vectors of one family, with a constant 1 appended:
 // M[a][b] = sum_s f_a(s) f_b(s), a, b in [0, nf]  (index nf = the constant) -> mean and covariance on the host.
-__global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int fam, int nf, int64_t stride_structs,
-                                                          int n_samples, double *__restrict__ M) {
+// blockIdx.y = family: both moment matrices come out of one launch.
+__global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int nf0, int nf1, int64_t stride_structs,
+                                                          int n_samples, double *__restrict__ M0, double *__restrict__ M1) {
     extern __shared__ __attribute__((aligned(16))) double s_n[];  // [chunk][nf + 1]
+    const int fam = blockIdx.y, nf = fam == 0 ? nf0 : nf1;
+    double *__restrict__ M = fam == 0 ? M0 : M1;
+    if (nf == 0) return;
     const int m = nf + 1;
     constexpr int CHUNK = 32;
     const int n_chunks = (n_samples + CHUNK - 1) / CHUNK;
@@ -116,37 +121,11 @@ __device__ inline float screen_limit32_dot(float dmaxf, double limit) {
     return (l32 < 3.0e38) ? f : 3.4e38f;
 }
 
-// D[i][2k + fam] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space, the two families
-// interleaved; the bias is the projection of the mean feature vector and cancels in every difference),
-// G[i] = sum_a |x_ia|^2; *dmax_bits = max |D| over everything as the bit pattern of a non-negative float (atomicMax on the
-// integer view; zero on entry) -- the pair kernel turns it into the fp32 limit of the screen (screen_limit32).
-// A block stages S structures in LDS with coalesced loads (a thread-per-structure walk reads 64 lines per instruction and
-// thrashes the L1); T = 256 / S consecutive lanes share a structure (atoms sub, sub + T, ...) and reduce with shuffles.
-__global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
-                                                      const double *__restrict__ Q, const double *__restrict__ bias, float *__restrict__ D,
-                                                      double *__restrict__ G, unsigned *__restrict__ dmax_bits, int S) {
-    extern __shared__ __attribute__((aligned(16))) double s_mem[];  // [KD][nf0], [KD][nf1], then S rows of pitch doubles
-    const int h3 = h * 3, pitch = h3 | 1, T = 256 / S;
-    double *s_q = s_mem, *s_x = s_mem + KD * (nf0 + nf1);
-    for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += 256) s_q[e] = Q[e];
-    const int64_t i0 = int64_t(blockIdx.x) * S;
-    const int ns = int(min<int64_t>(S, n - i0));
-    const double *src = heavy + i0 * h3;
-    // eight loads in flight per thread before the first LDS store (a plain copy loop waits for every load in turn)
-    for (int base = threadIdx.x; base < ns * h3; base += 256 * 8) {
-        double v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (base + 256 * j < ns * h3) ? src[base + 256 * j] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = base + 256 * j;
-            if (e < ns * h3) {
-                const int row = e / h3;
-                s_x[row * pitch + (e - row * h3)] = v[j];
-            }
-        }
-    }
-    __syncthreads();
+// The descriptor rows of the ns structures staged in LDS (s_x, `pitch` doubles apart; s_q = both bases): T = 256 / S
+// consecutive lanes share a structure (atoms sub, sub + T, ...) and reduce with shuffles.  Called by all 256 threads.
+__device__ inline void describe_from_lds(const double *s_q, const double *s_x, int pitch, int h, int nf0, int nf1, const double *__restrict__ bias,
+                                         int ns, int S, int64_t i0, float *__restrict__ D, double *__restrict__ G, unsigned *__restrict__ dmax_bits) {
+    const int T = 256 / S;
     const int sidx = threadIdx.x / T, sub = threadIdx.x - sidx * T;
     const bool mine = sidx < ns;
     double d[DW], g = 0.0;
@@ -194,6 +173,101 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
         atomicMax(dmax_bits, __float_as_uint(mx));
 }
 
+// D[i][2k + fam] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space, the two families
+// interleaved; the bias is the projection of the mean feature vector and cancels in every difference),
+// G[i] = sum_a |x_ia|^2; *dmax_bits = max |D| over everything as the bit pattern of a non-negative float (atomicMax on the
+// integer view; zero on entry) -- the pair kernel turns it into the fp32 limit of the screen (screen_limit32).
+// A block stages S structures in LDS with coalesced loads (a thread-per-structure walk reads 64 lines per instruction and
+// thrashes the L1); T = 256 / S consecutive lanes share a structure (atoms sub, sub + T, ...) and reduce with shuffles.
+__global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
+                                                      const double *__restrict__ Q, const double *__restrict__ bias, float *__restrict__ D,
+                                                      double *__restrict__ G, unsigned *__restrict__ dmax_bits, int S) {
+    extern __shared__ __attribute__((aligned(16))) double s_mem[];  // [KD][nf0], [KD][nf1], then S rows of pitch doubles
+    const int h3 = h * 3, pitch = h3 | 1;
+    double *s_q = s_mem, *s_x = s_mem + KD * (nf0 + nf1);
+    for (int e = threadIdx.x; e < KD * (nf0 + nf1); e += 256) s_q[e] = Q[e];
+    const int64_t i0 = int64_t(blockIdx.x) * S;
+    const int ns = int(min<int64_t>(S, n - i0));
+    const double *src = heavy + i0 * h3;
+    // eight loads in flight per thread before the first LDS store (a plain copy loop waits for every load in turn)
+    for (int base = threadIdx.x; base < ns * h3; base += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (base + 256 * j < ns * h3) ? src[base + 256 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + 256 * j;
+            if (e < ns * h3) {
+                const int row = e / h3;
+                s_x[row * pitch + (e - row * h3)] = v[j];
+            }
+        }
+    }
+    __syncthreads();
+    describe_from_lds(s_q, s_x, pitch, h, nf0, nf1, bias, ns, S, i0, D, G, dmax_bits);
+}
+
+// K1 with the descriptors of the prune fused in (tsc_pipeline_dev, when the basis is ready before the passing poses are
+// embedded): k_transform's workgroup of TR_POSES poses keeps the heavy atoms it has just computed in LDS and takes their
+// descriptor rows from there, so the 24 h bytes per structure are not read back by a k_descriptors launch.
+// dynamic LDS: transform_lds_bytes(n_mols), then [KD][nf0 + nf1] basis doubles, then TR_POSES rows of (3 h | 1) doubles.
+__global__ __launch_bounds__(256) void k_transform_describe(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
+                                                             const double *__restrict__ rot, const double *__restrict__ pos,
+                                                             const int32_t *__restrict__ idx, double *__restrict__ out,
+                                                             const int32_t *__restrict__ heavy_slot, int n_heavy, double *__restrict__ heavy_out,
+                                                             const int32_t *__restrict__ n_out_dev, int nf0, int nf1, const double *__restrict__ Q,
+                                                             const double *__restrict__ bias, float *__restrict__ D, double *__restrict__ G,
+                                                             unsigned *__restrict__ dmax_bits) {
+    extern __shared__ __attribute__((aligned(16))) double s_tr[];
+    const int n = ft.n_total, nm = ft.n_mols, tid = threadIdx.x, pitch = (n_heavy * 3) | 1;
+    const int64_t n_out = *n_out_dev;
+    int64_t *sP = reinterpret_cast<int64_t *>(s_tr);
+    double *sR = s_tr + TR_POSES, *sT = sR + TR_POSES * nm * 9;
+    int *sC = reinterpret_cast<int *>(sT + TR_POSES * nm * 3);
+    double *s_q = s_tr + (transform_lds_bytes(nm) + 15) / 16 * 2, *s_x = s_q + KD * (nf0 + nf1);
+    for (int e = tid; e < KD * (nf0 + nf1); e += 256) s_q[e] = Q[e];
+    for (int64_t r0 = int64_t(blockIdx.x) * TR_POSES; r0 < n_out; r0 += int64_t(gridDim.x) * TR_POSES) {
+        const int np = int(min<int64_t>(TR_POSES, n_out - r0));
+        if (tid < np) sP[tid] = int64_t(idx[r0 + tid]);
+        __syncthreads();
+        for (int q = tid; q < np * nm * 9; q += 256) {
+            const int row = q / (nm * 9), w = q - row * nm * 9;
+            sR[q] = rot[sP[row] * nm * 9 + w];
+        }
+        for (int q = tid; q < np * nm * 3; q += 256) {
+            const int row = q / (nm * 3), w = q - row * nm * 3;
+            sT[q] = pos[sP[row] * nm * 3 + w];
+        }
+        for (int q = tid; q < np * nm; q += 256) {
+            const int row = q / nm, w = q - row * nm;
+            sC[q] = conf_idx[sP[row] * nm + w];
+        }
+        __syncthreads();
+        for (int e = tid; e < np * n; e += 256) {
+            const int row = e / n, a = e - row * n;
+            const int64_t r = r0 + row;
+            double v[3];
+            embed_atom_staged(frags, ft, sR, sT, sC, row, a, v);
+            if (out) {
+                double *o = out + (r * n + a) * 3;
+                o[0] = v[0], o[1] = v[1], o[2] = v[2];
+            }
+            const int hs = heavy_slot[a];
+            if (hs >= 0) {
+                double *hv = heavy_out + (r * n_heavy + hs) * 3, *x = s_x + row * pitch + hs * 3;
+                hv[0] = x[0] = v[0], hv[1] = x[1] = v[1], hv[2] = x[2] = v[2];
+            }
+        }
+        __syncthreads();
+        describe_from_lds(s_q, s_x, pitch, n_heavy, nf0, nf1, bias, np, TR_POSES, r0, D, G, dmax_bits);
+        __syncthreads();
+    }
+}
+
+inline size_t transform_describe_lds_bytes(int n_mols, int h) {
+    return (transform_lds_bytes(n_mols) + 15) / 16 * 16 + (size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + size_t(TR_POSES) * ((h * 3) | 1)) * sizeof(double);
+}
+
 // Device-side descriptor basis: one wavefront per feature family.  Orthonormal rows spanning the leading principal
 // axes of the feature covariance by a few steps of block power iteration (the spectrum of these features decays
 // fast: one step gives the screening power of three to within 3 % of the pairs that reach H).  Rows are re-orthonormalised by
@@ -209,7 +283,10 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
 constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
 __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
-                                                          int n_samples, double *__restrict__ Q, double *__restrict__ bias) {
+                                                          int n_samples, double *__restrict__ Q, double *__restrict__ bias,
+                                                          unsigned *__restrict__ zero_word) {
+    // zero_word (optional): the running max |D| of a descriptor build that follows this kernel, cleared here
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
     __shared__ double V[KD][DESC_MAX_FEAT], Z[KD][DESC_MAX_FEAT], mu[DESC_MAX_FEAT];
     __shared__ double Cs[BASIS_LDS_C][BASIS_LDS_C + 1];
     __shared__ double Gm[KD][KD];  // Gram matrix of the rows being orthonormalised

@@ -558,7 +558,8 @@ static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_f
 
 // Basis of the descriptors: leading principal axes of the two feature families (sieve.hpp) over `n_samples` structures
 // heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
-static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *heavy, int h, int n_samples, int64_t stride, double *d_Q) {
+static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *heavy, int h, int n_samples, int64_t stride, double *d_Q,
+                       unsigned *zero_word = nullptr) {
     const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
     double *d_M[NFAM], *d_zero;
@@ -567,19 +568,25 @@ static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *hea
     TSC_TRY(s.get(m0 + m1, &d_zero));
     TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1) * sizeof(double), st));
     d_M[0] = d_zero, d_M[1] = d_zero + m0;
-    for (int f = 0; f < NFAM; ++f) {
-        const int m = nf[f] + 1;
-        if (nf[f] == 0) continue;
-        size_t lds = size_t(32) * m * sizeof(double);
+    {
+        const size_t lds = size_t(32) * (std::max(nf[0], nf[1]) + 1) * sizeof(double);
         if (lds > 64 * 1024)
             TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32)), dim3(256), lds, st, heavy, h, f, nf[f], stride, n_samples, d_M[f]);
+        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32), NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0],
+                           d_M[1]);
     }
     hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
-                       d_Q + q_doubles);
+                       d_Q + q_doubles, zero_word);
     TSC_HIP(hipGetLastError());
     return 0;
 }
+
+// Descriptors built outside the prune (tsc_pipeline_dev: by the kernel that embeds the passing poses)
+struct ExternalDescriptors {
+    float *D = nullptr;
+    double *G = nullptr;
+    unsigned *dmax_bits = nullptr;
+};
 
 // Descriptors of every structure for the sieve.  `basis` (optional): a basis already enqueued elsewhere (any orthonormal
 // rows are valid: the choice only moves how many pairs the screen drops); otherwise it is estimated from the structures.
@@ -626,7 +633,7 @@ static int get_event(tsc_ctx *c, hipEvent_t *e) {
 }
 
 static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask_buffer, tsc_prune **out,
-                             const double *basis = nullptr) {
+                             const double *basis = nullptr, const ExternalDescriptors *ext = nullptr) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
     TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
@@ -668,10 +675,15 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     if (!rc) rc = palloc(p, 1, &p->counters);
     if (!rc) rc = palloc(p, 1, &p->state);
     if (!rc) rc = palloc(p, TSC_MAX_PASSES, &p->records);
+    const bool own_desc = !(ext && ext->D);  // (external descriptors: already enqueued on this stream, the caller owns the buffers)
     if (!rc && p->algo == ALGO_SIEVE) {
-        rc = palloc(p, size_t(n) * DW, &p->Dall);
-        if (!rc) rc = palloc(p, size_t(n), &p->Gall);
-        if (!rc) rc = palloc(p, 4, &p->dmax_bits);
+        if (own_desc) {
+            rc = palloc(p, size_t(n) * DW, &p->Dall);
+            if (!rc) rc = palloc(p, size_t(n), &p->Gall);
+            if (!rc) rc = palloc(p, 4, &p->dmax_bits);
+        } else {
+            p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
+        }
         if (!rc) rc = palloc(p, 1, &p->tickets);
     }
     if (!rc && p->algo == ALGO_TILE) {
@@ -683,7 +695,8 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     if (!rc) {
         hipStream_t st = c->stream;
         hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
-                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE, p->dmax_bits,
+                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE,
+                           own_desc ? p->dmax_bits : nullptr,
                            reinterpret_cast<unsigned *>(p->tickets), p->tickets ? int(sizeof(LocalTickets) / sizeof(unsigned)) : 0, p->act);
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
@@ -693,7 +706,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         if (e == hipSuccess && p->G) e = hipMemsetAsync(p->G, 0, size_t(p->npad) * sizeof(double), st);
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "prune state setup failed: %s", hipGetErrorString(e));
     }
-    if (!rc && p->Dall) rc = build_descriptors(p, basis);
+    if (!rc && p->Dall && own_desc) rc = build_descriptors(p, basis);
     if (rc) {
         tsc_prune_destroy(p);
         return rc;
@@ -974,10 +987,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
 // One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
 // synchronisation (the statistics read-back).
 static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
-                     tsc_pass_stats *stats, int *n_passes, const double *basis = nullptr) {
+                     tsc_pass_stats *stats, int *n_passes, const double *basis = nullptr, const ExternalDescriptors *ext = nullptr) {
     tsc_prune *p = nullptr;
     const bool in_place = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;  // run on the caller's buffer: no copy at the end
-    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis));
+    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis, ext));
     int rc = 0;
     for (;;) {
         int64_t k = 0;
@@ -1048,6 +1061,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "sieve_cpl") == 0) {
         TSC_REQUIRE(value == 1 || value == 2 || value == 4, "sieve_cpl must be 1, 2 or 4");
         c->sieve_cpl = int(value);
+        return 0;
+    }
+    if (strcmp(name, "fuse_descriptors") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "fuse_descriptors must be 0 or 1");
+        c->fuse_descriptors = int(value);
         return 0;
     }
     if (strcmp(name, "early_basis") == 0) {
@@ -1497,6 +1515,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // kernel: 3 small launches and a one-wavefront kernel (about 45 us of latency at C3) leave the critical path.  Any
     // orthonormal basis gives the same verdicts; poses that fail the clash check are as good a sample of the geometry.
     double *d_basis = nullptr;
+    ExternalDescriptors ext;  // set when the embedding of the passing poses also writes their descriptors
     struct BasisJoin {  // declared after the scratch: whatever path leaves this function, the side stream is idle before its blocks go back
         tsc_ctx *c;
         bool pending;
@@ -1520,13 +1539,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         double *d_sample;
         TSC_TRY(s.get(size_t(n_samples) * n_heavy * 3, &d_sample));
         TSC_TRY(s.get(basis_doubles(n_heavy), &d_basis));
+        if (c->fuse_descriptors && transform_describe_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024) {
+            TSC_TRY(s.get(size_t(n_poses) * DW, &ext.D));
+            TSC_TRY(s.get(size_t(n_poses), &ext.G));
+            TSC_TRY(s.get(4, &ext.dmax_bits));
+        }
         TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
         TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
         basis_join.pending = true;
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
                            rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
                            (const int32_t *)nullptr);
-        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis));
+        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits));
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
     // K1+K2 fused verdicts
@@ -1539,8 +1563,16 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
     TSC_TRY(read_i32_begin(c, total));
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
-                       int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
+    if (ext.D) {
+        const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
+        TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));  // the basis (and the cleared maximum) from the side stream
+        hipLaunchKernelGGL(k_transform_describe, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_describe_lds_bytes(ft.n_mols, n_heavy), st,
+                           frags, ft, conf_idx, rot, pos, (const int32_t *)act, structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total,
+                           nf0, nf1, (const double *)d_basis, (const double *)(d_basis + size_t(KD) * (nf0 + nf1)), ext.D, ext.G, ext.dmax_bits);
+    } else {
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos,
+                           (const int32_t *)act, int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
+    }
     TSC_HIP(hipGetLastError());
     int32_t n_pass = 0;
     TSC_TRY(read_i32_finish(c, &n_pass));
@@ -1550,7 +1582,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     if (d_basis) TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
     if (n_pass > 0) {
         if (timed) TSC_HIP(hipEventRecord(ev[2], st));
-        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np, d_basis));
+        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np, d_basis, ext.D ? &ext : nullptr));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
         if (!stats) {  // count survivors without the stats array
             TSC_TRY(scan_mask(st, keep_mask, n_pass, bsum, nullptr, nullptr, nullptr, total));
