@@ -498,16 +498,22 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
                                                     const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
                                                     const unsigned long long *__restrict__ dsum, int32_t *__restrict__ cend,
-                                                    int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax) {
+                                                    int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
+                                                    const float *__restrict__ D, float *__restrict__ Dc) {
     // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
+    // D (optional): the 16 descriptor components of the row's structure are copied to position r of Dc on the way (one
+    // float per lane), so that the pair kernel reads rows and columns by position -- no gather through the active list
+    // in front of every column tile (a dependent round trip per tile)
     if (st->pass_on == 0) return;
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
     const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
     const bool mine = r < st->A;
     int64_t i = 0, first = 0, last = 0;
+    float dval = 0.0f;
     if (mine) {
         i = act_idx[r];
         chunk_of(g, i, first, last);
+        if (D) dval = D[i * 16 + sl];
     }
     int64_t found = last;
     if (use_cache) {
@@ -553,6 +559,7 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
             }
         }
     }
+    if (mine && D) Dc[int64_t(r) * 16 + sl] = dval;
     int my_c = 0;
     if (mine && sl == 0) {
         my_c = pos[found];

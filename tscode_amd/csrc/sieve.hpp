@@ -21,8 +21,9 @@
 // lower bound certainly exceeds h thr^2.  Pairs in the sliver between the two limits are simply not dropped.
 //
 // Pass kernel (k_rmsd_sieve): one wavefront = 16 rows x one column segment, lane = CPL columns of a tile.
-//   screen : descriptors are gathered straight from the per-structure table through the active list (no per-pass
-//            copy); the two families of a component sit side by side, so one v_pk_add_f32 + one v_pk_fma_f32 advance both
+//   screen : descriptors are read by position from a copy in active order that k_stop_scan writes on its way (one float
+//            per lane of its 16 lanes per row), so no index load stands in front of a column tile; the two families of a
+//            component sit side by side, so one v_pk_add_f32 + one v_pk_fma_f32 advance both
 //            distances; the 16 row descriptors sit in LDS and are read as broadcasts; ONE compare per (row, tile) decides
 //            whether any column is within the limit; survivors go to a per-wavefront LDS queue (ballot + prefix popcount);
 //   drain  : stage 1, whenever the queue holds 64 pairs (or at the end, spread over several lanes per pair): H from the
@@ -512,11 +513,9 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     // most items of a pass with long chunks start beyond every stop column of their row tile: two scalar loads and out
     if (st->pass_on == 0 || a.tile_cmax[tile] <= seg_lo) return;
 
-    // ---- prologue in two memory round trips: (1) the state, this item's 16 stop columns / best columns (they decide
-    // whether it has work at all: most items of a late pass have none) and the structure indices of its rows and of its
-    // first column tile; (2) the descriptors of those rows and columns, gathered straight from the per-structure table
-    // D[N][DW] through act[] (active structures are in increasing index order, so the gather is nearly contiguous and
-    // no per-pass compacted copy of the descriptors is needed).  act[x] is a valid structure index for every x < n:
+    // ---- prologue in one memory round trip: the state, this item's 16 stop columns / best columns (they decide whether
+    // it has work at all: most items of a late pass have none) and the descriptors of its rows and first column tile.
+    // act[x] (needed for the coordinates of the pairs that reach H) is a valid structure index for every x < n:
     // k_init_run fills it with the identity, every pass rewrites a prefix.
     const int pass_on = st->pass_on, n_active = st->A;
     int my_cend = 0, my_best = 0;
@@ -525,13 +524,16 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static_assert(DW == 16 && TI * DW == 256, "row staging: 4 rows x 16 components per 64 lanes");
+    // D holds the descriptors in ACTIVE order (position r = the r-th active structure; k_stop_scan copies them there every
+    // pass): rows and columns are read by position, nothing is gathered through act[] in front of the screen.  Positions
+    // up to n - 1 are readable; those beyond the active count hold stale values that no row's range admits.
     int row_src[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) row_src[j] = act[min(r0 + 4 * j + (lane >> 4), a.n - 1)];
+    for (int j = 0; j < 4; ++j) row_src[j] = min(r0 + 4 * j + (lane >> 4), a.n - 1);
     int col_src[CPL];
     auto load_cols = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < CPL; ++u) col_src[u] = act[min(c0 + 64 * u + lane, a.n - 1)];
+        for (int u = 0; u < CPL; ++u) col_src[u] = min(c0 + 64 * u + lane, a.n - 1);
     };
     load_cols(seg_lo);
     if (pass_on == 0 || r0 >= n_active) return;
