@@ -872,6 +872,20 @@ __global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, PruneState *__re
     if (threadIdx.x == 0) st->ticket = 0;
 }
 
+// End of a run: the pass records and (optionally) the survivor mask go to host-visible memory from ONE small launch instead
+// of two copy commands.  `rec_host` and `mask_host` are pinned host allocations mapped into the device's address space.
+__global__ __launch_bounds__(256) void k_export_run(const unsigned long long *__restrict__ rec, int rec_words, unsigned long long *__restrict__ rec_host,
+                                                     const unsigned long long *__restrict__ mask, int64_t mask_words, const uint8_t *__restrict__ mask_bytes,
+                                                     int64_t n, unsigned long long *__restrict__ mask_host) {
+    const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = tid; e < rec_words; e += stride) rec_host[e] = rec[e];
+    if (mask_host) {
+        for (int64_t e = tid; e < mask_words; e += stride) mask_host[e] = mask[e];
+        uint8_t *tail = reinterpret_cast<uint8_t *>(mask_host);
+        for (int64_t b = mask_words * 8 + tid; b < n; b += stride) tail[b] = mask_bytes[b];
+    }
+}
+
 __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = v;
 }

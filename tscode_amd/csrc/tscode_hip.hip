@@ -515,6 +515,7 @@ struct tsc_prune {
     double *Gall = nullptr;
     LocalTickets *tickets = nullptr;  // chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
+    uint8_t *export_mask_host = nullptr;  // set by prune_run: pinned host buffer that receives the mask with the statistics
     unsigned *dmax_bits = nullptr;  // device scalar: largest |descriptor component| as float bits (zeroed by k_init_run)
     PassCounters *counters = nullptr;
     PruneState *state = nullptr;
@@ -963,8 +964,17 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
             p->last_slot = -1;
         }
-        static_assert(sizeof(PassRecord) * TSC_MAX_PASSES <= 4096, "records fit the pinned staging buffer");
-        TSC_HIP(hipMemcpyAsync(c->pinned, p->records, sizeof(PassRecord) * TSC_MAX_PASSES, hipMemcpyDeviceToHost, st));
+        static_assert(sizeof(PassRecord) * TSC_MAX_PASSES <= 4096 && sizeof(PassRecord) % 8 == 0, "records fit the pinned staging buffer");
+        {
+            const int rec_words = int(sizeof(PassRecord) * TSC_MAX_PASSES / 8);
+            const int64_t mask_words = p->export_mask_host ? p->n / 8 : 0;
+            hipLaunchKernelGGL(k_export_run, dim3(grid_for(std::max<int64_t>(mask_words, rec_words), 256, 64)), dim3(256), 0, st,
+                               reinterpret_cast<const unsigned long long *>(p->records), rec_words, static_cast<unsigned long long *>(c->pinned),
+                               reinterpret_cast<const unsigned long long *>(p->mask), mask_words, (const uint8_t *)p->mask, p->n,
+                               reinterpret_cast<unsigned long long *>(p->export_mask_host));
+            TSC_HIP(hipGetLastError());
+            p->export_mask_host = nullptr;
+        }
         TSC_HIP(hipStreamSynchronize(st));
         const PassRecord *rec = static_cast<const PassRecord *>(c->pinned);
         p->n_passes = 0;
@@ -1003,7 +1013,20 @@ static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double r
     if (!rc) {
         DeviceGuard guard(c->device);
         hipError_t e = in_place ? hipSuccess : hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess && mask_host) e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
+        // the verdicts go to the host with the statistics (one launch, k_export_run) when the buffer is pinned host memory the
+        // device can write; any other pointer takes a copy command
+        p->export_mask_host = nullptr;
+        if (e == hipSuccess && mask_host) {
+            hipPointerAttribute_t at;
+            const bool mapped = (reinterpret_cast<uintptr_t>(mask_host) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p->mask) & 7u) == 0 &&
+                                hipPointerGetAttributes(&at, mask_host) == hipSuccess && at.type == hipMemoryTypeHost;
+            if (mapped) {
+                p->export_mask_host = mask_host;
+            } else {
+                (void)hipGetLastError();
+                e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
+            }
+        }
         if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
     }
     if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
@@ -1525,8 +1548,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             if (pending) (void)hipStreamSynchronize(c->basis_stream);
         }
     } basis_join{c, false};
+    int n_samples = 0;
+    double *d_sample = nullptr;
     if (c->early_basis && c->prune_algo != ALGO_TILE) {
-        const int n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
+        n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
         const int64_t stride = std::max<int64_t>(1, n_poses / n_samples);
         if (!(c->sample_dev && int(c->sample_host.size()) == n_samples && c->sample_host.back() == int32_t(stride * (n_samples - 1)))) {
             if (c->sample_dev) c->release(c->sample_dev);
@@ -1538,7 +1563,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             c->sample_dev = static_cast<int32_t *>(q);
             TSC_HIP(hipMemcpyAsync(c->sample_dev, c->sample_host.data(), size_t(n_samples) * sizeof(int32_t), hipMemcpyHostToDevice, st));
         }
-        double *d_sample;
         TSC_TRY(s.get(size_t(n_samples) * n_heavy * 3, &d_sample));
         TSC_TRY(s.get(basis_doubles(n_heavy), &d_basis));
         if (c->fuse_descriptors && transform_describe_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024) {
@@ -1547,6 +1571,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(s.get(4, &ext.dmax_bits));
         }
         TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
+    }
+    // K1+K2 fused verdicts
+    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
+                                     clash_mask, nullptr));
+    if (timed) TSC_HIP(hipEventRecord(ev[1], st));
+    // ordered compaction: embed only the passing poses, all atoms + heavy atoms
+    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
+    if (d_basis) {  // the side stream's work is enqueued while the clash kernel already runs (it only waits for ev_fork)
         TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
         basis_join.pending = true;
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
@@ -1555,12 +1587,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits));
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
-    // K1+K2 fused verdicts
-    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
-                                     clash_mask, nullptr));
-    if (timed) TSC_HIP(hipEventRecord(ev[1], st));
-    // ordered compaction: embed only the passing poses, all atoms + heavy atoms
-    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     // the passing poses are embedded (all atoms + heavy atoms) by a launch sized for every pose that reads the count on the
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));

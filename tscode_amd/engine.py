@@ -62,6 +62,41 @@ def _stats_list(stats, n):
     return [stats[i].as_dict() for i in range(n)]
 
 
+class PipelineResult:
+    """What one tsc_pipeline_dev call returned.  Reads like the dict it used to be (res["n_pass"], res["stats"], ...);
+    the per-pass statistics are turned into Python objects only when somebody asks for them -- a dozen structs of a dozen
+    fields cost more host time than several of the step's kernels take."""
+    __slots__ = ("n_pass", "n_keep", "_stats", "_n_passes", "_tm", "_cache")
+
+    def __init__(self, n_pass, n_keep, stats, n_passes, tm):
+        self.n_pass, self.n_keep, self._stats, self._n_passes, self._tm, self._cache = n_pass, n_keep, stats, n_passes, tm, None
+
+    @property
+    def stats(self):
+        if self._cache is None:
+            self._cache = _stats_list(self._stats, self._n_passes)
+        return self._cache
+
+    @property
+    def ms(self):
+        t = self._tm
+        return {"embed_clash": t[0], "compact": t[1], "prune": t[2], "total": t[3]}
+
+    def __getitem__(self, key):
+        if key in ("n_pass", "n_keep", "stats", "ms"):
+            return getattr(self, key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        return ("n_pass", "n_keep", "stats", "ms")
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.lib = _lib.load()
@@ -336,8 +371,27 @@ class Engine:
                                         ptr(clash_mask), ptr(structures), ptr(keep_mask), ptr(keep_mask_host), C.byref(n_pass),
                                         C.byref(n_keep), stats,
                                         C.byref(np_), tm))
-        return {"n_pass": n_pass.value, "n_keep": n_keep.value, "stats": _stats_list(stats, np_.value),
-                "ms": {"embed_clash": tm[0], "compact": tm[1], "prune": tm[2], "total": tm[3]}}
+        return PipelineResult(n_pass.value, n_keep.value, stats, np_.value, tm)
+
+    def pipeline_dev_prepare(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, heavy_idx, clash_thresh, max_clashes,
+                             rmsd_thr, mode, clash_mask, structures, keep_mask, keep_mask_host=None):
+        """The same call with every argument converted once: returns run() -> PipelineResult for callers that repeat the
+        step on resident buffers (the ctypes conversions of 25 arguments are host time in front of the first launch)."""
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        fixed = (self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos), C.c_int64(n_poses),
+                 heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)), C.c_double(clash_thresh), C.c_int64(int(max_clashes)),
+                 C.c_double(rmsd_thr), C.c_int(mode), ptr(clash_mask), ptr(structures), ptr(keep_mask), ptr(keep_mask_host))
+        keep_alive = (frags, frags_dev, conf_idx, rot, pos, heavy_idx, clash_mask, structures, keep_mask, keep_mask_host)
+        fn, byref = self.lib.tsc_pipeline_dev, C.byref
+        stats_t, tm_t = PassStats * TSC_MAX_PASSES, C.c_float * 4
+
+        def run(_keep=keep_alive):
+            n_pass, n_keep, np_ = C.c_int64(), C.c_int64(), C.c_int()
+            stats, tm = stats_t(), tm_t()
+            check(fn(*fixed, byref(n_pass), byref(n_keep), stats, byref(np_), tm))
+            return PipelineResult(n_pass.value, n_keep.value, stats, np_.value, tm)
+
+        return run
 
 
 class PruneStepper:

@@ -210,6 +210,7 @@ class DevicePipeline:
         self.torch, self.ens = torch, ens
         self.rank, self.world, self.pg = int(rank), int(world), process_group
         self.params = (clash_thresh, max_clashes, rmsd_thr, mode)
+        self._run = None
         self.sharded = self.world > 1 or force_sharded
         self.shard_min_pairs = shard_min_pairs                  # None: SHARD_MIN_PAIRS (tests lower it to shard small passes too)
         if self.sharded:
@@ -236,7 +237,10 @@ class DevicePipeline:
         """One pass of the hot path over the resident ensemble.  Returns counts/statistics; the verdicts
         stay on the device (d_clash, d_structures, d_keep)."""
         if not self.sharded:
-            c, m, r, mode = self.params
-            return self.eng.pipeline_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx,
-                                         c, m, r, mode, self.d_clash, self.d_structures, self.d_keep, self.h_keep)
+            if self._run is None:      # arguments converted once: the buffers are resident and do not change between steps
+                c, m, r, mode = self.params
+                self._run = self.eng.pipeline_dev_prepare(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses,
+                                                          self.heavy_idx, c, m, r, mode, self.d_clash, self.d_structures, self.d_keep,
+                                                          self.h_keep)
+            return self._run()
         return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs)
