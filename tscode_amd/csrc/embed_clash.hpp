@@ -69,11 +69,15 @@ __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ fr
                                                     const double *__restrict__ pos, const int32_t *__restrict__ idx,
                                                     int64_t n_out, double *__restrict__ out,
                                                     const int32_t *__restrict__ heavy_slot, int n_heavy,
-                                                    double *__restrict__ heavy_out, const int32_t *__restrict__ n_out_dev) {
+                                                    double *__restrict__ heavy_out, const int32_t *__restrict__ n_out_dev,
+                                                    double *__restrict__ zero_me = nullptr, int n_zero = 0) {
     // n_out_dev (optional): the row count lives on the device (the total of the scan that made idx); the grid is then
     // sized for an upper bound and the host need not wait for the count before launching
+    // zero_me (optional): n_zero doubles cleared on the way (the moment accumulators of the basis estimate that follows
+    // the sample embed: a memset in that short chain is two more launches)
     extern __shared__ __attribute__((aligned(16))) double s_tr[];
     const int n = ft.n_total, nm = ft.n_mols, tid = threadIdx.x;
+    for (int e = blockIdx.x * 256 + tid; e < n_zero; e += gridDim.x * 256) zero_me[e] = 0.0;
     if (n_out_dev) n_out = *n_out_dev;
     int64_t *sP = reinterpret_cast<int64_t *>(s_tr);  // pose of every local row
     double *sR = s_tr + TR_POSES, *sT = sR + TR_POSES * nm * 9;

@@ -560,15 +560,25 @@ static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_f
 
 // Basis of the descriptors: leading principal axes of the two feature families (sieve.hpp) over `n_samples` structures
 // heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
+static size_t moment_doubles(int h) {
+    const size_t a = size_t(n_features(h, 0) + 1), b = size_t(n_features(h, 1) + 1);
+    return a * a + b * b;
+}
+
+// d_moments (optional): moment_doubles(h) doubles already zeroed on `st` by the caller; otherwise taken from `s` and cleared here
 static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *heavy, int h, int n_samples, int64_t stride, double *d_Q,
-                       unsigned *zero_word = nullptr) {
+                       unsigned *zero_word = nullptr, double *d_moments = nullptr) {
     const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
     double *d_M[NFAM], *d_zero;
     // the moment matrices of both families in one block (one memset)
     const size_t m0 = size_t(nf[0] + 1) * (nf[0] + 1), m1 = size_t(nf[1] + 1) * (nf[1] + 1);
-    TSC_TRY(s.get(m0 + m1, &d_zero));
-    TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1) * sizeof(double), st));
+    if (d_moments) {
+        d_zero = d_moments;
+    } else {
+        TSC_TRY(s.get(m0 + m1, &d_zero));
+        TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1) * sizeof(double), st));
+    }
     d_M[0] = d_zero, d_M[1] = d_zero + m0;
     {
         const size_t lds = size_t(32) * (std::max(nf[0], nf[1]) + 1) * sizeof(double);
@@ -1549,7 +1559,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         }
     } basis_join{c, false};
     int n_samples = 0;
-    double *d_sample = nullptr;
+    double *d_sample = nullptr, *d_moments = nullptr;
     if (c->early_basis && c->prune_algo != ALGO_TILE) {
         n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
         const int64_t stride = std::max<int64_t>(1, n_poses / n_samples);
@@ -1570,23 +1580,26 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(s.get(size_t(n_poses), &ext.G));
             TSC_TRY(s.get(4, &ext.dmax_bits));
         }
+        TSC_TRY(s.get(moment_doubles(n_heavy), &d_moments));
         TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
     }
     // K1+K2 fused verdicts
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
                                      clash_mask, nullptr));
     if (timed) TSC_HIP(hipEventRecord(ev[1], st));
-    // ordered compaction: embed only the passing poses, all atoms + heavy atoms
-    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
-    if (d_basis) {  // the side stream's work is enqueued while the clash kernel already runs (it only waits for ev_fork)
+    if (d_basis) {
+        // The side stream's chain (sample embed, moments, basis: about 50 us) is enqueued right behind the clash launch: the
+        // clash kernel is already running, and the chain has the whole of it (and the scan) to finish in.
         TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
         basis_join.pending = true;
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
                            rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
-                           (const int32_t *)nullptr);
-        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits));
+                           (const int32_t *)nullptr, d_moments, int(moment_doubles(n_heavy)));
+        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments));
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
+    // ordered compaction: embed only the passing poses, all atoms + heavy atoms
+    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     // the passing poses are embedded (all atoms + heavy atoms) by a launch sized for every pose that reads the count on the
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
