@@ -138,7 +138,9 @@ def main():
     from tscode_amd.pipeline import DevicePipeline
     from tscode_amd.synthetic import make_config
 
-    ens = make_config(args.config, args.n_poses)            # every rank draws the same ensemble
+    # every rank draws the SAME ensemble, also in the one-ensemble-per-GPU mode: per-GPU work is then exactly fixed as N grows,
+    # and every rank's survivor set is checked against the recorded oracle mask (parity_vs_recorded_oracle = all ranks agree)
+    ens = make_config(args.config, args.n_poses)
     sharded_mode = (world > 1 and args.multi == "sharded") or args.force_sharded
     if sharded_mode:                                        # ONE ensemble, every rank keeps only its block of the pose axis
         pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
