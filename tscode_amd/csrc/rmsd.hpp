@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
                                                    PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
                                                    PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items,
                                                    unsigned *__restrict__ dmax_bits, unsigned *__restrict__ zero_words, int n_zero_words,
-                                                   int32_t *__restrict__ act) {
+                                                   int32_t *__restrict__ act, int first_slot, long long first_k, int first_algo, int dbit_extra_words) {
+    // first_slot >= 0: the first pass of the schedule is opened here as well (gate of rmsd_pruning.py:192 on the full count,
+    // its record), which is all a k_pass_step launch would do at this point
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
     for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
@@ -326,11 +328,13 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
     // act[x] for x up to n without knowing the active count, and the first global pass may come after chunk-local ones
     for (int64_t e = tid; e < n; e += stride) act[e] = int32_t(e);
     for (int64_t e = tid; e < bit_words; e += stride) mbit[e] = 0, dbit[e] = 0;
+    for (int64_t e = tid; e < dbit_extra_words; e += stride) dbit[bit_words + e] = 0;  // the summary bitmap behind dbit
     unsigned long long *c = &cnt->w[0][0];
     for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
     for (int64_t e = tid; e < n_zero_words; e += stride) zero_words[e] = 0;  // tickets of the chunk-local pass kernel
     char *r = reinterpret_cast<char *>(rec);
-    for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride) r[e] = 0;
+    for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride)
+        if (int(e / int64_t(sizeof(PassRecord))) != first_slot) r[e] = 0;  // (the first pass's record is written whole below)
     // per-block counts of the mask for the exclusive scan of every pass; k_apply_pass keeps them current
     for (int64_t e = tid; e < n_blocks; e += stride) {
         const int64_t lo = e * block_items;
@@ -340,6 +344,13 @@ __global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict
         n_keys[0] = 0;
         if (dmax_bits) *dmax_bits = 0;  // running maximum of the descriptor build (sieve.hpp)
         st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0;
+        if (first_slot >= 0) {
+            const int on = (first_k == 1 || 20 * first_k < (long long)n) ? 1 : 0;
+            PassRecord &fr = rec[first_slot];
+            fr.k = first_k, fr.n_before = fr.n_after = (long long)n, fr.on = on, fr.algo = first_algo;
+            fr.formed = fr.exact = fr.screened = fr.evaluated = fr.removed = 0;
+            st->pass_on = on;
+        }
     }
 }
 

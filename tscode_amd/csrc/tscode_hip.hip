@@ -707,10 +707,15 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     }
     if (!rc) {
         hipStream_t st = c->stream;
+        int first_slot = -1;  // the pass tsc_prune_next_pass will hand out first: opened by k_init_run itself
+        for (int slot = 0; slot < TSC_MAX_PASSES && first_slot < 0; ++slot)
+            if (int64_t(KS[slot]) == 1 || 20 * int64_t(KS[slot]) < n) first_slot = slot;
+        p->opened_slot = first_slot;
         hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
                            p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE,
                            own_desc ? p->dmax_bits : nullptr,
-                           reinterpret_cast<unsigned *>(p->tickets), p->tickets ? int(sizeof(LocalTickets) / sizeof(unsigned)) : 0, p->act);
+                           reinterpret_cast<unsigned *>(p->tickets), p->tickets ? int(sizeof(LocalTickets) / sizeof(unsigned)) : 0, p->act,
+                           first_slot, first_slot >= 0 ? (long long)KS[first_slot] : 0ll, p->algo, int(p->dsum_words));
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
         // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
