@@ -860,8 +860,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int max_range = int(std::min<int64_t>(A, longest_chunk));
     // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
     // work (many small chunks), long ones amortise the per-item setup when it has a lot
-    // (measured on MI355X: 512 columns is best up to ~1.5e5 structures, 2048 at 1e6; "seg_cols" overrides)
-    int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 150000 ? 512 : (n <= 400000 ? 1024 : 2048));
+    // (measured on MI355X, tools/sweep.py: 512 columns at 57k structures, 1024 at 126k, 4096 at 483k; "seg_cols" overrides)
+    int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
