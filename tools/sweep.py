@@ -16,6 +16,9 @@ grid = {"seg_cols": [0, 256, 512, 1024], "drain_min": [16, 32, 64], "local_max_c
 if cfg != "C3":
     grid = {"seg_cols": [0, 1024, 2048, 4096], "drain_min": [32, 64], "local_max_chunk": [256]}
 defaults = {"seg_cols": 0, "drain_min": 64, "local_max_chunk": 256}
+if len(sys.argv) > 2:      # a grid of one's own: python tools/sweep.py C3 '{"early_basis": [0, 1], "sieve_cpl": [1, 2, 4]}' (first values = defaults)
+    grid = json.loads(sys.argv[2])
+    defaults = {k: v[0] for k, v in grid.items()}
 combos = [dict(zip(grid, v)) for v in itertools.product(*grid.values())]
 steps = 20 if cfg == "C3" else 4
 res = {i: [] for i in range(len(combos))}
