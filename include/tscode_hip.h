@@ -262,6 +262,10 @@ int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the 
                                                                       device, a pass whose gate is closed does nothing */
 int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs);        /* upper bound of the pairs of the open pass: lets every
                                                                       rank decide alike whether sharding it pays */
+/* Runs every pass that needs no exchange (world == 1: all; world > 1: those with an estimate below min_pairs, computed whole by
+ * every rank) and returns with the first pass that does left open (*k = its k) or *k = 0 at the end of the schedule
+ * (rmsd_pruning.py:186-204).  One host call instead of three per small pass. */
+int tsc_prune_run_replicated(tsc_prune *run, int world, int64_t min_pairs, int64_t *k);
 int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous.  With world_size == 1 a pass whose chunks
                                                                       are short runs whole in here (chunk-local kernel, option
                                                                       "local_pass"): best[] is then not produced and

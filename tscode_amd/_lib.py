@@ -88,6 +88,7 @@ _SIGNATURES = {
     "tsc_prune_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, C.POINTER(_vp)]),
     "tsc_prune_next_pass": (C.c_int, [_vp, c_i64p]),
     "tsc_prune_pass_estimate": (C.c_int, [_vp, c_i64p]),
+    "tsc_prune_run_replicated": (C.c_int, [_vp, C.c_int, C.c_int64, c_i64p]),
     "tsc_prune_pass_local": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsc_prune_best_ptr": (C.c_int, [_vp, C.POINTER(_vp), c_i64p]),
     "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),

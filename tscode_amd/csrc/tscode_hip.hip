@@ -952,6 +952,23 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     return 0;
 }
 
+// Runs every pass that needs no exchange between ranks (all of them for world == 1; for world > 1 those whose estimate is
+// below min_pairs: every rank computes them whole and reaches the same verdicts) and returns with the first pass that does
+// open (*k_out = its k; the caller runs tsc_prune_pass_local(rank, world), merges best[], tsc_prune_pass_finish) or with
+// *k_out = 0 when the schedule is exhausted.  One host call instead of three per small pass.
+extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(tsc_prune *p, int world, int64_t min_pairs, int64_t *k_out) {
+    TSC_REQUIRE(p && k_out && world >= 1, "null argument");
+    for (;;) {
+        int64_t k = 0;
+        TSC_TRY(tsc_prune_next_pass(p, &k));
+        *k_out = k;
+        if (k == 0) return 0;
+        if (world > 1 && p->n * (p->n / k) / 2 >= min_pairs) return 0;
+        TSC_TRY(tsc_prune_pass_local(p, 0, 1));
+        TSC_TRY(tsc_prune_pass_finish(p));
+    }
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev) {
     TSC_REQUIRE(p && mask_dev, "null argument");
     *mask_dev = p->mask;

@@ -416,6 +416,12 @@ class PruneStepper:
         check(self.e.lib.tsc_prune_pass_estimate(self._p, C.byref(n)))
         return n.value
 
+    def run_replicated(self, world, min_pairs) -> int:
+        """Every pass that needs no exchange, in one call; returns the k of the first pass that does (left open) or 0."""
+        k = C.c_int64()
+        check(self.e.lib.tsc_prune_run_replicated(self._p, C.c_int(world), C.c_int64(int(min_pairs)), C.byref(k)))
+        return k.value
+
     def pass_local(self, rank=0, world=1):
         check(self.e.lib.tsc_prune_pass_local(self._p, C.c_int(rank), C.c_int(world)))
 

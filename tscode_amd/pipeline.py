@@ -99,12 +99,20 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
     stats = []
     if n_pass > 0:
         st = backend.make_stepper(n_pass)
+        limit = SHARD_MIN_PAIRS if min_pairs is None else min_pairs
         try:
             while True:
-                k = st.next_pass()
-                if k == 0:
-                    break
-                if world > 1 and st.pass_estimate() >= (SHARD_MIN_PAIRS if min_pairs is None else min_pairs):
+                if hasattr(st, "run_replicated"):       # the small passes in one library call; back here for an exchange
+                    k = st.run_replicated(world, limit)
+                    if k == 0:
+                        break
+                    shard = True
+                else:
+                    k = st.next_pass()
+                    if k == 0:
+                        break
+                    shard = world > 1 and st.pass_estimate() >= limit
+                if shard:
                     st.pass_local(rank, world)          # this rank's row tiles only ...
                     _all_reduce(dist, backend.best[:st.n_active()], dist.ReduceOp.MIN, group)   # ... merged
                 else:
@@ -129,6 +137,9 @@ class _HipStepper:
 
     def pass_estimate(self):
         return self.s.pass_estimate()
+
+    def run_replicated(self, world, min_pairs):
+        return self.s.run_replicated(world, min_pairs)
 
     def pass_local(self, rank, world):
         self.s.pass_local(rank, world)
