@@ -476,6 +476,28 @@ def test_prune_random_small_ensembles(eng, oracle, algo):
     assert checked > 100
 
 
+def test_prune_children_spread_around_the_threshold(eng, oracle, algo):
+    """A mid-size ensemble whose children scatter AROUND the threshold (rotations of several degrees, 0.12 A shifts): many
+    pairs the quartic tests cannot decide, long walks of the exact path, every large-pass code path of the pair kernels.
+    Masks, pass schedule and the reference's pair-evaluation counts equal the oracle's (tools/stress_parity.py runs five
+    such ensembles; this is its first)."""
+    from tscode_amd.synthetic import make_ensemble
+    ens = make_ensemble(12000, (25, 25), 7000, children=10, sigma_rot_deg=6.0, sigma_t=0.12, shell=(4.0, 9.0))
+    poses = ens.poses()
+    poses = poses[oracle.compenetration_mask(poses, ens.ids, 1.5, 0)]
+    heavy = np.ascontiguousarray(poses[:, ens.atomnos != 1])
+    for mode in (0, 1):
+        mr, mm = oracle.prune_margins(heavy, 0.5, mode)
+        assert min(mr, mm) > 1e-9, "a pair sits on a threshold: redraw the ensemble"
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=True)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"]), (mode, int(mask.sum()), int(ref["mask"].sum()))
+        assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+        assert sum(s["candidates"] for s in stats) > 100        # the explicit-rotation path really ran
+    assert 0.05 < mask.mean() < 0.95
+
+
 def test_prune_when_descriptors_cannot_separate(eng, oracle):
     """Worst case for the sieve: two rigid bodies, A fixed and B rotated about the origin, with the atoms ordered so that
     every descriptor pair (a, a + h/2) lies inside one body.  Atom norms and those pair distances (both descriptor
