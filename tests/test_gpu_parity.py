@@ -388,6 +388,35 @@ def test_full_size_properties_c3(eng):
     assert out[1][2]["n_keep"] < out[0][2]["n_keep"]          # the reference-exact mode keeps more
 
 
+@pytest.mark.parametrize("cfg", ["C3", "C5", "C4"])
+def test_full_size_against_the_recorded_oracle(eng, cfg):
+    """BASELINE configs 3, 5 and 4 at FULL size (100k x 50, 500k x 200, 1M x 50) against what the CPU oracle gave on the same
+    seeded inputs (tests/golden/expected_full.json, generated by gen_expected_full.py / tools/record_c4.py: 50 s, 8 min and
+    48 min of CPU): clash mask, survivor mask (SHA-256 of the packed bits), and the reference's pair-evaluation count of
+    every pass."""
+    import hashlib
+    import json
+    import os
+
+    import torch
+
+    from tscode_amd.pipeline import DevicePipeline
+    from tscode_amd.synthetic import make_config
+    ens = make_config(cfg)
+    exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expected_full.json")))[f"{cfg}:{ens.n_poses}:mode0"]
+    pipe = DevicePipeline(ens, device_index=0, mode=0)
+    res = pipe.step()
+    torch.cuda.synchronize()
+    sha = lambda bits: hashlib.sha256(np.packbits(bits.astype(bool)).tobytes()).hexdigest()[:16]
+    assert (res["n_pass"], res["n_keep"]) == (exp["n_pass"], exp["n_keep"])
+    assert sha(pipe.d_clash.cpu().numpy()) == exp["clash_sha256_16"]
+    assert sha(pipe.h_keep[:res["n_pass"]].numpy()) == exp["keep_sha256_16"]
+    assert [s["pairs_evaluated"] for s in res["stats"]] == [p["pairs_evaluated"] for p in exp["passes"]]
+    assert [s["n_active_after"] for s in res["stats"]] == [p["active_after"] for p in exp["passes"]]
+    del pipe
+    torch.cuda.empty_cache()
+
+
 class _SoloDist:
     """torch.distributed stand-in for a world of one rank: collectives are identities."""
 
