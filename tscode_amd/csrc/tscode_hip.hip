@@ -1165,7 +1165,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter_de
     Scratch s(c);
     double *G;
     TSC_TRY(s.get(size_t(n_poses), &G));
-    hipLaunchKernelGGL(k_greedy_group_filter, dim3(ceil_div(n_groups, 4)), dim3(256), 0, c->stream, poses, group_off_dev, n_groups, n_atoms, rmsd_thr,
+    hipLaunchKernelGGL(k_greedy_group_filter, dim3(n_groups), dim3(256), 0, c->stream, poses, group_off_dev, n_groups, n_atoms, rmsd_thr,
                        accepted, G);
     TSC_HIP(hipGetLastError());
     return 0;
