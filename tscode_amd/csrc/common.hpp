@@ -74,6 +74,7 @@ struct tsc_ctx {
     int seg_cols = 0;                     // columns per pair-kernel work item (0 = chosen from the problem size)
     int drain_min = 64;                   // sieve: queued pairs that trigger an evaluation batch
     int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
+    int64_t pca_min_n = 6000;             // below this many structures the descriptors use the identity basis (no principal-axis estimate)
     int fuse_descriptors = 1;             // ... and the descriptors by the kernel that embeds the passing poses (needs early_basis)
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int local_max_chunk = 256;            // longest chunk (structures) of a pass that the chunk-local kernel takes

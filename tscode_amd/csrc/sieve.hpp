@@ -269,6 +269,18 @@ inline size_t transform_describe_lds_bytes(int n_mols, int h) {
     return (transform_lds_bytes(n_mols) + 15) / 16 * 16 + (size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + size_t(TR_POSES) * ((h * 3) | 1)) * sizeof(double);
 }
 
+// The trivial basis for small ensembles: component k of a family = its feature k (rows of the identity: |Q x| <= |x|), no
+// centring.  Any basis gives the same verdicts; with a few thousand structures the screen has little to do, and estimating
+// principal axes (a memset, a moments launch and the one-wavefront basis kernel: about 45 us of latency) costs more than it saves.
+__global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, double *__restrict__ bias) {
+    const int total = KD * (nf0 + nf1);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int fam = e < KD * nf0 ? 0 : 1, r = fam == 0 ? e : e - KD * nf0, nf = fam == 0 ? nf0 : nf1;
+        Q[e] = (r / nf == r % nf) ? 1.0 : 0.0;
+    }
+    for (int e = threadIdx.x; e < DW; e += blockDim.x) bias[e] = 0.0;
+}
+
 // Device-side descriptor basis: one wavefront per feature family.  Orthonormal rows spanning the leading principal
 // axes of the feature covariance by a few steps of block power iteration (the spectrum of these features decays
 // fast: one step gives the screening power of three to within 3 % of the pairs that reach H).  Rows are re-orthonormalised by

@@ -616,7 +616,12 @@ static int build_descriptors(tsc_prune *p, const double *basis) {
         const int64_t stride = std::max<int64_t>(1, p->n / n_samples);
         double *q;
         TSC_TRY(s.get(basis_doubles(h), &q));
-        TSC_TRY(build_basis(c, st, s, p->heavy, h, n_samples, stride, q));
+        if (p->n < c->pca_min_n) {  // small ensemble: the identity basis, one tiny launch (sieve.hpp)
+            hipLaunchKernelGGL(k_identity_basis, dim3(1), dim3(256), 0, st, nf[0], nf[1], q, q + q_doubles);
+            TSC_HIP(hipGetLastError());
+        } else {
+            TSC_TRY(build_basis(c, st, s, p->heavy, h, n_samples, stride, q));
+        }
         d_Q = q;
     }
     // structures per block of k_descriptors: as many as fit 48 KB of LDS next to the basis (a power of two, 4..64: the
@@ -1123,6 +1128,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "fuse_descriptors") == 0) {
         TSC_REQUIRE(value == 0 || value == 1, "fuse_descriptors must be 0 or 1");
         c->fuse_descriptors = int(value);
+        return 0;
+    }
+    if (strcmp(name, "pca_min_n") == 0) {
+        TSC_REQUIRE(value >= 0 && value <= 1e9, "pca_min_n must be in [0, 1e9]");
+        c->pca_min_n = int64_t(value);
         return 0;
     }
     if (strcmp(name, "early_basis") == 0) {
