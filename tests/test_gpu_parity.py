@@ -417,6 +417,23 @@ def test_full_size_against_the_recorded_oracle(eng, cfg):
     torch.cuda.empty_cache()
 
 
+def test_concurrent_processes_share_the_gpu():
+    """TSCoDe's multiembed runs the path from several processes at once.  Three processes step the C2 pipeline
+    1000 times each on this one GPU; every step of every process must give the first step's survivor mask and evaluation
+    counts, which equal the recorded oracle result (tools/soak.py).  Contention reorders workgroups: this is the test that
+    found the chunk-local kernel reading a mask that workgroups of the same launch were already clearing."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "soak.py"), "C2", "1000"], cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    for pr in procs:
+        out, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, (out[-500:], err[-1500:])
+        assert "1000 steps, 0 differ" in out and "recorded oracle result: True" in out, out[-500:]
+
+
 class _SoloDist:
     """torch.distributed stand-in for a world of one rank: collectives are identities."""
 

@@ -9,6 +9,10 @@ cfg, steps = (sys.argv[1] if len(sys.argv) > 1 else "C3"), int(sys.argv[2]) if l
 ens = make_config(cfg)
 exp = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_poses}:mode0")
 pipe = DevicePipeline(ens, device_index=0, mode=0)
+for opt in sys.argv[3:]:                                  # library tunables name=value
+    from tscode_amd import get_engine
+    get_engine(0).set_option(opt.split("=")[0], float(opt.split("=")[1]))
+kinds = {}
 bad, first, t0 = 0, None, time.time()
 for i in range(steps):
     res = pipe.step()
@@ -18,6 +22,13 @@ for i in range(steps):
         first = key
         if exp:
             assert (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"]) == key[:3], key[:3]
-    bad += key != first
+    if key != first:
+        bad += 1
+        what = ("n_pass" if key[0] != first[0] else "") + (" n_keep" if key[1] != first[1] else "") + (" mask" if key[2] != first[2] else "") + \
+               (" evals" if key[3] != first[3] else "")
+        kinds[what] = kinds.get(what, 0) + 1
+        if bad <= 3:
+            print("step", i, what, key[:2], first[:2], [a - b for a, b in zip(key[3], first[3])] if len(key[3]) == len(first[3]) else (len(key[3]), len(first[3])), flush=True)
+print(kinds)
 print(f"{cfg}: {steps} steps, {bad} differ from the first (which equals the recorded oracle result: {bool(exp)}), {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

@@ -52,6 +52,7 @@ __device__ inline unsigned long long lds_extract64(const unsigned long long *bit
 }
 
 __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
+                                                             const unsigned long long *__restrict__ mbit,
                                                              const unsigned long long *__restrict__ dbit, const double *__restrict__ heavy,
                                                              const double *__restrict__ Gall, const float *__restrict__ D,
                                                              int32_t *__restrict__ key_a, int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
@@ -89,16 +90,15 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0, n_evaluated = 0, n_removed = 0;
 
     if (pass_on) {
-        // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures
-        for (int base = 0; base < nw * 64; base += LP_THREADS) {
-            const int t = base + tid;
-            const unsigned long long w = __builtin_amdgcn_ballot_w64(t < L && mask[first + t] != 0);
-            if (lane == 0 && (t >> 6) < nw) s_mb[t >> 6] = w;
-        }
+        // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures.  The mask comes from the snapshot
+        // k_dbit_build took before this launch (mbit), NOT from the byte mask: other workgroups -- of this very chunk when it
+        // is shared -- clear bytes of it in step 4, and they may be done before this one starts
         for (int w = tid; w < nw; w += LP_THREADS) {
+            unsigned long long m = extract64(mbit, int64_t(first) + 64 * w);
             unsigned long long v = a.use_cache ? extract64(dbit, int64_t(first) + 64 * w) : 0ull;
             const int rem = L - 64 * w;
-            if (rem < 64) v &= (1ull << rem) - 1ull;
+            if (rem < 64) m &= (1ull << rem) - 1ull, v &= (1ull << rem) - 1ull;
+            s_mb[w] = m;
             s_db[w] = v;
         }
         if (tid < 2) s_mb[nw + tid] = 0, s_db[nw + tid] = 0;

@@ -466,11 +466,20 @@ __device__ inline void build_cache_view(const PassGeom &g, const int32_t *__rest
 
 // Cache view of a pass on its own (the chunk-local pass kernel, local_pass.hpp, needs nothing else from k_open_pass):
 // key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
-__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
+// It also takes the SNAPSHOT of the mask that the pass reads (mbit, one bit per structure): the workgroups of the chunk-local
+// kernel remove rows from the byte mask while others, possibly of the same chunk, have not started yet -- every row of a
+// pass must see the mask as it was when the pass began (rmsd_pruning.py:151-157), whatever order the workgroups run in.
+__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, int use_cache, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
                                                      const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
-                                                     const PruneState *__restrict__ st, unsigned long long *__restrict__ dsum) {
+                                                     const PruneState *__restrict__ st, unsigned long long *__restrict__ dsum,
+                                                     const uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit) {
     if (st->pass_on == 0) return;
-    build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
+    const int n64 = (g.n + 63) & ~63;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n64; t += gridDim.x * blockDim.x) {  // (wave-uniform bounds)
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(t < g.n && mask[t] != 0);
+        if ((threadIdx.x & 63) == 0) mbit[t >> 6] = w;
+    }
+    if (use_cache) build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
 }
 
 // Opens the data of a pass in one launch: ranks of the active structures, their index list and the mask as bits

@@ -822,9 +822,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // 50 -- and is no better than the four-launch path beyond; "local_max_chunk" moves the limit)
     p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= std::min(LP_MAX_ROWS, c->local_max_chunk);
     if (p->cur_local) {
-        if (use_cache)
-            hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
-                               (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state, p->dbit + p->bit_words);
+        // the pass's view of the mask (a bit snapshot: the kernel below clears bytes of the mask while it runs) and of the cache
+        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, use_cache, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
+                           (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state, p->dbit + p->bit_words, (const uint8_t *)p->mask, p->mbit);
         LocalPassArgs a;
         a.h = p->h, a.use_cache = use_cache;
         a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
@@ -839,7 +839,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         const int64_t blocks = (k - 1) * a.nb_regular + a.nb_last;
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
         hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask,
-                              (const unsigned long long *)p->dbit, p->heavy, (const double *)p->Gall, (const float *)p->Dall, p->key_a, p->key_b,
+                              (const unsigned long long *)p->mbit, (const unsigned long long *)p->dbit, p->heavy, (const double *)p->Gall, (const float *)p->Dall, p->key_a, p->key_b,
                               p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit, p->tickets);
         TSC_HIP(hipGetLastError());
         p->opened_slot = nxt;
