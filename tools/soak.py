@@ -6,6 +6,23 @@ import numpy as np, torch
 from tscode_amd.pipeline import DevicePipeline
 from tscode_amd.synthetic import make_config
 cfg, steps = (sys.argv[1] if len(sys.argv) > 1 else "C3"), int(sys.argv[2]) if len(sys.argv) > 2 else 300
+args = [a for a in sys.argv[3:] if a.startswith("--")]
+sys.argv = sys.argv[:3] + [a for a in sys.argv[3:] if not a.startswith("--")]
+if "--dropin" in args:      # the host-array drop-in call instead of the resident pipeline: prune_conformers_rmsd on the config's survivors of the clash check
+    import oracle
+    import tscode_amd
+    ens = make_config(cfg)
+    poses = ens.poses()
+    poses = poses[tscode_amd.compenetration_mask(poses, ens.ids, 1.5, 0)]
+    first, bad, t0 = None, 0, time.time()
+    for i in range(steps):
+        _, mask = tscode_amd.prune_conformers_rmsd(poses, ens.atomnos, 0.5)
+        d = hashlib.sha256(np.packbits(mask).tobytes()).hexdigest()[:16]
+        first = first or d
+        bad += d != first
+    e = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_poses}:mode0")
+    print(f"{cfg} drop-in: {steps} steps, {bad} differ from the first; first equals the recorded oracle mask: {bool(e) and e['keep_sha256_16'] == first}, {time.time() - t0:.1f} s")
+    sys.exit(1 if bad else 0)
 ens = make_config(cfg)
 exp = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_poses}:mode0")
 pipe = DevicePipeline(ens, device_index=0, mode=0)
