@@ -840,7 +840,7 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     got = json.loads(line)
-    assert got["world"] == world and got["ranks_agree"]
+    assert got["world"] == world and got["ranks_agree"] and got["steps_that_differ"] == 0
     if cfg == "C3":
         exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))["C3:100000:mode0"]
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
