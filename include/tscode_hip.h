@@ -130,7 +130,9 @@ int tsc_gather_heavy_dev(tsc_ctx *ctx, const double *coords, const uint8_t *mask
 /* The first half of tsc_pipeline_dev on its own (one rank's block of the pose axis in the sharded protocol): fused
  * embed + clash verdicts, ordered compaction, then the passing poses embedded straight into `structures` (all atoms,
  * may be NULL) and `heavy` (their heavy atoms, f64[n_pass, n_heavy, 3]) -- rejected poses are never materialised.
- * n_pass_host receives the count (the call synchronises for it while the embed runs). */
+ * n_pass_host receives the count (the call synchronises for it while the embed runs).  With "early_basis" (default) the call also
+ * estimates a descriptor basis from a sample of these poses on a side stream; the next tsc_prune_create on this context with
+ * the same heavy-atom count uses it (once) instead of estimating its own -- a choice that never changes a verdict. */
 int tsc_embed_clash_compact_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
                                 int n_mols, const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses,
                                 const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, uint8_t *clash_mask,

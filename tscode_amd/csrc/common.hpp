@@ -81,6 +81,10 @@ struct tsc_ctx {
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback
     int pass_timing = 0;                  // HIP events per pass: 0 none, 1 on the pair kernel's dispatch, 2 also around the whole pass
+    // basis estimated by tsc_embed_clash_compact_dev beside its clash kernel, for the tsc_prune_create that follows (consumed once)
+    double *eb_block = nullptr;           // [sample coordinates | moment accumulators | basis]
+    int eb_h = 0, eb_samples = 0;
+    bool eb_valid = false;
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
     std::vector<int32_t> slot_host;       // heavy-atom slot table of the last tsc_pipeline_dev call and its device copy

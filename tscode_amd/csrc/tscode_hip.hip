@@ -81,6 +81,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->basis_stream) (void)hipStreamDestroy(c->basis_stream);
+    if (c->basis_stream) (void)hipStreamSynchronize(c->basis_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -739,7 +740,16 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
-    return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out);
+    TSC_REQUIRE(c != nullptr, "tsc_prune_create: null argument");
+    // a basis that tsc_embed_clash_compact_dev estimated beside its clash kernel is used once, by the run created next
+    const double *basis = nullptr;
+    if (c->eb_valid && c->eb_h == h && c->prune_algo != ALGO_TILE) {
+        DeviceGuard guard(c->device);
+        TSC_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        basis = c->eb_block + size_t(c->eb_samples) * h * 3 + moment_doubles(h);
+    }
+    c->eb_valid = false;
+    return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, basis);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out) {
@@ -1513,6 +1523,24 @@ static int heavy_slot_table(tsc_ctx *c, const FragTable &ft, const int32_t *heav
     return 0;
 }
 
+// pose indices 0, stride, 2 stride, ... of the basis sample, cached on the device between calls
+static int basis_sample_table(tsc_ctx *c, int64_t n_poses, int *n_samples_out) {
+    const int n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
+    const int64_t stride = std::max<int64_t>(1, n_poses / n_samples);
+    if (!(c->sample_dev && int(c->sample_host.size()) == n_samples && c->sample_host.back() == int32_t(stride * (n_samples - 1)))) {
+        if (c->sample_dev) c->release(c->sample_dev);
+        c->sample_dev = nullptr;
+        c->sample_host.resize(size_t(n_samples));
+        for (int i = 0; i < n_samples; ++i) c->sample_host[size_t(i)] = int32_t(stride * i);
+        void *q = nullptr;
+        TSC_TRY(c->alloc(size_t(n_samples) * sizeof(int32_t), &q));
+        c->sample_dev = static_cast<int32_t *>(q);
+        TSC_HIP(hipMemcpyAsync(c->sample_dev, c->sample_host.data(), size_t(n_samples) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    *n_samples_out = n_samples;
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                                                                   const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                                                                   const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy,
@@ -1533,7 +1561,35 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_de
     TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
     TSC_TRY(s.get(size_t(n_poses), &act));
     TSC_TRY(s.get(1, &total));
+    // The descriptor basis of the prune that follows (tsc_prune_create on the gathered survivors), from a sample of THIS block's
+    // unfiltered poses, on the side stream beside the clash kernel -- as tsc_pipeline_dev does.  Every rank of a sharded run
+    // ends up with a basis of its own; any basis gives the same verdicts.
+    int n_samples = 0;
+    double *eb_sample = nullptr, *eb_moments = nullptr, *eb_basis = nullptr;
+    if (c->early_basis && c->prune_algo != ALGO_TILE) {
+        TSC_TRY(basis_sample_table(c, n_poses, &n_samples));
+        const size_t need = size_t(n_samples) * n_heavy * 3 + moment_doubles(n_heavy) + basis_doubles(n_heavy);
+        if (!(c->eb_block && c->eb_h == n_heavy && c->eb_samples == n_samples)) {
+            TSC_HIP(hipStreamSynchronize(c->basis_stream));
+            if (c->eb_block) c->release(c->eb_block);
+            c->eb_block = nullptr;
+            void *q = nullptr;
+            TSC_TRY(c->alloc(need * sizeof(double), &q));
+            c->eb_block = static_cast<double *>(q), c->eb_h = n_heavy, c->eb_samples = n_samples;
+        }
+        eb_sample = c->eb_block, eb_moments = eb_sample + size_t(n_samples) * n_heavy * 3, eb_basis = eb_moments + moment_doubles(n_heavy);
+        TSC_HIP(hipEventRecord(c->ev_fork, st));
+    }
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes, clash_mask, nullptr));
+    if (eb_basis) {
+        TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
+                           rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, eb_sample,
+                           (const int32_t *)nullptr, eb_moments, int(moment_doubles(n_heavy)));
+        TSC_TRY(build_basis(c, c->basis_stream, s, eb_sample, n_heavy, n_samples, 1, eb_basis, nullptr, eb_moments));
+        TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
+        c->eb_valid = true;
+    }
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     TSC_TRY(read_i32_begin(c, total));
     hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,
@@ -1593,18 +1649,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     int n_samples = 0;
     double *d_sample = nullptr, *d_moments = nullptr;
     if (c->early_basis && c->prune_algo != ALGO_TILE) {
-        n_samples = int(std::min<int64_t>(n_poses, DESC_SAMPLE));
-        const int64_t stride = std::max<int64_t>(1, n_poses / n_samples);
-        if (!(c->sample_dev && int(c->sample_host.size()) == n_samples && c->sample_host.back() == int32_t(stride * (n_samples - 1)))) {
-            if (c->sample_dev) c->release(c->sample_dev);
-            c->sample_dev = nullptr;
-            c->sample_host.resize(size_t(n_samples));
-            for (int i = 0; i < n_samples; ++i) c->sample_host[size_t(i)] = int32_t(stride * i);
-            void *q = nullptr;
-            TSC_TRY(c->alloc(size_t(n_samples) * sizeof(int32_t), &q));
-            c->sample_dev = static_cast<int32_t *>(q);
-            TSC_HIP(hipMemcpyAsync(c->sample_dev, c->sample_host.data(), size_t(n_samples) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        }
+        TSC_TRY(basis_sample_table(c, n_poses, &n_samples));
         TSC_TRY(s.get(size_t(n_samples) * n_heavy * 3, &d_sample));
         TSC_TRY(s.get(basis_doubles(n_heavy), &d_basis));
         if (c->fuse_descriptors && transform_describe_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024) {
