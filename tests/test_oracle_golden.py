@@ -197,3 +197,21 @@ def test_tfd_single_match_chunks_need_no_graph():
     rows = np.flatnonzero(first >= 0)
     _tfd_reject_graph(first, d, k, b, [rows[rows // d == c] for c in np.unique(rows // d)])
     assert np.array_equal(a, b) and a.sum() < n - 300
+
+
+def test_cluster_heads_shortcut_matches_networkx():
+    """The member of a cluster that survives TFD / MOI pruning is tuple(subgraph.nodes)[0] (numba_functions.py:209-214): the
+    shortcut that avoids one subgraph view per component must give the same member as networkx itself, on graphs built the
+    way the pruning builds them (a set of (i, j) tuples) -- and the package's own start-up check must have accepted it here."""
+    import networkx as nx
+    from tscode_amd.numba_functions import _cluster_heads_fast, _cluster_heads_reference, _fast_cluster_heads_ok
+    assert _fast_cluster_heads_ok()
+    rng = np.random.default_rng(11)
+    for n, m in ((3, 2), (30, 12), (500, 700), (3000, 2500), (3000, 20000)):
+        matches = set()
+        for a, b in rng.integers(0, n, size=(m, 2)).tolist():
+            if a != b:
+                matches.add((min(a, b), max(a, b)))
+        g = nx.Graph(matches)
+        ref = {frozenset(mem): h for mem, h in _cluster_heads_reference(g)}
+        assert {frozenset(mem): h for mem, h in _cluster_heads_fast(g)} == ref

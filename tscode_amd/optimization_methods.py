@@ -56,14 +56,12 @@ def prune_by_moment_of_inertia(structures, atomnos, max_deviation=1e-2, masses=N
     heavy_structures = np.ascontiguousarray(structures[:, heavy], dtype=np.float64)
     matches = get_moi_similarity_matches(heavy_structures, heavy_masses, max_deviation=max_deviation)
     G = nx.Graph(matches)                                                # :341
-    subgraphs = [G.subgraph(c) for c in nx.connected_components(G)]
-    groups = [tuple(graph.nodes) for graph in subgraphs]
-    best_of_cluster = [group[0] for group in groups]
-    rejects_sets = [set(a) - {b} for a, b in zip(groups, best_of_cluster)]
+    from .numba_functions import _cluster_heads
     mask = np.ones(structures.shape[0], dtype=bool)
-    for _s in rejects_sets:
-        for i in _s:
-            mask[i] = False
+    for members, head in _cluster_heads(G):                              # :342-346: tuple(subgraph.nodes)[0] survives
+        for i in members:
+            if i != head:
+                mask[i] = False
     return structures[mask], mask
 
 
