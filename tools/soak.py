@@ -24,8 +24,9 @@ if "--dropin" in args:      # the host-array drop-in call instead of the residen
     print(f"{cfg} drop-in: {steps} steps, {bad} differ from the first; first equals the recorded oracle mask: {bool(e) and e['keep_sha256_16'] == first}, {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 ens = make_config(cfg)
-exp = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_poses}:mode0")
-pipe = DevicePipeline(ens, device_index=0, mode=0)
+mode = 1 if "--mode1" in args else 0          # (--mode1: the cache-free prune)
+exp = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_poses}:mode{mode}")
+pipe = DevicePipeline(ens, device_index=0, mode=mode)
 for opt in sys.argv[3:]:                                  # library tunables name=value
     from tscode_amd import get_engine
     get_engine(0).set_option(opt.split("=")[0], float(opt.split("=")[1]))
