@@ -19,6 +19,9 @@
  *     context's stream and return without synchronising unless stated.
  *   - the caller owns every buffer it passes; the library keeps no pointer after return except
  *     inside a tsc_prune object, which borrows `heavy` until tsc_prune_destroy.
+ *   - a context (tsc_ctx: one device, its streams, its scratch cache) is for ONE thread at a time, like the reference's
+ *     callers (single-threaded Python; multiembed.py uses processes): threads that want to work concurrently create a
+ *     context each.  Any number of processes may use a device at once (tests/: three processes stepping one GPU).
  */
 #ifndef TSCODE_HIP_H
 #define TSCODE_HIP_H
