@@ -253,6 +253,11 @@ typedef struct {
  * For n > 200 000 the reference itself fails (a float k reaches range()); the schedule is used with int(k). */
 int tsc_prune_rmsd(tsc_ctx *ctx, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
                    tsc_pass_stats *stats, int *n_passes);
+/* The same from the arrays the reference's prune_conformers_rmsd receives (rmsd_pruning.py:164-206): structures f64[n, n_atoms, 3]
+ * with ALL atoms in host memory and heavy_idx i32[n_heavy] (= flatnonzero(atomnos != 1), increasing): the gather of :178-179 runs on
+ * the device. */
+int tsc_prune_structures(tsc_ctx *ctx, const double *structures, int64_t n, int n_atoms, const int32_t *heavy_idx, int n_heavy,
+                         double rmsd_thr, int mode, uint8_t *mask, tsc_pass_stats *stats, int *n_passes);
 int tsc_prune_rmsd_dev(tsc_ctx *ctx, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
                        tsc_pass_stats *stats, int *n_passes); /* synchronises (the schedule gate reads counts) */
 

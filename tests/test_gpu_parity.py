@@ -344,6 +344,28 @@ def test_pipeline_c2_vs_oracle(eng, oracle):
     assert res3["n_pass"] == 0 and res3["n_keep"] == 0
 
 
+def test_dropin_prune_gathers_heavy_atoms_on_the_device(eng, oracle):
+    """tscode_amd.prune_conformers_rmsd on C2's survivors of the clash check (7 290 all-atom structures: above the size from which
+    the heavy-atom gather of rmsd_pruning.py:178-179 runs on the device) against the oracle; the same call on a
+    non-contiguous view and on float32 input (the host-gather branch) returns the same."""
+    import tscode_amd
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2")
+    poses = ens.poses()
+    poses = poses[oracle.compenetration_mask(poses, ens.ids, 1.5, 0)]
+    _, want = oracle.prune_conformers_rmsd(poses, ens.atomnos, 0.5)
+    kept, mask = tscode_amd.prune_conformers_rmsd(poses, ens.atomnos, 0.5)
+    assert np.array_equal(mask, want) and np.array_equal(kept, poses[want])
+    assert [s["pairs_evaluated"] for s in tscode_amd.rmsd_pruning.last_prune_stats()]
+    wide = np.zeros((len(poses), poses.shape[1] + 3, 3))
+    wide[:, :poses.shape[1]] = poses
+    view = wide[:, :poses.shape[1]]                       # not C-contiguous
+    assert not view.flags.c_contiguous
+    assert np.array_equal(tscode_amd.prune_conformers_rmsd(view, ens.atomnos, 0.5)[1], want)
+    small = poses[:1500]                                  # below the size threshold: host gather
+    assert np.array_equal(tscode_amd.prune_conformers_rmsd(small, ens.atomnos, 0.5)[1], oracle.prune_conformers_rmsd(small, ens.atomnos, 0.5)[1])
+
+
 # ----------------------------------------------------------------------------- full size, by properties
 def test_full_size_properties_c3(eng):
     """BASELINE config 3 (100k x 50) at full size, checked through size-independent properties:

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "tsc_greedy_group_filter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp]),
     "tsc_greedy_group_filter_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, _vp]),
     "tsc_prune_rmsd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
+    "tsc_prune_structures": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats),
+                                       C.POINTER(C.c_int)]),
     "tsc_prune_rmsd_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, C.POINTER(_vp)]),
     "tsc_prune_next_pass": (C.c_int, [_vp, c_i64p]),

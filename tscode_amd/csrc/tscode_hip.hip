@@ -1111,6 +1111,32 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c,
     return 0;
 }
 
+// prune_conformers_rmsd as the reference calls it (rmsd_pruning.py:164-206): ALL atoms of every structure in host memory plus
+// the indices of the heavy ones.  The heavy-atom gather `structures[:, atomnos != 1]` (:178-179) runs on the device: on the
+// host it is a strided 40 MB copy that costs ten times the prune at 57k structures.
+extern "C" __attribute__((visibility("default"))) int tsc_prune_structures(tsc_ctx *c, const double *structures, int64_t n, int n_atoms, const int32_t *heavy_idx,
+                                                                           int n_heavy, double rmsd_thr, int mode, uint8_t *mask, tsc_pass_stats *stats,
+                                                                           int *n_passes) {
+    TSC_REQUIRE(c && structures && heavy_idx && mask, "tsc_prune_structures: null argument");
+    TSC_REQUIRE(n >= 0 && n_atoms > 0 && n_heavy > 0 && n_heavy <= n_atoms, "bad sizes");
+    if (n == 0) {
+        if (n_passes) *n_passes = 0;
+        return 0;
+    }
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_all, *d_heavy;
+    uint8_t *d_mask;
+    TSC_TRY(upload(c, s, structures, size_t(n) * n_atoms * 3, &d_all));
+    TSC_TRY(s.get(size_t(n) * n_heavy * 3, &d_heavy));
+    TSC_TRY(s.get(size_t(n), &d_mask));
+    TSC_TRY(tsc_gather_heavy_dev(c, d_all, nullptr, n, n_atoms, heavy_idx, n_heavy, d_heavy, nullptr));
+    TSC_TRY(tsc_prune_rmsd_dev(c, d_heavy, n, n_heavy, rmsd_thr, mode, d_mask, stats, n_passes));
+    TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // Tunables: "prune_algo" 0 / 2 = descriptor sieve (any size), 1 = register-tiled all-pairs kernel (h <= 32);
 // "seg_cols" = columns per work item.
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx *c, const char *name, double value) {

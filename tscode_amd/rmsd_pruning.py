@@ -35,10 +35,15 @@ def prune_conformers_rmsd(structures, atomnos, rmsd_thr=0.5, mode=0, **_ignored)
     n = structures.shape[0]
     if n == 0:
         return structures[:0], np.zeros(0, dtype=bool)
-    heavy = np.ascontiguousarray(structures[:, atomnos != 1], dtype=np.float64)   # :178-179
-    if heavy.shape[1] == 0:
+    heavy_idx = np.flatnonzero(atomnos != 1)                                        # :178
+    if len(heavy_idx) == 0:
         raise ZeroDivisionError("no non-hydrogen atoms: the reference divides by zero (rmsd_pruning.py:35)")
-    mask, _last_stats = get_engine().prune_heavy(heavy, float(rmsd_thr), int(mode))
+    if structures.dtype == np.float64 and structures.flags.c_contiguous and n >= 2048:
+        # the gather structures[:, heavy] (:179) on the device: as a strided host copy it is most of a large call's time
+        mask, _last_stats = get_engine().prune_structures(structures, heavy_idx, float(rmsd_thr), int(mode))
+    else:
+        heavy = np.ascontiguousarray(structures[:, heavy_idx], dtype=np.float64)    # :179
+        mask, _last_stats = get_engine().prune_heavy(heavy, float(rmsd_thr), int(mode))
     return structures[mask], mask                                                   # :206
 
 
