@@ -102,7 +102,11 @@ def test_install_patches_every_binding_site():
                      "all_dists", "count_clashes"):
             setattr(m, attr, "reference")
         fake[n] = m
-    done = tscode_amd.install(modules=fake)
+    done = tscode_amd.install(modules=fake)               # default: only what takes a whole ensemble per call
+    assert ("tscode.embedder", "prune_conformers_rmsd") in done and ("tscode.embeds", "compenetration_check") not in done
+    assert fake["tscode.embeds"].compenetration_check == "reference" and fake["tscode.embedder"].prune_conformers_rmsd is tscode_amd.prune_conformers_rmsd
+    tscode_amd.uninstall(modules=fake)
+    done = tscode_amd.install(modules=fake, per_item=True)
     assert ("tscode.embedder", "prune_conformers_rmsd") in done and ("tscode.embeds", "compenetration_check") in done
     for n in ("tscode.rmsd_pruning", "tscode.embedder", "tscode.operators", "tscode.optimization_methods", "tscode.atropisomer_module"):
         assert fake[n].prune_conformers_rmsd is tscode_amd.prune_conformers_rmsd

@@ -35,15 +35,26 @@ _PATCHES = {
                              ("tscode.numba_functions", "tscode.embedder", "tscode.operators", "tscode.torsion_module")),
 }
 
+# Functions that take a whole ensemble per call: what install() replaces by default.  The others are called by TSCoDe once per
+# pose / pair from Python loops; a GPU call (upload, launch, download, synchronise) takes 35-185 us against the few microseconds of
+# the reference's jitted function (tools/dropin_latency.py), so replacing them would SLOW those loops down -- they are drop-in
+# equivalents for checking and for callers that move to the batched forms, patched only on request.
+_WHOLE_ENSEMBLE = ("prune_conformers_rmsd", "prune_conformers_tfd", "get_moi_similarity_matches", "_score_embed_poses")
+
 _saved = {}
 
 
-def install(modules=None):
-    """Replace the hot-path functions in every already-imported tscode module.
+def install(modules=None, per_item=False):
+    """Replace the hot-path functions in every already-imported tscode module: by default those that work on a whole ensemble
+    per call (prune_conformers_rmsd, prune_conformers_tfd, get_moi_similarity_matches, _score_embed_poses); with
+    ``per_item=True`` also the per-pose / per-pair ones (compenetration_check, get_embed, rmsd_and_max_numba, ...), which are
+    equivalent but slower than the reference's jitted code when called one item at a time.
     Returns the list of (module, attribute) pairs that were patched."""
     mods = sys.modules if modules is None else modules
     done = []
     for attr, (fn, names) in _PATCHES.items():
+        if not per_item and attr not in _WHOLE_ENSEMBLE:
+            continue
         for name in names:
             mod = mods.get(name)
             if mod is not None and hasattr(mod, attr):
