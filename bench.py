@@ -8,7 +8,7 @@ A "step" is one pass of the hot path over one synthetic ensemble that is already
 fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_conformers_rmsd
 (reference-exact mode), verdict masks left on the device and copied to pinned host memory.
 
-N > 1 (one process per GPU).  The 100k x 50 pipeline is a 1.1 ms job on one MI355X, a chain of ~50 dependent
+N > 1 (one process per GPU).  The 100k x 50 pipeline is a 0.9 ms job on one MI355X, a chain of ~50 dependent
 launches, so the two ways the path shards behave very differently and the line reports both:
   * `value` (scaling "weak", --multi ensembles, the default): every GPU runs the whole pipeline on its own 100k x 50
     ensemble -- ensembles are independent, no data-path collective; this is how a batch of embeds uses a node;
@@ -16,6 +16,10 @@ launches, so the two ways the path shards behave very differently and the line r
     the ranks -- pose blocks for embed/clash, one RCCL all-gather of the surviving heavy-atom coordinates, row tiles of
     every large prune pass dealt round-robin with an all-reduce(MIN) per pass (tscode_amd/pipeline.py::sharded_step).
     It is what an ensemble too large for one GPU's patience (C4: 1M x 50) needs.
+
+The timed region (K steps between barrier + synchronize) carries the HIP start/stop events of every pair-kernel dispatch that
+`roofline.avg_launch_us` needs; the same K steps with those events off follow (`events_off`), then three steps with every
+library event on for `stage_ms_per_step` and `passes[].ms` -- both outside the timed region.
 
 Rank 0 prints ONE JSON line (see the keys below).  The CPU baseline leg (rank 0, N = 1 only) times the
 oracle -- this repo's C restatement of the reference algorithm, "port" -- on a bounded sample of the same
