@@ -152,12 +152,11 @@ def main():
     else:                                                   # one whole ensemble per GPU: the single-GPU pipeline on every rank
         pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
     units_per_step = ens.n_poses * (1 if sharded_mode else world)     # conformers all ranks process in one step
-    from tscode_amd import get_engine
-    get_engine(local_rank).set_option("prune_algo", args.algo)
-    get_engine(local_rank).set_option("pass_timing", args.pass_timing)
+    pipe.set_option("prune_algo", args.algo)
+    pipe.set_option("pass_timing", args.pass_timing)
     for opt in args.opt:
         name, val = opt.split("=")
-        get_engine(local_rank).set_option(name, float(val))
+        pipe.set_option(name, float(val))
 
     def sync():
         torch.cuda.synchronize()
@@ -200,17 +199,17 @@ def main():
     # stream costs about 4 us on MI355X; the kernel durations of the roofline need them, the product does not)
     events_off = None
     if args.pass_timing != 0:
-        get_engine(local_rank).set_option("pass_timing", 0)
+        pipe.set_option("pass_timing", 0)
         dt0, _, _ = timed_loop(args.steps)
-        get_engine(local_rank).set_option("pass_timing", args.pass_timing)
+        pipe.set_option("pass_timing", args.pass_timing)
         events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": units_per_step * args.steps / dt0, "unit": "conformers/s"}
     # where a step goes: three more steps with every library event on (stages of the pipeline, whole passes), outside both
     # timed regions -- these events cost about 4 us each and would distort what they measure
     pass_ms = None
     if args.pass_timing != 0:
-        get_engine(local_rank).set_option("pass_timing", 2)
+        pipe.set_option("pass_timing", 2)
         _, res_d, acc_d = timed_loop(3)
-        get_engine(local_rank).set_option("pass_timing", args.pass_timing)
+        pipe.set_option("pass_timing", args.pass_timing)
         stage_ms = {k: v * args.steps / 3 for k, v in acc_d["stage_ms"].items()}
         pass_ms = [s["gpu_ms"] for s in res_d["stats"]]
     # verdict fingerprint (after the timed region)

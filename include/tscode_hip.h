@@ -226,6 +226,42 @@ int tsc_greedy_group_filter(tsc_ctx *ctx, const double *poses, const int32_t *gr
 int tsc_greedy_group_filter_dev(tsc_ctx *ctx, const double *poses, const int32_t *group_off_dev, int n_groups, int64_t n_poses,
                                 int n_atoms, double rmsd_thr, uint8_t *accepted);
 
+/* The embed loops as one call each.  Both take HOST pointers, keep every intermediate on the device
+ * (pose parameters, candidate poses, fingerprints) and return, per candidate in the reference's loop order, the
+ * compenetration_check verdict (clash_ok u8[N]) and whether the reference would have appended the pose (kept u8[N]);
+ * the kept poses themselves come back compacted in candidate order (poses f64[n_kept, n_atoms_total, 3]; poses may be
+ * NULL; poses_capacity = rows the buffer holds, an error if fewer than n_kept).
+ *
+ * tsc_tfd_greedy_filter: is_new_structure (tscode/embeds.py:47-69) over a whole ordered list of torsion fingerprints
+ *   tf f32[n, n_quads]: accepted[s] = 1 iff no fingerprint accepted before s is tfd_similar (tscode/numba_functions.py:242-253,
+ *   sum of wrapped differences < thresh) to s's.  The reference's list never evicts (`lru_cache = lru_cache[1:]` rebinds a
+ *   local, :66-67) and neither does this.
+ *
+ * tsc_string_embed: the loop of tscode/embeds.py:91-120.  Two fragments (frags / frag_off / n_atoms / n_conf as in
+ *   tsc_transform_batch); n_sites rows (conformer pair, reactive-centre pair) in the reference's order and n_angles angles,
+ *   candidate = site * n_angles + angle index (tsc_string_embed_params); compenetration_check(ids = the two fragments,
+ *   thresh = clash_thresh, max_clashes) (:118); is_new_structure over the passing poses with the torsion fingerprints of
+ *   quads i32[n_quads, 4] (atom indices in the embedded structure) and tfd_thresh (the reference uses 10) (:119).
+ *
+ * tsc_cyclical_embed: the inner loops of tscode/embeds.py:657-717 and :785-847 for any number of (conformers, pivots,
+ *   polygon orientation) groups at once.  One row per (pose, molecule), row = pose * n_mols + m, with the inputs of
+ *   tsc_cyclical_embed_params plus conf_idx i32[rows]; group_off i32[n_groups + 1] cuts the poses into the reference's
+ *   `angular_poses` groups (consecutive, sizes <= 1024); compenetration_check (:714) and then, inside each group and in
+ *   order, `not _rmsd_similarity(pose, kept poses of the group, rmsd_thr)` (:715; the reference passes 1). */
+int tsc_tfd_greedy_filter(tsc_ctx *ctx, const float *tf, int64_t n_structs, int n_quads, double thresh, uint8_t *accepted,
+                          int64_t *n_kept);
+int tsc_string_embed(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
+                     const double *p1, const double *p2, const double *ref_vec, const double *mol_vec, const int32_t *conf_pair,
+                     int64_t n_sites, const double *angles, int n_angles, double clash_thresh, int64_t max_clashes,
+                     const int32_t *quads, int n_quads, double tfd_thresh, uint8_t *clash_ok, uint8_t *kept, double *poses,
+                     int64_t poses_capacity, int64_t *n_pass, int64_t *n_kept);
+int tsc_cyclical_embed(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
+                       int n_mols, const double *start, const double *end, const double *direction, const double *pivot,
+                       const double *meanpoint, const double *r0, const double *r1, const int32_t *n_reactive, const double *angle,
+                       const int32_t *conf_idx, int64_t n_poses, const int32_t *group_off, int n_groups, double clash_thresh,
+                       int64_t max_clashes, double rmsd_thr, uint8_t *clash_ok, uint8_t *kept, double *poses, int64_t poses_capacity,
+                       int64_t *n_pass, int64_t *n_kept);
+
 /* Per-pass statistics of a prune run (one entry per executed k of the schedule). */
 typedef struct {
     int64_t k;               /* number of chunks (tscode/rmsd_pruning.py:186-188) */

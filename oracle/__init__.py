@@ -292,6 +292,23 @@ def torsion_fingerprints(structures, quadruplets):
     return out
 
 
+def torsion_rounding_margin(structures, quadruplets):
+    """Smallest distance (degrees) of any fingerprint angle, as a double, from the nearest float32 rounding tie."""
+    s = _f64(structures)
+    q = np.ascontiguousarray(quadruplets, dtype=np.int32).reshape(-1, 4)
+    out = np.empty((len(s), len(q)))
+    lib().orc_torsion_angles_f64.restype = None
+    lib().orc_torsion_angles_f64(_p(s), C.c_int64(len(s)), C.c_int(s.shape[1]), _p(q), C.c_int(len(q)), _p(out))
+    if out.size == 0:
+        return np.inf
+    f = out.astype(np.float32)
+    lo = np.minimum(np.nextafter(f, np.float32(-np.inf)), f).astype(np.float64)
+    hi = np.maximum(np.nextafter(f, np.float32(np.inf)), f).astype(np.float64)
+    f64 = f.astype(np.float64)
+    ties = np.stack([(lo + f64) / 2, (hi + f64) / 2])
+    return float(np.abs(ties - out[None]).min())
+
+
 def tfd_similarity(a, b, thresh=10):
     a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
     lib().orc_tfd_similarity.restype = C.c_int
@@ -346,3 +363,106 @@ def embed_scores(structures, indices, distances):
     lib().orc_embed_scores.restype = None
     lib().orc_embed_scores(_p(s), C.c_int64(len(s)), C.c_int(s.shape[1]), _p(idx), _p(dist), C.c_int(idx.shape[1]), _p(sc), _p(err))
     return sc, err
+
+
+# ---- the embed loops, restated with plain Python loops over the C functions above ---------------
+def tfd_greedy_filter(tf_mat, thresh=10, return_margin=False):
+    """embeds.py:47-69 is_new_structure over an ordered list: bool[N]."""
+    tf = np.ascontiguousarray(tf_mat, dtype=np.float32)
+    acc = np.zeros(len(tf), dtype=np.uint8)
+    margin = C.c_double(np.inf)
+    lib().orc_tfd_greedy_filter.restype = C.c_int64
+    lib().orc_tfd_greedy_filter(_p(tf), C.c_int64(len(tf)), C.c_int(tf.shape[1]), C.c_double(thresh), _p(acc, _u8p), C.byref(margin) if return_margin else None)
+    return (acc.astype(bool), margin.value) if return_margin else acc.astype(bool)
+
+
+def polygonize(lengths):
+    """utils.py:210-261; raises ValueError where the reference raises TriangleError."""
+    ln = _f64(lengths)
+    out = np.empty((2, 2, 2, 3) if len(ln) == 2 else (8, 3, 2, 3))
+    lib().orc_polygonize.restype = C.c_int
+    if lib().orc_polygonize(_p(ln), C.c_int(len(ln)), _p(out)) != 0:
+        raise ValueError("TriangleError")
+    return out
+
+
+def cartesian_product(*sizes):
+    """utils.py:180-181 for index ranges, written out as loops: np.meshgrid's 'xy' order swaps the roles of the first two
+    inputs -- the second runs slowest, then the first, then the others in turn (the last fastest)."""
+    n = len(sizes)
+    order = list(range(n))
+    if n >= 2:
+        order[0], order[1] = 1, 0                     # slowest axis first
+    out = []
+
+    def rec(level, row):
+        if level == n:
+            out.append(list(row))
+            return
+        ax = order[level]
+        for i in range(sizes[ax]):
+            row[ax] = i
+            rec(level + 1, row)
+    rec(0, [0] * n)
+    return np.array(out, dtype=np.int64).reshape(-1, n)
+
+
+def string_embed(coords1, coords2, centers1, orb_vecs1, centers2, orb_vecs2, angles, clash_thresh, quadruplets, tfd_thresh=10, return_margin=False):
+    """embeds.py:91-120 one candidate at a time: (candidates, clash_ok, kept)."""
+    cands, ok = [], []
+    ids = [coords1.shape[1], coords2.shape[1]]
+    for c1, c2 in cartesian_product(len(coords1), len(coords2)):
+        for a1, a2 in cartesian_product(centers1.shape[1], centers2.shape[1]):
+            rot, pos, ci = string_embed_params([centers1[c1, a1]], [centers2[c2, a2]], [orb_vecs1[c1, a1]], [orb_vecs2[c2, a2]], [[c1, c2]], angles)
+            poses = transform_batch([coords1, coords2], ci, rot, pos)
+            cands.extend(poses)
+            ok.extend(compenetration_mask(poses, ids, clash_thresh, 0))
+    cands, ok = np.array(cands), np.array(ok, dtype=bool)
+    kept = np.zeros(len(cands), dtype=bool)
+    margin = np.inf
+    if ok.any():
+        tf = torsion_fingerprints(cands[ok], quadruplets)
+        acc, margin = tfd_greedy_filter(tf, tfd_thresh, return_margin=True)
+        kept[np.flatnonzero(ok)[acc]] = True
+    return (cands, ok, kept, margin) if return_margin else (cands, ok, kept)
+
+
+def cyclical_embed(coords, reactive, pivots, angles, clash_thresh, rigid_shortcut=True, max_norm_delta=5, rmsd_thr=1):
+    """embeds.py:470-732 / :734-860 for two molecules, one group at a time: (candidates, group_of, clash_ok, kept, ids per group).
+    pivots[m][c] = (pivot [P,3], meanpoint [P,3], cumnums [P,2])."""
+    directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])
+    ids_len = [c.shape[1] for c in coords]
+    cands, group_of, ok, kept, gids = [], [], [], [], []
+    for conf_ids in cartesian_product(*[len(c) for c in coords]):
+        pv = [pivots[m][conf_ids[m]] for m in range(2)]
+        for pi in cartesian_product(*[len(p[0]) for p in pv]):
+            norms = [float(np.sqrt((np.asarray(pv[m][0][pi[m]]) ** 2).sum())) for m in range(2)]
+            delta = abs(norms[0] - norms[1])
+            if rigid_shortcut and delta > max_norm_delta:
+                continue
+            if not rigid_shortcut and not delta < max_norm_delta:
+                continue
+            poly = polygonize(norms)
+            for v in range(2):
+                cum = [list(pv[m][2][pi[m]]) for m in range(2)]
+                if v == 1:
+                    cum[1] = cum[1][::-1]
+                gids.append([[cum[0][0], cum[1][0]], [cum[0][1], cum[1][1]]])
+                g = len(gids) - 1
+                group_poses = []
+                for ang in angles:
+                    rot, pos = np.empty((1, 2, 3, 3)), np.empty((1, 2, 3))
+                    for m in range(2):
+                        r = coords[m][conf_ids[m]][reactive[m]]
+                        rm, pm = cyclical_embed_params([poly[v, m, 0]], [poly[v, m, 1]], [directions[m]], [pv[m][0][pi[m]]], [pv[m][1][pi[m]]], [r[0]],
+                                                       [r[1] if len(r) == 2 else r[0]], [len(r)], [ang[m]])
+                        rot[0, m], pos[0, m] = rm[0], pm[0]
+                    pose = transform_batch(coords, [list(conf_ids)], rot, pos)[0]
+                    good = bool(compenetration_mask(pose[None], ids_len, clash_thresh, 0)[0])
+                    keep = False
+                    if good:
+                        keep = not _rmsd_similarity(pose, group_poses, rmsd_thr)
+                        if keep:
+                            group_poses.append(pose)
+                    cands.append(pose), group_of.append(g), ok.append(good), kept.append(keep)
+    return np.array(cands), np.array(group_of), np.array(ok, dtype=bool), np.array(kept, dtype=bool), np.array(gids)

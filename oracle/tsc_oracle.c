@@ -841,6 +841,19 @@ ORC_API void orc_torsion_fingerprints(const double *coords, int64_t N, int n, co
     }
 }
 
+/* the same angles before the float32 store: lets a test measure how far each value is from a float32 rounding tie (a
+ * fingerprint that differs in one float32 bit can flip a `sum < thresh` verdict when the sum sits exactly on the threshold,
+ * as it does for poses that differ by one 10-degree step of the string embed) */
+ORC_API void orc_torsion_angles_f64(const double *coords, int64_t N, int n, const int32_t *quads, int T, double *out) {
+    for (int64_t s = 0; s < N; ++s) {
+        const double *c = coords + (size_t)s * n * 3;
+        for (int t = 0; t < T; ++t) {
+            const int32_t *q = quads + 4 * t;
+            out[s * T + t] = dihedral_deg(c + 3 * q[0], c + 3 * q[1], c + 3 * q[2], c + 3 * q[3]);
+        }
+    }
+}
+
 /* numba_functions.py:242-253 tfd_similarity: deltas = |tfp1 - tfp2| (float32); deltas = |deltas - (deltas > 180) * 360|
  * (float64 after the integer term); True iff sum(deltas) < thresh.  *sum_out (optional) = the sum. */
 ORC_API int orc_tfd_similarity(const float *a, const float *b, int T, double thresh, double *sum_out) {
@@ -881,6 +894,63 @@ ORC_API void orc_tfd_first_similar(const float *tf, int64_t N, int T, int64_t d,
             }
     }
     if (min_margin) *min_margin = margin;
+}
+
+/* embeds.py:47-69 is_new_structure over an ordered list of fingerprints: structure s is accepted iff tfd_similarity(tfp_s,
+ * ref) is False for every fingerprint accepted before it (:58-60); an accepted fingerprint joins the list (:63) and is never
+ * dropped: `lru_cache = lru_cache[1:]` (:66-67) rebinds the local name only, the caller's list keeps growing.
+ * accepted u8[N]; min_margin (optional, in/out) = smallest |sum - thresh| met. */
+ORC_API int64_t orc_tfd_greedy_filter(const float *tf, int64_t N, int T, double thresh, uint8_t *accepted, double *min_margin) {
+    int64_t *kept = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1)), nk = 0;
+    double margin = min_margin ? *min_margin : 0.0;
+    for (int64_t s = 0; s < N; ++s) {
+        int is_new = 1;
+        for (int64_t k = 0; k < nk; ++k) {
+            double sum;
+            const int sim = orc_tfd_similarity(tf + s * T, tf + kept[k] * T, T, thresh, &sum);
+            if (min_margin && fabs(sum - thresh) < margin) margin = fabs(sum - thresh);
+            if (sim) {
+                is_new = 0;
+                break;
+            }
+        }
+        accepted[s] = (uint8_t)is_new;
+        if (is_new) kept[nk++] = s;
+    }
+    free(kept);
+    if (min_margin) *min_margin = margin;
+    return nk;
+}
+
+/* utils.py:210-261 polygonize.  n = 2: out f64[2][2][2][3] (two orientations of two centred superposed segments);
+ * n = 3: out f64[8][3][2][3] (the eight orientation patterns of a triangle's sides).  Returns 0, or -1 where the reference
+ * raises TriangleError (:236-237). */
+ORC_API int orc_polygonize(const double *lengths, int n, double *out) {
+    double arr[3][2][3];
+    memset(arr, 0, sizeof(arr));
+    if (n == 2) {
+        arr[0][0][0] = -lengths[0] / 2, arr[0][1][0] = +lengths[0] / 2;
+        arr[1][0][0] = -lengths[1] / 2, arr[1][1][0] = +lengths[1] / 2;
+        for (int t = 0; t < 2; ++t) memcpy(out + t * 12, arr, sizeof(double) * 12);
+        for (int i = 0; i < 6; ++i) out[12 + 6 + i] *= -1;      /* vertices_out[1,1] *= -1 */
+        return 0;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (!(lengths[i] < lengths[(i + 2) % 3] + lengths[(i + 1) % 3])) return -1;
+    arr[0][1][0] = lengths[0], arr[1][0][0] = lengths[0];
+    const double a = lengths[0] * lengths[0], b = lengths[1] * lengths[1], c = lengths[2] * lengths[2];
+    const double x = (a - b + c) / (2 * sqrt(a)), y = sqrt(c - x * x);
+    arr[1][1][0] = x, arr[1][1][1] = y, arr[2][0][0] = x, arr[2][0][1] = y;
+    for (int t = 0; t < 8; ++t) memcpy(out + t * 18, arr, sizeof(double) * 18);
+    static const int swaps[12][2] = {{1, 2}, {2, 1}, {3, 1}, {3, 2}, {4, 0}, {5, 0}, {5, 1}, {6, 0}, {6, 2}, {7, 0}, {7, 1}, {7, 2}};
+    for (int q = 0; q < 12; ++q) {
+        double *side = out + swaps[q][0] * 18 + swaps[q][1] * 6;
+        for (int i = 0; i < 3; ++i) {
+            const double tmp = side[i];
+            side[i] = side[3 + i], side[3 + i] = tmp;
+        }
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -1,16 +1,15 @@
-"""Golden-vector generator: runs ONLY in the build container, never on the GPU box.
+"""Golden-vector generator: runs ONLY in the build container, never on the GPU box (.gpurunignore lists it).
 
-It imports the reference's three hot-path modules (tscode.algebra,
-tscode.rmsd_pruning, tscode.numba_functions) from /root/reference and records
-their outputs on seeded inputs as small .npz fixtures next to this file.
-The reference is executed as plain NumPy: Numba is not loadable in this image
-(SURVEY.md F8), so an in-memory stand-in module named ``numba`` whose ``njit``
-is the identity decorator is put in ``sys.modules`` before the import (nothing
-is written next to the reference; no bytecode is written either).  What the
-stand-in does not reproduce (fastmath re-association, Numba's own LAPACK build)
-only moves last bits; the fixtures are compared at 1e-9 or looser.
+It imports the reference's own Python from /root/reference (tscode.algebra, tscode.rmsd_pruning,
+tscode.numba_functions for G1-G6 and G8; tscode.utils, tscode.torsion_module and tscode.optimization_methods for
+G7 and G9) and records their outputs on seeded inputs as small .npz fixtures next to this file.  The reference is
+executed as plain NumPy: Numba is not loadable in this image, so name-only stand-ins for it and for
+the off-path packages the reference imports at module level are registered in ``sys.modules`` first
+(tests/golden/_reference.py; nothing is written next to the reference, no bytecode either).  What the Numba stand-in
+does not reproduce (fastmath re-association, Numba's own LAPACK build) only moves last bits; the fixtures are compared
+at 1e-9 or looser.  G10-G12 (embed helpers and the embed loops) are made by gen_golden_embeds.py.
 
-Usage:  python tests/golden/gen_golden.py [G1 G2 ...]
+Usage:  python -B tests/golden/gen_golden.py [G1 G2 ...]
 """
 
 from __future__ import annotations
@@ -18,53 +17,26 @@ from __future__ import annotations
 import os
 import sys
 import time
-import types
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-REFERENCE = "/root/reference"
+sys.path.insert(0, HERE)
+import _reference as R                      # noqa: E402
 
+R.install_standins(full=True)
+import networkx as nx                       # noqa: E402
 
-def _install_standins():
-    sys.dont_write_bytecode = True
+if not hasattr(nx, "from_numpy_matrix"):    # networkx 3.x renamed it; the reference was written for 2.x
+    nx.from_numpy_matrix = nx.from_numpy_array
 
-    def njit(*args, **kwargs):
-        if len(args) == 1 and callable(args[0]) and not kwargs and not isinstance(args[0], _Sig):
-            return args[0]
-        return lambda f: f
-
-    class _Sig:
-        def __getitem__(self, item):
-            return self
-
-        def __call__(self, *a, **k):
-            return self
-
-    nb = types.ModuleType("numba")
-    nb.njit = nb.jit = njit
-    nb.prange = range
-    nb.float32, nb.float64, nb.boolean = np.float32, np.float64, np.bool_
-    nb.int32 = _Sig()
-    typed = types.ModuleType("numba.typed")
-
-    class List(list):
-        pass
-
-    typed.List = List
-    nb.typed = typed
-    rmsd = types.ModuleType("rmsd")
-    rmsd.kabsch_rotate = rmsd.kabsch = rmsd.kabsch_rmsd = None   # off-path names only
-    sys.modules.update({"numba": nb, "numba.typed": typed, "rmsd": rmsd})
-    sys.path.insert(0, REFERENCE)
-    sys.path.insert(0, REPO)
-
-
-_install_standins()
 import tscode.algebra as ref_alg            # noqa: E402
 import tscode.numba_functions as ref_nf     # noqa: E402
 import tscode.rmsd_pruning as ref_rp        # noqa: E402
+import tscode.optimization_methods as ref_om   # noqa: E402
+import tscode.torsion_module as ref_tm      # noqa: E402
+import tscode.utils as ref_utils            # noqa: E402
 from numba.typed import List                # noqa: E402
 
 from tscode_amd.synthetic import make_ensemble, make_fragment, quat_to_mat   # noqa: E402
@@ -304,81 +276,106 @@ def _chain_molecule(rng, n_backbone, branches):
     return np.array(coords), bonds
 
 
-def _rotation_mask(n, bonds, torsion):
-    """What torsion_module.py:301-325 (_get_rotation_mask) computes, on the bond list: atoms reachable from i1 without
-    crossing i2-i3, inverted if more than half, i2 cleared."""
-    i1, i2, i3, _ = torsion
-    adj = {a: set() for a in range(n)}
-    for a, b in bonds:
-        if {a, b} != {i2, i3}:
-            adj[a].add(b), adj[b].add(a)
-    seen, todo = {i1}, [i1]
-    while todo:
-        for b in adj[todo.pop()]:
-            if b not in seen:
-                seen.add(b), todo.append(b)
-    mask = np.array([a in seen for a in range(n)])
-    if np.count_nonzero(mask) > int(n / 2):
-        mask = ~mask
-    mask[i2] = False
-    return mask
-
-
 def gen_g7():
-    """csearch rotations (next-row N3).  tscode.utils / tscode.torsion_module do not import here (cclib, _tkinter,
-    periodictable are absent), so rotate_dihedral (utils.py:389-414) and the candidate loop (torsion_module.py:463-500)
-    are written out below around the REFERENCE's own rot_mat_from_pointer (tscode.algebra) and torsion_comp_check
-    (tscode.numba_functions); every verdict and every matrix in the fixture comes from those two."""
-    print("G7 csearch dihedral rotations (next-row N3)")
+    """csearch rotations (next-row N3): every number comes from the reference's own random_csearch
+    (tscode/torsion_module.py:399-521), which calls its _get_rotation_mask, rotate_dihedral and torsion_comp_check.
+    Part A runs it once per candidate (duck-typed torsions whose get_angles() offer that candidate's angle only), with
+    note-taking wrappers around rotate_dihedral / torsion_comp_check, so that every candidate's final coordinates, every
+    verdict and the number of bonds that really rotated are recorded -- also for the candidates the function drops.  Part B
+    runs it as its callers do: the n-fold angle tables, np.random.shuffle (seeded) and the n_out / max_tries selection."""
+    print("G7 csearch dihedral rotations (next-row N3): the reference's random_csearch")
     rng = np.random.default_rng(9107)
 
-    def rotate_dihedral(coords, dihedral, angle, mask):                 # utils.py:389-414 (in place)
-        i1, i2, i3, _ = dihedral
-        axis = coords[i2] - coords[i3]
-        mat = ref_alg.rot_mat_from_pointer(axis, angle)
-        center = coords[i3]
-        coords[mask] = (mat @ (coords[mask] - center).T).T + center
-        return coords
+    class OneAngle(ref_tm.Torsion):
+        def __init__(self, torsion, angle):
+            super().__init__(*[int(i) for i in torsion])
+            self.n_fold, self._angle = 1, angle
 
+        def get_angles(self):
+            return (self._angle,)
+
+    events = []
+    real_rd, real_cc = ref_tm.rotate_dihedral, ref_tm.torsion_comp_check
+
+    def rd(coords, dihedral, angle, mask=None, indices_to_be_moved=None):
+        out = real_rd(coords, dihedral, angle, mask=mask, indices_to_be_moved=indices_to_be_moved)
+        events.append(("rot", angle, out))
+        return out
+
+    def cc(coords, torsion, mask, thresh=1.5, max_clashes=0):
+        ok = real_cc(coords, torsion=torsion, mask=mask, thresh=thresh, max_clashes=max_clashes)
+        events.append(("chk", bool(ok), None))
+        return ok
+
+    quiet = dict(logfunction=lambda *a, **k: None, interactive_print=False)
     cases = []
     for case, (nb, br, n_tors, n_cand) in enumerate(((10, 4, 3, 60), (24, 12, 5, 80), (40, 30, 6, 60))):
         coords, bonds = _chain_molecule(rng, nb, br)
         n = len(coords)
+        graph = nx.Graph()
+        graph.add_nodes_from(range(n))                               # node order 0..n-1: _get_rotation_mask walks graph.nodes
+        graph.add_edges_from(bonds)
+        atomnos = np.full(n, 6)
         centres = rng.choice(np.arange(1, nb - 2), size=n_tors, replace=False)
         torsions = np.array([(c - 1, c, c + 1, c + 2) for c in centres], dtype=np.int32)
-        masks = np.array([_rotation_mask(n, bonds, t) for t in torsions])
+        masks = np.array([ref_tm._get_rotation_mask(graph, tuple(int(i) for i in t)) for t in torsions])
         angles = rng.choice(np.array([0, 60, 120, 180, 240, 300, -60, -120, 30, 7]), size=(n_cand, n_tors)).astype(np.int32)
         out = np.empty((n_cand, n, 3))
         rb = np.zeros(n_cand, dtype=np.int32)
-        checks = []
-        for a, angle_set in enumerate(angles):                           # torsion_module.py:463-500
-            new_coords = np.copy(coords)
-            rotated_bonds = 0
-            for t, torsion in enumerate(torsions):
-                angle = int(angle_set[t])
-                if angle != 0:
-                    mask = masks[t]
-                    temp_coords = rotate_dihedral(new_coords, torsion, angle, mask=mask)
-                    ok = ref_nf.torsion_comp_check(temp_coords, torsion=torsion, mask=mask, thresh=1.5)
-                    checks.append(int(ok))
-                    if not ok:
-                        for _ in range(angle // 5):
-                            temp_coords = rotate_dihedral(temp_coords, torsion, -5, mask=mask)
-                            if ref_nf.torsion_comp_check(temp_coords, torsion=torsion, mask=mask, thresh=1.5):
-                                rotated_bonds += 1
-                                break
-                    else:
-                        rotated_bonds += 1
-                    new_coords = temp_coords
-            out[a], rb[a] = new_coords, rotated_bonds
+        kept_by_ref = np.zeros(n_cand, dtype=bool)
+        first_checks = []
+        ref_tm.rotate_dihedral, ref_tm.torsion_comp_check = rd, cc
+        try:
+            for a, angle_set in enumerate(angles):
+                events.clear()
+                tors = [OneAngle(t, int(x)) for t, x in zip(torsions, angle_set)]
+                res = ref_tm.random_csearch(coords.copy(), atomnos, tors, graph, n_out=1, **quiet)
+                rots = [e for e in events if e[0] == "rot"]
+                out[a] = rots[-1][2] if rots else coords
+                rb[a] = sum(1 for e in events if e[0] == "chk" and e[1])
+                kept_by_ref[a] = len(res) == 1
+                if len(res):
+                    assert np.array_equal(res[0], out[a])
+                for i, e in enumerate(events):                      # the check right after a forward rotation
+                    if e[0] == "rot" and e[1] != -5:
+                        first_checks.append(int(events[i + 1][1]))
+        finally:
+            ref_tm.rotate_dihedral, ref_tm.torsion_comp_check = real_rd, real_cc
+        assert np.array_equal(kept_by_ref, rb != 0)
         cases.append(dict(coords=coords, torsions=torsions, masks=masks, angles=angles, out=out, rotated_bonds=rb,
-                          first_checks=np.array(checks, dtype=np.int8)))
+                          first_checks=np.array(first_checks, dtype=np.int8), bonds=np.array(bonds)))
         print(f"  case {case}: n = {n}, {n_tors} torsions, {n_cand} candidates, rotated_bonds histogram {np.bincount(rb)}, "
-              f"{np.mean(checks):.2f} of the first checks pass")
+              f"{np.mean(first_checks):.2f} of the first checks pass")
     flat = {"n_cases": len(cases), "seed": 9107}
     for i, c in enumerate(cases):
         for k, v in c.items():
             flat[f"{k}{i}"] = v
+
+    # Part B: the whole function, as torsion_module.csearch calls it
+    coords, bonds = _chain_molecule(rng, 16, 8)
+    n = len(coords)
+    graph = nx.Graph()
+    graph.add_nodes_from(range(n))
+    graph.add_edges_from(bonds)
+    tors = []
+    for c, nf in zip((2, 6, 9, 12), (3, 2, 6, 3)):
+        t = ref_tm.Torsion(c - 1, c, c + 1, c + 2)
+        t.n_fold = nf
+        tors.append(t)
+    table = ref_utils.cartesian_product(*[t.get_angles() for t in tors])
+    for b, (seed, n_out, max_tries, rotations) in enumerate(((41, 25, 10000, None), (42, 1000, 40, None), (43, 30, 10000, 2))):
+        tab = table.copy()
+        if rotations is not None:
+            tab = tab[np.count_nonzero(tab, axis=1) == rotations]
+        np.random.seed(seed)
+        np.random.shuffle(tab)                                      # the table random_csearch will walk (same seed, same call)
+        np.random.seed(seed)
+        res = ref_tm.random_csearch(coords.copy(), np.full(n, 6), tors, graph, n_out=n_out, max_tries=max_tries, rotations=rotations, **quiet)
+        flat[f"b_angles{b}"], flat[f"b_out{b}"], flat[f"b_n_out{b}"], flat[f"b_max_tries{b}"] = tab, res, n_out, max_tries
+        print(f"  part B run {b}: {len(tab)} angle sets, n_out {n_out}, max_tries {max_tries}: {len(res)} structures")
+    flat["b_coords"], flat["b_torsions"] = coords, np.array([t.torsion for t in tors], dtype=np.int32)
+    flat["b_masks"] = np.array([ref_tm._get_rotation_mask(graph, t.torsion) for t in tors])
+    flat["b_n"] = 3
     _save("G7_csearch", **flat)
 
 
@@ -413,54 +410,56 @@ def gen_g8():
 
 # --------------------------------------------------------------------------- G9
 def gen_g9():
-    """Moment-of-inertia matches and embed scores (next-row N4): the reference's get_inertia_moments /
-    get_moi_similarity_matches (tscode.algebra) and _score_embed_poses (tscode.numba_functions); the graph step of
-    prune_by_moment_of_inertia (optimization_methods.py:341-358) and fitness_check (:544-557) are written out here because
-    tscode.optimization_methods does not import in this image (ase, periodictable, ...)."""
-    import networkx as nx
-    print("G9 moments of inertia / embed scores (next-row N4)")
+    """Moment-of-inertia pruning and embed scores (next-row N4): the reference's get_inertia_moments /
+    get_moi_similarity_matches (tscode.algebra), prune_by_moment_of_inertia and fitness_check
+    (tscode.optimization_methods:327-358, :544-557) and _score_embed_poses (tscode.numba_functions).  The masses
+    prune_by_moment_of_inertia reads from tscode.pt are the element data of tests/golden/_reference.py."""
+    import networkx
+    print(f"G9 moments of inertia / embed scores (next-row N4), networkx {networkx.__version__}")
     rng = np.random.default_rng(9109)
-    flat = {"n_cases": 0, "seed": 9109}
+    flat = {"n_cases": 0, "seed": 9109, "networkx": networkx.__version__, "python": sys.version.split()[0]}
     for case, (n_par, n_child, n_atoms) in enumerate(((10, 4, 9), (60, 5, 14))):
-        masses = rng.choice(np.array([12.0107, 14.0067, 15.9994, 32.065, 35.453]), size=n_atoms)
+        atomnos = rng.choice(np.array([6, 7, 8, 16, 17]), size=n_atoms)
+        masses = np.array([R.ELEMENTS[int(z)][2] for z in atomnos])
         parents = rng.normal(size=(n_par, n_atoms, 3)) * 2
         structures = (parents[:, None] + rng.normal(size=(n_par, n_child, n_atoms, 3)) * 0.004).reshape(-1, n_atoms, 3)
         # rigid motions and mirror images keep the moments: rotamer / enantiomer duplicates
         for s in range(0, len(structures), 3):
             q = rng.normal(size=4)
-            R = ref_alg.quaternion_to_rotation_matrix(q / np.linalg.norm(q))
-            structures[s] = structures[s] @ R.T + rng.normal(size=3)
+            Rm = ref_alg.quaternion_to_rotation_matrix(q / np.linalg.norm(q))
+            structures[s] = structures[s] @ Rm.T + rng.normal(size=3)
         structures[1] = structures[0] * np.array([1.0, 1.0, -1.0])
         structures = np.ascontiguousarray(structures[rng.permutation(len(structures))])
         moments = np.array([ref_alg.get_inertia_moments(s.copy(), masses) for s in structures])
         matches = ref_alg.get_moi_similarity_matches(structures.copy(), masses, max_deviation=1e-2)
-        G = nx.Graph(matches)                                             # optimization_methods.py:341-358
-        subgraphs = [G.subgraph(c) for c in nx.connected_components(G)]
-        groups = [tuple(graph.nodes) for graph in subgraphs]
-        best_of_cluster = [group[0] for group in groups]
-        rejects_sets = [set(a) - {b} for a, b in zip(groups, best_of_cluster)]
-        mask = np.ones(structures.shape[0], dtype=bool)
-        for _s in rejects_sets:
-            for i in _s:
-                mask[i] = False
+        pruned, mask = ref_om.prune_by_moment_of_inertia(structures.copy(), atomnos, max_deviation=1e-2)
+        assert np.array_equal(pruned, structures[mask])
         flat[f"structures{case}"], flat[f"masses{case}"], flat[f"moments{case}"] = structures, masses, moments
+        flat[f"atomnos{case}"] = atomnos
         flat[f"matches{case}"], flat[f"mask{case}"] = np.array(matches, dtype=np.int64).reshape(-1, 2), mask
         flat["n_cases"] = case + 1
         print(f"  case {case}: N = {len(structures)}, {len(matches)} matches, {mask.sum()} survive")
+    # a case with hydrogens: prune_by_moment_of_inertia drops them before taking the moments (:335-336)
+    atomnos = np.array([6, 1, 1, 8, 6, 1, 7, 1, 17, 6, 1, 1])
+    parents = rng.normal(size=(25, 12, 3)) * 2
+    structures = (parents[:, None] + rng.normal(size=(25, 4, 12, 3)) * 0.003).reshape(-1, 12, 3)
+    structures = np.ascontiguousarray(structures[rng.permutation(len(structures))])
+    pruned, mask = ref_om.prune_by_moment_of_inertia(structures.copy(), atomnos, max_deviation=1e-2)
+    flat["h_structures"], flat["h_atomnos"], flat["h_mask"] = structures, atomnos, mask
+    flat["h_masses"] = np.array([R.ELEMENTS[int(z)][2] for z in atomnos])
+    print(f"  with hydrogens: N = {len(structures)}, {mask.sum()} survive")
     # embed scores and fitness
     structures = rng.normal(size=(40, 12, 3)) * 2
     ci = rng.integers(0, 12, size=(40, 3, 2))
     ci[:, :, 1] = (ci[:, :, 0] + 1 + rng.integers(0, 10, size=(40, 3))) % 12
     cd = rng.uniform(1.0, 4.0, size=(40, 3))
     scores = ref_nf._score_embed_poses(structures, ci, cd)
-    fit = []
-    for s in range(40):                                                   # optimization_methods.py:544-557
-        error = 0
-        for (a, b), target in zip(ci[s], cd[s]):
-            if target is not None:
-                error += (ref_alg.norm_of(structures[s][a] - structures[s][b]) - target)
-        fit.append(error)
-    flat.update(sc_structures=structures, sc_indices=ci, sc_distances=cd, scores=scores, fitness_error=np.array(fit))
+    thr = 0.5
+    fit = np.array([ref_om.fitness_check(structures[s], ci[s], cd[s], thr) for s in range(40)])
+    targets_none = [[None if (s + c) % 4 == 0 else cd[s, c] for c in range(3)] for s in range(40)]
+    fit_none = np.array([ref_om.fitness_check(structures[s], ci[s], targets_none[s], thr) for s in range(40)])
+    flat.update(sc_structures=structures, sc_indices=ci, sc_distances=cd, scores=scores, fitness_threshold=thr, fitness_ok=fit,
+                fitness_none=np.array([[np.nan if t is None else t for t in row] for row in targets_none]), fitness_ok_none=fit_none)
     _save("G9_moi_scores", **flat)
 
 

@@ -490,7 +490,41 @@ def test_shard_backend_world1_equals_one_shot(eng, oracle):
     assert res["n_pass"] == cm.sum() and res["n_keep"] == mask.sum()
     assert np.array_equal(be.keep[:res["n_pass"]].cpu().numpy().astype(bool), mask)
     assert np.abs(be.structures[:res["n_pass"]].cpu().numpy() - poses[cm]).max() < 1e-12
-    eng.set_stream(None)
+
+
+def test_pipelines_of_both_kinds_interleave_in_one_process(eng, oracle):
+    """A sharded pipeline built FIRST, then a one-call pipeline, then steps of both in turn with drop-in calls (the shared
+    get_engine() context) in between: every pipeline owns its library context and stream, so nobody can switch the stream
+    another one's kernels and collectives are ordered on."""
+    import tscode_amd
+    from tscode_amd.pipeline import DevicePipeline
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 6000)
+    poses = ens.poses()
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    _, mask = oracle.prune_conformers_rmsd(poses[cm], ens.atomnos, 0.5)
+    import torch.distributed as dist
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sharded = DevicePipeline(ens, device_index=0, rank=0, world=1, mode=0, force_sharded=True)
+        single = DevicePipeline(ens, device_index=0, mode=0)
+        assert sharded.engine is not single.engine and single.engine is not eng
+        for it in range(6):
+            a = sharded.step()
+            kept, m2 = tscode_amd.prune_conformers_rmsd(poses[cm][:1500], ens.atomnos, 0.5)       # a drop-in call on the shared context
+            b = single.step()
+            sharded.torch.cuda.synchronize()
+            assert a["n_pass"] == b["n_pass"] == cm.sum() and a["n_keep"] == b["n_keep"] == mask.sum(), it
+            assert np.array_equal(sharded.h_keep[:a["n_pass"]].numpy().astype(bool), mask)
+            assert np.array_equal(single.h_keep[:b["n_pass"]].numpy().astype(bool), mask)
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_greedy_group_filter(eng, oracle):
@@ -636,6 +670,11 @@ def test_csearch_rotations_golden(eng, oracle):
         assert tscode_amd.torsion_comp_check(one, torsions[t0], masks[t0].astype(bool), 1.5) == int(g[f"first_checks{c}"][0])
         kept = tscode_amd.csearch_candidates(coords, torsions, masks, angles, n_out=7)
         assert kept.shape == (7, len(coords), 3) and np.abs(kept - g[f"out{c}"][np.flatnonzero(g[f"rotated_bonds{c}"])[:7]]).max() < VAL_TOL
+    # part B: the reference's whole random_csearch -- shuffled n-fold angle tables, n_out / max_tries selection (:505-511)
+    for b in range(int(g["b_n"])):
+        got = tscode_amd.csearch_candidates(g["b_coords"], g["b_torsions"], g["b_masks"], g[f"b_angles{b}"], n_out=int(g[f"b_n_out{b}"]),
+                                            max_tries=int(g[f"b_max_tries{b}"]))
+        assert got.shape == g[f"b_out{b}"].shape and np.abs(got - g[f"b_out{b}"]).max() < VAL_TOL
 
 
 def test_csearch_rotations_vs_oracle_large(eng, oracle):
@@ -793,19 +832,26 @@ def test_moi_and_scores_golden(eng, oracle):
         assert margin > 1e-9
         matches = tscode_amd.get_moi_similarity_matches(structures, masses, max_deviation=1e-2)
         assert matches == [tuple(m) for m in g[f"matches{c}"].tolist()]
-        # prune_by_moment_of_inertia: no hydrogens here, masses given per atom
-        atomnos = np.full(structures.shape[1], 6)
+        # prune_by_moment_of_inertia: the reference's own function (no hydrogens in these cases), masses given per atom and
+        # from the built-in table (the fixture's elements are in it)
+        atomnos = g[f"atomnos{c}"]
         pruned, mask = tscode_amd.prune_by_moment_of_inertia(structures, atomnos, max_deviation=1e-2, masses=masses)
         assert np.array_equal(mask, g[f"mask{c}"]) and np.array_equal(pruned, structures[mask])
+        _, mask_t = tscode_amd.prune_by_moment_of_inertia(structures, atomnos, max_deviation=1e-2)
+        assert np.array_equal(mask_t, g[f"mask{c}"])
         assert np.abs(tscode_amd.get_inertia_moments(structures[2], masses) - g[f"moments{c}"][2]).max() < 1e-9 * np.abs(g[f"moments{c}"][2]).max()
+    _, mask_h = tscode_amd.prune_by_moment_of_inertia(g["h_structures"], g["h_atomnos"], max_deviation=1e-2, masses=g["h_masses"])
+    assert np.array_equal(mask_h, g["h_mask"])                                # hydrogens are dropped before the moments (:335-336)
     sc = tscode_amd._score_embed_poses(g["sc_structures"], g["sc_indices"], g["sc_distances"])
     assert sc.dtype == np.float32 and np.abs(sc - g["scores"]).max() < 1e-5
     so, eo = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
     _, err = eng.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
-    assert np.abs(err - g["fitness_error"]).max() < 1e-12 and np.array_equal(sc, so)
-    thr = float(np.median(g["fitness_error"]))
-    assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], g["sc_distances"], thr), g["fitness_error"] < thr)
-    assert tscode_amd.fitness_check(g["sc_structures"][0], g["sc_indices"][0], list(g["sc_distances"][0]), thr) == bool(g["fitness_error"][0] < thr)
+    assert np.abs(err - eo).max() < 1e-12 and np.array_equal(sc, so)
+    thr = float(g["fitness_threshold"])
+    assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], g["sc_distances"], thr), g["fitness_ok"])
+    none_targets = [[None if np.isnan(t) else float(t) for t in row] for row in g["fitness_none"]]
+    assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], none_targets, thr), g["fitness_ok_none"])
+    assert tscode_amd.fitness_check(g["sc_structures"][0], g["sc_indices"][0], list(g["sc_distances"][0]), thr) == bool(g["fitness_ok"][0])
 
 
 def test_adjacent_rows_edge_cases(eng, oracle):
@@ -841,6 +887,107 @@ def test_adjacent_rows_edge_cases(eng, oracle):
     # N1: no sites
     r, p, c = eng.string_embed_params(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2), np.int32), [0.0, 10.0])
     assert r.shape == (0, 2, 3, 3) and p.shape == (0, 2, 3) and c.shape == (0, 2)
+
+
+# ----------------------------------------------------------------------------- N1: the embed loops as drivers (G10-G12, config C1)
+def test_embed_helpers_golden(eng, oracle):
+    """Row a4 on the device and the other helpers of the embed loops against the reference's own outputs (G10)."""
+    import types
+    import tscode_amd
+    g = load_golden("G10_embed_helpers")
+    # rotation_matrix_from_vectors inside k_string_embed_params: angle 0, so R = R0 = rmfv(mol_vec, -ref_vec) (embeds.py:108)
+    v1, v2 = g["rmfv_v1"], g["rmfv_v2"]
+    zero = np.zeros_like(v1)
+    rot, pos, _ = eng.string_embed_params(zero, zero, -v2, v1, np.zeros((len(v1), 2), np.int32), [0.0])
+    assert np.abs(rot[:, 1] - g["rmfv_out"]).max() < 1e-12 and np.array_equal(rot[0, 1], np.eye(3))
+    assert np.abs(rot[1, 1] - np.diag([-1.0, -1.0, 1.0])).max() < 1e-15 and np.abs(pos).max() == 0
+    for a, b, ref in zip(v1, v2, g["rmfv_out"]):
+        assert np.abs(tscode_amd.rotation_matrix_from_vectors(a, b) - ref).max() < 1e-12
+    # get_embed on duck-typed molecules
+    for k in range(int(g["ge_n"])):
+        nm = int(g[f"ge{k}_n_mols"])
+        mols = [types.SimpleNamespace(atomcoords=g[f"ge{k}_coords{m}"], rotation=g[f"ge{k}_rot{m}"], position=g[f"ge{k}_pos{m}"]) for m in range(nm)]
+        assert np.abs(tscode_amd.get_embed(mols, g[f"ge{k}_conf_ids"]) - g[f"ge{k}_out"]).max() < 1e-12
+    # rotate_dihedral: mask, indices_to_be_moved, neither
+    for a, rm, ri, rf in zip(g["rd_angles"], g["rd_out_mask"], g["rd_out_indices"], g["rd_out_first"]):
+        assert np.abs(tscode_amd.rotate_dihedral(g["rd_coords"].copy(), g["rd_dihedral"], int(a), mask=g["rd_mask"]) - rm).max() < VAL_TOL
+        assert np.abs(tscode_amd.rotate_dihedral(g["rd_coords"].copy(), g["rd_dihedral"], int(a), indices_to_be_moved=list(g["rd_moved"])) - ri).max() < VAL_TOL
+        assert np.abs(tscode_amd.rotate_dihedral(g["rd_coords"].copy(), g["rd_dihedral"], int(a)) - rf).max() < VAL_TOL
+
+
+def test_tfd_greedy_filter_vs_oracle(eng, oracle):
+    """is_new_structure over whole lists (embeds.py:47-69): clustered fingerprints, several blocks of 64, kept list in the hundreds."""
+    rng = np.random.default_rng(77)
+    for n, T, n_par, noise in ((1, 3, 1, 0.0), (63, 4, 9, 0.7), (64, 2, 64, 0.0), (65, 5, 20, 1.0), (700, 6, 150, 0.8), (5000, 8, 900, 0.6)):
+        parents = rng.uniform(-180, 180, size=(n_par, T))
+        tf = (parents[rng.integers(0, n_par, size=n)] + rng.normal(size=(n, T)) * noise).astype(np.float32)
+        tf = ((tf + 180) % 360 - 180).astype(np.float32)                  # wrap-around pairs (+179 vs -179) included
+        ref, margin = oracle.tfd_greedy_filter(tf, 10, return_margin=True)
+        assert margin > 1e-6
+        got = eng.tfd_greedy_filter(tf, 10.0)
+        assert np.array_equal(got, ref), (n, T, got.sum(), ref.sum())
+    assert eng.tfd_greedy_filter(np.zeros((0, 4), np.float32)).shape == (0,)
+    assert eng.tfd_greedy_filter(np.zeros((5, 0), np.float32)).tolist() == [True, False, False, False, False]   # no torsions: sum 0 < 10
+
+
+def _string_case(g, k):
+    return dict(coords1=g[f"coords0_{k}"], coords2=g[f"coords1_{k}"], centers1=g[f"centers0_{k}"], orb_vecs1=g[f"orb_vecs0_{k}"],
+                centers2=g[f"centers1_{k}"], orb_vecs2=g[f"orb_vecs1_{k}"], angles=g[f"angles_{k}"])
+
+
+def test_string_embed_c1_golden(eng, oracle):
+    """BASELINE config C1: the reference's own string_embed on tests/CH3Cl.xyz + tests/HCOOH.xyz (case 0 is tests/string.txt) and
+    variants, recorded in G11, against ONE call of the product driver: string_embed_params -> embed -> compenetration mask ->
+    torsion fingerprints -> is_new_structure, all on the device."""
+    import tscode_amd
+    g = load_golden("G11_string_embed")
+    for k in range(int(g["n_cases"])):
+        case = _string_case(g, k)
+        thresh, quads = float(g[f"clash_thresh_{k}"]), g[f"quadruplets_{k}"]
+        poses, tr = tscode_amd.string_embed_batch(**case, clash_thresh=thresh, quadruplets=quads, return_trace=True)
+        assert np.array_equal(tr.clash_ok, g[f"clash_ok_{k}"])                               # every compenetration_check verdict
+        assert np.array_equal(tr.kept, g[f"kept_{k}"]), (k, tr.kept.sum(), g[f"kept_{k}"].sum())   # every is_new_structure verdict
+        assert poses.shape == g[f"poses_{k}"].shape and np.abs(poses - g[f"poses_{k}"]).max() < VAL_TOL
+        # the stages one by one: every candidate pose, and the fingerprints bit for bit (the verdicts at `sum == 10` hang on them)
+        c1, c2, a1, a2 = tr.sites.T
+        rot, pos, ci = tscode_amd.string_embed_params(case["centers1"][c1, a1], case["centers2"][c2, a2], case["orb_vecs1"][c1, a1],
+                                                      case["orb_vecs2"][c2, a2], np.stack([c1, c2], 1), case["angles"])
+        cands = tscode_amd.embed_batch([case["coords1"], case["coords2"]], ci, rot, pos)
+        assert np.abs(cands - g[f"candidates_{k}"]).max() < VAL_TOL
+        assert np.array_equal(tscode_amd.compenetration_mask(cands, g[f"ids_{k}"], thresh, 0), g[f"clash_ok_{k}"])
+        fp = tscode_amd._get_tf_mat(cands[g[f"fp_index_{k}"]], quads)
+        assert np.array_equal(fp, g[f"fingerprints_{k}"])
+        assert np.array_equal(eng.tfd_greedy_filter(fp, 10.0), g[f"kept_{k}"][g[f"clash_ok_{k}"]])
+    # nothing passes the clash check: an empty result where the reference raises ZeroCandidatesError
+    poses, tr = tscode_amd.string_embed_batch(**_string_case(g, 0), clash_thresh=9.0, quadruplets=g["quadruplets_0"], return_trace=True)
+    assert poses.shape == (0, 10, 3) and not tr.clash_ok.any() and not tr.kept.any()
+
+
+def _cyclical_case(g, k):
+    coords = [g[f"coords{m}_{k}"] for m in range(2)]
+    return [dict(coords=coords[m], reactive_indices=g[f"reactive_indices{m}_{k}"],
+                 pivots=[(g[f"pivot_vec{m}_{c}_{k}"], g[f"pivot_mean{m}_{c}_{k}"], g[f"pivot_cumnums{m}_{c}_{k}"]) for c in range(len(coords[m]))])
+            for m in range(2)]
+
+
+def test_cyclical_embed_golden(eng, oracle):
+    """The reference's cyclical_embed (rigid shortcut and general loop; tests/cyclical.txt's molecules and variants), G12, against
+    ONE call of the product driver: polygonize + group layout on the host, pose parameters -> embed -> compenetration mask ->
+    greedy per-group _rmsd_similarity filter on the device."""
+    import tscode_amd
+    g = load_golden("G12_cyclical_embed")
+    for k in range(int(g["n_cases"])):
+        mols = _cyclical_case(g, k)
+        poses, cons, tr = tscode_amd.cyclical_embed_batch(mols, g[f"angles_{k}"], clash_thresh=float(g[f"clash_thresh_{k}"]),
+                                                          rigid_shortcut=bool(g[f"rigid_{k}"]), return_trace=True)
+        assert np.array_equal(tr.group_of, g[f"group_of_{k}"])
+        assert np.array_equal(np.array([grp[3] for grp in tr.groups]), g[f"group_ids_{k}"])
+        assert np.array_equal(tr.clash_ok, g[f"clash_ok_{k}"])
+        assert np.array_equal(tr.kept, g[f"kept_{k}"]), (k, tr.kept.sum(), g[f"kept_{k}"].sum())
+        assert poses.shape == g[f"poses_{k}"].shape and np.abs(poses - g[f"poses_{k}"]).max() < VAL_TOL
+        assert np.array_equal(cons, g[f"constrained_indices_{k}"])
+    with pytest.raises(ValueError):
+        tscode_amd.cyclical_embed_batch(_cyclical_case(g, 0) * 2, g["angles_0"])           # not two molecules
 
 
 @pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000)])

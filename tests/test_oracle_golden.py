@@ -136,6 +136,17 @@ def test_g7_csearch_rotations(oracle):
         t0 = next(t for t in range(len(torsions)) if angles[0][t] != 0)
         one = oracle.rotate_dihedral(coords, torsions[t0], float(angles[0][t0]), masks[t0])
         assert oracle.torsion_comp_check(one, torsions[t0], masks[t0], 1.5) == int(g[f"first_checks{c}"][0])
+    # part B: the reference's whole random_csearch (shuffled n-fold angle tables, n_out / max_tries selection, :505-511)
+    for b in range(int(g["b_n"])):
+        angles, n_out, max_tries = g[f"b_angles{b}"], int(g[f"b_n_out{b}"]), int(g[f"b_max_tries{b}"])
+        out, rb = oracle.csearch_rotate(g["b_coords"], g["b_torsions"], g["b_masks"], angles.astype(np.int32), 1.5, 0)
+        kept = []
+        for a in range(len(angles)):
+            if rb[a] != 0:
+                kept.append(a)
+                if len(kept) == n_out or a == max_tries:
+                    break
+        assert len(kept) == len(g[f"b_out{b}"]) and np.abs(out[kept] - g[f"b_out{b}"]).max() < 1e-9
 
 
 def test_g6_g8_torsion_fingerprint_pruning(oracle):
@@ -177,7 +188,12 @@ def test_g9_moments_and_scores(oracle):
         ref[g[f"matches{c}"][:, 0]] = g[f"matches{c}"][:, 1]
         assert margin > 1e-9 and np.array_equal(first, ref)
     sc, err = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["sc_distances"])
-    assert np.abs(sc - g["scores"]).max() < 1e-6 and np.abs(err - g["fitness_error"]).max() < 1e-12
+    assert np.abs(sc - g["scores"]).max() < 1e-6
+    thr = float(g["fitness_threshold"])
+    assert np.abs(err - thr).min() > 1e-9                      # guard band of the reference's own fitness_check verdicts
+    assert np.array_equal(err < thr, g["fitness_ok"])
+    _, err_none = oracle.embed_scores(g["sc_structures"], g["sc_indices"], g["fitness_none"])       # targets of None are skipped (:552)
+    assert np.array_equal(err_none < thr, g["fitness_ok_none"])
 
 
 def test_tfd_single_match_chunks_need_no_graph():
@@ -215,3 +231,95 @@ def test_cluster_heads_shortcut_matches_networkx():
         g = nx.Graph(matches)
         ref = {frozenset(mem): h for mem, h in _cluster_heads_reference(g)}
         assert {frozenset(mem): h for mem, h in _cluster_heads_fast(g)} == ref
+
+
+# ----------------------------------------------------------------------------- G10-G12: the embed loops
+def test_g10_embed_helpers(oracle):
+    """rotation_matrix_from_vectors (row a4), polygonize, cartesian_product, get_embed, rotate_dihedral against the reference's
+    own outputs: the oracle AND the product's host-side mirrors (tscode_amd.algebra / utils are plain NumPy)."""
+    import tscode_amd.algebra as alg
+    import tscode_amd.utils as ut
+    g = load_golden("G10_embed_helpers")
+    for a, b, ref in zip(g["rmfv_v1"], g["rmfv_v2"], g["rmfv_out"]):
+        assert np.abs(oracle.rotation_matrix_from_vectors(a, b) - ref).max() < 1e-12
+        assert np.abs(alg.rotation_matrix_from_vectors(a, b) - ref).max() < 1e-12
+    assert np.array_equal(g["rmfv_out"][0], np.eye(3))                                         # parallel: the exact-zero branch
+    assert np.abs(g["rmfv_out"][1] - np.diag([-1.0, -1.0, 1.0])).max() < 1e-15                  # antiparallel: 180 degrees about z
+    for ln, ref in list(zip(g["poly2_lengths"], g["poly2_out"])) + list(zip(g["poly3_lengths"], g["poly3_out"])):
+        assert np.abs(oracle.polygonize(ln) - ref).max() < 1e-14 and np.abs(ut.polygonize(ln) - ref).max() < 1e-14
+    for ln, raises in zip(g["poly3_bad"], g["poly3_bad_raises"]):
+        assert raises
+        with pytest.raises(ValueError):
+            oracle.polygonize(ln)
+        with pytest.raises(ut.TriangleError):
+            ut.polygonize(ln)
+    for i in range(int(g["cp_n"])):
+        sizes = g[f"cp_sizes{i}"]
+        assert np.array_equal(oracle.cartesian_product(*sizes), g[f"cp_out{i}"])
+        assert np.array_equal(ut.cartesian_product(*[np.arange(s) for s in sizes]), g[f"cp_out{i}"])
+    for k in range(int(g["ge_n"])):
+        nm = int(g[f"ge{k}_n_mols"])
+        frags = [g[f"ge{k}_coords{m}"] for m in range(nm)]
+        rot = np.array([g[f"ge{k}_rot{m}"] for m in range(nm)])[None]
+        pos = np.array([g[f"ge{k}_pos{m}"] for m in range(nm)])[None]
+        out = oracle.transform_batch(frags, g[f"ge{k}_conf_ids"][None], rot, pos)[0]
+        assert np.abs(out - g[f"ge{k}_out"]).max() < 1e-13
+    for a, ref in zip(g["rd_angles"], g["rd_out_mask"]):
+        assert np.abs(oracle.rotate_dihedral(g["rd_coords"], g["rd_dihedral"], float(a), g["rd_mask"]) - ref).max() < 1e-12
+    moved = np.zeros(len(g["rd_coords"]), dtype=bool)
+    moved[g["rd_moved"]] = True
+    first = np.zeros(len(g["rd_coords"]), dtype=bool)
+    first[g["rd_dihedral"][0]] = True
+    for a, ref_i, ref_f in zip(g["rd_angles"], g["rd_out_indices"], g["rd_out_first"]):
+        assert np.abs(oracle.rotate_dihedral(g["rd_coords"], g["rd_dihedral"], float(a), moved) - ref_i).max() < 1e-12
+        assert np.abs(oracle.rotate_dihedral(g["rd_coords"], g["rd_dihedral"], float(a), first) - ref_f).max() < 1e-12
+
+
+def _string_case(g, k):
+    return dict(coords1=g[f"coords0_{k}"], coords2=g[f"coords1_{k}"], centers1=g[f"centers0_{k}"], orb_vecs1=g[f"orb_vecs0_{k}"],
+                centers2=g[f"centers1_{k}"], orb_vecs2=g[f"orb_vecs1_{k}"], angles=g[f"angles_{k}"])
+
+
+def test_g11_string_embed_c1(oracle):
+    """BASELINE config C1: the reference's string_embed on its own CH3Cl + HCOOH (and variants): every candidate pose, every
+    clash verdict, every fingerprint and the kept set, from the oracle's restatement of embeds.py:91-120."""
+    g = load_golden("G11_string_embed")
+    assert int(g["n_cases"]) >= 4 and len(g["candidates_0"]) == 72 and g["atomnos0_0"].tolist() == [6, 1, 1, 1, 17]
+    for k in range(int(g["n_cases"])):
+        cands, ok, kept, margin = oracle.string_embed(**_string_case(g, k), clash_thresh=float(g[f"clash_thresh_{k}"]),
+                                                      quadruplets=g[f"quadruplets_{k}"], return_margin=True)
+        assert cands.shape == g[f"candidates_{k}"].shape and np.abs(cands - g[f"candidates_{k}"]).max() < 1e-9
+        assert oracle.clash_margin(g[f"candidates_{k}"], g[f"ids_{k}"], float(g[f"clash_thresh_{k}"])) > 1e-9
+        assert np.array_equal(ok, g[f"clash_ok_{k}"])
+        fp = oracle.torsion_fingerprints(g[f"candidates_{k}"][g[f"fp_index_{k}"]], g[f"quadruplets_{k}"])
+        # Poses one 10-degree step apart differ by 10 degrees in one torsion: their sums sit ON is_new_structure's threshold of
+        # 10 and `sum < 10` is decided by the float32 roundings of the angles.  The sum itself is exact (a few float32 values
+        # added in float64), so verdicts are reproducible iff the fingerprints are bit-identical: required here, with the
+        # distance of every angle from a float32 rounding tie as the guard band.
+        assert np.array_equal(fp, g[f"fingerprints_{k}"]) and margin >= 0.0
+        assert oracle.torsion_rounding_margin(g[f"candidates_{k}"][g[f"fp_index_{k}"]], g[f"quadruplets_{k}"]) > 1e-12
+        assert np.array_equal(kept, g[f"kept_{k}"]), (k, kept.sum(), g[f"kept_{k}"].sum())
+        assert np.abs(cands[kept] - g[f"poses_{k}"]).max() < 1e-9
+
+
+def _cyclical_case(g, k):
+    coords = [g[f"coords{m}_{k}"] for m in range(2)]
+    reactive = [g[f"reactive_indices{m}_{k}"] for m in range(2)]
+    pivots = [[(g[f"pivot_vec{m}_{c}_{k}"], g[f"pivot_mean{m}_{c}_{k}"], g[f"pivot_cumnums{m}_{c}_{k}"]) for c in range(len(coords[m]))] for m in range(2)]
+    return coords, reactive, pivots
+
+
+def test_g12_cyclical_embed(oracle):
+    """The reference's cyclical_embed (rigid shortcut and general loop, tests/cyclical.txt's molecules and variants) against
+    the oracle's restatement: candidates, groups, clash verdicts, greedy similarity verdicts, constrained indices."""
+    g = load_golden("G12_cyclical_embed")
+    for k in range(int(g["n_cases"])):
+        coords, reactive, pivots = _cyclical_case(g, k)
+        cands, group_of, ok, kept, gids = oracle.cyclical_embed(coords, reactive, pivots, g[f"angles_{k}"], float(g[f"clash_thresh_{k}"]),
+                                                                rigid_shortcut=bool(g[f"rigid_{k}"]))
+        assert cands.shape == g[f"candidates_{k}"].shape and np.abs(cands - g[f"candidates_{k}"]).max() < 1e-9
+        assert np.array_equal(group_of, g[f"group_of_{k}"]) and np.array_equal(gids, g[f"group_ids_{k}"])
+        assert oracle.clash_margin(g[f"candidates_{k}"], g[f"ids_{k}"], float(g[f"clash_thresh_{k}"])) > 1e-9
+        assert np.array_equal(ok, g[f"clash_ok_{k}"])
+        assert np.array_equal(kept, g[f"kept_{k}"]), (k, kept.sum(), g[f"kept_{k}"].sum())
+        assert np.array_equal(gids[group_of[kept]], g[f"constrained_indices_{k}"])

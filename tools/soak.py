@@ -29,7 +29,7 @@ exp = json.load(open("tests/golden/expected_full.json")).get(f"{cfg}:{ens.n_pose
 pipe = DevicePipeline(ens, device_index=0, mode=mode)
 for opt in sys.argv[3:]:                                  # library tunables name=value
     from tscode_amd import get_engine
-    get_engine(0).set_option(opt.split("=")[0], float(opt.split("=")[1]))
+    pipe.set_option(opt.split("=")[0], float(opt.split("=")[1]))
 kinds = {}
 bad, first, t0 = 0, None, time.time()
 for i in range(steps):

@@ -9,7 +9,7 @@ from tscode_amd.synthetic import make_config
 cfg, steps = (sys.argv[1] if len(sys.argv) > 1 else "C2"), int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pipe = DevicePipeline(make_config(cfg), device_index=0, mode=0)
 for opt in sys.argv[3:]:
-    get_engine(0).set_option(opt.split("=")[0], float(opt.split("=")[1]))
+    pipe.set_option(opt.split("=")[0], float(opt.split("=")[1]))
 stop = False
 def hammer():
     s = torch.cuda.Stream()

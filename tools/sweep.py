@@ -10,7 +10,7 @@ from tscode_amd.synthetic import make_config
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 ens = make_config(cfg)
 pipe = DevicePipeline(ens, device_index=0, mode=0)
-eng = get_engine(0)
+eng = pipe.engine
 eng.set_option("pass_timing", 0)
 grid = {"seg_cols": [0, 256, 512, 1024], "drain_min": [16, 32, 64], "local_max_chunk": [128, 256, 512]}
 if cfg != "C3":

@@ -11,7 +11,9 @@ include/tscode_hip.h).  There is no CPU fallback; importing this package does no
 
 from .algebra import (align_vec_pair, all_dists, norm, norm_of, quaternion_to_rotation_matrix,  # noqa: F401
                       rot_mat_from_pointer, rotation_matrix_from_vectors, transform_coords, vec_angle)
-from .embeds import cyclical_embed_params, embed_batch, filter_angular_groups, get_embed, string_embed_params, string_embed_poses  # noqa: F401
+from .embeds import (EmbedTrace, cyclical_embed_batch, cyclical_embed_params, embed_batch, filter_angular_groups, get_embed,  # noqa: F401
+                     string_embed_batch, string_embed_params, string_embed_poses)
+from .utils import TriangleError, cartesian_product, polygonize  # noqa: F401
 from .engine import Engine, FragmentSet, device_count, get_engine  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .numba_functions import (_get_tf_mat, compenetration_check, compenetration_mask, count_clashes, get_torsion_fingerprint,  # noqa: F401

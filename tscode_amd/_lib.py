@@ -83,6 +83,11 @@ _SIGNATURES = {
     "tsc_torsion_comp_check": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_double, C.c_int64, _vp]),
     "tsc_greedy_group_filter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp]),
     "tsc_greedy_group_filter_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, _vp]),
+    "tsc_tfd_greedy_filter": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, _vp, c_i64p]),
+    "tsc_string_embed": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_double, C.c_int64,
+                                   _vp, C.c_int, C.c_double, _vp, _vp, _vp, C.c_int64, c_i64p, c_i64p]),
+    "tsc_cyclical_embed": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int] + [_vp] * 10 + [C.c_int64, _vp, C.c_int, C.c_double, C.c_int64,
+                                     C.c_double, _vp, _vp, _vp, C.c_int64, c_i64p, c_i64p]),
     "tsc_prune_rmsd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_structures": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats),
                                        C.POINTER(C.c_int)]),

@@ -83,4 +83,87 @@ __global__ __launch_bounds__(256) void k_tfd_first_similar(const float *__restri
     }
 }
 
+// tfd_similarity (:242-253) of two fingerprints: float32 difference, float64 after the wrap, summed in order
+__device__ inline bool tfd_similar_dev(const float *__restrict__ a, const float *__restrict__ b, int T, double thresh) {
+    double sum = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const float d32 = fabsf(a[t] - b[t]);
+        double dd = double(d32);
+        if (d32 > 180.0f) dd -= 360.0;
+        sum += fabs(dd);
+    }
+    return sum < thresh;
+}
+
+// is_new_structure of the string embed (tscode/embeds.py:47-69), whole list in one launch: structure s is kept iff its
+// fingerprint is not tfd-similar to the fingerprint of any structure KEPT before it.  The reference's "LRU" never evicts
+// (`lru_cache = lru_cache[1:]` rebinds a local name, :66-67), so every kept fingerprint is compared for ever.
+// The filter is sequential by definition; what runs in parallel is the work of a block of 64 candidates: (1) all of them
+// against every structure kept in earlier blocks (16 wavefronts, each a slice of the kept list), (2) all pairs inside the
+// block into a 64 x 64 bit matrix, then (3) one scalar replay of the greedy order on the bits.  ONE workgroup: a block's
+// verdicts feed the next block's kept list.  kept_list i32[N] scratch; *n_kept_out = how many were kept.
+constexpr int TG_THREADS = 1024;
+__global__ __launch_bounds__(TG_THREADS) void k_tfd_greedy_filter(const float *__restrict__ tf, int64_t N, int T, double thresh,
+                                                                   uint8_t *__restrict__ accepted, int32_t *__restrict__ kept_list,
+                                                                   int32_t *__restrict__ n_kept_out) {
+    __shared__ int s_dead[64];
+    __shared__ int s_nk;
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < N; base += 64) {
+        const int nb = int(N - base < 64 ? N - base : 64);
+        const int nk = s_nk;
+        if (tid < 64) s_dead[tid] = 0;
+        __syncthreads();
+        // (1) candidate `lane` against the kept structures slice, slice + 16, ...
+        if (lane < nb) {
+            const float *a = tf + (base + lane) * T;
+            bool dead = false;
+            for (int k = slice; k < nk && !dead; k += TG_THREADS / 64) dead = tfd_similar_dev(a, tf + int64_t(kept_list[k]) * T, T, thresh);
+            if (dead) s_dead[lane] = 1;
+        }
+        __syncthreads();
+        // (2) + (3): wavefront 0
+        if (slice == 0) {
+            unsigned long long sim = 0ull;                      // bit j: candidate `lane` is similar to candidate j < lane of this block
+            if (lane < nb) {
+                const float *a = tf + (base + lane) * T;
+                for (int j = 0; j < lane; ++j)
+                    if (tfd_similar_dev(a, tf + (base + j) * T, T, thresh)) sim |= 1ull << j;
+            }
+            const bool dead = lane < nb ? s_dead[lane] != 0 : true;
+            unsigned long long acc = 0ull;
+            for (int c = 0; c < nb; ++c) {
+                const unsigned lo = __builtin_amdgcn_readlane(unsigned(sim), c), hi = __builtin_amdgcn_readlane(unsigned(sim >> 32), c);
+                const unsigned long long m = (static_cast<unsigned long long>(hi) << 32) | lo;
+                const int d = __builtin_amdgcn_readlane(int(dead), c);
+                if (!d && (m & acc) == 0ull) acc |= 1ull << c;
+            }
+            if (lane < nb) {
+                const bool ok = (acc >> lane) & 1ull;
+                accepted[base + lane] = ok ? 1 : 0;
+                if (ok) kept_list[nk + __popcll(acc & ((1ull << lane) - 1ull))] = int32_t(base + lane);
+            }
+            if (lane == 0) s_nk = nk + __popcll(acc);
+        }
+        __syncthreads();                                        // kept_list and s_nk of this block are visible to the next round
+    }
+    if (tid == 0) *n_kept_out = s_nk;
+}
+
+// flags of a compacted list back onto the full index space: full[idx[r]] = part[r] (full is zeroed by the caller)
+__global__ __launch_bounds__(256) void k_scatter_flags(const uint8_t *__restrict__ part, const int32_t *__restrict__ idx, const int32_t *__restrict__ n_dev,
+                                                        uint8_t *__restrict__ full) {
+    const int n = *n_dev;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) full[idx[r]] = part[r];
+}
+
+// offsets of candidate groups in the list of the candidates that passed a filter: out[g] = pos[group_off[g]] (pos = exclusive
+// scan of the filter's mask), out[n_groups] = total
+__global__ __launch_bounds__(256) void k_group_offsets_after_filter(const int32_t *__restrict__ group_off, int n_groups, const int32_t *__restrict__ pos,
+                                                                     int64_t n, const int32_t *__restrict__ total, int32_t *__restrict__ out) {
+    for (int g = blockIdx.x * 256 + threadIdx.x; g <= n_groups; g += gridDim.x * 256) out[g] = (g == n_groups || group_off[g] >= n) ? *total : pos[group_off[g]];
+}
+
 }  // namespace tsc

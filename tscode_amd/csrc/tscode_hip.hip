@@ -60,7 +60,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
         e = hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault);
     }
     if (e != hipSuccess) {
-        delete c;
+        (void)tsc_ctx_destroy(c);       // streams, events and the pinned buffer created so far
         return fail(TSC_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -70,7 +70,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c) {
     if (!c) return 0;
     DeviceGuard guard(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // everything enqueued on any of the context's streams ends before what it uses is freed (also the teardown of a context
+    // whose creation failed half way: whatever exists by then is released here)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->basis_stream) (void)hipStreamSynchronize(c->basis_stream);
     for (auto &kv : c->cache) (void)hipFree(kv.second);
     for (auto &kv : c->live) (void)hipFree(kv.first);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -81,7 +85,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->basis_stream) (void)hipStreamDestroy(c->basis_stream);
-    if (c->basis_stream) (void)hipStreamSynchronize(c->basis_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1067,8 +1070,11 @@ static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double r
             hipPointerAttribute_t at;
             const bool mapped = (reinterpret_cast<uintptr_t>(mask_host) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p->mask) & 7u) == 0 &&
                                 hipPointerGetAttributes(&at, mask_host) == hipSuccess && at.type == hipMemoryTypeHost;
-            if (mapped) {
-                p->export_mask_host = mask_host;
+            // the address the DEVICE sees: for hipHostRegister'ed or non-mapped pinned memory it need not be the host address,
+            // and may not exist at all
+            uint8_t *dev_view = mapped ? static_cast<uint8_t *>(at.devicePointer) : nullptr;
+            if (dev_view && (reinterpret_cast<uintptr_t>(dev_view) & 7u) == 0) {
+                p->export_mask_host = dev_view;
             } else {
                 (void)hipGetLastError();
                 e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
@@ -1523,6 +1529,192 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(
     TSC_HIP(hipMemcpyAsync(pos, d_pos, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// --------------------------------------------------------------------------------------------------
+// the embed loops as drivers: string_embed (tscode/embeds.py:91-120) and cyclical_embed (:636-717, :771-847)
+
+extern "C" __attribute__((visibility("default"))) int tsc_tfd_greedy_filter(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, double thresh,
+                                                                            uint8_t *accepted, int64_t *n_kept) {
+    TSC_REQUIRE(c && tf && accepted, "tsc_tfd_greedy_filter: null argument");
+    TSC_REQUIRE(n_structs >= 0 && n_structs < INT32_MAX && n_quads >= 0, "bad sizes");
+    if (n_kept) *n_kept = 0;
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    float *d_tf;
+    uint8_t *d_acc;
+    int32_t *d_list, *d_nk;
+    TSC_TRY(upload(c, s, tf, std::max<size_t>(size_t(n_structs) * n_quads, 1), &d_tf));
+    TSC_TRY(s.get(size_t(n_structs), &d_acc));
+    TSC_TRY(s.get(size_t(n_structs), &d_list));
+    TSC_TRY(s.get(1, &d_nk));
+    hipLaunchKernelGGL(k_tfd_greedy_filter, dim3(1), dim3(TG_THREADS), 0, c->stream, (const float *)d_tf, n_structs, n_quads, thresh, d_acc, d_list, d_nk);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(accepted, d_acc, size_t(n_structs), hipMemcpyDeviceToHost, c->stream));
+    int32_t nk = 0;
+    TSC_TRY(read_i32(c, d_nk, &nk));
+    if (n_kept) *n_kept = nk;
+    return 0;
+}
+
+// What both drivers share once the pose parameters are on the device: clash verdicts of all candidates, the passing poses
+// embedded in candidate order, a filter over them (`filter(d_structs, n_pass, d_pos_scan, d_acc)`), the kept poses compacted
+// and copied out, both verdicts per candidate.
+template <typename Filter>
+static int embed_filter_run(tsc_ctx *c, Scratch &s, const double *d_frags, const FragTable &ft, const int64_t *frag_off, const int32_t *n_atoms,
+                            const int32_t *n_conf, const int32_t *d_ci, const double *d_rot, const double *d_pos, int64_t N, double clash_thresh,
+                            int64_t max_clashes, uint8_t *clash_ok, uint8_t *kept, double *poses, int64_t poses_capacity, int64_t *n_pass_out,
+                            int64_t *n_kept_out, Filter filter) {
+    hipStream_t st = c->stream;
+    const int n = ft.n_total;
+    uint8_t *d_mask, *d_kept_full, *d_acc;
+    int32_t *bsum, *act, *pos_scan, *total, *act2, *total2;
+    TSC_TRY(s.get(size_t(N), &d_mask));
+    TSC_TRY(s.get(size_t(N), &d_kept_full));
+    TSC_TRY(s.get(scan_bsum_count(N), &bsum));
+    TSC_TRY(s.get(size_t(N), &act));
+    TSC_TRY(s.get(size_t(N) + 1, &pos_scan));
+    TSC_TRY(s.get(1, &total));
+    TSC_TRY(s.get(size_t(N), &act2));
+    TSC_TRY(s.get(1, &total2));
+    TSC_TRY(tsc_embed_clash_mask_dev(c, d_frags, frag_off, n_atoms, n_conf, ft.n_mols, d_ci, d_rot, d_pos, N, clash_thresh, max_clashes, d_mask, nullptr));
+    TSC_TRY(scan_mask(st, d_mask, N, bsum, pos_scan, act, nullptr, total));
+    TSC_HIP(hipMemcpyAsync(clash_ok, d_mask, size_t(N), hipMemcpyDeviceToHost, st));
+    TSC_HIP(hipMemsetAsync(d_kept_full, 0, size_t(N), st));
+    int32_t n_pass = 0, n_kept = 0;
+    TSC_TRY(read_i32(c, total, &n_pass));
+    *n_pass_out = n_pass;
+    if (n_pass > 0) {
+        double *d_structs, *d_out;
+        TSC_TRY(s.get(size_t(n_pass) * n * 3, &d_structs));
+        TSC_TRY(s.get(size_t(n_pass), &d_acc));
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_pass, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, d_frags, ft, d_ci, d_rot, d_pos,
+                           (const int32_t *)act, int64_t(n_pass), d_structs, (const int32_t *)nullptr, 0, (double *)nullptr, (const int32_t *)nullptr);
+        TSC_HIP(hipGetLastError());
+        TSC_TRY(filter(d_structs, n_pass, pos_scan, total, d_acc));
+        hipLaunchKernelGGL(k_scatter_flags, dim3(grid_for(n_pass, 256, 1024)), dim3(256), 0, st, (const uint8_t *)d_acc, (const int32_t *)act, (const int32_t *)total,
+                           d_kept_full);
+        TSC_TRY(scan_mask(st, d_acc, n_pass, bsum, nullptr, act2, nullptr, total2));
+        TSC_TRY(read_i32(c, total2, &n_kept));
+        if (poses && n_kept > 0) {
+            TSC_REQUIRE(n_kept <= poses_capacity, "poses holds %lld rows, %d poses were kept", (long long)poses_capacity, n_kept);
+            TSC_TRY(s.get(size_t(n_kept) * n * 3, &d_out));
+            TSC_TRY(launch_gather_rows(st, d_structs, act2, n_kept, n * 3, nullptr, n * 3, d_out));
+            TSC_HIP(hipMemcpyAsync(poses, d_out, size_t(n_kept) * n * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+    }
+    TSC_HIP(hipMemcpyAsync(kept, d_kept_full, size_t(N), hipMemcpyDeviceToHost, st));
+    TSC_HIP(hipStreamSynchronize(st));
+    *n_kept_out = n_kept;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_string_embed(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                                                       const int32_t *n_conf, const double *p1, const double *p2, const double *ref_vec,
+                                                                       const double *mol_vec, const int32_t *conf_pair, int64_t n_sites, const double *angles,
+                                                                       int n_angles, double clash_thresh, int64_t max_clashes, const int32_t *quads, int n_quads,
+                                                                       double tfd_thresh, uint8_t *clash_ok, uint8_t *kept, double *poses,
+                                                                       int64_t poses_capacity, int64_t *n_pass, int64_t *n_kept) {
+    TSC_REQUIRE(c && frags && frag_off && n_atoms && n_conf && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && clash_ok && kept && n_pass && n_kept,
+                "tsc_string_embed: null argument");
+    TSC_REQUIRE(n_sites >= 0 && n_angles >= 0 && n_quads >= 0 && (n_quads == 0 || quads), "bad sizes");
+    const int64_t N = n_sites * n_angles;
+    TSC_REQUIRE(N < INT32_MAX, "too many candidates");
+    *n_pass = *n_kept = 0;
+    if (N == 0) return 0;
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, 2, &ft));
+    for (int64_t q = 0; q < n_sites; ++q)
+        TSC_REQUIRE(conf_pair[2 * q] >= 0 && conf_pair[2 * q] < n_conf[0] && conf_pair[2 * q + 1] >= 0 && conf_pair[2 * q + 1] < n_conf[1],
+                    "site %lld: conformer index out of range", (long long)q);
+    for (int q = 0; q < 4 * n_quads; ++q) TSC_REQUIRE(quads[q] >= 0 && quads[q] < ft.n_total, "quadruplet atom index %d out of range", quads[q]);
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_frags, *d_p1, *d_p2, *d_rv, *d_mv, *d_ang, *d_rot, *d_pos;
+    int32_t *d_cp, *d_ci, *d_quads = nullptr;
+    TSC_TRY(upload(c, s, frags, size_t(frags_total_doubles(frag_off, n_atoms, n_conf, 2)), &d_frags));
+    TSC_TRY(upload(c, s, p1, size_t(n_sites) * 3, &d_p1));
+    TSC_TRY(upload(c, s, p2, size_t(n_sites) * 3, &d_p2));
+    TSC_TRY(upload(c, s, ref_vec, size_t(n_sites) * 3, &d_rv));
+    TSC_TRY(upload(c, s, mol_vec, size_t(n_sites) * 3, &d_mv));
+    TSC_TRY(upload(c, s, conf_pair, size_t(n_sites) * 2, &d_cp));
+    TSC_TRY(upload(c, s, angles, size_t(n_angles), &d_ang));
+    if (n_quads) TSC_TRY(upload(c, s, quads, size_t(n_quads) * 4, &d_quads));
+    TSC_TRY(s.get(size_t(N) * 18, &d_rot));
+    TSC_TRY(s.get(size_t(N) * 6, &d_pos));
+    TSC_TRY(s.get(size_t(N) * 2, &d_ci));
+    TSC_TRY(tsc_string_embed_params_dev(c, d_p1, d_p2, d_rv, d_mv, d_cp, n_sites, d_ang, n_angles, d_rot, d_pos, d_ci));
+    const int n = ft.n_total;
+    // is_new_structure (:47-69, :119): torsion fingerprints of the passing poses, then the greedy filter over the whole list
+    auto filter = [&](const double *d_structs, int32_t np, const int32_t *, const int32_t *, uint8_t *d_acc) -> int {
+        float *d_tf;
+        int32_t *d_list, *d_nk;
+        TSC_TRY(s.get(std::max<size_t>(size_t(np) * n_quads, 1), &d_tf));
+        TSC_TRY(s.get(size_t(np), &d_list));
+        TSC_TRY(s.get(1, &d_nk));
+        if (n_quads)
+            hipLaunchKernelGGL(k_torsion_fingerprints, dim3(grid_for(int64_t(np) * n_quads, 256, 256 * 8)), dim3(256), 0, c->stream, d_structs, int64_t(np), n,
+                               (const int32_t *)d_quads, n_quads, d_tf);
+        hipLaunchKernelGGL(k_tfd_greedy_filter, dim3(1), dim3(TG_THREADS), 0, c->stream, (const float *)d_tf, int64_t(np), n_quads, tfd_thresh, d_acc, d_list, d_nk);
+        TSC_HIP(hipGetLastError());
+        return 0;
+    };
+    return embed_filter_run(c, s, d_frags, ft, frag_off, n_atoms, n_conf, d_ci, d_rot, d_pos, N, clash_thresh, max_clashes, clash_ok, kept, poses, poses_capacity,
+                            n_pass, n_kept, filter);
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                                                         const int32_t *n_conf, int n_mols, const double *start, const double *end,
+                                                                         const double *direction, const double *pivot, const double *meanpoint, const double *r0,
+                                                                         const double *r1, const int32_t *n_reactive, const double *angle, const int32_t *conf_idx,
+                                                                         int64_t n_poses, const int32_t *group_off, int n_groups, double clash_thresh,
+                                                                         int64_t max_clashes, double rmsd_thr, uint8_t *clash_ok, uint8_t *kept, double *poses,
+                                                                         int64_t poses_capacity, int64_t *n_pass, int64_t *n_kept) {
+    TSC_REQUIRE(c && frags && frag_off && n_atoms && n_conf && start && end && direction && pivot && meanpoint && r0 && r1 && n_reactive && angle && conf_idx &&
+                    group_off && clash_ok && kept && n_pass && n_kept,
+                "tsc_cyclical_embed: null argument");
+    TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX && n_groups >= 0 && rmsd_thr > 0, "bad sizes");
+    *n_pass = *n_kept = 0;
+    if (n_poses == 0) return 0;
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    const int64_t rows = n_poses * n_mols;
+    for (int64_t q = 0; q < rows; ++q) {
+        TSC_REQUIRE(n_reactive[q] == 1 || n_reactive[q] == 2, "row %lld: n_reactive must be 1 or 2", (long long)q);
+        TSC_REQUIRE(conf_idx[q] >= 0 && conf_idx[q] < n_conf[q % n_mols], "row %lld: conformer index out of range", (long long)q);
+    }
+    TSC_REQUIRE(n_groups > 0 && group_off[0] == 0 && group_off[n_groups] == n_poses, "group_off must run from 0 to n_poses");
+    for (int g = 0; g < n_groups; ++g)
+        TSC_REQUIRE(group_off[g + 1] >= group_off[g] && group_off[g + 1] - group_off[g] <= GF_MAX_GROUP, "group %d: sizes must be in [0, %d]", g, GF_MAX_GROUP);
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    const double *host[7] = {start, end, direction, pivot, meanpoint, r0, r1};
+    double *d_frags, *dev[7], *d_angle, *d_rot, *d_pos;
+    int32_t *d_nr, *d_ci, *d_goff, *d_goff_pass;
+    TSC_TRY(upload(c, s, frags, size_t(frags_total_doubles(frag_off, n_atoms, n_conf, n_mols)), &d_frags));
+    for (int i = 0; i < 7; ++i) TSC_TRY(upload(c, s, host[i], size_t(rows) * 3, &dev[i]));
+    TSC_TRY(upload(c, s, n_reactive, size_t(rows), &d_nr));
+    TSC_TRY(upload(c, s, angle, size_t(rows), &d_angle));
+    TSC_TRY(upload(c, s, conf_idx, size_t(rows), &d_ci));
+    TSC_TRY(upload(c, s, group_off, size_t(n_groups) + 1, &d_goff));
+    TSC_TRY(s.get(size_t(n_groups) + 1, &d_goff_pass));
+    TSC_TRY(s.get(size_t(rows) * 9, &d_rot));
+    TSC_TRY(s.get(size_t(rows) * 3, &d_pos));
+    hipLaunchKernelGGL(k_cyclical_embed_params, dim3(grid_for(rows, 256, 256 * 8)), dim3(256), 0, c->stream, (const double *)dev[0], (const double *)dev[1],
+                       (const double *)dev[2], (const double *)dev[3], (const double *)dev[4], (const double *)dev[5], (const double *)dev[6],
+                       (const int32_t *)d_nr, (const double *)d_angle, rows, d_rot, d_pos);
+    TSC_HIP(hipGetLastError());
+    const int n = ft.n_total;
+    // not _rmsd_similarity(pose, angular_poses, rmsd_thr=1) (:715, :843): greedy inside each group of passing poses
+    auto filter = [&](const double *d_structs, int32_t np, const int32_t *pos_scan, const int32_t *total, uint8_t *d_acc) -> int {
+        hipLaunchKernelGGL(k_group_offsets_after_filter, dim3(grid_for(n_groups + 1, 256, 1024)), dim3(256), 0, c->stream, (const int32_t *)d_goff, n_groups, pos_scan,
+                           n_poses, total, d_goff_pass);
+        TSC_HIP(hipGetLastError());
+        return tsc_greedy_group_filter_dev(c, d_structs, d_goff_pass, n_groups, np, n, rmsd_thr, d_acc);
+    };
+    return embed_filter_run(c, s, d_frags, ft, frag_off, n_atoms, n_conf, d_ci, d_rot, d_pos, n_poses, clash_thresh, max_clashes, clash_ok, kept, poses,
+                            poses_capacity, n_pass, n_kept, filter);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -11,8 +11,10 @@ import numpy as np
 
 from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors  # noqa: F401  (host-side singles, re-exported)
 from .engine import FragmentSet, get_engine
+from .utils import cartesian_product, polygonize
 
-__all__ = ["get_embed", "embed_batch", "string_embed_poses", "filter_angular_groups"]
+__all__ = ["get_embed", "embed_batch", "string_embed_poses", "filter_angular_groups", "string_embed_batch", "cyclical_embed_batch",
+           "EmbedTrace"]
 
 
 def get_embed(mols, conf_ids):
@@ -74,3 +76,142 @@ def filter_angular_groups(poses, group_sizes, rmsd_thr=1.0):
     group_sizes = np.asarray(group_sizes, dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(group_sizes)]).astype(np.int32)
     return get_engine().greedy_group_filter(poses, off, float(rmsd_thr))
+
+
+class EmbedTrace:
+    """What an embed driver decided about every candidate, in the reference's loop order: ``clash_ok`` (compenetration_check),
+    ``kept`` (the pose was appended), ``group_of`` (cyclical embeds: index of the candidate's angular group), plus the driver's
+    own bookkeeping (``sites`` / ``groups``: what each candidate row was built from)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def string_embed_batch(coords1, coords2, centers1, orb_vecs1, centers2, orb_vecs2, angles, clash_thresh=1.5, max_clashes=0,
+                       quadruplets=(), tfd_thresh=10, return_trace=False):
+    """The whole loop of ``string_embed`` (tscode/embeds.py:91-120) in one GPU call.
+
+    The reference walks conformer pairs x reactive-centre pairs x angles in Python, one pose at a time: rotation and position
+    of molecule 2 (:100-114), ``get_embed`` (:116), ``compenetration_check`` (:118), ``is_new_structure`` (:119, torsion
+    fingerprints against every pose kept so far -- its "LRU" never evicts) and appends what survives.  Here the candidate list
+    is built in that order on the host (a few integers per candidate) and everything per pose runs on the device
+    (``tsc_string_embed``); the order-dependent filter included.
+
+    coords1 f64[n_conf1, n1, 3], coords2 f64[n_conf2, n2, 3]   ``mol.atomcoords``
+    centers*, orb_vecs* f64[n_conf, n_centers, 3]               ``mol.get_r_atoms(c)[0].center`` / ``.orb_vecs`` per conformer
+    angles                                                      ``embedder.systematic_angles`` (degrees)
+    quadruplets i32[T, 4]                                       ``_get_quadruplets(get_sum_graph(...))`` (:87), embedded-structure indices
+
+    Returns the kept poses f64[n_kept, n1 + n2, 3] (the reference's ``np.array(poses)``; empty where the reference raises
+    ZeroCandidatesError); with ``return_trace`` also an EmbedTrace.
+    """
+    coords1, coords2 = (np.ascontiguousarray(x, dtype=np.float64) for x in (coords1, coords2))
+    centers1, orb_vecs1, centers2, orb_vecs2 = (np.asarray(x, dtype=np.float64) for x in (centers1, orb_vecs1, centers2, orb_vecs2))
+    if coords1.ndim != 3 or coords2.ndim != 3 or centers1.ndim != 3 or centers2.ndim != 3:
+        raise ValueError("coords* must be (n_conf, n_atoms, 3) and centers* / orb_vecs* (n_conf, n_centers, 3)")
+    conf_indices = cartesian_product(np.arange(len(coords1)), np.arange(len(coords2)))               # :73-74
+    centre_indices = cartesian_product(np.arange(centers1.shape[1]), np.arange(centers2.shape[1]))   # :77 (counted on conformer 0)
+    # site = (conformer pair, centre pair), conformer pairs outermost (:91, :97)
+    c1 = np.repeat(conf_indices[:, 0], len(centre_indices))
+    c2 = np.repeat(conf_indices[:, 1], len(centre_indices))
+    a1 = np.tile(centre_indices[:, 0], len(conf_indices))
+    a2 = np.tile(centre_indices[:, 1], len(conf_indices))
+    p1, p2 = centers1[c1, a1], centers2[c2, a2]                                                      # :103-104
+    ref_vec, mol_vec = orb_vecs1[c1, a1], orb_vecs2[c2, a2]                                          # :105-106
+    conf_pair = np.stack([c1, c2], axis=1)
+    ok, kept, poses = get_engine().string_embed(FragmentSet([coords1, coords2]), p1, p2, ref_vec, mol_vec, conf_pair, angles, clash_thresh,
+                                                max_clashes, quadruplets, tfd_thresh)
+    if return_trace:
+        return poses, EmbedTrace(clash_ok=ok, kept=kept, sites=np.stack([c1, c2, a1, a2], axis=1), n_angles=len(np.atleast_1d(angles)))
+    return poses
+
+
+def _reactive_pair_indices(pivot_cumnums, v):
+    """_get_cyclical_reactive_indices for two molecules (tscode/embeds.py:862-883): which atoms face each other in polygon
+    orientation v."""
+    swaps = ((0, 0), (0, 1))
+    oriented = [list(reversed(ids)) if swaps[v][i] else list(ids) for i, ids in enumerate(pivot_cumnums)]
+    return [[oriented[0][0], oriented[1][0]], [oriented[0][1], oriented[1][1]]]
+
+
+def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=0, rigid_shortcut=True, max_norm_delta=5, pairings=None,
+                         internal_constraints=(), rmsd_thr=1, return_trace=False):
+    """The loops of a BImolecular ``cyclical_embed`` (tscode/embeds.py:470-732, rigid shortcut :734-860) in one GPU call.
+
+    Per (conformer pair, pivot pair) the reference takes the pivots' lengths, ``polygonize``s them into two orientations of two
+    superposed segments, and per orientation walks ``systematic_angles``: alignment + step rotation of both molecules (:659-709),
+    ``get_embed``, ``compenetration_check``, and keeps a pose unless it is ``_rmsd_similarity``-similar (threshold 1) to a pose
+    already kept in the same (conformers, pivots, orientation) group.  Here the host lays out one row per (pose, molecule) in that
+    order and ``tsc_cyclical_embed`` does everything per pose, the greedy per-group filter included.
+
+    mols: two objects (or dicts) with
+        coords            f64[n_conf, n, 3]            ``mol.atomcoords``
+        reactive_indices  1 or 2 atom indices          ``mol.reactive_indices``
+        pivots            per conformer: (pivot f64[P, 3], meanpoint f64[P, 3], cumnums int[P, 2])
+                          ``[(p.pivot, p.meanpoint, (p.start_atom.cumnum, p.end_atom.cumnum)) for p in mol.pivots[c]]``
+    systematic_angles     f64[A, 2]                    ``embedder.systematic_angles`` (tscode/embedder.py:714-715)
+    rigid_shortcut        True: ``_fast_bimol_rigid_cyclical_embed`` (pivot pairs are skipped when their lengths differ by MORE than
+                          max_norm_delta, :762); False: the general loop (skipped unless they differ by LESS, :492).  The general
+                          loop's bending of such pairs (ase_bend, an external optimiser) is outside this path: they are skipped, as
+                          the reference does under RIGID.
+    pairings              ``embedder.pairings_table.values()``: orientations that do not contain every pairing are skipped (:642)
+
+    Returns ``(poses f64[n_kept, n_total, 3], constrained_indices int[n_kept, 2, 2])`` -- the reference's return value and
+    ``embedder.constrained_indices`` -- plus an EmbedTrace with ``return_trace``.
+
+    Trimolecular embeds are not offered: the reference's ``_get_directions`` calls ``vec_angle`` on 2-vectors (:297-299) and
+    ``algebra.norm`` reads ``vec[2]`` of them (tscode/algebra.py:87) -- an unchecked out-of-bounds read under Numba, an
+    IndexError as plain NumPy: what it computes is undefined in the reference itself.
+    """
+    get = lambda m, k: m[k] if isinstance(m, dict) else getattr(m, k)
+    if len(mols) != 2:
+        raise ValueError("cyclical_embed_batch embeds two molecules (the reference's trimolecular path reads out of bounds: see the docstring)")
+    coords = [np.ascontiguousarray(get(m, "coords"), dtype=np.float64) for m in mols]
+    reactive = [np.atleast_1d(np.asarray(get(m, "reactive_indices"), dtype=np.int64)) for m in mols]
+    pivots = [get(m, "pivots") for m in mols]
+    angles = np.asarray(systematic_angles, dtype=np.float64).reshape(-1, 2)
+    A = len(angles)
+    directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])                                      # _get_directions for two, :252-253 / :768
+    conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])                           # :470-471
+    blocks, groups = [], []
+    for conf_ids in conf_indices:
+        pv = [pivots[m][conf_ids[m]] for m in range(2)]
+        vec = [np.asarray(p[0], dtype=np.float64).reshape(-1, 3) for p in pv]
+        mean = [np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in pv]
+        cum = [np.asarray(p[2]).reshape(-1, 2) for p in pv]
+        rc = [coords[m][conf_ids[m]][reactive[m]] for m in range(2)]                                 # reactive_coords, :667
+        for pi in cartesian_product(*[np.arange(len(v)) for v in vec]):                              # :477
+            norms = np.linalg.norm(np.array([vec[m][pi[m]] for m in range(2)]), axis=1)              # :487
+            delta = abs(norms[0] - norms[1])
+            if (delta > max_norm_delta) if rigid_shortcut else not (delta < max_norm_delta):         # :762 / :492-496, :630-631
+                continue
+            polygon_vectors = polygonize(norms)                                                      # :507 / :766
+            for v, vecs in enumerate(polygon_vectors):
+                ids = _reactive_pair_indices([cum[m][pi[m]] for m in range(2)], v)
+                if pairings and not all((list(pair) in ids) or (list(pair) in [list(c) for c in internal_constraints]) for pair in pairings):
+                    continue                                                                         # :642 / :777
+                rows = np.empty((A, 2, 23))
+                for m in range(2):
+                    start, end = vecs[m]
+                    r = rc[m]
+                    rows[:, m, 0:3], rows[:, m, 3:6], rows[:, m, 6:9] = start, end, directions[m]
+                    rows[:, m, 9:12], rows[:, m, 12:15] = vec[m][pi[m]], mean[m][pi[m]]
+                    rows[:, m, 15:18], rows[:, m, 18:21] = r[0], r[1] if len(r) == 2 else r[0]
+                    rows[:, m, 21], rows[:, m, 22] = len(r), conf_ids[m]
+                blocks.append(rows)
+                groups.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi), v, ids))
+    n_total = sum(c.shape[1] for c in coords)
+    if not blocks:
+        out = (np.zeros((0, n_total, 3)), np.zeros((0, 2, 2), dtype=np.int64))
+        return (*out, EmbedTrace(clash_ok=np.zeros(0, bool), kept=np.zeros(0, bool), group_of=np.zeros(0, np.int64), groups=[])) if return_trace else out
+    rows = np.concatenate(blocks).reshape(-1, 23)
+    angle_rows = np.tile(angles, (len(blocks), 1)).reshape(-1)                                       # angles[i] for molecule i, :665
+    group_off = np.arange(len(blocks) + 1, dtype=np.int32) * A
+    ok, kept, poses = get_engine().cyclical_embed(FragmentSet(coords), rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15],
+                                                  rows[:, 15:18], rows[:, 18:21], rows[:, 21].astype(np.int32), angle_rows,
+                                                  rows[:, 22].astype(np.int32), group_off, clash_thresh, max_clashes, rmsd_thr)
+    group_of = np.repeat(np.arange(len(blocks)), A)
+    constrained = np.array([groups[g][3] for g in group_of[kept]], dtype=np.int64).reshape(-1, 2, 2)   # :718
+    if return_trace:
+        return poses, constrained, EmbedTrace(clash_ok=ok, kept=kept, group_of=group_of, groups=groups)
+    return poses, constrained

@@ -306,6 +306,60 @@ class Engine:
         check(self.lib.tsc_cyclical_embed_params(self._h, *[ptr(a) for a in arrs], ptr(n_reactive), ptr(angle), C.c_int64(n), ptr(rot), ptr(pos)))
         return rot, pos
 
+    # ---- N1: the embed loops as one call each ----------------------------------------------------
+    def tfd_greedy_filter(self, tf_mat, thresh=10.0):
+        """is_new_structure (tscode/embeds.py:47-69) over an ordered list of fingerprints f32[N, T]: bool[N]."""
+        tf = np.ascontiguousarray(tf_mat, dtype=np.float32)
+        if tf.ndim != 2:
+            raise ValueError("tf_mat must be (N, n_quadruplets)")
+        acc = np.zeros(len(tf), dtype=np.uint8)
+        nk = C.c_int64()
+        check(self.lib.tsc_tfd_greedy_filter(self._h, ptr(tf), C.c_int64(len(tf)), C.c_int(tf.shape[1]), C.c_double(float(thresh)), ptr(acc), C.byref(nk)))
+        return acc.astype(bool)
+
+    def string_embed(self, frags: FragmentSet, p1, p2, ref_vec, mol_vec, conf_pair, angles, clash_thresh, max_clashes, quadruplets, tfd_thresh=10.0,
+                     want_poses=True):
+        """tscode/embeds.py:91-120 for every (site, angle) candidate: (clash_ok bool[N], kept bool[N], poses f64[n_kept, n, 3] or None)."""
+        if frags.n_mols != 2:
+            raise ValueError("the string embed takes two fragments")
+        p1, p2, ref_vec, mol_vec = (np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64) for x in (p1, p2, ref_vec, mol_vec))
+        conf_pair = np.ascontiguousarray(np.atleast_2d(conf_pair), dtype=np.int32)
+        angles = np.ascontiguousarray(angles, dtype=np.float64)
+        quads = np.ascontiguousarray(quadruplets, dtype=np.int32).reshape(-1, 4)
+        S, A = len(p1), len(angles)
+        if not (p1.shape == p2.shape == ref_vec.shape == mol_vec.shape == (S, 3)) or conf_pair.shape != (S, 2):
+            raise ValueError("p1, p2, ref_vec, mol_vec must be (n_sites, 3) and conf_pair (n_sites, 2)")
+        N = S * A
+        ok, kept = np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.uint8)
+        poses = np.empty((N, frags.n_total, 3)) if want_poses else None        # rows beyond n_kept are never touched
+        n_pass, n_kept = C.c_int64(), C.c_int64()
+        check(self.lib.tsc_string_embed(self._h, ptr(frags.flat), *frags.table_args()[:3], ptr(p1), ptr(p2), ptr(ref_vec), ptr(mol_vec), ptr(conf_pair),
+                                        C.c_int64(S), ptr(angles), C.c_int(A), C.c_double(float(clash_thresh)), C.c_int64(int(max_clashes)),
+                                        ptr(quads), C.c_int(len(quads)), C.c_double(float(tfd_thresh)), ptr(ok), ptr(kept), ptr(poses), C.c_int64(N),
+                                        C.byref(n_pass), C.byref(n_kept)))
+        return ok.astype(bool), kept.astype(bool), (poses[:n_kept.value].copy() if want_poses else None)
+
+    def cyclical_embed(self, frags: FragmentSet, start, end, direction, pivot, meanpoint, r0, r1, n_reactive, angle, conf_idx, group_off, clash_thresh,
+                       max_clashes, rmsd_thr=1.0, want_poses=True):
+        """tscode/embeds.py:657-717 / :785-847 over rows = pose * n_mols + molecule: (clash_ok bool[N], kept bool[N], poses or None)."""
+        arrs = [np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64) for x in (start, end, direction, pivot, meanpoint, r0, r1)]
+        n_reactive = np.ascontiguousarray(n_reactive, dtype=np.int32).ravel()
+        angle = np.ascontiguousarray(angle, dtype=np.float64).ravel()
+        conf_idx = np.ascontiguousarray(conf_idx, dtype=np.int32).ravel()
+        group_off = np.ascontiguousarray(group_off, dtype=np.int32)
+        rows = len(angle)
+        if rows % frags.n_mols or any(a.shape != (rows, 3) for a in arrs) or n_reactive.shape != (rows,) or conf_idx.shape != (rows,):
+            raise ValueError("every per-row input must have n_poses * n_mols rows")
+        N = rows // frags.n_mols
+        ok, kept = np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.uint8)
+        poses = np.empty((N, frags.n_total, 3)) if want_poses else None
+        n_pass, n_kept = C.c_int64(), C.c_int64()
+        check(self.lib.tsc_cyclical_embed(self._h, ptr(frags.flat), *frags.table_args(), *[ptr(a) for a in arrs], ptr(n_reactive), ptr(angle), ptr(conf_idx),
+                                          C.c_int64(N), ptr(group_off), C.c_int(len(group_off) - 1), C.c_double(float(clash_thresh)),
+                                          C.c_int64(int(max_clashes)), C.c_double(float(rmsd_thr)), ptr(ok), ptr(kept), ptr(poses), C.c_int64(N),
+                                          C.byref(n_pass), C.byref(n_kept)))
+        return ok.astype(bool), kept.astype(bool), (poses[:n_kept.value].copy() if want_poses else None)
+
     # ---- N3: conformational-search rotations ---------------------------------------------------
     def csearch_rotate(self, coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
         """Every candidate of tscode/torsion_module.py:463-500: (new_coords f64[M, n, 3], rotated_bonds i32[M])."""

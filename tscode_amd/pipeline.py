@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .engine import FragmentSet, get_engine
+from .engine import Engine, FragmentSet
 
 __all__ = ["DevicePipeline", "HipShardBackend", "sharded_step", "block_bounds", "SHARD_MIN_PAIRS"]
 
@@ -169,7 +169,10 @@ class HipShardBackend:
         self.clash_thresh, self.max_clashes, self.rmsd_thr, self.mode = clash_thresh, max_clashes, rmsd_thr, mode
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
-        self.eng = get_engine(device_index)
+        # An engine (library context) of its own: the stream a context launches on is part of its state, and a context shared
+        # with other pipelines or with the drop-in functions (get_engine()) could be switched to another stream between two
+        # steps -- kernels and collectives would then no longer be ordered.
+        self.eng = Engine(device_index)
         # This library's kernels, torch's copies and the collectives must be ordered on ONE stream.  torch's default stream
         # has handle 0, which tsc_ctx_set_stream reads as "use the library's own stream": a dedicated torch stream is made
         # current for every step instead (torch.distributed orders its collectives against the current stream).
@@ -231,8 +234,7 @@ class DevicePipeline:
             return
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
-        self.eng = get_engine(device_index)
-        self.eng.set_stream(None)                           # the library's own stream: a step makes no torch call
+        self.eng = Engine(device_index)                     # its own context (and so its own stream): see HipShardBackend
         self.fs = FragmentSet(ens.frag_coords)
         n = ens.n_poses
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -243,6 +245,14 @@ class DevicePipeline:
         self.d_keep = torch.empty(n, dtype=torch.uint8, device=self.dev)
         self.h_keep = torch.empty(n, dtype=torch.uint8).pin_memory()      # verdicts, copied back at the end of every step
         torch.cuda.synchronize(self.dev)
+
+    @property
+    def engine(self):
+        """The library context this pipeline launches on (its own, not get_engine()'s)."""
+        return self.backend.eng if self.sharded else self.eng
+
+    def set_option(self, name, value):
+        self.engine.set_option(name, value)
 
     def step(self):
         """One pass of the hot path over the resident ensemble.  Returns counts/statistics; the verdicts

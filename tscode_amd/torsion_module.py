@@ -20,18 +20,27 @@ def csearch_rotate(coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
     return get_engine().csearch_rotate(coords, torsions, masks, angles, thresh, max_clashes)
 
 
-def csearch_candidates(coords, torsions, masks, angles, n_out=100, max_tries=10000, thresh=1.5):
+def csearch_candidates(coords, torsions, masks, angles, n_out=100, max_tries=10000, thresh=1.5, block=8192):
     """The ``new_structures`` array of tscode/torsion_module.py:463-509: candidates in the order of ``angles`` (shuffle it
-    first, :459), kept iff at least one bond really rotated (:505), until ``n_out`` are kept or row ``max_tries`` is reached."""
+    first, :459), kept iff at least one bond really rotated (:505), until ``n_out`` are kept or row ``max_tries`` is reached.
+    The angle table is walked in blocks of ``block`` rows and the walk stops where the reference's loop stops: a
+    cartesian-product table (3^12 rows x 100 atoms ...) is never rotated, stored or downloaded as a whole."""
     angles = np.asarray(angles)
-    new_coords, rotated = csearch_rotate(coords, torsions, masks, angles, thresh)
-    kept = []
-    for a in range(len(angles)):
-        if rotated[a] != 0:
+    coords = np.asarray(coords, dtype=np.float64)
+    out, n_kept = [], 0
+    for lo in range(0, len(angles), block):
+        new_coords, rotated = csearch_rotate(coords, torsions, masks, angles[lo:lo + block], thresh)
+        kept, done = [], False
+        for a in np.flatnonzero(rotated != 0):
             kept.append(a)
-            if len(kept) == n_out or a == max_tries:
+            n_kept += 1
+            if n_kept == n_out or lo + a == max_tries:          # :510 (tested only when a structure has just been kept)
+                done = True
                 break
-    return new_coords[kept]
+        out.append(new_coords[kept])
+        if done:
+            break
+    return np.concatenate(out) if out else np.zeros((0,) + coords.shape)
 
 
 def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None):
