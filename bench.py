@@ -1,38 +1,43 @@
 #!/usr/bin/env python
 """bench.py -- conformers/sec of the geometry hot path on the BASELINE config 3 workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode 0|1] [--config C3] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode 0|1] [--config C3|C4|C5] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one synthetic ensemble that is already resident in HBM:
 fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_conformers_rmsd
 (reference-exact mode), verdict masks left on the device and copied to pinned host memory.
 
-N > 1 (one process per GPU).  The 100k x 50 pipeline is a 0.9 ms job on one MI355X, a chain of ~50 dependent
-launches, so the two ways the path shards behave very differently and the line reports both:
-  * `value` (scaling "weak", --multi ensembles, the default): every GPU runs the whole pipeline on its own 100k x 50
-    ensemble -- ensembles are independent, no data-path collective; this is how a batch of embeds uses a node;
-  * `sharded_single_ensemble` (scaling "strong"; --multi sharded makes it the line's value): ONE ensemble sharded over
-    the ranks -- pose blocks for embed/clash, one RCCL all-gather of the surviving heavy-atom coordinates, row tiles of
-    every large prune pass dealt round-robin with an all-reduce(MIN) per pass (tscode_amd/pipeline.py::sharded_step).
-    It is what an ensemble too large for one GPU's patience (C4: 1M x 50) needs.
+N = 1: the one-call pipeline (tsc_pipeline_dev).
+
+N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): the line's `value` is ONE ensemble sharded over the
+ranks, `"scaling": "strong"` -- pose blocks for embed/clash, one RCCL all-gather of the surviving heavy-atom shards, the row
+tiles of every large prune pass dealt round-robin with an all-reduce(MIN) over best[] per pass
+(tscode_amd/pipeline.py::sharded_step); `rccl_world`, `allgather_bytes_per_step` and `allreduce_bytes_per_step` say what
+crossed xGMI.  `replicas` beside it (`"scaling": "weak"`): every GPU runs the whole pipeline on its own ensemble, no
+data-path collective -- how a batch of independent embeds uses a node.  The 100k x 50 pipeline is a 0.9 ms chain of dependent
+launches of which about 0.5 ms shards (the Amdahl ceiling of C3 is stated there); `--config C4` (1M x 50)
+is the workload on which sharding one ensemble pays.  Should the sharded leg fail or hang (180 s watchdog), the line falls
+back to the replicas figure, says so in `error`, and the process exits non-zero.
 
 The timed region (K steps between barrier + synchronize) carries the HIP start/stop events of every pair-kernel dispatch that
 `roofline.avg_launch_us` needs; the same K steps with those events off follow (`events_off`), then three steps with every
 library event on for `stage_ms_per_step` and `passes[].ms` -- both outside the timed region.
 
-Rank 0 prints ONE JSON line (see the keys below).  The CPU baseline leg (rank 0, N = 1 only) times the
-oracle -- this repo's C restatement of the reference algorithm, "port" -- on a bounded sample of the same
-generator; it is a reported baseline, not the thing measured.
+Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N = 1 only) times the oracle -- this repo's C restatement of the
+reference algorithm, "port" -- on the SAME workload (full C3: about a minute on 16 threads; other configs on a bounded
+sample, extrapolation stated); it is a reported baseline, not the thing measured.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,7 +47,7 @@ if ROOT not in sys.path:
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 157.3 / 2), no MFMA on this path
 FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-PMC_PROFILE = "r01_final_pmc_hbm_counters.json"   # committed rocprofv3 --pmc summary the roofline's `traffic` is read from
+PMC_PROFILES = ("r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
 
 
 def parse():
@@ -55,23 +60,33 @@ def parse():
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
     ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (seg_cols, drain_min), repeatable")
-    ap.add_argument("--multi", choices=["ensembles", "sharded"], default="ensembles",
-                    help="N > 1: 'ensembles' = one whole ensemble per GPU, no data-path collective (weak scaling; the line's value), "
-                         "'sharded' = ONE ensemble sharded over the ranks (strong scaling; all-gather + per-pass all-reduce). "
-                         "With 'ensembles' the sharded protocol is timed too and reported beside it.")
+    ap.add_argument("--multi", choices=["sharded", "replicas"], default="sharded",
+                    help="N > 1: what the line's value is.  'sharded' (default) = ONE ensemble sharded over the ranks under RCCL "
+                         "(strong scaling; all-gather + per-pass all-reduce), 'replicas' = one whole ensemble per GPU, no data-path "
+                         "collective (weak scaling).  The other one is timed too and reported beside it.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one GPU to rehearse "
-                                                      "the 'ensembles' mode (the sharded protocol needs nccl = RCCL)")
+                                                      "(device tensors then travel over the host)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--pass-timing", type=int, default=1,
                     help="library HIP events in the timed region: 1 = start/stop events on every pair-kernel dispatch (feeds the roofline), 0 = none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=40000, help="poses of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="poses of the CPU baseline run (default: the whole workload for C3, 40000 otherwise)")
+    ap.add_argument("--no-side-leg", action="store_true", help="N > 1: time only the leg that is the line's value")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg_name, n_sample, mode):
-    """Oracle (CPU restatement of the reference algorithm) on a bounded sample. Only called on rank 0 at N=1."""
+def csrc_digest():
+    """SHA-256 (16 hex digits) over the HIP sources: ties a profile under profiles/ to the kernels it was taken from."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "tscode_amd", "csrc", "*"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cfg_name, n_sample, n_full, mode):
+    """Oracle (CPU restatement of the reference algorithm). Only called on rank 0 at N=1."""
     import numpy as np
     import oracle
     from tscode_amd.synthetic import make_config
@@ -98,12 +113,20 @@ def cpu_baseline(cfg_name, n_sample, mode):
     dt_rp = time.perf_counter() - t1
     assert np.array_equal(res_rp["mask"], res["mask"])
     cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
-    return {"value": n_sample / dt, "unit": "conformers/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "sample": f"{cfg_name} generator at N={n_sample} (embed + clash + prune mode {mode}; {int(cm.sum())} pass the clash check, "
-                      f"{int(res['mask'].sum())} survive; {evals} pair evaluations; chunk-parallel like the reference's prange)",
-            "seconds": dt, "pair_evals_per_s": evals / dt,
-            "row_parallel_variant": {"prune_seconds": dt_rp, "pair_evals_per_s": evals / dt_rp,
-                                     "note": "prune only, rows of a chunk also spread over the threads: not the reference's parallelisation"}}
+    whole = n_sample == n_full
+    digest = hashlib.sha256(np.packbits(res["mask"].astype(bool)).tobytes()).hexdigest()[:16]
+    out = {"value": n_sample / dt, "unit": "conformers/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+           "sample": (f"the whole workload: {cfg_name} at N={n_sample}" if whole else f"{cfg_name} generator at N={n_sample} of {n_full}")
+                     + f" (embed + clash + prune mode {mode}; {int(cm.sum())} pass the clash check, {int(res['mask'].sum())} survive; "
+                       f"{evals} pair evaluations; chunk-parallel like the reference's prange)",
+           "same_workload_as_value": whole, "seconds": dt, "pair_evals_per_s": evals / dt, "n_pass_clash": int(cm.sum()),
+           "n_survivors": int(res["mask"].sum()), "keep_sha256_16": digest,
+           "row_parallel_variant": {"prune_seconds": dt_rp, "pair_evals_per_s": evals / dt_rp,
+                                    "note": "prune only, rows of a chunk also spread over the threads: not the reference's parallelisation"}}
+    if not whole:
+        out["note"] = ("a sample, not the workload: the prune's work grows faster than N (pair evaluations ~ N^2 / k in the late passes), so "
+                       "conformers/s on the sample overstates what the CPU would reach on the whole workload; compare pair_evals_per_s")
+    return out
 
 
 def main():
@@ -124,7 +147,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     pg = None
-    if world > 1 or args.force_sharded:
+    use_dist = world > 1 or args.force_sharded
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:                       # --force-sharded without a launcher: a one-rank group
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -142,21 +166,13 @@ def main():
     from tscode_amd.pipeline import DevicePipeline
     from tscode_amd.synthetic import make_config
 
-    # every rank draws the SAME ensemble, also in the one-ensemble-per-GPU mode: per-GPU work is then exactly fixed as N grows,
-    # and every rank's survivor set is checked against the recorded oracle mask (parity_vs_recorded_oracle = all ranks agree)
+    # every rank draws the SAME ensemble, also for the replicas leg: per-GPU work is then exactly fixed as N grows, and every
+    # rank's survivor set is checked against the recorded oracle mask (parity_vs_recorded_oracle = all ranks agree)
     ens = make_config(args.config, args.n_poses)
-    sharded_mode = (world > 1 and args.multi == "sharded") or args.force_sharded
-    if sharded_mode:                                        # ONE ensemble, every rank keeps only its block of the pose axis
-        pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
-                              force_sharded=args.force_sharded)
-    else:                                                   # one whole ensemble per GPU: the single-GPU pipeline on every rank
-        pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
-    units_per_step = ens.n_poses * (1 if sharded_mode else world)     # conformers all ranks process in one step
-    pipe.set_option("prune_algo", args.algo)
-    pipe.set_option("pass_timing", args.pass_timing)
-    for opt in args.opt:
-        name, val = opt.split("=")
-        pipe.set_option(name, float(val))
+    expected = None
+    exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")
+    if os.path.exists(exp_path):
+        expected = json.load(open(exp_path)).get(f"{args.config}:{ens.n_poses}:mode{args.mode}")
 
     def sync():
         torch.cuda.synchronize()
@@ -164,7 +180,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_loop(steps, pipe=pipe):
+    def configure(pipe, pass_timing):
+        pipe.set_option("prune_algo", args.algo)
+        pipe.set_option("pass_timing", pass_timing)
+        for opt in args.opt:
+            name, val = opt.split("=")
+            pipe.set_option(name, float(val))
+
+    def timed_loop(pipe, steps):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks. Returns (seconds, last result, sums)."""
         acc = {"tile_ms": 0.0, "evals": 0, "computed": 0, "screened": 0,
                "stage_ms": {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}}
@@ -190,44 +213,116 @@ def main():
                 acc["stage_ms"][k] += r.get("ms", {}).get(k, 0.0)
         return dt, res, acc
 
-    res = None
-    for _ in range(args.warmup):
-        res = pipe.step()
-    dt, res, acc = timed_loop(args.steps)           # THE timed region (library events as --pass-timing says)
-    tile_ms, evals, computed, screened, stage_ms = acc["tile_ms"], acc["evals"], acc["computed"], acc["screened"], acc["stage_ms"]
-    # the same K steps once more with every library event off: what a production caller sees (an event record on the
-    # stream costs about 4 us on MI355X; the kernel durations of the roofline need them, the product does not)
-    events_off = None
-    if args.pass_timing != 0:
-        pipe.set_option("pass_timing", 0)
-        dt0, _, _ = timed_loop(args.steps)
-        pipe.set_option("pass_timing", args.pass_timing)
-        events_off = {"ms_per_step": dt0 / args.steps * 1e3, "value": units_per_step * args.steps / dt0, "unit": "conformers/s"}
-    # where a step goes: three more steps with every library event on (stages of the pipeline, whole passes), outside both
-    # timed regions -- these events cost about 4 us each and would distort what they measure
-    pass_ms = None
-    if args.pass_timing != 0:
-        pipe.set_option("pass_timing", 2)
-        _, res_d, acc_d = timed_loop(3)
-        pipe.set_option("pass_timing", args.pass_timing)
-        stage_ms = {k: v * args.steps / 3 for k, v in acc_d["stage_ms"].items()}
-        pass_ms = [s["gpu_ms"] for s in res_d["stats"]]
-    # verdict fingerprint (after the timed region)
-    n_pass, n_keep = res["n_pass"], res["n_keep"]
-    keep = pipe.h_keep[:n_pass].numpy().copy()             # the host copy every step produces
-    digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
-    expected = None
-    exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")
-    if os.path.exists(exp_path):
-        expected = json.load(open(exp_path)).get(f"{args.config}:{ens.n_poses}:mode{args.mode}")
-    parity = None
-    if expected is not None:
-        parity = bool(expected["n_pass"] == n_pass and expected["n_keep"] == n_keep and expected["keep_sha256_16"] == digest)
-        if world > 1:                                       # every rank checks its own result
-            flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            parity = bool(flag.item())
+    def verdict(pipe, res, expected=expected):
+        """(digest of the packed survivor mask, parity with the recorded oracle run on every rank)."""
+        keep = pipe.h_keep[:res["n_pass"]].numpy().copy()             # the host copy every step produces
+        digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
+        parity = None
+        if expected is not None:
+            parity = bool(expected["n_pass"] == res["n_pass"] and expected["n_keep"] == res["n_keep"] and expected["keep_sha256_16"] == digest)
+            if world > 1:                                       # every rank checks its own result
+                flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                parity = bool(flag.item())
+        return digest, parity
 
+    def run_leg(sharded, ens=ens, expected=expected, detail=True):
+        """One leg: its own pipeline, warm-up, THE timed region, then (detail) the same steps with the library's events off and
+        three steps with all of them on.  Returns a dict of everything measured."""
+        if sharded:
+            pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
+                                  force_sharded=args.force_sharded or world == 1)
+        else:
+            pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
+        configure(pipe, args.pass_timing)
+        for _ in range(args.warmup):
+            pipe.step()
+        dt, res, acc = timed_loop(pipe, args.steps)           # THE timed region (library events as --pass-timing says)
+        leg = {"dt": dt, "res": res, "acc": acc, "pipe": pipe, "sharded": sharded, "events_off": None, "pass_ms": None, "stage_ms": acc["stage_ms"]}
+        units = ens.n_poses * (1 if sharded else world)
+        leg["units_per_step"] = units
+        if args.pass_timing != 0 and detail:
+            # the same K steps once more with every library event off: what a production caller sees (an event record on the
+            # stream costs about 4 us on MI355X; the kernel durations of the roofline need them, the product does not)
+            pipe.set_option("pass_timing", 0)
+            dt0, _, _ = timed_loop(pipe, args.steps)
+            leg["events_off"] = {"ms_per_step": dt0 / args.steps * 1e3, "value": units * args.steps / dt0, "unit": "conformers/s"}
+            # where a step goes: three more steps with every library event on (stages of the pipeline, whole passes), outside
+            # both timed regions -- these events cost about 4 us each and would distort what they measure
+            pipe.set_option("pass_timing", 2)
+            _, res_d, acc_d = timed_loop(pipe, 3)
+            pipe.set_option("pass_timing", args.pass_timing)
+            leg["stage_ms"] = {k: v * args.steps / 3 for k, v in acc_d["stage_ms"].items()}
+            leg["pass_ms"] = [s["gpu_ms"] for s in res_d["stats"]]
+        leg["digest"], leg["parity"] = verdict(pipe, res, expected)
+        return leg
+
+    def leg_summary(leg, what):
+        res = leg["res"]
+        out = {"ms_per_step": leg["dt"] / args.steps * 1e3, "value": leg["units_per_step"] * args.steps / leg["dt"], "unit": "conformers/s",
+               "scaling": "strong" if leg["sharded"] else "weak", "conformers_per_step_all_ranks": leg["units_per_step"],
+               "n_survivors": int(res["n_keep"]), "keep_sha256_16": leg["digest"], "parity_vs_recorded_oracle": leg["parity"],
+               "events_off": leg["events_off"], "what": what}
+        return out
+
+    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom shards, "
+                    "all-reduce(MIN) over best[] per large pass")
+    REPLICAS_WHAT = "one whole ensemble per GPU (the same ensemble on every rank), no data-path collective"
+
+    main_sharded = (world > 1 and args.multi == "sharded") or args.force_sharded
+    side = None
+    error = None
+    exit_code = 0
+    if world > 1 and main_sharded:
+        # the replicas leg first (it cannot hang on a collective), then the sharded leg under a watchdog: if RCCL should hang
+        # on some node, a line is still printed -- with the replicas figure as its value, the failure named, exit code 3
+        replicas = None if args.no_side_leg else run_leg(False)
+        box = {}
+
+        def bail():
+            if rank == 0:
+                line = {"metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
+                        "value": None, "unit": "conformers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": f"{args.config}: {ens.n_poses} conformers x {ens.n_atoms} atoms"},
+                        "error": "the sharded single-ensemble leg did not finish within 180 s (collective hung?); value = replicas leg"}
+                if replicas is not None:
+                    s = leg_summary(replicas, REPLICAS_WHAT)
+                    line.update(value=s["value"], ms_per_step=s["ms_per_step"], replicas=s)
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            os._exit(3)
+        watchdog = threading.Timer(180.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            leg = run_leg(True)
+        except Exception as exc:
+            error = f"sharded single-ensemble leg failed: {type(exc).__name__}: {exc}; value = replicas leg"
+            exit_code = 3
+            leg = replicas
+            if leg is None:
+                raise
+        watchdog.cancel()
+        if leg is not replicas and replicas is not None:
+            side = ("replicas", leg_summary(replicas, REPLICAS_WHAT))
+    elif world > 1:
+        leg = run_leg(False)
+        if not args.no_side_leg and args.backend == "nccl":
+            try:
+                side = ("sharded_single_ensemble", leg_summary(run_leg(True), SHARDED_WHAT))
+            except Exception as exc:
+                side = ("sharded_single_ensemble", {"error": f"{type(exc).__name__}: {exc}"})
+    else:
+        leg = run_leg(main_sharded)
+
+    res, acc, dt = leg["res"], leg["acc"], leg["dt"]
+    tile_ms, evals, computed, screened = acc["tile_ms"], acc["evals"], acc["computed"], acc["screened"]
+    stage_ms, pass_ms = leg["stage_ms"], leg["pass_ms"]
+    n_pass, n_keep = res["n_pass"], res["n_keep"]
+    sharded_mode = leg["sharded"]
+    units_per_step = leg["units_per_step"]
+
+    out = None
     if rank == 0:
         h = ens.n_heavy
         n = ens.n_poses
@@ -241,29 +336,41 @@ def main():
         b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
         b_big = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in big)
         b_launch = b_big / n_launch if n_launch else None
-        b_k12 = n * ens.frag_coords.__len__() * 96 + n_pass * ens.n_atoms * 24 + n
+        b_k12 = n * len(ens.frag_coords) * 96 + n_pass * ens.n_atoms * 24 + n
         ms_per_step = dt / args.steps * 1e3
         kernel = "k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile"
-        # HBM bytes per launch from the committed PMC passes of this same command (tools/profile.sh: FETCH_SIZE and
-        # WRITE_SIZE in separate runs, KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # HBM bytes per launch: NOT measurable inside this process (rocprofv3 --pmc wraps the whole command, one counter per
+        # pass); taken from the committed PMC passes of this same command (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in
+        # separate runs, KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- and only if that profile was
+        # taken from the kernels that run now (digest of tscode_amd/csrc recorded in it); otherwise null, labelled stale
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if os.path.exists(pmc_path) and args.config == "C3" and args.n_poses is None and world == 1:
-            pmc = json.load(open(pmc_path))
-            f = next((v for k, v in pmc.get("FETCH_SIZE", {}).items() if kernel in k), None)
-            w = next((v for k, v in pmc.get("WRITE_SIZE", {}).items() if kernel in k), None)
-            if f and w:
-                traffic = (2.0 * f["per_call_KB"] + w["per_call_KB"]) * 1024.0
-                traffic_src = f"profiles/{PMC_PROFILE}: (2 x FETCH_SIZE + WRITE_SIZE) per launch, rocprofv3 --pmc, separate passes"
+        now = csrc_digest()
+        if args.config == "C3" and args.n_poses is None and world == 1:
+            for name in PMC_PROFILES:
+                pmc_path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc_path):
+                    continue
+                pmc = json.load(open(pmc_path))
+                if pmc.get("csrc_sha256_16") != now:
+                    traffic_src = (f"profiles/{name} is STALE (taken from csrc {pmc.get('csrc_sha256_16', 'unrecorded')}, the kernels now are "
+                                   f"{now}): traffic withheld; re-run tools/profile.sh")
+                    break
+                f = next((v for k, v in pmc.get("FETCH_SIZE", {}).items() if kernel in k), None)
+                w = next((v for k, v in pmc.get("WRITE_SIZE", {}).items() if kernel in k), None)
+                if f and w:
+                    traffic = (2.0 * f["per_call_KB"] + w["per_call_KB"]) * 1024.0
+                    traffic_src = (f"profiles/{name} (csrc {now}, the kernels of this run): (2 x FETCH_SIZE + WRITE_SIZE) per launch, "
+                                   f"rocprofv3 --pmc, separate passes")
+                break
         hbm_achieved = b_launch / avg_launch_s / 1e9 if avg_launch_s else None
-        # SURVEY.md 8(d) flop accounting beside it: the reference's own pair evaluations x (46 h + 500) flop each over the
-        # kernel time.  The sieve reaches the reference's verdicts without forming H for most pairs, so this "algorithmic"
-        # figure exceeds the FP64 peak; `executed` is what the instructions really do: the fp32 screen (2 families x (8 fma +
-        # add + fma) = 34 flop per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per
-        # pair that reaches them; register-tiled kernel: every computed pair, h padded to a multiple of 4)
+        # What the instructions execute (the PRIMARY compute figure): the fp32 screen (2 families x (8 fma + add + fma) = 34 flop
+        # per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per pair that reaches them; register-tiled
+        # kernel: every computed pair, h padded to a multiple of 4).  Beside it SURVEY.md 8(d)'s accounting: the reference's own
+        # pair evaluations x (46 h + 500) flop each over the kernel time -- the sieve reaches the reference's verdicts without
+        # forming H for most pairs, so that ratio exceeds 1 and is NOT a roofline fraction.
         evals_big = sum(s["pairs_evaluated"] for s in big)
         screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
-        achieved_alg = evals_big * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
+        ref_equiv = evals_big * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
         if screened_big:
             f32_flops = screened_big * 34        # dot-product form: 2 families x (8 fma + add + fma) per pair
             f64_flops = computed_big * (18 * h + 110)
@@ -271,6 +378,7 @@ def main():
             f32_flops = 0.0
             f64_flops = computed_big * (18 * ((h + 3) // 4 * 4) + 110)
         per_s = (lambda x: x / (tile_s / args.steps) / 1e12) if tile_s > 0 else (lambda x: None)
+        ex32, ex64 = per_s(f32_flops), per_s(f64_flops)
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
             "value": units_per_step * args.steps / dt,
@@ -284,11 +392,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n} conformers x {ens.n_atoms} atoms ({h} heavy), 2 rigid fragments, "
+            "config": {"workload": f"{args.config}: {n} conformers x {ens.n_atoms} atoms ({h} heavy), {len(ens.frag_coords)} rigid fragments, "
                                    f"10 children per parent, seed {ens.seed}; clash_thresh 1.5, max_clashes 0, rmsd_thr 0.5, "
                                    f"mode {args.mode} ({'reference-exact' if args.mode == 0 else 'cache-free'})",
-                       "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": digest,
-                       "parity_vs_recorded_oracle": parity,
+                       "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": leg["digest"],
+                       "parity_vs_recorded_oracle": leg["parity"],
                        "parallelism": (f"one ensemble sharded over {world} rank(s): pose blocks, all-gather, per-pass all-reduce" if sharded_mode else
                                        f"{world} x (one whole ensemble per GPU), no data-path collective"),
                        "conformers_per_step_all_ranks": units_per_step,
@@ -302,24 +410,29 @@ def main():
                 "frac": (hbm_achieved / HBM_PEAK_GBS) if hbm_achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "csrc_sha256_16": now,
                 "algorithmic_bytes_per_launch": b_launch,
                 "avg_launch_us": avg_launch_s * 1e6 if avg_launch_s else None,
                 "launches_per_step": n_launch,
                 "kernel_ms_per_step": tile_ms / args.steps,
                 "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
                 "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
-                "fp64_valu": {"algorithmic_pair_evals_per_step": evals_big, "flops_per_eval": flops_per_eval,
-                              "achieved_algorithmic_TFLOPs": achieved_alg, "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
-                              "frac_algorithmic": (achieved_alg / FP64_VALU_PEAK_TFLOPS) if achieved_alg else None,
-                              "pairs_screened_per_step": screened_big, "pairs_with_H_formed_per_step": computed_big,
-                              "executed_fp32_TFLOPs": per_s(f32_flops), "executed_fp64_TFLOPs": per_s(f64_flops),
-                              "peak_fp32_TFLOPs": FP32_VALU_PEAK_TFLOPS},
+                "executed": {"what": "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
+                                     "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers",
+                             "fp32_TFLOPs": ex32, "fp32_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS, "fp32_frac": (ex32 / FP32_VALU_PEAK_TFLOPS) if ex32 else None,
+                             "fp64_TFLOPs": ex64, "fp64_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS, "fp64_frac": (ex64 / FP64_VALU_PEAK_TFLOPS) if ex64 else None,
+                             "pairs_screened_per_step": screened_big, "pairs_with_H_formed_per_step": computed_big},
+                "reference_flop_equivalent": {"what": "SURVEY.md 8(d)'s accounting, NOT a roofline fraction: the pair evaluations the REFERENCE would make "
+                                                      "x (46 h + 500) flop over the kernel time; above the fp64 peak because the sieve decides most pairs "
+                                                      "without the work this formula counts",
+                                              "pair_evals_per_step": evals_big, "flops_per_eval": flops_per_eval, "TFLOPs_equivalent": ref_equiv,
+                                              "ratio_to_fp64_peak": (ref_equiv / FP64_VALU_PEAK_TFLOPS) if ref_equiv else None},
             },
             "pipeline_hbm": {"algorithmic_bytes": (b_k12 + b_k3) * (units_per_step // n),
                              "achieved_GBs": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9,
                              "peak_GBs": HBM_PEAK_GBS * world,
                              "frac": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9 / (HBM_PEAK_GBS * world)},
-            "events_off": events_off,
+            "events_off": leg["events_off"],
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(pass_ms[i] if pass_ms and i < len(pass_ms) else s["gpu_ms"], 4),
@@ -328,47 +441,62 @@ def main():
             "detail_note": "stage_ms_per_step and passes[].ms come from 3 extra steps with every library event on (pass_timing 2), "
                            "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region",
         }
-    else:
-        out = None
-    # N > 1 in 'ensembles' mode: the sharded single-ensemble protocol (strong scaling) timed beside it, same K steps.
-    # The line's value is already measured; a watchdog makes sure it is printed even if a collective of this extra
-    # leg should hang on some node (this leg runs under RCCL with N > 1 only on the driver's hardware).
-    sharded_beside = None
-    if world > 1 and not sharded_mode and args.backend == "nccl":
-        import threading
-
-        def bail():
+        if sharded_mode:
+            out["rccl_world"] = dist.get_world_size() if use_dist else 1
+            out["collective_backend"] = dist.get_backend() if use_dist else None
+            out["allgather_bytes_per_step"] = res.get("allgather_bytes")
+            out["allreduce_bytes_per_step"] = res.get("allreduce_bytes")
+            out["sharded_passes"] = [{"k": k, "best_entries": nb} for k, nb in res.get("exchanges", [])]
+            out["collectives_per_step"] = 2 + len(res.get("exchanges", []))           # counts all-reduce, coordinates all-gather, one per sharded pass
+        if side is not None:
+            out[side[0]] = side[1]
+        if error is not None:
+            out["error"] = error
+    # beside the C3 line: config C4 (1M x 50), the workload large enough for sharding one ensemble to pay -- one GPU: the one-call
+    # pipeline; N > 1: the same sharded protocol.  A side figure of the default run, so that every N of a scaling series has it.
+    # Under a watchdog of its own: the line above is complete and is printed whatever happens here.
+    if args.config == "C3" and args.n_poses is None and not args.no_side_leg and not (world > 1 and args.backend != "nccl") and exit_code == 0:
+        def bail4():
             if rank == 0:
-                out["sharded_single_ensemble"] = {"error": "timed out after 120 s"}
+                out["c4"] = {"error": "the C4 side leg did not finish within 240 s"}
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(0)
-        watchdog = threading.Timer(120.0, bail)
-        watchdog.daemon = True
-        watchdog.start()
+            os._exit(3)
+        watchdog4 = threading.Timer(240.0, bail4)
+        watchdog4.daemon = True
+        watchdog4.start()
         try:
-            spipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg)
-            for _ in range(args.warmup):
-                spipe.step()
-            dts, sres, _ = timed_loop(args.steps, spipe)
-            skeep = spipe.h_keep[:sres["n_pass"]].numpy().copy()
-            sharded_beside = {"ms_per_step": dts / args.steps * 1e3, "value": ens.n_poses * args.steps / dts, "unit": "conformers/s",
-                              "scaling": "strong", "n_survivors": int(sres["n_keep"]),
-                              "keep_sha256_16": hashlib.sha256(np.packbits(skeep.astype(bool)).tobytes()).hexdigest()[:16],
-                              "what": "ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom "
-                                      "shards, all-reduce(MIN) per large pass"}
-        except Exception as exc:                             # the line's value above is already measured
-            sharded_beside = {"error": f"{type(exc).__name__}: {exc}"}
-        watchdog.cancel()
-    if rank == 0:
-        out["sharded_single_ensemble"] = sharded_beside
+            leg["pipe"] = None                               # the C3 buffers are no longer needed
+            ens4 = make_config("C4")
+            exp4 = json.load(open(exp_path)).get(f"C4:{ens4.n_poses}:mode{args.mode}") if os.path.exists(exp_path) else None
+            leg4 = run_leg(world > 1, ens4, exp4, detail=False)
+            c4 = leg_summary(leg4, SHARDED_WHAT if world > 1 else "the one-call pipeline on one GPU")
+            c4["workload"] = f"C4: {ens4.n_poses} conformers x {ens4.n_atoms} atoms ({ens4.n_heavy} heavy), seed {ens4.seed}"
+            c4["n_pass_clash"] = int(leg4["res"]["n_pass"])
+            if world > 1:
+                c4["allgather_bytes_per_step"] = leg4["res"].get("allgather_bytes")
+                c4["allreduce_bytes_per_step"] = leg4["res"].get("allreduce_bytes")
+                c4["sharded_passes"] = [k for k, _ in leg4["res"].get("exchanges", [])]
+            del leg4, ens4
+        except Exception as exc:
+            c4 = {"error": f"{type(exc).__name__}: {exc}"}
+        watchdog4.cancel()
+        if rank == 0:
+            out["c4"] = c4
     if rank == 0:
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, ens.n_poses), args.mode)
+            n_cpu = args.cpu_sample if args.cpu_sample else (ens.n_poses if args.config == "C3" else 40000)
+            out["cpu_baseline"] = cpu_baseline(args.config, min(n_cpu, ens.n_poses), ens.n_poses, args.mode)
+            cb = out["cpu_baseline"]
+            if cb["same_workload_as_value"]:
+                cb["gpu_over_cpu"] = out["value"] / cb["value"]
+                cb["survivors_identical_to_gpu"] = bool(cb["keep_sha256_16"] == leg["digest"])
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if world > 1 or args.force_sharded:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

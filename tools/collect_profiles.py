@@ -6,7 +6,9 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (MI355X_MICROARCH.md, HB
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import shutil
 import sys
 
@@ -14,7 +16,12 @@ src, prefix = sys.argv[1], sys.argv[2]
 stats = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(stats, f"profiles/{prefix}_kernel_stats.csv")
 shutil.copy(f"{src}/bench_trace.json", f"profiles/{prefix}_bench_under_rocprof.json")
-out = {}
+# digest of the HIP sources the profile was taken from (bench.py prints `traffic` only while it still matches)
+_h = hashlib.sha256()
+for _p in sorted(glob.glob("tscode_amd/csrc/*")):
+    _h.update(os.path.basename(_p).encode())
+    _h.update(open(_p, "rb").read())
+out = {"csrc_sha256_16": _h.hexdigest()[:16]}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(f"{src}/{name}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                     double Gi, Gj, H[9];
                     decode(e, t, col, pp, pq, Gi, Gj);
                     pair_H(pp, pq, a.h, sub, lpp, H);
-                    const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2);
+                    const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
                     cand = sub == 0 && verdict == PAIR_UNDECIDED;
                     sim = sub == 0 && verdict == PAIR_SIMILAR;
                 }

@@ -673,39 +673,66 @@ __device__ inline Quartic horn_quartic(const double H[9]) {
     q.c2 = -2.0 * q.F, q.c1 = -8.0 * det, q.c0 = q.F * q.F - 4.0 * q.CF;
     return q;
 }
-constexpr double QUARTIC_KAPPA = 1e-12;  // >> accumulated rounding of the coefficients for h up to ~1000 atoms
+// Rounding bound of the quartic tests: every comparison below is `value > kappa * (sum of the magnitudes of its terms)`.
+// Derivation (u = 2^-53, gamma = h u, S^2 = Gp Gq, rho = ((Gp + Gq) / 2) / L >= S / L, L = the test point):
+//   * H: an h-term fma chain per entry, |dH_ij| <= gamma sum_a |p_ai q_aj| <= gamma sqrt(sum p_ai^2 sum q_aj^2), so
+//     |dH|_F <= gamma S, and |H|_F <= S (Cauchy-Schwarz);
+//   * F = |H|_F^2:  dF <= 2 |H| |dH| <= 2 gamma S^2;  det: d det <= |cof H|_F |dH|_F <= gamma S^3;  CF = |cof H|_F^2:
+//     dCF <= 2 |cof| 2 |H| |dH| <= 4 gamma S^4;  hence d(c2 L^2) <= 4 gamma S^2 L^2, d(c1 L) <= 8 gamma S^3 L,
+//     d(c0) = 2 F dF + 4 dCF <= 20 gamma S^4: together <= 32 gamma rho^4 L^4 in P, and by the same steps
+//     <= 4 gamma rho^3 (4 L^3) in P' and <= gamma rho^2 (6 L^2) in P'';
+//   * the test point itself: Gp, Gq are 3h-term sums, |dL| <= 3 gamma (Gp + Gq) / 2 = 3 gamma rho L, which moves P by at most
+//     |P'| |dL| <= 12 gamma rho L^4 (and P', P'' by less, relative to their term sums);
+//   * evaluating the three polynomials: a few u times the term sums.
+// All of it is below 64 h u rho^4 times the respective term sum (each sum contains L^4, 4 L^3, 6 L^2).  kappa is that
+// bound, and never less than the 1e-12 the recorded runs were made with (which it exceeds only beyond about 140 heavy atoms
+// or where the structures sit so close to the origin that L is small against Gp + Gq): a larger kappa only hands more pairs
+// to the explicit-rotation path, it cannot change a verdict.  Structures far from the origin (the path never centres,
+// rmsd_pruning.py:7-41) make Gp, Gq and L grow with the square of the offset while the margin P(L) ~ P'(l1) (L - l1) keeps
+// L - l1 = h (rmsd^2 - thr^2) / 2: the tests decide less and less (at 10^4 A nothing) and everything takes the exact path.
+constexpr double QUARTIC_KAPPA_MIN = 1e-12;
+__device__ inline double quartic_kappa(int h, double half_sum, double L) {
+    const double rho = half_sum / L, r2 = rho * rho;          // callers test L > 0 themselves
+    const double k = 64.0 * 1.1102230246251565e-16 * double(h) * r2 * r2;
+    return (k > QUARTIC_KAPPA_MIN) ? k : QUARTIC_KAPPA_MIN;  // (a NaN k -- L == 0 -- keeps the minimum; the L > 0 test fails then)
+}
 
-__device__ inline bool quartic_above_top_root(const Quartic &q, double L) {
+__device__ inline bool quartic_above_top_root(const Quartic &q, double L, double kappa) {
     const double L2 = L * L;
     const double t4 = L2 * L2, t2 = q.c2 * L2, t1 = q.c1 * L;
     const double P = t4 + t2 + t1 + q.c0;
-    const double eP = QUARTIC_KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
+    const double eP = kappa * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
     const double P1 = 4.0 * L2 * L + 2.0 * q.c2 * L + q.c1;
-    const double e1 = QUARTIC_KAPPA * (4.0 * L2 * fabs(L) + 2.0 * fabs(q.c2 * L) + fabs(q.c1));
+    const double e1 = kappa * (4.0 * L2 * fabs(L) + 2.0 * fabs(q.c2 * L) + fabs(q.c1));
     const double P2 = 6.0 * L2 + q.c2;
-    const double e2 = QUARTIC_KAPPA * (6.0 * L2 + fabs(q.c2));
+    const double e2 = kappa * (6.0 * L2 + fabs(q.c2));
     return (L > 0.0) && (P > eP) && (P1 > e1) && (P2 > e2);
 }
-__device__ inline bool quartic_between_top_roots(const Quartic &q, double x) {
+__device__ inline bool quartic_between_top_roots(const Quartic &q, double x, double kappa) {
     const double x2 = x * x;
     const double t4 = x2 * x2, t2 = q.c2 * x2, t1 = q.c1 * x;
     const double P = t4 + t2 + t1 + q.c0;
-    const double eP = QUARTIC_KAPPA * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
+    const double eP = kappa * (t4 + fabs(t2) + fabs(t1) + fabs(q.c0) + 4.0 * q.CF + q.F * q.F);
     const double P1 = 4.0 * x2 * x + 2.0 * q.c2 * x + q.c1;
-    const double e1 = QUARTIC_KAPPA * (4.0 * x2 * fabs(x) + 2.0 * fabs(q.c2 * x) + fabs(q.c1));
+    const double e1 = kappa * (4.0 * x2 * fabs(x) + 2.0 * fabs(q.c2 * x) + fabs(q.c1));
     const double P2 = 6.0 * x2 + q.c2;
-    const double e2 = QUARTIC_KAPPA * (6.0 * x2 + fabs(q.c2));
+    const double e2 = kappa * (6.0 * x2 + fabs(q.c2));
     return (x > 0.0) && (P2 > e2) && (P1 > e1) && (P < -eP);
 }
 
-__device__ inline bool certainly_dissimilar(const double H[9], double L) { return quartic_above_top_root(horn_quartic(H), L); }
+// half_sum = (Gp + Gq) / 2, L = half_sum - h thr^2 / 2, h = atoms per structure
+__device__ inline bool certainly_dissimilar(const double H[9], double L, double half_sum, int h) {
+    return quartic_above_top_root(horn_quartic(H), L, quartic_kappa(h, half_sum, L));
+}
 
 // half_sum = (Gp + Gq) / 2, half_h_thr2 = h thr^2 / 2, two_thr2 = 2 thr^2 (pass a negative two_thr2 to switch the
 // near-duplicate test off: h < 4, or a maxdev threshold other than 2 thr)
-__device__ inline int pair_verdict(const double H[9], double half_sum, double half_h_thr2, double two_thr2) {
+__device__ inline int pair_verdict(const double H[9], double half_sum, double half_h_thr2, double two_thr2, int h) {
     const Quartic q = horn_quartic(H);
-    if (quartic_above_top_root(q, half_sum - half_h_thr2)) return PAIR_DISSIMILAR;
-    if (two_thr2 > 0.0 && quartic_between_top_roots(q, half_sum - two_thr2)) return PAIR_SIMILAR;
+    const double L = half_sum - half_h_thr2;
+    if (quartic_above_top_root(q, L, quartic_kappa(h, half_sum, L))) return PAIR_DISSIMILAR;
+    const double x = half_sum - two_thr2;
+    if (two_thr2 > 0.0 && quartic_between_top_roots(q, x, quartic_kappa(h, half_sum, x))) return PAIR_SIMILAR;
     return PAIR_UNDECIDED;
 }
 
@@ -778,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
             }
             const double L = 0.5 * (G[r] + Gq) - a.half_h_thr2;
             const bool valid = col > r && col < ce;
-            const bool cand = valid && !certainly_dissimilar(H, L);
+            const bool cand = valid && !certainly_dissimilar(H, L, 0.5 * (G[r] + Gq), a.h);
             const unsigned long long vm = __ballot(valid);
             n_computed += __popcll(vm);
             if (__ballot(cand)) candrows |= 1u << t;

@@ -484,7 +484,7 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
     double H[9];
     pair_H(p, q, h, sub, lpp, H);
     exact_taken = false;
-    if (certainly_dissimilar(H, 0.5 * (Gp + Gq) - half_h_thr2)) return false;
+    if (certainly_dissimilar(H, 0.5 * (Gp + Gq) - half_h_thr2, 0.5 * (Gp + Gq), h)) return false;
     exact_taken = true;
     double rm, md;
     exact_rmsd_maxdev(p, q, h, H, Gp, Gq, rm, md, sub, lpp);
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
             double Gi, Gj, H[9];
             decode(e, t, col, pp, pq, Gi, Gj);
             pair_H(pp, pq, a.h, sub, lpp, H);
-            const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2);
+            const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
             cand = sub == 0 && verdict == PAIR_UNDECIDED;
             sim = sub == 0 && verdict == PAIR_SIMILAR;
             if (sim) atomicMin(&best[r0 + t], col);

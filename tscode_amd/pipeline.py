@@ -97,6 +97,7 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
         off += c
     n_pass = off
     stats = []
+    exchanges = []                                      # (k, entries of best[] all-reduced) of every pass that was sharded
     if n_pass > 0:
         st = backend.make_stepper(n_pass)
         limit = SHARD_MIN_PAIRS if min_pairs is None else min_pairs
@@ -114,7 +115,9 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
                     shard = world > 1 and st.pass_estimate() >= limit
                 if shard:
                     st.pass_local(rank, world)          # this rank's row tiles only ...
-                    _all_reduce(dist, backend.best[:st.n_active()], dist.ReduceOp.MIN, group)   # ... merged
+                    n_best = st.n_active()
+                    _all_reduce(dist, backend.best[:n_best], dist.ReduceOp.MIN, group)   # ... merged
+                    exchanges.append((int(k), int(n_best)))
                 else:
                     st.pass_local(0, 1)                 # small pass: replicated, no exchange
                 st.pass_finish()
@@ -125,7 +128,8 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
         finally:
             st.close()
     n_keep = stats[-1]["n_active_after"] if stats else 0
-    return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts}
+    return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts, "exchanges": exchanges,
+            "allgather_bytes": int(backend.gather.numel() * backend.gather.element_size()), "allreduce_bytes": 4 * sum(n for _, n in exchanges) + 8 * world}
 
 
 class _HipStepper:
