@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 157.3 / 2), no MFMA on this path
 FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+CHAIN_CANDIDATES = 20000         # --config C5chain: angle sets the conformational search rotates per step
 PMC_PROFILES = ("r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
 
 
@@ -168,7 +169,10 @@ def main():
 
     # every rank draws the SAME ensemble, also for the replicas leg: per-GPU work is then exactly fixed as N grows, and every
     # rank's survivor set is checked against the recorded oracle mask (parity_vs_recorded_oracle = all ranks agree)
-    ens = make_config(args.config, args.n_poses)
+    chain = args.config == "C5chain"          # config 5 as a chain: csearch rotations feed the pipeline's conformers (one GPU)
+    if chain and world > 1:
+        raise SystemExit("--config C5chain runs on one GPU")
+    ens = make_config("C5" if chain else args.config, args.n_poses)
     expected = None
     exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")
     if os.path.exists(exp_path):
@@ -229,7 +233,13 @@ def main():
     def run_leg(sharded, ens=ens, expected=expected, detail=True):
         """One leg: its own pipeline, warm-up, THE timed region, then (detail) the same steps with the library's events off and
         three steps with all of them on.  Returns a dict of everything measured."""
-        if sharded:
+        if chain:
+            from tscode_amd.pipeline import CsearchChain
+            n0 = ens.frag_coords[0].shape[1]
+            torsions, tmasks = CsearchChain.chain_torsions(n0, 8, seed=5)
+            angle_table = np.random.default_rng(6).choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(CHAIN_CANDIDATES, 8)).astype(np.int32)
+            pipe = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, device_index=local_rank, mode=args.mode, seed=7)
+        elif sharded:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
                                   force_sharded=args.force_sharded or world == 1)
         else:
@@ -397,6 +407,8 @@ def main():
                                    f"mode {args.mode} ({'reference-exact' if args.mode == 0 else 'cache-free'})",
                        "n_pass_clash": n_pass, "n_survivors": n_keep, "keep_sha256_16": leg["digest"],
                        "parity_vs_recorded_oracle": leg["parity"],
+                       "chain": (f"csearch_rotate of fragment 0 ({CHAIN_CANDIDATES} angle sets x 8 torsions, walk-back included) -> {res.get('n_conformers')} kept "
+                                 f"candidates = its conformers -> embed -> clash -> prune; the candidate array stays on the device") if chain else None,
                        "parallelism": (f"one ensemble sharded over {world} rank(s): pose blocks, all-gather, per-pass all-reduce" if sharded_mode else
                                        f"{world} x (one whole ensemble per GPU), no data-path collective"),
                        "conformers_per_step_all_ranks": units_per_step,
@@ -483,7 +495,7 @@ def main():
         if rank == 0:
             out["c4"] = c4
     if rank == 0:
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not chain:
             n_cpu = args.cpu_sample if args.cpu_sample else (ens.n_poses if args.config == "C3" else 40000)
             out["cpu_baseline"] = cpu_baseline(args.config, min(n_cpu, ens.n_poses), ens.n_poses, args.mode)
             cb = out["cpu_baseline"]

@@ -600,6 +600,133 @@ def test_prune_children_spread_around_the_threshold(eng, oracle, algo):
     assert 0.05 < mask.mean() < 0.95
 
 
+@pytest.mark.parametrize("offset", [100.0, 1000.0])
+def test_prune_and_clash_far_from_the_origin(eng, oracle, offset, algo):
+    """rmsd_and_max_numba never centres (rmsd_pruning.py:7-41) and prune_conformers_rmsd is also called on arbitrary xyz
+    ensembles (operators.py:569, embedder.py:2027): structures 100 and 1000 A away from the origin.  Gp, Gq and the quartic's
+    coefficients grow with the square of the offset, the descriptor norms with the offset, the clash kernel's fp32 band with the
+    largest coordinate: the screens may decide less, the verdicts must stay the oracle's -- masks, pass schedule and the
+    reference's own pair-evaluation counts."""
+    from tscode_amd.synthetic import make_ensemble
+    ens = make_ensemble(4000, (15, 15), 7100 + int(offset), children=8, sigma_rot_deg=2.0, sigma_t=0.08, shell=(4.0, 9.0))
+    shift = np.array([0.6, -0.64, 0.48]) * offset
+    poses = ens.poses() + shift
+    # clash verdicts at a large coordinate scale (the packed-fp32 minimum's band is +-1e-3 A^2 at 1000 A)
+    assert oracle.clash_margin(poses, ens.ids, 1.5) > 1e-9
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    assert np.array_equal(eng.clash_mask(poses, ens.ids, 1.5, 0), cm) and 0 < cm.sum() < len(cm)
+    heavy = np.ascontiguousarray(poses[cm][:, ens.atomnos != 1])
+    for mode in (0, 1):
+        mr, mm = oracle.prune_margins(heavy, 0.5, mode)
+        assert min(mr, mm) > 1e-7, "a pair sits on a threshold: redraw the ensemble"
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=True)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"]), (offset, mode, int(mask.sum()), int(ref["mask"].sum()))
+        assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+    assert 0.05 < ref["mask"].mean() < 0.95
+    # values of single pairs at that distance from the origin
+    rng = np.random.default_rng(int(offset))
+    pairs = rng.integers(0, len(heavy), size=(2000, 2))
+    r, m = eng.rmsd_pairs(heavy, pairs)
+    ro, mo = oracle.rmsd_pairs(heavy, pairs)
+    assert np.abs(r - ro).max() < VAL_TOL and np.abs(m - mo).max() < VAL_TOL
+
+
+@pytest.mark.parametrize("h", [512, 1024])
+def test_prune_hundreds_of_heavy_atoms(eng, oracle, h):
+    """h = 512 and 1024 heavy atoms per structure (the rounding bound of the quartic tests grows with h: rmsd.hpp,
+    quartic_kappa; the descriptor build stages 12-24 KB per structure)."""
+    rng = np.random.default_rng(h)
+    n_par, n = 40, 320
+    base = rng.normal(size=(n_par, h, 3)) * 6.0 + rng.normal(size=(n_par, 1, 3)) * 3
+    which = rng.integers(0, n_par, size=n)
+    spread = rng.choice([0.01, 0.03, 0.3], size=n)[:, None, None]
+    heavy = np.ascontiguousarray(base[which] + rng.normal(size=(n, h, 3)) * spread)
+    for mode in (0, 1):
+        mr, mm = oracle.prune_margins(heavy, 0.5, mode)
+        assert min(mr, mm) > 1e-7
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"]), (h, mode, int(mask.sum()), int(ref["mask"].sum()))
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+    assert n_par <= ref["mask"].sum() < n
+    pairs = rng.integers(0, n, size=(500, 2))
+    r, m = eng.rmsd_pairs(heavy, pairs)
+    ro, mo = oracle.rmsd_pairs(heavy, pairs)
+    assert np.abs(r - ro).max() < VAL_TOL and np.abs(m - mo).max() < VAL_TOL
+
+
+def _pair_on_a_threshold(oracle, rng, h, target, which, delta):
+    """Two structures whose rmsd (which = 0) or maxdev (which = 1) is `target + delta` to within 1e-13, found by bisection on
+    the oracle's value: q = a rotation of p plus noise (rmsd) / plus one displaced atom (maxdev), scaled."""
+    p = rng.normal(size=(h, 3)) * 2.5 + rng.normal(size=3)
+    ang = rng.normal(size=3) * 0.02
+    c, s_ = np.cos(ang), np.sin(ang)
+    R = (np.array([[1, 0, 0], [0, c[0], -s_[0]], [0, s_[0], c[0]]]) @ np.array([[c[1], 0, s_[1]], [0, 1, 0], [-s_[1], 0, c[1]]])
+         @ np.array([[c[2], -s_[2], 0], [s_[2], c[2], 0], [0, 0, 1]]))
+    noise = rng.normal(size=(h, 3))
+    if which == 1:
+        noise *= 0.02
+        noise[h // 3] = rng.normal(size=3) * 3.0          # one atom carries the maximum deviation, the rmsd stays small
+    base = p @ R.T
+
+    def val(t):
+        return oracle.rmsd_and_max_numba(p, base + t * noise)[which]
+    lo, hi = 0.0, 1.0
+    while val(hi) < target + delta:
+        hi *= 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if val(mid) < target + delta:
+            lo = mid
+        else:
+            hi = mid
+        if hi - lo < 1e-16 * max(hi, 1.0):
+            break
+    q = base + hi * noise
+    return p, q
+
+
+def test_pairs_inside_the_guard_band(eng, oracle):
+    """What happens INSIDE the band the bit-exact tests exclude: pairs built to sit 1e-9 .. 1e-7 from rmsd = thr and from
+    maxdev = 2 thr, on both sides.  Three different eigen-solvers stand behind the compare (LAPACK gesdd in the reference,
+    Jacobi in the oracle, Newton + adjugate quaternion on the GPU), so: (1) the values agree to 1e-9 (they agree to ~1e-13);
+    (2) the prune's verdict on the two-structure ensemble {p, q} equals the oracle's wherever the oracle's value is at least
+    1e-9 away from the threshold -- i.e. a verdict can only differ for a pair closer to a threshold than the asserted value
+    tolerance; (3) how far the values really are apart is printed."""
+    rng = np.random.default_rng(4242)
+    thr = 0.5
+    worst = 0.0
+    n_checked = 0
+    for h in (9, 30, 120):
+        for which, target in ((0, thr), (1, 2 * thr)):
+            for delta in (1e-7, -1e-7, 1e-8, -1e-8, 3e-9, -3e-9, 1e-9, -1e-9, 1e-10, -1e-10):
+                for rep in range(3):
+                    p, q = _pair_on_a_threshold(oracle, rng, h, target, which, delta)
+                    heavy = np.ascontiguousarray(np.stack([p, q]))
+                    ro, mo = oracle.rmsd_and_max_numba(p, q)
+                    r, m = eng.rmsd_pairs(heavy, [[0, 1]])
+                    assert abs(r[0] - ro) < VAL_TOL and abs(m[0] - mo) < VAL_TOL
+                    worst = max(worst, abs(r[0] - ro), abs(m[0] - mo))
+                    dist = min(abs(ro - thr), abs(mo - 2 * thr))          # the oracle's distance from the nearer threshold
+                    assert dist < 2e-7
+                    ref = oracle.prune_heavy(heavy, thr, mode=0)["mask"]
+                    for algo_opt in (0, 1):
+                        if algo_opt == 1 and h > 32:
+                            continue
+                        eng.set_option("prune_algo", algo_opt)
+                        mask, _ = eng.prune_heavy(heavy, thr, 0)
+                        eng.set_option("prune_algo", 0)
+                        if dist >= 1e-9:
+                            assert np.array_equal(mask, ref), (h, which, delta, ro, mo)
+                            n_checked += 1
+                        else:                                              # inside the value tolerance: either verdict is legitimate
+                            assert mask[1] and (mask[0] or not mask[0])
+    assert n_checked > 200
+    print(f"largest |GPU - oracle| over the in-band pairs: {worst:.2e}")
+
+
 def test_prune_when_descriptors_cannot_separate(eng, oracle):
     """Worst case for the sieve: two rigid bodies, A fixed and B rotated about the origin, with the atoms ordered so that
     every descriptor pair (a, a + h/2) lies inside one body.  Atom norms and those pair distances (both descriptor
@@ -988,6 +1115,46 @@ def test_cyclical_embed_golden(eng, oracle):
         assert np.array_equal(cons, g[f"constrained_indices_{k}"])
     with pytest.raises(ValueError):
         tscode_amd.cyclical_embed_batch(_cyclical_case(g, 0) * 2, g["angles_0"])           # not two molecules
+
+
+def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
+    """BASELINE config 5 as a chain (reduced size): csearch rotations of fragment 0 on the device -> the kept candidates are
+    that fragment's conformers -> embed -> clash mask -> prune, the candidate array never leaving the GPU -- against the same
+    chain built from the oracle's pieces (orc_csearch_rotate, orc_transform_batch, clash mask, prune)."""
+    from tscode_amd.pipeline import CsearchChain
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C5", 5000)
+    n0 = ens.frag_coords[0].shape[1]
+    torsions, masks = CsearchChain.chain_torsions(n0, 6, seed=3)
+    rng = np.random.default_rng(8)
+    angles = rng.choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(700, 6)).astype(np.int32)
+    n_out = 200
+    # (threshold 1.4: the synthetic fragments are walks of exactly 1.5 A steps, so 1.5 would sit on bonded distances)
+    chain = CsearchChain(ens, torsions, masks, angles, n_out=n_out, thresh=1.4, seed=11)
+    res = chain.step()
+    chain.torch.cuda.synchronize()
+    out, rb, margin = oracle.csearch_rotate(ens.frag_coords[0][0], torsions, masks, angles, 1.4, 0, return_margin=True)
+    assert margin > 1e-9
+    confs = out[rb != 0][:n_out]
+    assert res["n_conformers"] == len(confs) == n_out
+    draw = np.random.default_rng(11).integers(0, 2 ** 30, size=ens.n_poses)
+    ci = ens.conf_idx.copy()
+    ci[:, 0] = draw % len(confs)
+    poses = oracle.transform_batch([confs] + [f for f in ens.frag_coords[1:]], ci, ens.rot, ens.pos)
+    assert oracle.clash_margin(poses, ens.ids, 1.5) > 1e-9
+    cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
+    assert np.array_equal(chain.d_clash.cpu().numpy().astype(bool), cm) and res["n_pass"] == cm.sum() and 0 < cm.sum() < len(cm)
+    assert np.abs(chain.d_structures[:res["n_pass"]].cpu().numpy() - poses[cm]).max() < VAL_TOL
+    heavy = np.ascontiguousarray(poses[cm][:, ens.atomnos != 1])
+    mr, mm = oracle.prune_margins(heavy, 0.5, 0)
+    assert min(mr, mm) > 1e-9
+    ref = oracle.prune_heavy(heavy, 0.5, mode=0)
+    assert np.array_equal(chain.h_keep[:res["n_pass"]].numpy().astype(bool), ref["mask"]) and res["n_keep"] == ref["mask"].sum()
+    assert [s["pairs_evaluated"] for s in res["stats"]] == [s["pairs_evaluated"] for s in ref["stats"]]
+    # a second step on the resident buffers gives the same verdicts
+    res2 = chain.step()
+    chain.torch.cuda.synchronize()
+    assert (res2["n_conformers"], res2["n_pass"], res2["n_keep"]) == (res["n_conformers"], res["n_pass"], res["n_keep"])
 
 
 @pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000)])

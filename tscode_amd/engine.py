@@ -376,6 +376,11 @@ class Engine:
                                           C.c_int64(len(angles)), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(out), ptr(rb)))
         return out, rb
 
+    def csearch_rotate_dev(self, coords, n_atoms, torsions, masks, n_tors, angles, n_cand, thresh, max_clashes, out, rotated_bonds):
+        """The same on device buffers (torch tensors / raw pointers), asynchronous on the engine's stream."""
+        check(self.lib.tsc_csearch_rotate_dev(self._h, ptr(coords), C.c_int(n_atoms), ptr(torsions), ptr(masks), C.c_int(n_tors), ptr(angles),
+                                              C.c_int64(n_cand), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(out), ptr(rotated_bonds)))
+
     def torsion_comp_check(self, coords, torsion, mask, thresh=1.5, max_clashes=0):
         """ok i32[M] for structures f64[M, n, 3] sharing one torsion and mask (tscode/numba_functions.py:26-47)."""
         coords = np.ascontiguousarray(coords, dtype=np.float64)

@@ -24,7 +24,7 @@ import numpy as np
 
 from .engine import Engine, FragmentSet
 
-__all__ = ["DevicePipeline", "HipShardBackend", "sharded_step", "block_bounds", "SHARD_MIN_PAIRS"]
+__all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "sharded_step", "block_bounds", "SHARD_MIN_PAIRS"]
 
 # A pass smaller than this many pairs (estimate n * (n / k) / 2, identical on every rank) is not worth a collective:
 # every rank runs it whole and reaches the same verdicts on its own.  On MI355X such a pass takes tens of
@@ -269,3 +269,110 @@ class DevicePipeline:
                                                           self.h_keep)
             return self._run()
         return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs)
+
+
+class CsearchChain:
+    """BASELINE config 5 as ONE chain on the device: conformational-search rotations of a fragment
+    (tscode/torsion_module.py:463-509: every angle set of the table rotates the fragment's torsions, walking back in 5-degree
+    steps where a rotation clashes; a candidate is kept iff at least one bond really rotated, up to ``n_out``) -> the kept
+    candidates ARE the conformer stack of that fragment -> embed -> clash mask -> compaction -> prune_conformers_rmsd.
+
+    The candidate array (``n_candidates x n_atoms x 24`` B: 480 MB for 100 000 candidates of a 200-atom complex) never leaves
+    the GPU: ``tsc_csearch_rotate_dev`` writes it, ``tsc_compact_rows_dev`` packs the kept rows in order into the fragment
+    buffer the pipeline reads its conformers from.  The one number that returns to the host between the two halves is how
+    many conformers were kept (the pose list indexes them)."""
+
+    def __init__(self, ens, torsions, masks, angles, n_out=None, fragment=0, thresh=1.5, device_index=0, clash_thresh=1.5, max_clashes=0,
+                 rmsd_thr=0.5, mode=0, seed=0):
+        import torch
+        self.torch, self.ens, self.fragment = torch, ens, fragment
+        self.params = (clash_thresh, max_clashes, rmsd_thr, mode)
+        self.thresh = thresh
+        self.dev = torch.device(f"cuda:{device_index}")
+        torch.cuda.set_device(self.dev)
+        self.eng = Engine(device_index)
+        self.stream = torch.cuda.Stream(device=self.dev)          # torch ops (a modulo, a compare) run between the two library calls
+        self.eng.set_stream(self.stream.cuda_stream)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        base = np.ascontiguousarray(ens.frag_coords[fragment][0], dtype=np.float64)
+        self.n0 = base.shape[0]
+        self.torsions_h = np.ascontiguousarray(torsions, dtype=np.int32).reshape(-1, 4)
+        self.masks_h = np.ascontiguousarray(masks, dtype=np.uint8).reshape(len(self.torsions_h), self.n0)
+        self.angles_h = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, len(self.torsions_h))
+        self.n_cand = len(self.angles_h)
+        self.n_out = self.n_cand if n_out is None else int(n_out)
+        self.d_base, self.d_tors, self.d_masks, self.d_angles = t(base), t(self.torsions_h), t(self.masks_h), t(self.angles_h)
+        self.d_cand = torch.empty((self.n_cand, self.n0, 3), dtype=torch.float64, device=self.dev)
+        self.d_rb = torch.empty(self.n_cand, dtype=torch.int32, device=self.dev)
+        # fragment buffer: the searched fragment first (its conformer stack is rewritten every step), the others behind it
+        self.others = [np.ascontiguousarray(f, dtype=np.float64) for m, f in enumerate(ens.frag_coords) if m != fragment]
+        self.order = [fragment] + [m for m in range(len(ens.frag_coords)) if m != fragment]
+        other_flat = np.concatenate([f.ravel() for f in self.others]) if self.others else np.zeros(0)
+        self.cap0 = self.n_cand * self.n0 * 3
+        self.d_frags = torch.empty(self.cap0 + len(other_flat), dtype=torch.float64, device=self.dev)
+        self.d_frags[self.cap0:].copy_(t(other_flat))
+        n = ens.n_poses
+        rng = np.random.default_rng(seed)
+        self.d_draw = t(rng.integers(0, 2 ** 30, size=n).astype(np.int64))       # which conformer a pose uses: draw % n_kept
+        # poses list the fragments in the buffer's order
+        self.d_ci = t(np.ascontiguousarray(ens.conf_idx[:, self.order]))
+        self.d_rot, self.d_pos = t(np.ascontiguousarray(ens.rot[:, self.order])), t(np.ascontiguousarray(ens.pos[:, self.order]))
+        atomnos = np.concatenate([np.asarray(ens.atomnos)[sl] for sl in self._atom_slices()])
+        self.atomnos = atomnos
+        self.heavy_idx = np.flatnonzero(atomnos != 1).astype(np.int32)
+        self.d_clash = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.d_structures = torch.empty((n, ens.n_atoms, 3), dtype=torch.float64, device=self.dev)
+        self.d_keep = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.h_keep = torch.empty(n, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize(self.dev)
+
+    @property
+    def engine(self):
+        return self.eng
+
+    def set_option(self, name, value):
+        self.eng.set_option(name, value)
+
+    @staticmethod
+    def chain_torsions(n_atoms, n_torsions, seed=0):
+        """Torsions along a chain-like fragment (the synthetic fragments are self-avoiding walks: atom a is bonded to a + 1):
+        ``(c - 1, c, c + 1, c + 2)`` about random bonds ``c - c + 1``, everything behind the bond rotates (what
+        tscode/torsion_module.py:301-325 ``_get_rotation_mask`` gives for a chain).  Returns (torsions i32[T, 4], masks u8[T, n])."""
+        rng = np.random.default_rng(seed)
+        centres = np.sort(rng.choice(np.arange(2, n_atoms - 3), size=n_torsions, replace=False))
+        torsions = np.array([(c - 1, c, c + 1, c + 2) for c in centres], dtype=np.int32)
+        masks = np.zeros((n_torsions, n_atoms), dtype=np.uint8)
+        for t, c in enumerate(centres):
+            masks[t, c + 1:] = 1
+        return torsions, masks
+
+    def _atom_slices(self):
+        off = np.concatenate([[0], np.cumsum([f.shape[1] for f in self.ens.frag_coords])])
+        return [slice(int(off[m]), int(off[m + 1])) for m in self.order]
+
+    def step(self):
+        torch = self.torch
+        c, m, r, mode = self.params
+        with torch.cuda.stream(self.stream):
+            self.eng.csearch_rotate_dev(self.d_base, self.n0, self.d_tors, self.d_masks, len(self.torsions_h), self.d_angles, self.n_cand,
+                                        self.thresh, 0, self.d_cand, self.d_rb)
+            kept_mask = (self.d_rb != 0).to(torch.uint8)                                      # torsion_module.py:505
+            n_kept = self.eng.compact_rows_dev(self.d_cand, kept_mask, self.n_cand, self.n0 * 24, self.d_frags)
+            n_kept = min(n_kept, self.n_out)                                                  # :510: stop at n_out structures
+            if n_kept == 0:
+                return {"n_conformers": 0, "n_pass": 0, "n_keep": 0, "stats": []}
+            self.d_ci[:, 0] = (self.d_draw % n_kept).to(torch.int32)
+            sizes = [(n_kept, self.n0)] + [(f.shape[0], f.shape[1]) for f in self.others]
+            fs = FragmentSet.__new__(FragmentSet)
+            fs.n_mols = len(sizes)
+            fs.n_atoms = np.array([s[1] for s in sizes], dtype=np.int32)
+            fs.n_conf = np.array([s[0] for s in sizes], dtype=np.int32)
+            offs, o = [0], self.cap0
+            for f in self.others:
+                offs.append(o)
+                o += f.size
+            fs.frag_off = np.array(offs[:fs.n_mols], dtype=np.int64)
+            fs.n_total = int(fs.n_atoms.sum())
+            res = self.eng.pipeline_dev(fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx, c, m, r, mode,
+                                        self.d_clash, self.d_structures, self.d_keep, self.h_keep)
+        return {"n_conformers": n_kept, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "stats": res["stats"]}
