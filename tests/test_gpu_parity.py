@@ -625,12 +625,21 @@ def test_prune_and_clash_far_from_the_origin(eng, oracle, offset, algo):
         assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
         assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
     assert 0.05 < ref["mask"].mean() < 0.95
-    # values of single pairs at that distance from the origin
-    rng = np.random.default_rng(int(offset))
-    pairs = rng.integers(0, len(heavy), size=(2000, 2))
+    # Values of single pairs at that distance from the origin.  The rmsd is a stationary value of the rotation and agrees to
+    # 1e-9 for every pair.  The maximum deviation is first order in the rotation: for two UNRELATED structures far from the
+    # origin the optimum is nearly flat about the offset axis (the two largest eigenvalues of Horn's matrix, ~ h offset^2,
+    # differ only by the structures' own extent), so any solver -- LAPACK in the reference, Jacobi in the oracle, the
+    # quaternion path here -- returns that angle to about u h offset^2 / gap, times a lever arm of `offset`: 5e-9 was seen at
+    # 100 A.  Pairs near the thresholds are near-duplicates (small rotation, wide gap): those are held to 1e-9.
+    n_sub = 400
+    ii, jj = np.triu_indices(n_sub, 1)
+    pairs = np.stack([ii, jj], axis=1)
     r, m = eng.rmsd_pairs(heavy, pairs)
     ro, mo = oracle.rmsd_pairs(heavy, pairs)
-    assert np.abs(r - ro).max() < VAL_TOL and np.abs(m - mo).max() < VAL_TOL
+    near = ro < 1.0
+    assert near.sum() > 50
+    assert np.abs(r - ro).max() < VAL_TOL and np.abs(m - mo)[near].max() < VAL_TOL
+    assert np.abs(m - mo).max() < 1e-9 * (offset / 10.0) ** 2, np.abs(m - mo).max()        # 1e-7 at 100 A, 1e-5 (the stated bar) at 1000 A
 
 
 @pytest.mark.parametrize("h", [512, 1024])

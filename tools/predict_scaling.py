@@ -1,0 +1,131 @@
+"""Predicted strong-scaling curve of the sharded single-ensemble protocol, from ONE GPU.
+
+The builder has one MI355X at a time; the N = 2, 4, 8 line of bench.py can only run on the driver's node.  What one GPU can
+measure is every rank's SHARE of the work: for N in {1, 2, 4, 8} and every rank r < N this script times, with HIP events,
+  * the embed + clash + compaction of rank r's pose block (HipShardBackend.embed_clash_block),
+  * for every pass that the protocol shards: tsc_prune_pass_local(r, N) -- rank r's row tiles -- one rank after the other on
+    the same card (best[] accumulates by atomicMin, so after the last rank the pass is complete and the run continues with
+    the true verdicts),
+  * everything the ranks replicate (the small passes, the per-pass bookkeeping around a sharded pass, the export),
+and combines them as the protocol would run:  max_r front(r) + counts all-reduce + coordinates all-gather +
+sum over passes [replicated part + max_r local(r) + all-reduce(best[])] .  The collectives are MODELLED, not measured:
+per-link xGMI bandwidth 153 GB/s x 0.7 efficiency, ring all-gather / ring all-reduce (per-link bound, the conservative
+reading of point-to-point xGMI), 20 us fixed cost per collective (RCCL launch + N - 1 hops) -- all stated in the output.
+
+usage (GPU box): python tools/predict_scaling.py [C3 C4] > profiles/r02_predicted_scaling.json
+"""
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+from tscode_amd.pipeline import SHARD_MIN_PAIRS, HipShardBackend
+from tscode_amd.synthetic import make_config
+
+LINK_GBS, LINK_EFF, COLL_FIXED_US = 153.0, 0.7, 20.0
+
+
+class Timer:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __call__(self, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            a.record(self.stream)
+            out = fn()
+            b.record(self.stream)
+        b.synchronize()
+        return a.elapsed_time(b), out
+
+
+def allgather_ms(total_bytes, n):
+    if n == 1:
+        return 0.0
+    return total_bytes * (n - 1) / n / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
+
+
+def allreduce_ms(nbytes, n):
+    if n == 1:
+        return 0.0
+    return 2.0 * nbytes * (n - 1) / n / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
+
+
+def measure(cfg, n_ranks, reps=3):
+    ens = make_config(cfg)
+    # front half: every rank's block
+    front = []
+    for r in range(n_ranks):
+        be = HipShardBackend(ens, 0, r, n_ranks, 1.5, 0, 0.5, 0)
+        be.eng.set_option("pass_timing", 0)
+        tm = Timer(be.stream)
+        best = min(tm(be.embed_clash_block)[0] for _ in range(reps + 1))
+        front.append(best)
+        del be
+        torch.cuda.empty_cache()
+    # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
+    be = HipShardBackend(ens, 0, 0, 1, 1.5, 0, 0.5, 0)
+    be.eng.set_option("pass_timing", 0)
+    tm = Timer(be.stream)
+    n_pass = int(be.embed_clash_block())
+    with torch.cuda.stream(be.stream):
+        be.heavy_all[:n_pass].copy_(be.heavy_local[:n_pass])
+    h = be.h
+    runs = []
+    for rep in range(reps):
+        passes, replicated = [], 0.0
+        t_create, st = tm(lambda: be.make_stepper(n_pass))
+        replicated += t_create
+        while True:
+            t_rep, k = tm(lambda: st.run_replicated(n_ranks, SHARD_MIN_PAIRS))
+            replicated += t_rep
+            if k == 0:
+                break
+            local = [tm(lambda r=r: st.pass_local(r, n_ranks))[0] for r in range(n_ranks)]
+            n_best = st.n_active()
+            t_fin, _ = tm(st.pass_finish)
+            replicated += t_fin
+            passes.append({"k": int(k), "best_entries": int(n_best), "local_ms_per_rank": local})
+        t_tail, _ = tm(lambda: st.copy_mask(be.keep))
+        replicated += t_tail
+        stats = st.stats()
+        st.close()
+        runs.append({"replicated_ms": replicated, "passes": passes, "n_keep": int(stats[-1]["n_active_after"])})
+    best = min(runs, key=lambda r: r["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in r["passes"]))
+    gather_bytes = n_ranks * ((ens.n_poses + n_ranks - 1) // n_ranks + 1) * h * 24
+    comm = allreduce_ms(8 * n_ranks, n_ranks) + allgather_ms(gather_bytes, n_ranks) + sum(allreduce_ms(4 * p["best_entries"], n_ranks) for p in best["passes"])
+    compute = max(front) + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
+    return {"n_ranks": n_ranks, "front_ms_per_rank": front, "replicated_ms": best["replicated_ms"],
+            "sharded_passes": [{"k": p["k"], "best_entries": p["best_entries"], "max_local_ms": max(p["local_ms_per_rank"]),
+                                "sum_local_ms": sum(p["local_ms_per_rank"]), "imbalance": max(p["local_ms_per_rank"]) * n_ranks / max(sum(p["local_ms_per_rank"]), 1e-9)}
+                               for p in best["passes"]],
+            "compute_ms": compute, "modelled_comm_ms": comm, "allgather_bytes": gather_bytes, "predicted_ms_per_step": compute + comm,
+            "predicted_conformers_per_s": ens.n_poses / (compute + comm) * 1e3, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}
+
+
+def main():
+    cfgs = [a for a in sys.argv[1:] if a.startswith("C")] or ["C3", "C4"]
+    out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
+           "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
+                     "allgather": "ring, per-link bound: bytes (N-1)/N / (link x eff) + fixed", "allreduce": "ring: 2 bytes (N-1)/N / (link x eff) + fixed",
+                     "shard_min_pairs": SHARD_MIN_PAIRS},
+           "measured_on": torch.cuda.get_device_name(0), "configs": {}}
+    for cfg in cfgs:
+        rows = []
+        for n in (1, 2, 4, 8):
+            t0 = time.time()
+            rows.append(measure(cfg, n))
+            print(f"{cfg} N={n}: predicted {rows[-1]['predicted_ms_per_step']:.3f} ms/step "
+                  f"(compute {rows[-1]['compute_ms']:.3f}, modelled comm {rows[-1]['modelled_comm_ms']:.3f}) [{time.time() - t0:.0f} s]", file=sys.stderr)
+        base = rows[0]["predicted_ms_per_step"]
+        for r in rows:
+            r["speedup_vs_1_rank_protocol"] = base / r["predicted_ms_per_step"]
+        out["configs"][cfg] = rows
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
