@@ -318,6 +318,10 @@ int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronou
                                                                       are short runs whole in here (chunk-local kernel, option
                                                                       "local_pass"): best[] is then not produced and
                                                                       tsc_prune_pass_finish only does the bookkeeping */
+int tsc_prune_pass_rows(tsc_prune *p, int rank, int world_size);  /* after tsc_prune_pass_local: the pair search of ANOTHER rank's row
+                                                                     tiles of the same pass, into the same best[] (atomicMin).  Lets
+                                                                     one GPU stand in for several ranks (tools/predict_scaling.py times
+                                                                     every rank's share this way; repeating a share changes nothing) */
 int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i32[n_entries], valid until finish */
 /* Make the run keep best[] in a caller-owned device buffer of n int32 (e.g. a torch tensor that
  * torch.distributed can all-reduce); call right after tsc_prune_create. */

@@ -176,15 +176,19 @@ def test_prune_golden(eng, algo):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
-@pytest.fixture(params=[(0, 1), (1, 1), (2, 0)], ids=["algo-auto", "algo-tile", "algo-sieve-global"])
+@pytest.fixture(params=[(0, 1, 0), (1, 1, 0), (2, 0, 0), (2, 0, 1)], ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-ws"])
 def algo(request, eng):
     """Runs a test once per pair kernel: automatic choice (descriptor sieve; passes with short chunks in the chunk-local
-    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path."""
+    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path, and the sieve
+    with the screen and the evaluation on different wavefronts of a workgroup (k_rmsd_sieve_ws), every pass through it."""
+    ws_default = 0
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
+    eng.set_option("sieve_ws", request.param[2])
     yield request.param[0]
     eng.set_option("prune_algo", 0)
     eng.set_option("local_pass", 1)
+    eng.set_option("sieve_ws", ws_default)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -300,6 +304,19 @@ def test_prune_sharded_rows_equal_single(eng, oracle):
         s.close()
     for m in masks:
         assert np.array_equal(m, ref_mask)
+    # ONE stepper standing in for all three ranks: rank 0 opens the pass, the others' rows follow (tsc_prune_pass_rows)
+    s = eng.prune_stepper(d_heavy.value, len(heavy), heavy.shape[1], 0.5, 0)
+    while s.next_pass() != 0:
+        s.pass_local(0, 3)
+        s.pass_rows(2, 3)
+        s.pass_rows(1, 3)
+        s.pass_rows(2, 3)                                 # a share twice: the same minimum
+        s.pass_finish()
+    m = np.empty(len(heavy), dtype=np.uint8)
+    _lib.check(lib.tsc_memcpy_d2h(eng._h, _lib.ptr(m), C.c_void_p(s.mask_ptr()), m.nbytes))
+    assert np.array_equal(m.astype(bool), ref_mask)
+    assert [x["pairs_evaluated"] for x in s.stats()] == [x["pairs_evaluated"] for x in ref_stats]
+    s.close()
     _lib.check(lib.tsc_free(eng._h, d_heavy))
 
 

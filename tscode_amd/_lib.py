@@ -97,6 +97,7 @@ _SIGNATURES = {
     "tsc_prune_pass_estimate": (C.c_int, [_vp, c_i64p]),
     "tsc_prune_run_replicated": (C.c_int, [_vp, C.c_int, C.c_int64, c_i64p]),
     "tsc_prune_pass_local": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "tsc_prune_pass_rows": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsc_prune_best_ptr": (C.c_int, [_vp, C.POINTER(_vp), c_i64p]),
     "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),
     "tsc_prune_pass_finish": (C.c_int, [_vp]),

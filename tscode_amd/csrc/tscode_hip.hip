@@ -805,6 +805,83 @@ static StepArgs next_step_args(const tsc_prune *p, int *next_slot) {
     return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words + p->dsum_words) : 0, p->cur_local ? ALGO_LOCAL : -1};
 }
 
+// The pair search of one rank's row tiles of the open pass (step 3 of a pass; steps 1-2 have run).
+static int launch_pair_search(tsc_prune *p, int rank, int world) {
+    tsc_ctx *c = p->ctx;
+    hipStream_t st = c->stream;
+    const int64_t n = p->n, k = p->cur_k;
+    const int slot = p->cur_slot;
+    const int A = int(n);
+    PassGeom g{int(n), int(k), int(n / k)};
+    const int64_t longest_chunk = n - (k - 1) * g.cs;
+    // 3. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
+    const int n_tiles = ceil_div(A, TILE_ROWS);
+    const int max_range = int(std::min<int64_t>(A, longest_chunk));
+    // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
+    // work (many small chunks), long ones amortise the per-item setup when it has a lot
+    // (measured on MI355X, tools/sweep.py: 512 columns at 57k structures, 1024 at 126k, 4096 at 483k; "seg_cols" overrides)
+    int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
+    while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
+    const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
+    const int my_tiles = (n_tiles - rank + world - 1) / world;
+    dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
+    // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
+    // hipEventRecord before and after it costs about 4 us each on MI355X)
+    hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
+    if (p->algo == ALGO_TILE) {
+        TileArgs a;
+        a.ld = p->npad, a.h = p->h;
+        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        switch (p->hp) {
+            case 4: launch_tile<4>(st, grid, p, a, e0, e1); break;
+            case 8: launch_tile<8>(st, grid, p, a, e0, e1); break;
+            case 12: launch_tile<12>(st, grid, p, a, e0, e1); break;
+            case 16: launch_tile<16>(st, grid, p, a, e0, e1); break;
+            case 20: launch_tile<20>(st, grid, p, a, e0, e1); break;
+            case 24: launch_tile<24>(st, grid, p, a, e0, e1); break;
+            case 28: launch_tile<28>(st, grid, p, a, e0, e1); break;
+            case 32: launch_tile<32>(st, grid, p, a, e0, e1); break;
+            default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
+        }
+    } else {
+        SieveArgs a;
+        a.n = int(n), a.h = p->h;
+        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
+        a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.tile_cmax = p->tile_cmax;
+        a.drain_min = c->drain_min;
+        if (c->sieve_ws) {   // three screening wavefronts + one evaluating wavefront per workgroup: three work items per workgroup
+            dim3 grid_ws(std::max(1, ceil_div(my_tiles, WS_PRODUCERS)), n_seg);
+            if (c->sieve_cpl == 4)
+                hipExtLaunchKernelGGL((k_rmsd_sieve_ws<TILE_ROWS, 4>), grid_ws, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                      (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                      (const PruneState *)p->state, a);
+            else
+                hipExtLaunchKernelGGL((k_rmsd_sieve_ws<TILE_ROWS, 2>), grid_ws, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                      (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                      (const PruneState *)p->state, a);
+        } else if (c->sieve_cpl == 1)
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
+        else if (c->sieve_cpl == 2)
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
+        else
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 4>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
+    }
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
     TSC_REQUIRE(p != nullptr, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
@@ -873,63 +950,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, (const PruneState *)p->state,
                            p->Xr, p->Xc, p->npad, p->G);
     }
-    // 3. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
-    const int n_tiles = ceil_div(A, TILE_ROWS);
-    const int max_range = int(std::min<int64_t>(A, longest_chunk));
-    // a wavefront walks its segment tile by tile: short segments keep the critical path short when a pass has little
-    // work (many small chunks), long ones amortise the per-item setup when it has a lot
-    // (measured on MI355X, tools/sweep.py: 512 columns at 57k structures, 1024 at 126k, 4096 at 483k; "seg_cols" overrides)
-    int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
-    while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
-    const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
-    const int my_tiles = (n_tiles - rank + world - 1) / world;
-    dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
-    // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
-    // hipEventRecord before and after it costs about 4 us each on MI355X)
-    hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
-    if (p->algo == ALGO_TILE) {
-        TileArgs a;
-        a.ld = p->npad, a.h = p->h;
-        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
-        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
-        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
-        switch (p->hp) {
-            case 4: launch_tile<4>(st, grid, p, a, e0, e1); break;
-            case 8: launch_tile<8>(st, grid, p, a, e0, e1); break;
-            case 12: launch_tile<12>(st, grid, p, a, e0, e1); break;
-            case 16: launch_tile<16>(st, grid, p, a, e0, e1); break;
-            case 20: launch_tile<20>(st, grid, p, a, e0, e1); break;
-            case 24: launch_tile<24>(st, grid, p, a, e0, e1); break;
-            case 28: launch_tile<28>(st, grid, p, a, e0, e1); break;
-            case 32: launch_tile<32>(st, grid, p, a, e0, e1); break;
-            default: return fail(TSC_ERR_INVALID, "unsupported padded atom count %d", p->hp);
-        }
-    } else {
-        SieveArgs a;
-        a.n = int(n), a.h = p->h;
-        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
-        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
-        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
-        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
-        a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
-        a.tile_cmax = p->tile_cmax;
-        a.drain_min = c->drain_min;
-        if (c->sieve_cpl == 1)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else if (c->sieve_cpl == 2)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 4>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-    }
-    TSC_HIP(hipGetLastError());
+    TSC_TRY(launch_pair_search(p, rank, world));
     p->local_done = true;
     return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_rows(tsc_prune *p, int rank, int world) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    if (p->cur_k == 0 || !p->local_done || p->cur_local)
+        return fail(TSC_ERR_STATE, "tsc_prune_pass_rows: needs an open pass whose tsc_prune_pass_local ran with world_size > 1");
+    DeviceGuard guard(p->ctx->device);
+    return launch_pair_search(p, rank, world);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries) {
@@ -1160,6 +1192,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
+        return 0;
+    }
+    if (strcmp(name, "sieve_ws") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "sieve_ws must be 0 or 1");
+        c->sieve_ws = int(value);
         return 0;
     }
     if (strcmp(name, "sieve_cpl") == 0) {

@@ -496,6 +496,10 @@ class PruneStepper:
     def pass_local(self, rank=0, world=1):
         check(self.e.lib.tsc_prune_pass_local(self._p, C.c_int(rank), C.c_int(world)))
 
+    def pass_rows(self, rank, world):
+        """The pair search of another rank's row tiles of the open pass (after pass_local), into the same best[]."""
+        check(self.e.lib.tsc_prune_pass_rows(self._p, C.c_int(rank), C.c_int(world)))
+
     def best_ptr(self):
         p, n = C.c_void_p(), C.c_int64()
         check(self.e.lib.tsc_prune_best_ptr(self._p, C.byref(p), C.byref(n)))

@@ -148,6 +148,9 @@ class _HipStepper:
     def pass_local(self, rank, world):
         self.s.pass_local(rank, world)
 
+    def pass_rows(self, rank, world):
+        self.s.pass_rows(rank, world)
+
     def n_active(self):
         return self.s.best_ptr()[1]
 
