@@ -497,8 +497,8 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
 #endif
-template <int TI, int CPL>
-__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+template <int TI, int CPL, bool PIPE = false>
+__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIEVE_OCC2) : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
                                                         const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
@@ -722,21 +722,21 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         {   // ---- screen one tile against every live row
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
-            while (rows) {
-                const int t = __ffs(rows) - 1;
-                rows &= rows - 1;
-                const int r = r0 + t;
-                const int ce = __builtin_amdgcn_readlane(my_cend, t);
+            // one row of the tile against the lane's CPL columns; rd / nr = the row's descriptor and squared norms (from LDS)
+            auto fetch_row = [&](int t, f32x2 (&rd)[KD], f32x2 &nr) __attribute__((always_inline)) {
                 const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-                f32x2 rd[KD];
 #pragma unroll
                 for (int k = 0; k < KD; ++k) rd[k] = dr[k];
+                nr = s_rownorm[wid][t];
+            };
+            auto screen_row = [&](int t, const f32x2 (&rd)[KD], const f32x2 nr) __attribute__((always_inline)) {
+                const int r = r0 + t;
+                const int ce = __builtin_amdgcn_readlane(my_cend, t);
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
                 n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
                 // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
                 // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
                 // the error bound)
-                const f32x2 nr = s_rownorm[wid][t];
                 float mx[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL; ++u) {
@@ -766,6 +766,83 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
                         if (m) {
                             if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
                             qn += __popcll(m);
+                        }
+                    }
+                }
+            };
+            if constexpr (PIPE) {
+                // the LDS reads of the NEXT row are issued before the current row's arithmetic (two register sets, the loop
+                // unrolled by two so that no set is copied): a row iteration otherwise starts with a full LDS round trip
+                f32x2 rdA[KD], rdB[KD], nrA, nrB;
+                if (rows) {
+                    int tA = __ffs(rows) - 1;
+                    rows &= rows - 1;
+                    fetch_row(tA, rdA, nrA);
+                    for (;;) {
+                        int tB = -1;
+                        if (rows) {
+                            tB = __ffs(rows) - 1;
+                            rows &= rows - 1;
+                            fetch_row(tB, rdB, nrB);
+                        }
+                        screen_row(tA, rdA, nrA);
+                        if (tB < 0) break;
+                        tA = -1;
+                        if (rows) {
+                            tA = __ffs(rows) - 1;
+                            rows &= rows - 1;
+                            fetch_row(tA, rdA, nrA);
+                        }
+                        screen_row(tB, rdB, nrB);
+                        if (tA < 0) break;
+                    }
+                }
+            } else {
+                while (rows) {
+                    const int t = __ffs(rows) - 1;
+                    rows &= rows - 1;
+                    const int r = r0 + t;
+                    const int ce = __builtin_amdgcn_readlane(my_cend, t);
+                    const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
+                    f32x2 rd[KD];
+    #pragma unroll
+                    for (int k = 0; k < KD; ++k) rd[k] = dr[k];
+                    // columns of this tile inside the row's range (r, ce): counted without a ballot
+                    n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
+                    // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
+                    // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
+                    // the error bound)
+                    const f32x2 nr = s_rownorm[wid][t];
+                    float mx[CPL];
+    #pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        f32x2 dot = {0.0f, 0.0f};
+    #pragma unroll
+                        for (int k = 0; k < KD; ++k) dot = __builtin_elementwise_fma(rd[k], dq[u][k], dot);
+                        const f32x2 s2 = __builtin_elementwise_fma(dot, f32x2{-2.0f, -2.0f}, nr + cn[u]);
+                        mx[u] = fmaxf(s2.x, s2.y);
+                    }
+                    if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: mask the columns outside
+    #pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const int col = c0 + 64 * u + lane;
+                            mx[u] = (col > r && col < ce) ? mx[u] : __builtin_inff();
+                        }
+                    }
+                    // most rows of a tile have no column within the limit: one test for all CPL * 64 pairs (a NaN distance --
+                    // NaN coordinates -- is ignored by the minimum; such a pair is not similar for the reference either, :75)
+                    float mn = mx[0];
+    #pragma unroll
+                    for (int u = 1; u < CPL; ++u) mn = fminf(mn, mx[u]);
+                    if (__builtin_amdgcn_ballot_w64(!(mn > limit32))) {
+    #pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const bool pass = !(mx[u] > limit32);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                            if (m) {
+                                if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
+                                qn += __popcll(m);
+                            }
                         }
                     }
                 }
