@@ -497,10 +497,10 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
 #endif
-template <int TI, int CPL, bool PIPE = false>
-__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIEVE_OCC2) : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+template <int TI, int CPL, bool SROW = false>
+__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
-                                                        const int32_t *__restrict__ cend,
+                                                        const float *__restrict__ Dn, const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
@@ -555,9 +555,15 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIE
     if (!alive) return;
 
     const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
-    float rd_stage[4];
+    // SROW: the row descriptors are wave-uniform, so they can come through the SCALAR cache (s_load_dwordx16 from the positional
+    // copy, their squared norms from Dn) straight into SGPR operands of the packed FMAs, instead of through LDS: a broadcast
+    // ds_read_b128 still moves 1 KB through the CU's one 128 B/clk LDS port, 4.5 KB per (row, tile), and with 20 wavefronts per
+    // CU that port, not the VALU, was what bounded the screen (720 LDS cycles against 520 VALU cycles per round).
+    float rd_stage[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (!SROW) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
+        for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
+    }
     f32x2 dq[CPL][KD];  // .x = family 0, .y = family 1
     f32x2 cn[CPL];      // their squared norms
     auto load_tile = [&]() __attribute__((always_inline)) {
@@ -585,17 +591,19 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIE
 
     // the row descriptors of this work item -> LDS (rows beyond nrows are never read back)
     float *rowdesc = s_rowdesc[wid];
+    if constexpr (!SROW) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < TI) {  // squared norms of the row descriptors, per family
-        const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
-        f32x2 nr = {0.0f, 0.0f};
+        for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < TI) {  // squared norms of the row descriptors, per family
+            const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
+            f32x2 nr = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
-        s_rownorm[wid][lane] = nr;
+            for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
+            s_rownorm[wid][lane] = nr;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
 
     const int h3 = a.h * 3;
     unsigned short *queue = s_queue[wid];
@@ -722,16 +730,24 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIE
         {   // ---- screen one tile against every live row
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
-            // one row of the tile against the lane's CPL columns; rd / nr = the row's descriptor and squared norms (from LDS)
-            auto fetch_row = [&](int t, f32x2 (&rd)[KD], f32x2 &nr) __attribute__((always_inline)) {
-                const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-#pragma unroll
-                for (int k = 0; k < KD; ++k) rd[k] = dr[k];
-                nr = s_rownorm[wid][t];
-            };
-            auto screen_row = [&](int t, const f32x2 (&rd)[KD], const f32x2 nr) __attribute__((always_inline)) {
+            while (rows) {
+                const int t = __ffs(rows) - 1;
+                rows &= rows - 1;
                 const int r = r0 + t;
                 const int ce = __builtin_amdgcn_readlane(my_cend, t);
+                f32x2 rd[KD];
+                f32x2 nr;
+                if constexpr (SROW) {
+                    const float *rp = D + int64_t(r) * DW;       // r is wave-uniform: scalar loads
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) rd[k] = f32x2{rp[2 * k], rp[2 * k + 1]};
+                    nr = f32x2{Dn[2 * int64_t(r)], Dn[2 * int64_t(r) + 1]};
+                } else {
+                    const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) rd[k] = dr[k];
+                    nr = s_rownorm[wid][t];
+                }
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
                 n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
                 // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
@@ -769,83 +785,6 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIE
                         }
                     }
                 }
-            };
-            if constexpr (PIPE) {
-                // the LDS reads of the NEXT row are issued before the current row's arithmetic (two register sets, the loop
-                // unrolled by two so that no set is copied): a row iteration otherwise starts with a full LDS round trip
-                f32x2 rdA[KD], rdB[KD], nrA, nrB;
-                if (rows) {
-                    int tA = __ffs(rows) - 1;
-                    rows &= rows - 1;
-                    fetch_row(tA, rdA, nrA);
-                    for (;;) {
-                        int tB = -1;
-                        if (rows) {
-                            tB = __ffs(rows) - 1;
-                            rows &= rows - 1;
-                            fetch_row(tB, rdB, nrB);
-                        }
-                        screen_row(tA, rdA, nrA);
-                        if (tB < 0) break;
-                        tA = -1;
-                        if (rows) {
-                            tA = __ffs(rows) - 1;
-                            rows &= rows - 1;
-                            fetch_row(tA, rdA, nrA);
-                        }
-                        screen_row(tB, rdB, nrB);
-                        if (tA < 0) break;
-                    }
-                }
-            } else {
-                while (rows) {
-                    const int t = __ffs(rows) - 1;
-                    rows &= rows - 1;
-                    const int r = r0 + t;
-                    const int ce = __builtin_amdgcn_readlane(my_cend, t);
-                    const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-                    f32x2 rd[KD];
-    #pragma unroll
-                    for (int k = 0; k < KD; ++k) rd[k] = dr[k];
-                    // columns of this tile inside the row's range (r, ce): counted without a ballot
-                    n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
-                    // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
-                    // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
-                    // the error bound)
-                    const f32x2 nr = s_rownorm[wid][t];
-                    float mx[CPL];
-    #pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        f32x2 dot = {0.0f, 0.0f};
-    #pragma unroll
-                        for (int k = 0; k < KD; ++k) dot = __builtin_elementwise_fma(rd[k], dq[u][k], dot);
-                        const f32x2 s2 = __builtin_elementwise_fma(dot, f32x2{-2.0f, -2.0f}, nr + cn[u]);
-                        mx[u] = fmaxf(s2.x, s2.y);
-                    }
-                    if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: mask the columns outside
-    #pragma unroll
-                        for (int u = 0; u < CPL; ++u) {
-                            const int col = c0 + 64 * u + lane;
-                            mx[u] = (col > r && col < ce) ? mx[u] : __builtin_inff();
-                        }
-                    }
-                    // most rows of a tile have no column within the limit: one test for all CPL * 64 pairs (a NaN distance --
-                    // NaN coordinates -- is ignored by the minimum; such a pair is not similar for the reference either, :75)
-                    float mn = mx[0];
-    #pragma unroll
-                    for (int u = 1; u < CPL; ++u) mn = fminf(mn, mx[u]);
-                    if (__builtin_amdgcn_ballot_w64(!(mn > limit32))) {
-    #pragma unroll
-                        for (int u = 0; u < CPL; ++u) {
-                            const bool pass = !(mx[u] > limit32);
-                            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                            if (m) {
-                                if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
-                                qn += __popcll(m);
-                            }
-                        }
-                    }
-                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -876,347 +815,6 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? (PIPE ? 4 : TSC_SIE
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
         count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// k_rmsd_sieve_ws: the same pass with the two halves of a work item on DIFFERENT wavefronts of a workgroup.
-//
-// In k_rmsd_sieve every wavefront screens a tile, then stops to evaluate the pairs that survived: a batch is one dependent
-// gather round trip (indices -> 2 x 720 B per pair -> H) of a few microseconds during which that wavefront issues no VALU
-// work, and the last, half-empty batch of every work item sits on its critical path (the drains cost about as much as the
-// screen itself: 1.0 against 1.54 T pairs/s with them compiled out).  Here three wavefronts of a workgroup only screen
-// (producers: one work item each, as before) and push survivors into a ring in LDS of their own; the fourth only evaluates
-// (consumer): it gathers full batches of 64 from the three rings, so batches fill three times as fast, no screening
-// wavefront ever waits for memory on behalf of a candidate, and the gather latency overlaps the producers' VALU work on the
-// same SIMDs.  The role of a wavefront rotates with the workgroup index, so every SIMD hosts consumers and producers alike.
-//   ring p      single producer, single consumer: the producer writes entries, then its tail (release); the consumer reads the
-//               tail (acquire), the entries, then moves the head.  A full ring makes its producer wait -- the consumer never
-//               waits for a producer, so the wait ends;
-//   s_found p   bit t = row t of producer p has a similar column: the consumer sets it, the producer drops the row from its
-//               live set at the next tile (the reference returns at the first similar column, :75-77; screening a row a
-//               little longer only costs work, best[] takes the smallest column by atomicMin whatever the order);
-//   the end     a producer raises its done flag after its last tail; the consumer leaves when every flag is up and every
-//               ring is empty.  A workgroup none of whose three work items has any work returns before any of this.
-constexpr int WS_PRODUCERS = 3;
-constexpr int WS_RING = 4096;  // entries per ring (a power of two); one (row, tile) adds at most 64 * CPL
-
-template <int TI, int CPL>
-__global__ __launch_bounds__(256, CPL == 4 ? 4 : 5) void k_rmsd_sieve_ws(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                                           const double *__restrict__ Gall, const float *__restrict__ D,
-                                                                           const int32_t *__restrict__ cend, int32_t *__restrict__ best,
-                                                                           PassCounters *__restrict__ counters, const PruneState *__restrict__ st,
-                                                                           SieveArgs a) {
-    static_assert(TI <= 16 && DW == 16 && TI * DW == 256, "entries keep the row in 4 bits; row staging: 4 rows x 16 components per 64 lanes");
-    constexpr int TILE_COLS = 64 * CPL;
-    __shared__ unsigned short s_ring[WS_PRODUCERS][WS_RING];
-    __shared__ int s_tail[WS_PRODUCERS], s_head[WS_PRODUCERS], s_done[WS_PRODUCERS], s_r0[WS_PRODUCERS], s_seglo[WS_PRODUCERS];
-    __shared__ unsigned s_found[WS_PRODUCERS];
-    __shared__ unsigned s_exq[128];       // (producer << 16 | entry) of pairs waiting for the explicit-rotation path
-    __shared__ double s_jacobi[32];
-    __shared__ __attribute__((aligned(16))) float s_rowdesc[WS_PRODUCERS][TI * DW];
-    __shared__ f32x2 s_rownorm[WS_PRODUCERS][TI];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // which wavefront consumes: rotates with the workgroup, so that every SIMD of a CU hosts both roles
-    const int cons = int((blockIdx.x + blockIdx.y) & 3u);
-    const int role = wid == cons ? -1 : (wid < cons ? wid : wid - 1);   // producer number 0..2, or -1
-    if (st->pass_on == 0) return;
-    // ---- does any of the three work items have work?  (every wavefront evaluates the same three, so the workgroup leaves
-    // as one: most workgroups of a late pass do)
-    bool any = false;
-    const int n_active_all = st->A;
-#pragma unroll
-    for (int p = 0; p < WS_PRODUCERS; ++p) {
-        const int tile_p = a.tile_begin + (int(blockIdx.x) * WS_PRODUCERS + p) * a.tile_stride;
-        const int r0_p = tile_p * TI;
-        const int lo_p = ((r0_p + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
-        if (r0_p < n_active_all && r0_p < a.n && lo_p < a.n && a.tile_cmax[tile_p] > lo_p) any = true;
-    }
-    if (!any) return;
-    if (threadIdx.x < WS_PRODUCERS) s_tail[threadIdx.x] = 0, s_head[threadIdx.x] = 0, s_done[threadIdx.x] = 0, s_found[threadIdx.x] = 0u;
-    __syncthreads();
-    const int h3 = a.h * 3;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
-    if (role >= 0) {
-        // =============================================================================================== producer
-        const int slot = int(blockIdx.x) * WS_PRODUCERS + role;
-        const int tile = a.tile_begin + slot * a.tile_stride;
-        const int r0 = tile * TI;
-        const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
-        const int seg_hi = seg_lo + a.seg_cols;
-        auto finish = [&]() __attribute__((always_inline)) {
-            if (lane == 0) __hip_atomic_store(&s_done[role], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        if (lane == 0) s_r0[role] = r0, s_seglo[role] = seg_lo;
-        if (r0 >= a.n || seg_lo >= a.n || a.tile_cmax[tile] <= seg_lo) {
-            finish();
-            return;
-        }
-        const int n_active = st->A;
-        int my_cend = 0, my_best = 0;
-        if (lane < TI && r0 + lane < a.n) {
-            my_cend = cend[r0 + lane];
-            my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        int row_src[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) row_src[j] = min(r0 + 4 * j + (lane >> 4), a.n - 1);
-        int col_src[CPL];
-        auto load_cols = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) col_src[u] = min(c0 + 64 * u + lane, a.n - 1);
-        };
-        load_cols(seg_lo);
-        if (r0 >= n_active) {
-            finish();
-            return;
-        }
-        const int nrows = min(TI, n_active - r0);
-        const bool live0 = lane < nrows && my_cend > max(r0 + lane + 1, seg_lo) && my_best >= seg_lo;
-        unsigned alive = unsigned(__ballot(live0));
-        if (!alive) {
-            finish();
-            return;
-        }
-        const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
-        float rd_stage[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
-        f32x2 dq[CPL][KD];
-        f32x2 cn[CPL];
-        auto load_tile = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(D + int64_t(col_src[u]) * DW);
-#pragma unroll
-                for (int k = 0; k < KD / 2; ++k) {
-                    const f32x4 v = src[k];
-                    dq[u][2 * k] = f32x2{v.x, v.y};
-                    dq[u][2 * k + 1] = f32x2{v.z, v.w};
-                }
-                f32x2 nc = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < KD; ++k) nc = __builtin_elementwise_fma(dq[u][k], dq[u][k], nc);
-                cn[u] = nc;
-            }
-        };
-        load_tile();
-        int cmax = live0 ? my_cend : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-        cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
-        float *rowdesc = s_rowdesc[role];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < TI) {
-            const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
-            f32x2 nr = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
-            s_rownorm[role][lane] = nr;
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        unsigned short *ring = s_ring[role];
-        int tail = 0;                      // entries written (wave-uniform)
-        unsigned long long n_screened = 0;
-        for (int c0 = seg_lo; c0 < cmax;) {
-            alive &= ~__hip_atomic_load(&s_found[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // rows the consumer has settled
-            if (!alive) break;
-            const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
-            unsigned rows = unsigned(__ballot(here));
-            while (rows) {
-                const int t = __ffs(rows) - 1;
-                rows &= rows - 1;
-                const int r = r0 + t;
-                const int ce = __builtin_amdgcn_readlane(my_cend, t);
-                const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-                f32x2 rd[KD];
-#pragma unroll
-                for (int k = 0; k < KD; ++k) rd[k] = dr[k];
-                n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
-                const f32x2 nr = s_rownorm[role][t];
-                float mx[CPL];
-#pragma unroll
-                for (int u = 0; u < CPL; ++u) {
-                    f32x2 dot = {0.0f, 0.0f};
-#pragma unroll
-                    for (int k = 0; k < KD; ++k) dot = __builtin_elementwise_fma(rd[k], dq[u][k], dot);
-                    const f32x2 s2 = __builtin_elementwise_fma(dot, f32x2{-2.0f, -2.0f}, nr + cn[u]);
-                    mx[u] = fmaxf(s2.x, s2.y);
-                }
-                if (!(r < c0 && ce >= c0 + TILE_COLS)) {
-#pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        const int col = c0 + 64 * u + lane;
-                        mx[u] = (col > r && col < ce) ? mx[u] : __builtin_inff();
-                    }
-                }
-                float mn = mx[0];
-#pragma unroll
-                for (int u = 1; u < CPL; ++u) mn = fminf(mn, mx[u]);
-                if (__builtin_amdgcn_ballot_w64(!(mn > limit32))) {
-                    // room for this row's survivors (at most 64 * CPL): wait for the consumer if the ring is full
-                    while (tail + TILE_COLS - __hip_atomic_load(&s_head[role], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > WS_RING)
-                        __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        const bool pass = !(mx[u] > limit32);
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                        if (m) {
-                            if (pass)
-                                ring[(tail + __popcll(m & lt_mask)) & (WS_RING - 1)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
-                            tail += __popcll(m);
-                        }
-                    }
-                }
-            }
-            // publish what this tile added (the entries first, then the tail)
-            if (lane == 0) __hip_atomic_store(&s_tail[role], tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            c0 += TILE_COLS;
-            if (!(c0 < cmax)) break;
-            load_cols(c0);
-            load_tile();
-        }
-        if (lane == 0) count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
-        finish();
-        return;
-    }
-
-    // ===================================================================================================== consumer
-    int head[WS_PRODUCERS] = {0, 0, 0};
-    int qe = 0;
-    unsigned long long n_eval = 0, n_exact = 0;
-    auto decode = [&](unsigned e, int &t, int &row, int &col, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
-        const int pr = int(e >> 16);
-        t = int((e >> 12) & 0xfu);
-        row = s_r0[pr] + t;
-        col = s_seglo[pr] + int(e & 0xfffu);
-        const int64_t i = act[row], j = act[col];
-        pp = heavy + i * h3, pq = heavy + j * h3;
-        Gi = Gall[i], Gj = Gall[j];
-    };
-    auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
-        int lpp = 64;
-        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
-        const int g = lane / lpp, sub = lane - g * lpp;
-        bool degenerate = false;
-        unsigned ent = 0;
-        if (g < cnt) {
-            int t, row, col;
-            const double *pp, *pq;
-            double Gi, Gj, H[9], e[4];
-            ent = s_exq[base + g];
-            decode(ent, t, row, col, pp, pq, Gi, Gj);
-            pair_H(pp, pq, a.h, sub, lpp, H);
-            if (rotation_quaternion_fast(H, Gi, Gj, e)) {
-                double rm, md;
-                residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, sub, lpp);
-                if (sub == 0 && rm < a.thr && md < a.maxdev_thr) {  // rmsd_pruning.py:75
-                    atomicMin(&best[row], col);
-                    atomicOr(&s_found[ent >> 16], 1u << t);
-                }
-            } else {
-                degenerate = sub == 0;
-            }
-        }
-        for (unsigned long long dm = __builtin_amdgcn_ballot_w64(degenerate); dm; dm &= dm - 1) {   // see k_rmsd_sieve
-            const unsigned e1 = unsigned(__builtin_amdgcn_readlane(int(ent), __ffsll((long long)dm) - 1));
-            int t2, row2, col2;
-            const double *pp, *pq;
-            double Gi, Gj, H[9], e[4], rm, md;
-            decode(e1, t2, row2, col2, pp, pq, Gi, Gj);
-            pair_H(pp, pq, a.h, lane, 64, H);
-            if (lane == 0) {
-                horn_matrix(H, s_jacobi);
-                top_eigvec4_mem(s_jacobi, s_jacobi + 16, e);
-                s_jacobi[0] = e[0], s_jacobi[1] = e[1], s_jacobi[2] = e[2], s_jacobi[3] = e[3];
-            }
-            __builtin_amdgcn_wave_barrier();
-            e[0] = s_jacobi[0], e[1] = s_jacobi[1], e[2] = s_jacobi[2], e[3] = s_jacobi[3];
-            __builtin_amdgcn_wave_barrier();
-            residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, lane, 64);
-            if (rm < a.thr && md < a.maxdev_thr && lane == 0) {
-                atomicMin(&best[row2], col2);
-                atomicOr(&s_found[e1 >> 16], 1u << t2);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    for (;;) {
-        int tl[WS_PRODUCERS], avail = 0;
-        bool all_done = true;
-#pragma unroll
-        for (int p = 0; p < WS_PRODUCERS; ++p) {
-            // the done flag BEFORE the tail: a producer writes its last tail, then the flag
-            all_done = all_done && __hip_atomic_load(&s_done[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-            tl[p] = __hip_atomic_load(&s_tail[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            avail += tl[p] - head[p];
-        }
-        if (avail >= 64 || (all_done && avail > 0)) {
-            const int cnt = min(avail, 64);
-            int lpp = 64;
-            while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
-            const int g = lane / lpp, sub = lane - g * lpp;
-            // pair g of the batch: the rings in turn
-            int take[WS_PRODUCERS], left = cnt;
-#pragma unroll
-            for (int p = 0; p < WS_PRODUCERS; ++p) {
-                take[p] = min(tl[p] - head[p], left);
-                left -= take[p];
-            }
-            bool cand = false;
-            unsigned e = 0;
-            if (g < cnt) {
-                static_assert(WS_PRODUCERS == 3, "the batch is cut over three rings");
-                const int pr = g < take[0] ? 0 : (g < take[0] + take[1] ? 1 : 2);
-                const int gi = pr == 0 ? g : (pr == 1 ? g - take[0] : g - take[0] - take[1]);
-                const int hd = pr == 0 ? head[0] : (pr == 1 ? head[1] : head[2]);      // (selects: no register array is indexed)
-                e = (unsigned(pr) << 16) | unsigned(s_ring[pr][(hd + gi) & (WS_RING - 1)]);
-                int t, row, col;
-                const double *pp, *pq;
-                double Gi, Gj, H[9];
-                decode(e, t, row, col, pp, pq, Gi, Gj);
-                pair_H(pp, pq, a.h, sub, lpp, H);
-                const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
-                cand = sub == 0 && verdict == PAIR_UNDECIDED;
-                if (sub == 0 && verdict == PAIR_SIMILAR) {
-                    atomicMin(&best[row], col);
-                    atomicOr(&s_found[pr], 1u << t);
-                }
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-            if (m) {
-                if (cand) s_exq[qe + __popcll(m & lt_mask)] = e;
-                qe += __popcll(m);
-            }
-            n_eval += cnt;
-            n_exact += __popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            // the entries have been read: hand the space back
-#pragma unroll
-            for (int p = 0; p < WS_PRODUCERS; ++p) {
-                head[p] += take[p];
-                if (lane == 0 && take[p]) __hip_atomic_store(&s_head[p], head[p], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (qe >= 64) {
-                exact_stage(qe - 64, 64);
-                qe -= 64;
-            }
-        } else if (all_done) {
-            break;
-        } else {
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    if (qe > 0) exact_stage(0, qe);
-    if (lane == 0) {
-        count_add(counters, blockIdx.x + blockIdx.y, CNT_FORMED, n_eval);
-        count_add(counters, blockIdx.x + blockIdx.y, CNT_EXACT, n_exact);
     }
 }
 
