@@ -13,7 +13,6 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 VAL_TOL = 1e-9          # asserted; the stated bar is 1e-5 abs
-SIEVE_SROW_DEFAULT = 0   # the library's default of option sieve_srow (the fixture `algo` also runs the other setting)
 
 
 @pytest.fixture(scope="module")
@@ -177,20 +176,15 @@ def test_prune_golden(eng, algo):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
-@pytest.fixture(params=[(0, 1, None), (1, 1, None), (2, 0, None), (2, 0, "flip")], ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-rows"])
+@pytest.fixture(params=[(0, 1), (1, 1), (2, 0)], ids=["algo-auto", "algo-tile", "algo-sieve-global"])
 def algo(request, eng):
     """Runs a test once per pair kernel: automatic choice (descriptor sieve; passes with short chunks in the chunk-local
-    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path, and the sieve
-    with its row descriptors arriving the OTHER way than the default does (through LDS / through the scalar cache: option
-    sieve_srow), every pass through it."""
+    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
-    if request.param[2] == "flip":
-        eng.set_option("sieve_srow", 1 - SIEVE_SROW_DEFAULT)
     yield request.param[0]
     eng.set_option("prune_algo", 0)
     eng.set_option("local_pass", 1)
-    eng.set_option("sieve_srow", SIEVE_SROW_DEFAULT)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

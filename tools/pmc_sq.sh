@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): SQ counters of the pair kernel, three --pmc passes of a short bench run.
+# usage: tools/pmc_sq.sh OUTDIR [bench.py arguments]
+set -e
+P=gpurun_out/$1; shift
+mkdir -p "$P"
+export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --no-cpu --no-side-leg $*"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$P/p1" -- python3 bench.py $ARGS > "$P/b1.json" 2> "$P/p1.err"
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU --output-format csv -d "$P/p2" -- python3 bench.py $ARGS > "$P/b2.json" 2> "$P/p2.err"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d "$P/p3" -- python3 bench.py $ARGS > "$P/b3.json" 2> "$P/p3.err"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F32 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --output-format csv -d "$P/p4" -- python3 bench.py $ARGS > "$P/b4.json" 2> "$P/p4.err"
+python3 - "$P" <<'PY'
+import csv, glob, sys, collections, json
+P = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(int)
+for f in glob.glob(f"{P}/p*/**/*counter_collection.csv", recursive=True):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].split("<")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (f, k, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+out = {k: dict(v) for k, v in agg.items() if "sieve" in k or "stop_scan" in k or "apply" in k or "open_pass" in k}
+json.dump(out, open(f"{P}/sq_counters.json", "w"), indent=1)
+for k, v in out.items():
+    print(k)
+    for c, x in sorted(v.items()):
+        print("   ", c, f"{x:.4g}")
+PY

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
                                                     const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
                                                     const unsigned long long *__restrict__ dsum, int32_t *__restrict__ cend,
                                                     int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
-                                                    const float *__restrict__ D, float *__restrict__ Dc, float *__restrict__ Dn) {
+                                                    const float *__restrict__ D, float *__restrict__ Dc) {
     // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
     // D (optional): the 16 descriptor components of the row's structure are copied to position r of Dc on the way (one
     // float per lane), so that the pair kernel reads rows and columns by position -- no gather through the active list
@@ -580,13 +580,6 @@ __global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, co
         }
     }
     if (mine && D) Dc[int64_t(r) * 16 + sl] = dval;
-    if (D && Dn) {  // squared norm of the row's descriptor per family (components 2k + family): the pair kernel's screen reads it by position
-        float sq = dval * dval;
-        sq += __shfl_xor(sq, 2);
-        sq += __shfl_xor(sq, 4);
-        sq += __shfl_xor(sq, 8);
-        if (mine && sl < 2) Dn[int64_t(r) * 2 + sl] = sq;
-    }
     int my_c = 0;
     if (mine && sl == 0) {
         my_c = pos[found];

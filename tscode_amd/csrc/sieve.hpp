@@ -497,10 +497,10 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
 #endif
-template <int TI, int CPL, bool SROW = false>
+template <int TI, int CPL>
 __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
-                                                        const float *__restrict__ Dn, const int32_t *__restrict__ cend,
+                                                        const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                         const PruneState *__restrict__ st, SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
@@ -555,15 +555,9 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     if (!alive) return;
 
     const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
-    // SROW: the row descriptors are wave-uniform, so they can come through the SCALAR cache (s_load_dwordx16 from the positional
-    // copy, their squared norms from Dn) straight into SGPR operands of the packed FMAs, instead of through LDS: a broadcast
-    // ds_read_b128 still moves 1 KB through the CU's one 128 B/clk LDS port, 4.5 KB per (row, tile), and with 20 wavefronts per
-    // CU that port, not the VALU, was what bounded the screen (720 LDS cycles against 520 VALU cycles per round).
-    float rd_stage[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if constexpr (!SROW) {
+    float rd_stage[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
-    }
+    for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
     f32x2 dq[CPL][KD];  // .x = family 0, .y = family 1
     f32x2 cn[CPL];      // their squared norms
     auto load_tile = [&]() __attribute__((always_inline)) {
@@ -591,19 +585,17 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
 
     // the row descriptors of this work item -> LDS (rows beyond nrows are never read back)
     float *rowdesc = s_rowdesc[wid];
-    if constexpr (!SROW) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < TI) {  // squared norms of the row descriptors, per family
-            const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
-            f32x2 nr = {0.0f, 0.0f};
+    for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < TI) {  // squared norms of the row descriptors, per family
+        const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
+        f32x2 nr = {0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
-            s_rownorm[wid][lane] = nr;
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
+        s_rownorm[wid][lane] = nr;
     }
+    __builtin_amdgcn_wave_barrier();
 
     const int h3 = a.h * 3;
     unsigned short *queue = s_queue[wid];
@@ -735,24 +727,16 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
                 rows &= rows - 1;
                 const int r = r0 + t;
                 const int ce = __builtin_amdgcn_readlane(my_cend, t);
+                const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
                 f32x2 rd[KD];
-                f32x2 nr;
-                if constexpr (SROW) {
-                    const float *rp = D + int64_t(r) * DW;       // r is wave-uniform: scalar loads
 #pragma unroll
-                    for (int k = 0; k < KD; ++k) rd[k] = f32x2{rp[2 * k], rp[2 * k + 1]};
-                    nr = f32x2{Dn[2 * int64_t(r)], Dn[2 * int64_t(r) + 1]};
-                } else {
-                    const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-#pragma unroll
-                    for (int k = 0; k < KD; ++k) rd[k] = dr[k];
-                    nr = s_rownorm[wid][t];
-                }
+                for (int k = 0; k < KD; ++k) rd[k] = dr[k];
                 // columns of this tile inside the row's range (r, ce): counted without a ballot
                 n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
                 // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
                 // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
                 // the error bound)
+                const f32x2 nr = s_rownorm[wid][t];
                 float mx[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL; ++u) {

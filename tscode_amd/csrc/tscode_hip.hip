@@ -516,7 +516,6 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     float *Dc = nullptr;     // ... in active order, rewritten by k_stop_scan every pass: what the pair kernel reads
-    float *Dn = nullptr;     // squared norms of those rows per family, [n][2] (k_stop_scan): the screen's |row|^2, read through the scalar cache
     double *Gall = nullptr;
     LocalTickets *tickets = nullptr;  // chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
@@ -708,7 +707,6 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         }
         if (!rc) rc = palloc(p, 1, &p->tickets);
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
-        if (!rc) rc = palloc(p, size_t(n) * 2 + 16, &p->Dn);
     }
     if (!rc && p->algo == ALGO_TILE) {
         const size_t hp3 = size_t(p->hp) * 3;
@@ -859,19 +857,15 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
         a.drain_min = c->drain_min;
         if (c->sieve_cpl == 1)
             hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const float *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else if (c->sieve_cpl == 2 && c->sieve_srow)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2, true>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const float *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
                                   (const PruneState *)p->state, a);
         else if (c->sieve_cpl == 2)
             hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const float *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
                                   (const PruneState *)p->state, a);
         else
             hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 4>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const float *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
                                   (const PruneState *)p->state, a);
     }
     TSC_HIP(hipGetLastError());
@@ -939,7 +933,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
                        (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit, p->dbit + p->bit_words);
     // 2. stop column, best[] and compacted descriptor of every row
     hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, (const unsigned long long *)(p->dbit + p->bit_words), p->cend, p->best, p->tile_cmax, (const float *)p->Dall, p->Dc, p->Dn);
+                       p->dbit, (const unsigned long long *)(p->dbit + p->bit_words), p->cend, p->best, p->tile_cmax, (const float *)p->Dall, p->Dc);
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
@@ -1188,11 +1182,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
-        return 0;
-    }
-    if (strcmp(name, "sieve_srow") == 0) {
-        TSC_REQUIRE(value == 0 || value == 1, "sieve_srow must be 0 or 1");
-        c->sieve_srow = int(value);
         return 0;
     }
     if (strcmp(name, "sieve_cpl") == 0) {
