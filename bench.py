@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=None, help="poses of the CPU baseline run (default: the whole workload for C3, 40000 otherwise)")
     ap.add_argument("--no-side-leg", action="store_true", help="N > 1: time only the leg that is the line's value")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="N = 1 side figure `steps_in_flight`: this many independent steps at a time, each on its own library context, "
+                         "HIP stream and buffers, driven by one host thread each (0 = skip).  Never the line's value.")
     return ap.parse_args()
 
 
@@ -464,6 +467,41 @@ def main():
             out[side[0]] = side[1]
         if error is not None:
             out["error"] = error
+    # Beside the line's strictly sequential steps: D steps in flight at a time.  A step at 100k conformers is a chain of ~50
+    # dependent launches most of which occupy a small part of the chip for a few microseconds; a caller with several
+    # independent ensembles (TSCoDe embeds one per reactant pair / conformer set; multiembed runs them from several processes)
+    # gives each its own context and stream, and the GPU overlaps one chain's latency with another's kernels.  Every step does
+    # all of its work on its own buffers; the verdicts of every one are checked.  A side figure, never `value`.
+    if world == 1 and args.in_flight > 1 and not args.no_side_leg and not chain and rank == 0:
+        try:
+            D = args.in_flight
+            pipes = [DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode) for _ in range(D)]
+            for q in pipes:
+                configure(q, 0)
+                q.step()
+                q.step()
+            last = [None] * D
+
+            def worker(i):
+                for _ in range(args.steps):
+                    last[i] = pipes[i].step()
+            threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            ok = all(verdict(pipes[i], last[i])[1] in (True, None) and last[i]["n_keep"] == n_keep for i in range(D))
+            out["steps_in_flight"] = {"in_flight": D, "steps": args.steps * D, "ms_per_step": dtc / (args.steps * D) * 1e3,
+                                      "value": ens.n_poses * args.steps * D / dtc, "unit": "conformers/s", "every_step_checked": bool(ok),
+                                      "what": f"{D} independent steps at a time, each on its own library context, HIP stream and buffers (one host "
+                                              f"thread each, library events off); the line's `value` above is one step at a time"}
+            del pipes
+        except Exception as exc:
+            out["steps_in_flight"] = {"error": f"{type(exc).__name__}: {exc}"}
     # beside the C3 line: config C4 (1M x 50), the workload large enough for sharding one ensemble to pay -- one GPU: the one-call
     # pipeline; N > 1: the same sharded protocol.  A side figure of the default run, so that every N of a scaling series has it.
     # Under a watchdog of its own: the line above is complete and is printed whatever happens here.

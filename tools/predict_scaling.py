@@ -9,8 +9,9 @@ measure is every rank's SHARE of the work: for N in {1, 2, 4, 8} and every rank 
   * everything the ranks replicate (the small passes, the per-pass bookkeeping around a sharded pass, the export),
 and combines them as the protocol would run:  max_r front(r) + counts all-reduce + coordinates all-gather +
 sum over passes [replicated part + max_r local(r) + all-reduce(best[])] .  The collectives are MODELLED, not measured:
-per-link xGMI bandwidth 153 GB/s x 0.7 efficiency, ring all-gather / ring all-reduce (per-link bound, the conservative
-reading of point-to-point xGMI), 20 us fixed cost per collective (RCCL launch + N - 1 hops) -- all stated in the output.
+per-link xGMI bandwidth 153 GB/s x 0.7 efficiency, 20 us fixed cost per collective, and two readings of the mesh -- ring
+collectives bound by ONE link (conservative) and every shard sent straight to its N - 1 peers over all links at once
+(what the fully connected xGMI mesh allows) -- both stated in the output.
 
 usage (GPU box): python tools/predict_scaling.py [C3 C4] > profiles/r02_predicted_scaling.json
 """
@@ -42,28 +43,34 @@ class Timer:
         return a.elapsed_time(b), out
 
 
-def allgather_ms(total_bytes, n):
+def allgather_ms(total_bytes, n, all_links=False):
+    """ring: N - 1 steps of one shard over ONE link; all_links: every shard goes straight to its N - 1 peers, one link each."""
     if n == 1:
         return 0.0
-    return total_bytes * (n - 1) / n / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
+    shard = total_bytes / n
+    steps = 1 if all_links else n - 1
+    return shard * steps / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
 
 
-def allreduce_ms(nbytes, n):
+def allreduce_ms(nbytes, n, all_links=False):
+    """reduce-scatter + all-gather of the same pattern."""
     if n == 1:
         return 0.0
-    return 2.0 * nbytes * (n - 1) / n / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
+    steps = 1 if all_links else n - 1
+    return 2.0 * (nbytes / n) * steps / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
 
 
 def measure(cfg, n_ranks, reps=3):
     ens = make_config(cfg)
     # front half: every rank's block
-    front = []
+    front, counts = [], []
     for r in range(n_ranks):
         be = HipShardBackend(ens, 0, r, n_ranks, 1.5, 0, 0.5, 0)
         be.eng.set_option("pass_timing", 0)
         tm = Timer(be.stream)
-        best = min(tm(be.embed_clash_block)[0] for _ in range(reps + 1))
-        front.append(best)
+        runs_r = [tm(be.embed_clash_block) for _ in range(reps + 1)]
+        front.append(min(t for t, _ in runs_r))
+        counts.append(int(runs_r[-1][1]))
         del be
         torch.cuda.empty_cache()
     # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
@@ -100,22 +107,29 @@ def measure(cfg, n_ranks, reps=3):
         st.close()
         runs.append({"replicated_ms": replicated, "passes": passes, "n_keep": int(stats[-1]["n_active_after"])})
     best = min(runs, key=lambda r: r["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in r["passes"]))
-    gather_bytes = n_ranks * ((ens.n_poses + n_ranks - 1) // n_ranks + 1) * h * 24
-    comm = allreduce_ms(8 * n_ranks, n_ranks) + allgather_ms(gather_bytes, n_ranks) + sum(allreduce_ms(4 * p["best_entries"], n_ranks) for p in best["passes"])
+    gather_bytes = n_ranks * max(counts) * h * 24             # shards padded to the largest count (pipeline.py)
+
+    def comm_ms(all_links):
+        return (allreduce_ms(8 * n_ranks, n_ranks, all_links) + allgather_ms(gather_bytes, n_ranks, all_links)
+                + sum(allreduce_ms(4 * p["best_entries"], n_ranks, all_links) for p in best["passes"]))
+    comm, comm_fast = comm_ms(False), comm_ms(True)
     compute = max(front) + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
     return {"n_ranks": n_ranks, "front_ms_per_rank": front, "replicated_ms": best["replicated_ms"],
             "sharded_passes": [{"k": p["k"], "best_entries": p["best_entries"], "max_local_ms": max(p["local_ms_per_rank"]),
                                 "sum_local_ms": sum(p["local_ms_per_rank"]), "imbalance": max(p["local_ms_per_rank"]) * n_ranks / max(sum(p["local_ms_per_rank"]), 1e-9)}
                                for p in best["passes"]],
-            "compute_ms": compute, "modelled_comm_ms": comm, "allgather_bytes": gather_bytes, "predicted_ms_per_step": compute + comm,
-            "predicted_conformers_per_s": ens.n_poses / (compute + comm) * 1e3, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}
+            "compute_ms": compute, "modelled_comm_ms": comm, "modelled_comm_ms_all_links": comm_fast, "allgather_bytes": gather_bytes,
+            "pass_counts_per_rank": counts, "predicted_ms_per_step": compute + comm, "predicted_ms_per_step_all_links": compute + comm_fast,
+            "predicted_conformers_per_s": ens.n_poses / (compute + comm) * 1e3,
+            "predicted_conformers_per_s_all_links": ens.n_poses / (compute + comm_fast) * 1e3, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}
 
 
 def main():
     cfgs = [a for a in sys.argv[1:] if a.startswith("C")] or ["C3", "C4"]
     out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
            "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
-                     "allgather": "ring, per-link bound: bytes (N-1)/N / (link x eff) + fixed", "allreduce": "ring: 2 bytes (N-1)/N / (link x eff) + fixed",
+                     "ring (predicted_ms_per_step)": "per-link bound: all-gather = (N-1) steps of one shard over one link; all-reduce = reduce-scatter + all-gather of that pattern",
+                     "all_links (predicted_ms_per_step_all_links)": "the fully connected xGMI mesh used at once: every shard straight to its N-1 peers, one link each",
                      "shard_min_pairs": SHARD_MIN_PAIRS},
            "measured_on": torch.cuda.get_device_name(0), "configs": {}}
     for cfg in cfgs:
@@ -128,6 +142,7 @@ def main():
         base = rows[0]["predicted_ms_per_step"]
         for r in rows:
             r["speedup_vs_1_rank_protocol"] = base / r["predicted_ms_per_step"]
+            r["speedup_vs_1_rank_protocol_all_links"] = base / r["predicted_ms_per_step_all_links"]
         out["configs"][cfg] = rows
     print(json.dumps(out, indent=1))
 
