@@ -176,15 +176,22 @@ def test_prune_golden(eng, algo):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
-@pytest.fixture(params=[(0, 1), (1, 1), (2, 0)], ids=["algo-auto", "algo-tile", "algo-sieve-global"])
+SIEVE_TRIM_DEFAULT = 0   # the library's default of option sieve_trim; the fixture `algo` also runs the other setting
+
+
+@pytest.fixture(params=[(0, 1, False), (1, 1, False), (2, 0, False), (2, 0, True)], ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen"])
 def algo(request, eng):
     """Runs a test once per pair kernel: automatic choice (descriptor sieve; passes with short chunks in the chunk-local
-    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path."""
+    kernel), register-tiled all-pairs, descriptor sieve with every pass through the global four-launch path, and the same
+    with the screen's other instruction sequence (option sieve_trim flipped from its default)."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
+    if request.param[2]:
+        eng.set_option("sieve_trim", 1 - SIEVE_TRIM_DEFAULT)
     yield request.param[0]
     eng.set_option("prune_algo", 0)
     eng.set_option("local_pass", 1)
+    eng.set_option("sieve_trim", SIEVE_TRIM_DEFAULT)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -106,6 +106,10 @@ __device__ inline float screen_limit32(float dmaxf, double limit) {
 // vectors a, b (8-term fma chains), which costs 10 packed instructions per column instead of 16 for sum (a_k - b_k)^2.  With
 // u = 2^-24 and g8 = 8u / (1 - 8u):  | |a|^2_fl - |a|^2 | <= g8 |a|^2,  | a.b_fl - a.b | <= g8 (|a|^2 + |b|^2) / 2,  so the
 // exact T = |a - b|^2 satisfies  T >= S (1 - 2u) - E,  E = (2 g8 + u (1 + g8)) (|a|^2 + |b|^2) <= (2 g8 + u (1 + g8)) 2 KD M^2.
+// The kernel's other association, S' = fl(|a|^2_fl - 2 fl(-|b|^2_fl / 2 + a.b)) (the chain of 8 fmas starts from the
+// halved column norm, an exact scaling), carries g8 (|b|^2 (1 + g8) / 2 + (|a|^2 + |b|^2) / 2) in the chain, twice that after
+// the exact factor, plus the two norm roundings: at most g8 (2 |a|^2 + 3 |b|^2)(1 + g8) <= 3 g8 (|a|^2 + |b|^2) (1 + g8)
+// beside the final u: the E below (3 g8 in place of 2) covers both associations.
 // The stored components are roundings of the exact descriptors, each difference within eta = 3 * 2^-24 * 2M of the exact
 // one as above, so s_exact >= T - 2 eta sqrt(KD T) (increasing in T beyond KD eta^2): a pair whose S exceeds the returned
 // value certainly has s_exact > limit.
@@ -115,7 +119,7 @@ __device__ inline float screen_limit32_dot(float dmaxf, double limit) {
     const double eta = 3.0 * U * 2.0 * dmax;
     const double b = 2.0 * eta * sqrt(double(KD));
     const double y = 0.5 * (b + sqrt(b * b + 4.0 * limit));   // sqrt of the smallest T with T - b sqrt(T) >= limit
-    const double E = (2.0 * G8 + U * (1.0 + G8)) * 2.0 * double(KD) * dmax * dmax;
+    const double E = (3.0 * G8 * (1.0 + G8) + U * (1.0 + G8)) * 2.0 * double(KD) * dmax * dmax;
     const double l32 = (y * y + E) / (1.0 - 2.0 * U) * (1.0 + 1e-6) + 1e-30;
     float f = float(l32);
     if (double(f) < l32) f = __uint_as_float(__float_as_uint(f) + 1u);  // next float up (f > 0)
@@ -497,7 +501,7 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
 #endif
-template <int TI, int CPL>
+template <int TI, int CPL, bool TRIM = false>
 __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
                                                         const int32_t *__restrict__ cend,
@@ -512,8 +516,9 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     __shared__ unsigned short s_queue[4][QCAP];
     __shared__ unsigned short s_exq[4][128];  // pairs that the sign test could not reject, waiting for the exact path
     __shared__ double s_jacobi[4][32];        // scratch of the Jacobi fallback of the exact path (rmsd.hpp), per wavefront
-    __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * DW];
-    __shared__ f32x2 s_rownorm[4][TI];  // |row descriptor|^2 per family
+    constexpr int RS = TRIM ? 20 : DW;  // floats per row record in LDS; TRIM: 16 components, the two squared norms, 2 of padding (80 B)
+    __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * RS];
+    __shared__ f32x2 s_rownorm[4][TRIM ? 1 : TI];  // |row descriptor|^2 per family (TRIM keeps them in the row record)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * 4 + wid;
@@ -555,6 +560,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     if (!alive) return;
 
     const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
+    const int limit_bits = __float_as_int(limit32);  // (positive: the integer order of the bit patterns is the float order from zero up)
     float rd_stage[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd_stage[j] = D[int64_t(row_src[j]) * DW + (lane & 15)];
@@ -573,7 +579,9 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
             f32x2 nc = {0.0f, 0.0f};  // |column descriptor|^2 per family, once per tile (shared by its 16 rows)
 #pragma unroll
             for (int k = 0; k < KD; ++k) nc = __builtin_elementwise_fma(dq[u][k], dq[u][k], nc);
-            cn[u] = nc;
+            // TRIM: the dot-product chain of a row starts from -|c|^2 / 2 (exact: a power of two), so that one fma by -2 onto
+            // |r|^2 finishes |r|^2 + |c|^2 - 2 r.c without the separate packed add per column
+            cn[u] = TRIM ? nc * f32x2{-0.5f, -0.5f} : nc;
         }
     };
     load_tile();
@@ -586,14 +594,15 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     // the row descriptors of this work item -> LDS (rows beyond nrows are never read back)
     float *rowdesc = s_rowdesc[wid];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rowdesc[64 * j + lane] = rd_stage[j];
+    for (int j = 0; j < 4; ++j) rowdesc[(4 * j + (lane >> 4)) * RS + (lane & 15)] = rd_stage[j];
     __builtin_amdgcn_wave_barrier();
     if (lane < TI) {  // squared norms of the row descriptors, per family
-        const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * DW);
+        const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + lane * RS);
         f32x2 nr = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < KD; ++k) nr = __builtin_elementwise_fma(dr[k], dr[k], nr);
-        s_rownorm[wid][lane] = nr;
+        if constexpr (TRIM) *reinterpret_cast<f32x2 *>(rowdesc + lane * RS + DW) = nr;
+        else s_rownorm[wid][lane] = nr;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -722,6 +731,56 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         {   // ---- screen one tile against every live row
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
+            if constexpr (TRIM) {
+                // the same screen with fewer vector instructions per (row, tile): one LDS record per row (components and norms
+                // behind one address), the norms folded into the dot-product chain, and the two families compared with the limit
+                // separately instead of max / max / min / compare (NaN handling unchanged: a NaN component never rejects)
+                while (rows) {
+                    const int t = __ffs(rows) - 1;
+                    rows &= rows - 1;
+                    const int r = r0 + t;
+                    const int ce = __builtin_amdgcn_readlane(my_cend, t);
+                    const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc + t * RS);
+                    f32x2 rd[KD];
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) rd[k] = rec[k];
+                    const f32x2 nr = rec[KD];
+                    n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
+                    // Both family distances against the limit as INTEGER compares of the bit patterns (for a positive limit the
+                    // order of non-negative floats; a negative sum -- rounding -- is below it either way; a NaN with a clear sign
+                    // bit now counts as beyond the limit where the float compare let it through to H, which rejects it: :75):
+                    // two v_cmp per column straight into lane masks, no canonicalising max, nothing materialised per lane.
+                    unsigned long long pm[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        f32x2 acc = cn[u];                         // -|c|^2 / 2
+#pragma unroll
+                        for (int k = 0; k < KD; ++k) acc = __builtin_elementwise_fma(rd[k], dq[u][k], acc);
+                        const f32x2 s2 = __builtin_elementwise_fma(acc, f32x2{-2.0f, -2.0f}, nr);
+                        pm[u] = ~(__builtin_amdgcn_ballot_w64(__float_as_int(s2.x) > limit_bits) | __builtin_amdgcn_ballot_w64(__float_as_int(s2.y) > limit_bits));
+                    }
+                    if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: only the columns inside count
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const int col = c0 + 64 * u + lane;
+                            pm[u] &= __builtin_amdgcn_ballot_w64(col > r && col < ce);
+                        }
+                    }
+                    unsigned long long any = pm[0];
+#pragma unroll
+                    for (int u = 1; u < CPL; ++u) any |= pm[u];
+                    if (any) {
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const unsigned long long m = pm[u];
+                            if (m) {
+                                if ((m >> lane) & 1ull) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
+                                qn += __popcll(m);
+                            }
+                        }
+                    }
+                }
+            } else
             while (rows) {
                 const int t = __ffs(rows) - 1;
                 rows &= rows - 1;

@@ -859,6 +859,10 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
             hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
                                   (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
                                   (const PruneState *)p->state, a);
+        else if (c->sieve_cpl == 2 && c->sieve_trim)
+            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2, true>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
+                                  (const PruneState *)p->state, a);
         else if (c->sieve_cpl == 2)
             hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
                                   (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
@@ -1182,6 +1186,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "pass_timing") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "pass_timing must be 0, 1 or 2");
         c->pass_timing = int(value);
+        return 0;
+    }
+    if (strcmp(name, "sieve_trim") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "sieve_trim must be 0 or 1");
+        c->sieve_trim = int(value);
         return 0;
     }
     if (strcmp(name, "sieve_cpl") == 0) {
