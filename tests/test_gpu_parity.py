@@ -176,7 +176,7 @@ def test_prune_golden(eng, algo):
         assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g[f"pass_nkeys{c}"].tolist()
 
 
-SIEVE_TRIM_DEFAULT = 0   # the library's default of option sieve_trim; the fixture `algo` also runs the other setting
+SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixture `algo` also runs the other setting
 
 
 @pytest.fixture(params=[(0, 1, False), (1, 1, False), (2, 0, False), (2, 0, True)], ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen"])
