@@ -1146,6 +1146,79 @@ def test_cyclical_embed_golden(eng, oracle):
         tscode_amd.cyclical_embed_batch(_cyclical_case(g, 0) * 2, g["angles_0"])           # not two molecules
 
 
+def test_embed_dropins_with_the_reference_signatures(eng):
+    """tscode_amd.embeds.string_embed(embedder) / cyclical_embed(embedder): what install() puts in place of the reference's
+    functions.  Duck-typed Embedder and molecules carrying exactly the recorded inputs of G11 / G12 (the reference's own
+    Hypermolecule data); tscode.embeds is a stand-in module offering the helper names the drop-ins take from the live one."""
+    import sys
+    import types
+    import tscode_amd
+    from tscode_amd import embeds as E
+    g11, g12 = load_golden("G11_string_embed"), load_golden("G12_cyclical_embed")
+
+    class Zero(Exception):
+        pass
+    logs = []
+    standin = types.ModuleType("tscode.embeds")
+    standin.ZeroCandidatesError = Zero
+    standin.pretty_num = str
+    standin.get_sum_graph = lambda graphs, extra: ("sum", graphs, extra)
+    standin._get_string_constrained_indices = lambda emb, n: np.array([[[int(emb.objects[0].reactive_indices[0]),
+                                                                         int(emb.objects[1].reactive_indices[0] + emb.ids[0])]] for _ in range(n)])
+    standin.string_embed = standin.cyclical_embed = lambda emb, *a: "the reference's own function"
+    saved = sys.modules.get("tscode.embeds")
+    sys.modules["tscode.embeds"] = standin
+    try:
+        for k in range(int(g11["n_cases"])):
+            standin._get_quadruplets = lambda graph, k=k: g11[f"quadruplets_{k}"]
+            mols = []
+            for m in range(2):
+                centers, vecs = g11[f"centers{m}_{k}"], g11[f"orb_vecs{m}_{k}"]
+                r_atoms = [types.SimpleNamespace(center=centers[c], orb_vecs=vecs[c]) for c in range(len(centers))]
+                mols.append(types.SimpleNamespace(atomcoords=g11[f"coords{m}_{k}"], reactive_indices=np.array([int(g11[f"reactive_index{m}_{k}"])]), graph=None,
+                                                  get_r_atoms=lambda c, r=r_atoms: [r[c]], get_centers=lambda c, r=r_atoms: np.array([r[c].center])))
+            emb = types.SimpleNamespace(objects=mols, ids=g11[f"ids_{k}"], systematic_angles=list(g11[f"angles_{k}"]), candidates=len(g11[f"candidates_{k}"]),
+                                        options=types.SimpleNamespace(clash_thresh=float(g11[f"clash_thresh_{k}"])), log=lambda *a, **kw: logs.append(a))
+            poses = E.string_embed(emb)
+            assert poses.shape == g11[f"poses_{k}"].shape and np.abs(poses - g11[f"poses_{k}"]).max() < VAL_TOL
+            assert np.array_equal(emb.constrained_indices, g11[f"constrained_indices_{k}"])
+        emb.options.clash_thresh = 9.0
+        with pytest.raises(Zero):
+            E.string_embed(emb)
+        for k in range(int(g12["n_cases"])):
+            mols = []
+            for m in range(2):
+                coords = g12[f"coords{m}_{k}"]
+                piv = []
+                for c in range(len(coords)):
+                    vec, mean, cum = g12[f"pivot_vec{m}_{c}_{k}"], g12[f"pivot_mean{m}_{c}_{k}"], g12[f"pivot_cumnums{m}_{c}_{k}"]
+                    piv.append([types.SimpleNamespace(pivot=vec[i], meanpoint=mean[i], start_atom=types.SimpleNamespace(cumnum=int(cum[i, 0])),
+                                                      end_atom=types.SimpleNamespace(cumnum=int(cum[i, 1]))) for i in range(len(vec))])
+                mols.append(types.SimpleNamespace(atomcoords=coords, reactive_indices=g12[f"reactive_indices{m}_{k}"], pivots=piv))
+            emb = types.SimpleNamespace(objects=mols, ids=g12[f"ids_{k}"], systematic_angles=g12[f"angles_{k}"], candidates=len(g12[f"candidates_{k}"]),
+                                        embed="cyclical", pairings_table={}, internal_constraints=[],
+                                        options=types.SimpleNamespace(clash_thresh=float(g12[f"clash_thresh_{k}"]), rigid=bool(g12[f"rigid_{k}"])),
+                                        log=lambda *a, **kw: logs.append(a))
+            poses = E.cyclical_embed(emb)
+            assert poses.shape == g12[f"poses_{k}"].shape and np.abs(poses - g12[f"poses_{k}"]).max() < VAL_TOL
+            assert np.array_equal(emb.constrained_indices, g12[f"constrained_indices_{k}"])
+        # three molecules: handed to the reference's own function (recorded by install())
+        done = tscode_amd.install()
+        assert ("tscode.embeds", "string_embed") in done and ("tscode.embeds", "cyclical_embed") in done
+        assert standin.cyclical_embed is E.cyclical_embed
+        emb.objects = mols + [mols[0]]
+        assert standin.cyclical_embed(emb) == "the reference's own function"
+        tscode_amd.uninstall()
+        assert standin.cyclical_embed is not E.cyclical_embed
+    finally:
+        tscode_amd.uninstall()
+        if saved is None:
+            sys.modules.pop("tscode.embeds", None)
+        else:
+            sys.modules["tscode.embeds"] = saved
+    assert logs
+
+
 def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
     """BASELINE config 5 as a chain (reduced size): csearch rotations of fragment 0 on the device -> the kept candidates are
     that fragment's conformers -> embed -> clash mask -> prune, the candidate array never leaving the GPU -- against the same

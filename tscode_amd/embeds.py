@@ -14,7 +14,7 @@ from .engine import FragmentSet, get_engine
 from .utils import cartesian_product, polygonize
 
 __all__ = ["get_embed", "embed_batch", "string_embed_poses", "filter_angular_groups", "string_embed_batch", "cyclical_embed_batch",
-           "EmbedTrace"]
+           "EmbedTrace", "string_embed", "cyclical_embed"]
 
 
 def get_embed(mols, conf_ids):
@@ -215,3 +215,91 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
     if return_trace:
         return poses, constrained, EmbedTrace(clash_ok=ok, kept=kept, group_of=group_of, groups=groups)
     return poses, constrained
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Drop-ins with the reference's own signatures: what tscode_amd.install() puts in place of tscode.embeds.string_embed /
+# cyclical_embed (and of the names tscode/embedder.py:39-40 bound at import time).  They read the plain arrays out of the
+# Embedder's molecules, make ONE call of the batch drivers above, and leave the same return value and side effects.  The
+# graph helpers and the exception type are the reference's own (taken from the imported tscode.embeds), and whatever these
+# drivers do not cover is handed to the reference's original function.
+
+_originals = {}          # name -> the reference's function, recorded by install()
+
+
+def _reference_embeds():
+    import sys
+    ref = sys.modules.get("tscode.embeds")
+    if ref is None:
+        raise RuntimeError("tscode.embeds is not imported: these drop-ins run inside a live TSCoDe (tscode_amd.install()); "
+                           "from plain arrays call string_embed_batch / cyclical_embed_batch")
+    return ref
+
+
+def string_embed(embedder):
+    """Drop-in for tscode/embeds.py:36-133 ``string_embed(embedder)``: same poses, same ``embedder.constrained_indices``, same
+    ZeroCandidatesError -- the three nested Python loops replaced by one GPU call."""
+    ref = _reference_embeds()
+    assert len(embedder.objects) == 2
+    mol1, mol2 = embedder.objects
+    embedder.log(f"\n--> Performing string embed ({ref.pretty_num(embedder.candidates)} candidates, MI355X engine)")
+    constrained_indices = [[int(mol1.reactive_indices[0]), int(mol2.reactive_indices[0] + embedder.ids[0])]]            # :84-85
+    quadruplets = ref._get_quadruplets(ref.get_sum_graph((mol1.graph, mol2.graph), constrained_indices))               # :87
+    arrays = []
+    for mol in (mol1, mol2):
+        n_centers = len(mol.get_centers(0)[0])                                                                         # :77
+        r_atoms = [mol.get_r_atoms(c)[0] for c in range(len(mol.atomcoords))]
+        arrays.append((np.array([np.asarray(r.center)[:n_centers] for r in r_atoms]), np.array([np.asarray(r.orb_vecs)[:n_centers] for r in r_atoms])))
+    poses = string_embed_batch(np.asarray(mol1.atomcoords), np.asarray(mol2.atomcoords), arrays[0][0], arrays[0][1], arrays[1][0], arrays[1][1],
+                               embedder.systematic_angles, clash_thresh=embedder.options.clash_thresh, quadruplets=quadruplets)
+    if not len(poses):
+        msg = ("\n--> Cyclical embed did not find any suitable disposition of molecules.\n"
+               "    This is probably because the two molecules cannot find a correct interlocking pose.\n"
+               "    Try expanding the conformational space with the csearch> operator or see the SHRINK keyword.")
+        embedder.log(msg, p=False)
+        raise ref.ZeroCandidatesError(msg)
+    embedder.constrained_indices = ref._get_string_constrained_indices(embedder, len(poses))                           # :131
+    return poses
+
+
+def cyclical_embed(embedder, max_norm_delta=5):
+    """Drop-in for tscode/embeds.py:234-860 ``cyclical_embed(embedder)`` for two molecules (the rigid shortcut, and the general
+    loop where it bends nothing); trimolecular embeds and pivot pairs the reference would bend go to the reference's own
+    function."""
+    ref = _reference_embeds()
+    original = _originals.get("cyclical_embed")
+    mols = embedder.objects
+    rigid = bool(embedder.options.rigid)
+
+    def theirs():
+        if original is None:
+            raise RuntimeError("this embed needs the reference's own cyclical_embed (three molecules, or a pivot pair it would bend): "
+                               "tscode_amd.install() records it")
+        return original(embedder, max_norm_delta) if max_norm_delta != 5 else original(embedder)
+    if len(mols) != 2:
+        return theirs()
+    packed = []
+    for mol in mols:
+        pivots = [(np.array([p.pivot for p in pv]).reshape(-1, 3), np.array([p.meanpoint for p in pv]).reshape(-1, 3),
+                   np.array([[p.start_atom.cumnum, p.end_atom.cumnum] for p in pv]).reshape(-1, 2)) for pv in mol.pivots]
+        packed.append(dict(coords=np.asarray(mol.atomcoords), reactive_indices=np.asarray(mol.reactive_indices), pivots=pivots))
+    if not rigid:
+        # the general loop bends a molecule when two pivots differ by max_norm_delta or more (:574-628): not this driver's
+        for pv0 in packed[0]["pivots"]:
+            for pv1 in packed[1]["pivots"]:
+                n0, n1 = np.linalg.norm(pv0[0], axis=1), np.linalg.norm(pv1[0], axis=1)
+                if len(n0) and len(n1) and not (np.abs(n0[:, None] - n1[None, :]) < max_norm_delta).all():
+                    return theirs()
+    embedder.log(f"\n--> Performing {embedder.embed} embed ({ref.pretty_num(embedder.candidates)} candidates, MI355X engine)")
+    pairings = [list(p) for p in embedder.pairings_table.values()] if embedder.pairings_table else None
+    poses, constrained = cyclical_embed_batch(packed, embedder.systematic_angles, clash_thresh=embedder.options.clash_thresh,
+                                              rigid_shortcut=rigid, max_norm_delta=max_norm_delta, pairings=pairings,
+                                              internal_constraints=getattr(embedder, "internal_constraints", ()))
+    embedder.constrained_indices = constrained                                                                         # :723 / :851
+    if not len(poses):
+        msg = ("\n--> Cyclical embed did not find any suitable disposition of molecules.\n"
+               "    This is probably because one molecule has two reactive centers at a great distance,\n"
+               "    preventing the other two molecules from forming a closed, cyclical structure.")
+        embedder.log(msg, p=False)
+        raise ref.ZeroCandidatesError(msg)
+    return poses

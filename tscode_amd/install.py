@@ -33,20 +33,25 @@ _PATCHES = {
     "fitness_check": (optimization_methods.fitness_check, ("tscode.optimization_methods", "tscode.embedder")),
     "prune_conformers_tfd": (numba_functions.prune_conformers_tfd,
                              ("tscode.numba_functions", "tscode.embedder", "tscode.operators", "tscode.torsion_module")),
+    # the embed loops themselves (tscode/embedder.py:39-40 binds both names; generate_candidates looks them up at call time, :1141-1154)
+    "string_embed": (embeds.string_embed, ("tscode.embeds", "tscode.embedder")),
+    "cyclical_embed": (embeds.cyclical_embed, ("tscode.embeds", "tscode.embedder")),
 }
 
 # Functions that take a whole ensemble per call: what install() replaces by default.  The others are called by TSCoDe once per
 # pose / pair from Python loops; a GPU call (upload, launch, download, synchronise) takes 35-185 us against the few microseconds of
 # the reference's jitted function (tools/dropin_latency.py), so replacing them would SLOW those loops down -- they are drop-in
 # equivalents for checking and for callers that move to the batched forms, patched only on request.
-_WHOLE_ENSEMBLE = ("prune_conformers_rmsd", "prune_conformers_tfd", "get_moi_similarity_matches", "_score_embed_poses")
+_WHOLE_ENSEMBLE = ("prune_conformers_rmsd", "prune_conformers_tfd", "get_moi_similarity_matches", "_score_embed_poses", "string_embed",
+                   "cyclical_embed")
 
 _saved = {}
 
 
 def install(modules=None, per_item=False):
     """Replace the hot-path functions in every already-imported tscode module: by default those that work on a whole ensemble
-    per call (prune_conformers_rmsd, prune_conformers_tfd, get_moi_similarity_matches, _score_embed_poses); with
+    per call (prune_conformers_rmsd, prune_conformers_tfd, get_moi_similarity_matches, _score_embed_poses) and the two embed
+    loops (string_embed, cyclical_embed: one GPU call each instead of one Python iteration per pose); with
     ``per_item=True`` also the per-pose / per-pair ones (compenetration_check, get_embed, rmsd_and_max_numba, ...), which are
     equivalent but slower than the reference's jitted code when called one item at a time.
     Returns the list of (module, attribute) pairs that were patched."""
@@ -59,6 +64,8 @@ def install(modules=None, per_item=False):
             mod = mods.get(name)
             if mod is not None and hasattr(mod, attr):
                 _saved.setdefault((name, attr), getattr(mod, attr))
+                if attr in ("string_embed", "cyclical_embed") and name == "tscode.embeds":
+                    embeds._originals[attr] = _saved[(name, attr)]      # what the drop-in hands the cases it does not cover to
                 setattr(mod, attr, fn)
                 done.append((name, attr))
     return done
@@ -71,3 +78,4 @@ def uninstall(modules=None):
         if mod is not None:
             setattr(mod, attr, fn)
         del _saved[(name, attr)]
+    embeds._originals.clear()
