@@ -262,6 +262,16 @@ int tsc_cyclical_embed(tsc_ctx *ctx, const double *frags, const int64_t *frag_of
                        int64_t max_clashes, double rmsd_thr, uint8_t *clash_ok, uint8_t *kept, double *poses, int64_t poses_capacity,
                        int64_t *n_pass, int64_t *n_kept);
 
+/* HOST-side helper (no device, no context): the graph step of tscode/numba_functions.py:201-226 (prune_conformers_tfd) and
+ * tscode/optimization_methods.py:341-358 (prune_by_moment_of_inertia) for any number of chunks: the matches (rel_i[q], rel_j[q]),
+ * q in [chunk_ptr[c], chunk_ptr[c+1]), of chunk c are node indices relative to the chunk (0 <= index < chunk_len[c]), listed in the
+ * order the reference adds them to its set (rows ascending); of every connected component of a chunk's match graph only
+ * `tuple(subgraph.nodes)[0]` is kept: keep[chunk_off[c] + node] is cleared for the others (keep u8[n_total], set by the caller).
+ * Which node that expression names is decided by CPython's set / dict iteration orders inside networkx 3.x; this call re-plays
+ * them (tscode_amd/csrc/host_order.hpp).  The Python caller checks the emulation against the real objects before relying on it. */
+int tsc_host_graph_step(const int64_t *rel_i, const int64_t *rel_j, const int64_t *chunk_ptr, const int64_t *chunk_off,
+                        const int64_t *chunk_len, int64_t n_chunks, int64_t n_total, uint8_t *keep);
+
 /* Per-pass statistics of a prune run (one entry per executed k of the schedule). */
 typedef struct {
     int64_t k;               /* number of chunks (tscode/rmsd_pruning.py:186-188) */

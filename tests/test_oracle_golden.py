@@ -215,6 +215,36 @@ def test_tfd_single_match_chunks_need_no_graph():
     assert np.array_equal(a, b) and a.sum() < n - 300
 
 
+def test_host_graph_step_replays_cpython_and_networkx():
+    """tsc_host_graph_step (tscode_amd/csrc/host_order.hpp: CPython's set / tuple-hash / dict orders and networkx's traversals
+    re-played on plain arrays) against the reference's own expression on the real objects: the package's start-up checks (small
+    graphs, and the one beyond 50 000 entries where CPython grows its tables by 2x instead of 4x), and whole passes of
+    _tfd_reject_matches through both paths."""
+    pytest.importorskip("networkx")
+    import tscode_amd.numba_functions as nf
+    assert nf._host_graph_step_ok() and nf._host_graph_step_ok(big=True)
+    rng = np.random.default_rng(17)
+    for n, d, k, density in ((5000, 10, 500, 0.5), (5000, 250, 20, 0.7), (30000, 30000, 1, 0.6), (12000, 6000, 2, 0.3), (999, 7, 142, 0.9)):
+        first = np.full(n, -1, dtype=np.int32)
+        for c in range(k):
+            lo = c * d
+            hi = n if c == k - 1 else lo + d
+            for i in range(lo, hi - 1):
+                if rng.random() < density:
+                    first[i] = rng.integers(i + 1, min(hi, i + 1 + int(rng.choice([1, 2, 5, 50, hi]))))
+        a, b = np.ones(n, dtype=bool), np.ones(n, dtype=bool)
+        nf._tfd_reject_matches(first, d, k, a)                      # library path (the checks above passed)
+        saved = dict(nf._HOST_GRAPH_STEP)
+        nf._HOST_GRAPH_STEP.update(small=False, big=False)
+        try:
+            nf._tfd_reject_matches(first, d, k, b)                  # Python path: the real set / networkx objects
+        finally:
+            nf._HOST_GRAPH_STEP.clear()
+            nf._HOST_GRAPH_STEP.update(saved)
+        assert np.array_equal(a, b), (n, d, k, int(a.sum()), int(b.sum()))
+        assert a.sum() < n
+
+
 def test_cluster_heads_shortcut_matches_networkx():
     """The member of a cluster that survives TFD / MOI pruning is tuple(subgraph.nodes)[0] (numba_functions.py:209-214): the
     shortcut that avoids one subgraph view per component must give the same member as networkx itself, on graphs built the

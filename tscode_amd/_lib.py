@@ -88,6 +88,7 @@ _SIGNATURES = {
                                    _vp, C.c_int, C.c_double, _vp, _vp, _vp, C.c_int64, c_i64p, c_i64p]),
     "tsc_cyclical_embed": (C.c_int, [_vp, _vp, c_i64p, c_i32p, c_i32p, C.c_int] + [_vp] * 10 + [C.c_int64, _vp, C.c_int, C.c_double, C.c_int64,
                                      C.c_double, _vp, _vp, _vp, C.c_int64, c_i64p, c_i64p]),
+    "tsc_host_graph_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp]),
     "tsc_prune_rmsd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_structures": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, C.c_double, C.c_int, _vp, C.POINTER(PassStats),
                                        C.POINTER(C.c_int)]),

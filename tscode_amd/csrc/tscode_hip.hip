@@ -11,6 +11,7 @@
 #include "csearch.hpp"
 #include "tfd.hpp"
 #include "moi.hpp"
+#include "host_order.hpp"
 
 #include <algorithm>
 
@@ -1422,6 +1423,26 @@ extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipMemcpyAsync(first, d_first, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the graph step of the similarity prunings on the host (host_order.hpp): no device involved
+extern "C" __attribute__((visibility("default"))) int tsc_host_graph_step(const int64_t *rel_i, const int64_t *rel_j, const int64_t *chunk_ptr,
+                                                                          const int64_t *chunk_off, const int64_t *chunk_len, int64_t n_chunks,
+                                                                          int64_t n_total, uint8_t *keep) {
+    TSC_REQUIRE(rel_i && rel_j && chunk_ptr && chunk_off && chunk_len && keep && n_chunks >= 0 && n_total >= 0, "tsc_host_graph_step: bad argument");
+    int64_t longest = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        TSC_REQUIRE(chunk_ptr[c + 1] >= chunk_ptr[c] && chunk_off[c] >= 0 && chunk_len[c] >= 0 && chunk_off[c] + chunk_len[c] <= n_total,
+                    "chunk %lld: bad bounds", (long long)c);
+        for (int64_t q = chunk_ptr[c]; q < chunk_ptr[c + 1]; ++q)
+            TSC_REQUIRE(rel_i[q] >= 0 && rel_i[q] < chunk_len[c] && rel_j[q] >= 0 && rel_j[q] < chunk_len[c] && rel_i[q] != rel_j[q],
+                        "match %lld lies outside its chunk", (long long)q);
+        longest = std::max(longest, chunk_len[c]);
+    }
+    std::vector<int32_t> index_of(size_t(longest), -1);
+    for (int64_t c = 0; c < n_chunks; ++c)
+        tsc_host::graph_step_chunk(rel_i + chunk_ptr[c], rel_j + chunk_ptr[c], chunk_ptr[c + 1] - chunk_ptr[c], chunk_off[c], keep, index_of);
     return 0;
 }
 

@@ -68,7 +68,78 @@ def _tfd_reject_matches(first, d, k, final_mask):
     final_mask[first[rows[single]]] = 0
     if len(single) == len(starts):
         return
-    _tfd_reject_graph(first, d, k, final_mask, [rows[a:a + n] for a, n in zip(starts.tolist(), sizes.tolist()) if n > 1])
+    multi = sizes > 1
+    if _host_graph_step_ok(big=int(sizes.max()) > 40000):
+        # the graph step of all the other chunks in ONE library call: the same insertions into CPython's hash tables and
+        # networkx's traversals, re-played on plain arrays (tscode_amd/csrc/host_order.hpp)
+        sel = np.concatenate([rows[a:a + n] for a, n in zip(starts[multi].tolist(), sizes[multi].tolist())])
+        chunk_ptr = np.concatenate(([0], np.cumsum(sizes[multi]))).astype(np.int64)
+        chunk_step = steps[starts[multi]]
+        chunk_off = (chunk_step.astype(np.int64) * int(d))
+        n_total = len(final_mask)
+        chunk_len = np.where(chunk_step == int(k) - 1, n_total - chunk_off, int(d)).astype(np.int64)
+        off_per_match = np.repeat(chunk_off, sizes[multi])
+        _host_graph_step(sel - off_per_match, first[sel].astype(np.int64) - off_per_match, chunk_ptr, chunk_off, chunk_len, final_mask)
+        return
+    _tfd_reject_graph(first, d, k, final_mask, [rows[a:a + n] for a, n in zip(starts[multi].tolist(), sizes[multi].tolist())])
+
+
+def _host_graph_step(rel_i, rel_j, chunk_ptr, chunk_off, chunk_len, keep_mask):
+    """tsc_host_graph_step: clears keep_mask (bool[N], in place) for every member of a cluster that is not the one the
+    reference's graph step keeps."""
+    import ctypes as C
+    from . import _lib
+    rel_i, rel_j, chunk_ptr, chunk_off, chunk_len = (np.ascontiguousarray(a, dtype=np.int64) for a in (rel_i, rel_j, chunk_ptr, chunk_off, chunk_len))
+    keep = keep_mask.view(np.uint8)
+    assert keep.flags.c_contiguous
+    _lib.check(_lib.load().tsc_host_graph_step(_lib.ptr(rel_i), _lib.ptr(rel_j), _lib.ptr(chunk_ptr), _lib.ptr(chunk_off), _lib.ptr(chunk_len),
+                                               C.c_int64(len(chunk_off)), C.c_int64(len(keep)), _lib.ptr(keep)))
+
+
+_HOST_GRAPH_STEP = {}          # {"small": bool, "big": bool}: tsc_host_graph_step reproduces this interpreter + networkx or not
+
+
+def _host_graph_step_ok(big=False):
+    """Is the library's re-play of CPython's set order and networkx's traversals (host_order.hpp) exact HERE?  Checked once per
+    process, on random match graphs of the shapes the prunings produce (rows with one match each, j > i), against the
+    reference's own expression `tuple(G.subgraph(c).nodes)[0]` on the real objects; graphs beyond 50 000 entries (CPython grows
+    its tables differently there) are checked when a chunk of that size first shows up.  Any difference (another interpreter,
+    another networkx) switches the library path off for the process; the Python path builds the real objects and is right by
+    construction."""
+    key = "big" if big else "small"
+    if key not in _HOST_GRAPH_STEP:
+        import random
+        shapes = ((60000, 52000),) if big else ((2, 1), (3, 2), (9, 6), (40, 30), (64, 50), (300, 220), (1000, 900), (2500, 1700))
+        try:
+            rnd = random.Random(20240)
+            ok = True
+            for n_nodes, n_rows in shapes:
+                rows = sorted(rnd.sample(range(n_nodes - 1), min(n_rows, n_nodes - 1)))
+                first = {i: rnd.randrange(i + 1, min(n_nodes, i + 1 + rnd.choice((1, 3, 40, n_nodes)))) for i in rows}
+                keep_ref = np.ones(n_nodes, dtype=bool)
+                _tfd_reject_graph_python(rows, first, 0, keep_ref)
+                keep = np.ones(n_nodes, dtype=bool)
+                ri = np.array(rows, dtype=np.int64)
+                rj = np.array([first[i] for i in rows], dtype=np.int64)
+                _host_graph_step(ri, rj, [0, len(ri)], [0], [n_nodes], keep)
+                ok = ok and np.array_equal(keep, keep_ref)
+            _HOST_GRAPH_STEP[key] = bool(ok)
+        except Exception:
+            _HOST_GRAPH_STEP[key] = False
+    return _HOST_GRAPH_STEP[key] and (not big or _host_graph_step_ok(False))
+
+
+def _tfd_reject_graph_python(rows, first, off, keep):
+    """One chunk with the reference's own objects and expression (numba_functions.py:190, :209-214, :222-224)."""
+    import networkx as nx
+    matches = set()
+    for i in rows:
+        matches.add((i - off, int(first[i]) - off))
+    g = nx.Graph(matches)
+    for c in nx.connected_components(g):
+        group = tuple(g.subgraph(c).nodes)
+        for i in group[1:]:
+            keep[i + off] = False
 
 
 _FAST_CLUSTER_HEADS = None       # None: not checked yet; True / False: the shortcut below reproduces this networkx or not
