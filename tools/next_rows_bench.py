@@ -123,6 +123,58 @@ dt, (_, mask) = best_of(lambda: tscode_amd.prune_conformers_tfd(s, quads), 1)
 line("N2", "tscode_amd.prune_conformers_tfd", ["k_torsion_fingerprints", "k_tfd_first_similar"], N, "structures", dt, dc, ns, True, s.nbytes + N,
      f"whole schedule, {N} structures, {int(mask.sum())} survive (oracle figure: its k = 1 pass on {ns} only)")
 
+# ---- N1: the embed loops as drivers: greedy TFD filter, whole string embed, whole cyclical embed ------------------------------
+NF, TQ = 100_000, 6
+par = rng.uniform(-180, 180, size=(12000, TQ))
+tfq = (par[rng.integers(0, len(par), size=NF)] + rng.normal(size=(NF, TQ)) * 0.5).astype(np.float32)
+eng.tfd_greedy_filter(tfq[:100])
+dt, acc = best_of(lambda: eng.tfd_greedy_filter(tfq), 1)
+ns = 20000
+dc, ref = timed(lambda: oracle.tfd_greedy_filter(tfq[:ns]))
+line("N1", "tsc_tfd_greedy_filter", ["k_tfd_greedy_filter"], NF, "fingerprints", dt, dc, ns, np.array_equal(eng.tfd_greedy_filter(tfq[:ns]), ref), tfq.nbytes + NF,
+     f"is_new_structure over {NF} fingerprints x {TQ} torsions, {int(acc.sum())} kept")
+
+ens3 = make_config("C3", 10)
+f1, f2 = ens3.frag_coords[0][:1], ens3.frag_coords[1][:1]           # two 25-atom fragments
+n1, n2 = f1.shape[1], f2.shape[1]
+conf1 = f1 + rng.normal(size=(20, n1, 3)) * 0.05
+conf2 = f2 + rng.normal(size=(25, n2, 3)) * 0.05
+cen1, cen2 = conf1[:, :2] + rng.normal(size=(20, 2, 3)), conf2[:, :3] + rng.normal(size=(25, 3, 3))
+ov1, ov2 = rng.normal(size=(20, 2, 3)), rng.normal(size=(25, 3, 3))
+quadsx = np.array([[0, 1, 2, 3], [n1 - 1, 0, n1, n1 + 1], [n1, n1 + 1, n1 + 2, n1 + 3], [2, 1, 0, n1]])
+sangles = [n * 10.0 for n in range(36)]
+tscode_amd.string_embed_batch(conf1[:1], conf2[:1], cen1[:1], ov1[:1], cen2[:1], ov2[:1], sangles, 1.5, 0, quadsx)
+dt, (sposes, tr) = best_of(lambda: tscode_amd.string_embed_batch(conf1, conf2, cen1, ov1, cen2, ov2, sangles, 1.5, 0, quadsx, return_trace=True), 2)
+NS = len(tr.kept)
+dc, (oc, ook, okept) = timed(lambda: oracle.string_embed(conf1[:2], conf2[:3], cen1[:2], ov1[:2], cen2[:3], ov2[:3], sangles, 1.5, quadsx))
+_, tr_s = tscode_amd.string_embed_batch(conf1[:2], conf2[:3], cen1[:2], ov1[:2], cen2[:3], ov2[:3], sangles, 1.5, 0, quadsx, return_trace=True)
+line("N1", "tsc_string_embed", ["k_string_embed_params", "k_clash", "k_transform", "k_torsion_fingerprints", "k_tfd_greedy_filter"], NS, "candidate poses", dt, dc, len(ook),
+     np.array_equal(tr_s.clash_ok, ook) and np.array_equal(tr_s.kept, okept), NS * (2 * 96 + 1) + int(tr.clash_ok.sum()) * (n1 + n2) * 24,
+     f"whole string embed: 20 x 25 conformers, 2 x 3 centre pairs, 36 angles = {NS} candidates of {n1 + n2} atoms, {int(tr.clash_ok.sum())} pass the clash check, {int(tr.kept.sum())} kept")
+
+mols = []
+for cf, ri in ((conf1[:8], [0, 5]), (conf2[:8], [1, 7])):
+    piv = []
+    for c in range(len(cf)):
+        # "orbital centres": the reactive atoms pushed 2.2 A away from the molecule's centroid, four variants each
+        out = cf[c][ri] - cf[c].mean(axis=0)
+        out /= np.linalg.norm(out, axis=1, keepdims=True)
+        st_ = cf[c][ri[0]] + 2.2 * out[0] + rng.normal(size=(4, 3)) * 0.3
+        en_ = cf[c][ri[1]] + 2.2 * out[1] + rng.normal(size=(4, 3)) * 0.3
+        piv.append((en_ - st_, 0.5 * (st_ + en_), np.tile(np.array([[ri[0], ri[1]]]), (4, 1))))
+    mols.append(dict(coords=cf, reactive_indices=ri, pivots=piv))
+cang = np.stack(np.meshgrid(np.linspace(-45, 45, 6), np.linspace(-45, 45, 6)), -1).reshape(-1, 2)
+tscode_amd.cyclical_embed_batch([dict(m, coords=m["coords"][:1], pivots=m["pivots"][:1]) for m in mols], cang, 1.5)
+dt, (cposes, ccons, ctr) = best_of(lambda: tscode_amd.cyclical_embed_batch(mols, cang, 1.5, return_trace=True), 2)
+NCY = len(ctr.kept)
+small = [dict(m, coords=m["coords"][:2], pivots=m["pivots"][:2]) for m in mols]
+dc, orc = timed(lambda: oracle.cyclical_embed([m["coords"] for m in small], [np.array(m["reactive_indices"]) for m in small], [m["pivots"] for m in small], cang, 1.5))
+_, _, ctr_s = tscode_amd.cyclical_embed_batch(small, cang, 1.5, return_trace=True)
+line("N1", "tsc_cyclical_embed", ["k_cyclical_embed_params", "k_clash", "k_transform", "k_greedy_group_filter"], NCY, "candidate poses", dt, dc, len(orc[2]),
+     np.array_equal(ctr_s.clash_ok, orc[2]) and np.array_equal(ctr_s.kept, orc[3]), NCY * (2 * 184 + 1) + int(ctr.clash_ok.sum()) * (n1 + n2) * 24,
+     f"whole cyclical embed: 8 x 8 conformers, 4 x 4 pivots, 2 orientations, 36 angle sets = {NCY} candidates in {len(ctr.groups)} groups, "
+     f"{int(ctr.clash_ok.sum())} pass the clash check, {int(ctr.kept.sum())} kept")
+
 # ---- N4: moments of inertia, MOI pair search, embed scores --------------------------------------------------------------------
 ens = make_config("C3", 100_000)
 structs = ens.poses()
