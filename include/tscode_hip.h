@@ -19,6 +19,17 @@
  *     context's stream and return without synchronising unless stated.
  *   - the caller owns every buffer it passes; the library keeps no pointer after return except
  *     inside a tsc_prune object, which borrows `heavy` until tsc_prune_destroy.
+ *   - MULTI-GPU, a deliberate deviation from SURVEY.md 8(b): that sketch has "multi-GPU variants take a device list / an RCCL
+ *     communicator held in tsc_ctx".  This library opens no communicator and spawns no process.  The path shards as one
+ *     process per GPU, each with a context of its own, and the exchange steps (one all-gather of the surviving heavy-atom
+ *     shards, one all-reduce(MIN) over best[] per sharded pass) belong to the HOST that owns the process group: in this
+ *     repository torch.distributed over RCCL (tscode_amd/pipeline.py::sharded_step), in a C host ncclAllGather /
+ *     ncclAllReduce on the same device pointers.  What the C ABI provides for it is the part only the library can do: a
+ *     rank's block of poses (tsc_embed_clash_compact_dev), the stepping form of the prune with the row tiles of a pass dealt to
+ *     (rank, world_size) and best[] in a caller-owned buffer the collective can run on (tsc_prune_create ..
+ *     tsc_prune_pass_local(rank, world_size) .. tsc_prune_use_best_buffer .. tsc_prune_pass_finish), and
+ *     tsc_ctx_set_stream, so that kernels and collectives are ordered on one stream.  Linking RCCL into the library would tie
+ *     it to one launcher and one communicator lifetime for no kernel's benefit.
  *   - a context (tsc_ctx: one device, its streams, its scratch cache) is for ONE thread at a time, like the reference's
  *     callers (single-threaded Python; multiembed.py uses processes): threads that want to work concurrently create a
  *     context each.  Any number of processes may use a device at once (tests/: three processes stepping one GPU).

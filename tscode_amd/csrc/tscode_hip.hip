@@ -1586,6 +1586,24 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(
 // --------------------------------------------------------------------------------------------------
 // the embed loops as drivers: string_embed (tscode/embeds.py:91-120) and cyclical_embed (:636-717, :771-847)
 
+// is_new_structure over fingerprints on the device (tfd.hpp): super-blocks of TG_SUPER candidates, two launches each.
+// d_acc u8[n], d_list i32[n], d_nk i32[1] (the number kept, on the device)
+static int launch_tfd_greedy(tsc_ctx *c, Scratch &s, const float *d_tf, int64_t n, int T, double thresh, uint8_t *d_acc, int32_t *d_list, int32_t *d_nk) {
+    uint8_t *d_dead;
+    TSC_TRY(s.get(size_t(TG_SUPER), &d_dead));
+    TSC_HIP(hipMemsetAsync(d_nk, 0, sizeof(int32_t), c->stream));
+    for (int64_t base = 0; base < n; base += TG_SUPER) {
+        const int nc = int(std::min<int64_t>(TG_SUPER, n - base));
+        TSC_HIP(hipMemsetAsync(d_dead, 0, size_t(nc), c->stream));
+        if (base > 0)
+            hipLaunchKernelGGL(k_tfd_greedy_prior, dim3(ceil_div(nc, 64), 16), dim3(256), 0, c->stream, d_tf, base, nc, T, thresh, (const int32_t *)d_list,
+                               (const int32_t *)d_nk, d_dead);
+        hipLaunchKernelGGL(k_tfd_greedy_block, dim3(1), dim3(TG_THREADS), 0, c->stream, d_tf, base, nc, T, thresh, (const uint8_t *)d_dead, d_acc, d_list, d_nk);
+    }
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_tfd_greedy_filter(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, double thresh,
                                                                             uint8_t *accepted, int64_t *n_kept) {
     TSC_REQUIRE(c && tf && accepted, "tsc_tfd_greedy_filter: null argument");
@@ -1601,8 +1619,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_tfd_greedy_filter(tsc_
     TSC_TRY(s.get(size_t(n_structs), &d_acc));
     TSC_TRY(s.get(size_t(n_structs), &d_list));
     TSC_TRY(s.get(1, &d_nk));
-    hipLaunchKernelGGL(k_tfd_greedy_filter, dim3(1), dim3(TG_THREADS), 0, c->stream, (const float *)d_tf, n_structs, n_quads, thresh, d_acc, d_list, d_nk);
-    TSC_HIP(hipGetLastError());
+    TSC_TRY(launch_tfd_greedy(c, s, d_tf, n_structs, n_quads, thresh, d_acc, d_list, d_nk));
     TSC_HIP(hipMemcpyAsync(accepted, d_acc, size_t(n_structs), hipMemcpyDeviceToHost, c->stream));
     int32_t nk = 0;
     TSC_TRY(read_i32(c, d_nk, &nk));
@@ -1708,9 +1725,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed(tsc_ctx *
         if (n_quads)
             hipLaunchKernelGGL(k_torsion_fingerprints, dim3(grid_for(int64_t(np) * n_quads, 256, 256 * 8)), dim3(256), 0, c->stream, d_structs, int64_t(np), n,
                                (const int32_t *)d_quads, n_quads, d_tf);
-        hipLaunchKernelGGL(k_tfd_greedy_filter, dim3(1), dim3(TG_THREADS), 0, c->stream, (const float *)d_tf, int64_t(np), n_quads, tfd_thresh, d_acc, d_list, d_nk);
         TSC_HIP(hipGetLastError());
-        return 0;
+        return launch_tfd_greedy(c, s, d_tf, int64_t(np), n_quads, tfd_thresh, d_acc, d_list, d_nk);
     };
     return embed_filter_run(c, s, d_frags, ft, frag_off, n_atoms, n_conf, d_ci, d_rot, d_pos, N, clash_thresh, max_clashes, clash_ok, kept, poses, poses_capacity,
                             n_pass, n_kept, filter);
