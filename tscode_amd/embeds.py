@@ -180,31 +180,42 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
         mean = [np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in pv]
         cum = [np.asarray(p[2]).reshape(-1, 2) for p in pv]
         rc = [coords[m][conf_ids[m]][reactive[m]] for m in range(2)]                                 # reactive_coords, :667
-        for pi in cartesian_product(*[np.arange(len(v)) for v in vec]):                              # :477
-            norms = np.linalg.norm(np.array([vec[m][pi[m]] for m in range(2)]), axis=1)              # :487
-            delta = abs(norms[0] - norms[1])
-            if (delta > max_norm_delta) if rigid_shortcut else not (delta < max_norm_delta):         # :762 / :492-496, :630-631
-                continue
-            polygon_vectors = polygonize(norms)                                                      # :507 / :766
-            for v, vecs in enumerate(polygon_vectors):
-                ids = _reactive_pair_indices([cum[m][pi[m]] for m in range(2)], v)
+        # every pivot pair of this conformer pair at once (the order of pivots_indices, :477), both polygon orientations
+        pi = cartesian_product(*[np.arange(len(v)) for v in vec])
+        if not len(pi):
+            continue
+        norms = np.stack([np.linalg.norm(vec[m][pi[:, m]], axis=1) for m in range(2)], axis=1)       # :487
+        delta = np.abs(norms[:, 0] - norms[:, 1])
+        ok = ~(delta > max_norm_delta) if rigid_shortcut else (delta < max_norm_delta)               # :762 / :492-496, :630-631
+        pi, norms = pi[ok], norms[ok]
+        n_pi = len(pi)
+        if not n_pi:
+            continue
+        # polygonize(norms) for two lengths (tscode/utils.py:224-232): both segments centred on the origin along x,
+        # orientation 1 = the second one reversed (vertices_out[1, 1] *= -1)
+        half = norms / 2.0
+        rec = np.zeros((n_pi, 2, 2, 23))                                                             # [pivot pair, orientation, molecule, field]
+        for m in range(2):
+            rec[:, 0, m, 0], rec[:, 0, m, 3] = -half[:, m], +half[:, m]                                # start.x, end.x
+            rec[:, 1, m, 0], rec[:, 1, m, 3] = (-half[:, m], +half[:, m]) if m == 0 else (+half[:, m], -half[:, m])
+            r = rc[m]
+            rec[:, :, m, 6:9] = directions[m]
+            rec[:, :, m, 9:12] = vec[m][pi[:, m]][:, None, :]
+            rec[:, :, m, 12:15] = mean[m][pi[:, m]][:, None, :]
+            rec[:, :, m, 15:18], rec[:, :, m, 18:21] = r[0], r[1] if len(r) == 2 else r[0]
+            rec[:, :, m, 21], rec[:, :, m, 22] = len(r), conf_ids[m]
+        for q in range(n_pi):
+            for v in range(2):
+                ids = _reactive_pair_indices([cum[m][pi[q, m]] for m in range(2)], v)
                 if pairings and not all((list(pair) in ids) or (list(pair) in [list(c) for c in internal_constraints]) for pair in pairings):
                     continue                                                                         # :642 / :777
-                rows = np.empty((A, 2, 23))
-                for m in range(2):
-                    start, end = vecs[m]
-                    r = rc[m]
-                    rows[:, m, 0:3], rows[:, m, 3:6], rows[:, m, 6:9] = start, end, directions[m]
-                    rows[:, m, 9:12], rows[:, m, 12:15] = vec[m][pi[m]], mean[m][pi[m]]
-                    rows[:, m, 15:18], rows[:, m, 18:21] = r[0], r[1] if len(r) == 2 else r[0]
-                    rows[:, m, 21], rows[:, m, 22] = len(r), conf_ids[m]
-                blocks.append(rows)
-                groups.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi), v, ids))
+                blocks.append(rec[q, v])
+                groups.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi[q]), v, ids))
     n_total = sum(c.shape[1] for c in coords)
     if not blocks:
         out = (np.zeros((0, n_total, 3)), np.zeros((0, 2, 2), dtype=np.int64))
         return (*out, EmbedTrace(clash_ok=np.zeros(0, bool), kept=np.zeros(0, bool), group_of=np.zeros(0, np.int64), groups=[])) if return_trace else out
-    rows = np.concatenate(blocks).reshape(-1, 23)
+    rows = np.repeat(np.stack(blocks), A, axis=0).reshape(-1, 23)                                    # a group's A poses share everything but the angles
     angle_rows = np.tile(angles, (len(blocks), 1)).reshape(-1)                                       # angles[i] for molecule i, :665
     group_off = np.arange(len(blocks) + 1, dtype=np.int32) * A
     ok, kept, poses = get_engine().cyclical_embed(FragmentSet(coords), rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15],
