@@ -1259,13 +1259,13 @@ def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
     assert (res2["n_conformers"], res2["n_pass"], res2["n_keep"]) == (res["n_conformers"], res["n_pass"], res["n_keep"])
 
 
-@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000)])
+@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0)])
 def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     """The multi-rank protocol on the product backend (HIP kernels), several ranks sharing this box's one GPU: gloo as the
     transport (device tensors staged over the host), everything else as under RCCL -- pose blocks, all-gather of the
     survivors' heavy atoms, row tiles of the large passes dealt round-robin with all-reduce(MIN), small passes replicated.
-    C3 with two ranks against the recorded oracle result; C2 with three ranks and the sharding threshold lowered so that
-    small passes are sharded too, against the oracle run here."""
+    C3 with two and four ranks and C4 (1M x 50) with three against the recorded oracle results; C2 with three ranks and the
+    sharding threshold lowered so that small passes are sharded too, against the oracle run here."""
     import json
     import os
     import subprocess
@@ -1274,13 +1274,13 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     port = 29600 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "sharded_gpu_worker.py"), cfg, str(n_poses), str(min_pairs)]
-    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420)
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     got = json.loads(line)
     assert got["world"] == world and got["ranks_agree"] and got["steps_that_differ"] == 0
-    if cfg == "C3":
-        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))["C3:100000:mode0"]
+    if cfg in ("C3", "C4"):                              # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
+        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))[{"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0"}[cfg]]
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
         assert got["pairs_evaluated"] == [p["pairs_evaluated"] for p in exp["passes"]]
     else:
