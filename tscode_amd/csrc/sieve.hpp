@@ -740,7 +740,11 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
                     rows &= rows - 1;
                     const int r = r0 + t;
                     const int ce = __builtin_amdgcn_readlane(my_cend, t);
+#ifdef TSC_DBG_NOROWLOAD      // (measurement hook: every row of a tile uses row 0's record -- wrong verdicts, the screen without its per-row LDS reads)
+                    const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc);
+#else
                     const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc + t * RS);
+#endif
                     f32x2 rd[KD];
 #pragma unroll
                     for (int k = 0; k < KD; ++k) rd[k] = rec[k];
@@ -843,8 +847,10 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         // the next tile's columns (loaded here, after the drain, so that they do not occupy registers during it)
         c0 += TILE_COLS;
         if (!(c0 < cmax && alive)) break;
+#ifndef TSC_DBG_NOTILELOAD   // (measurement hook: keep the first tile's descriptors -- wrong verdicts, the screen without its global loads)
         load_cols(c0);
         load_tile();
+#endif
     }
 #ifdef TSC_DBG_NODRAIN
     qn = 0;
