@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): per-kernel durations of a bench command (rocprofv3 --kernel-trace --stats), printed per step.
+# usage: tools/kstats.sh OUTDIR [bench.py arguments]        (outputs under gpurun_out/OUTDIR)
+set -e
+P=gpurun_out/$1; shift
+mkdir -p "$P"
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-side-leg $* > "$P/bench.json" 2> "$P/trace.err"
+python3 - "$P" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+steps = 12
+tot = 0
+for r in rows:
+    tot += int(r["TotalDurationNs"])
+    print(f'{r["Name"][:70]:70s} calls/step {int(r["Calls"]) / steps:6.1f}  avg {float(r["AverageNs"]) / 1e3:8.2f} us  per step {int(r["TotalDurationNs"]) / steps / 1e3:8.1f} us')
+print("sum of kernel time per step (us):", tot / steps / 1e3)
+PY

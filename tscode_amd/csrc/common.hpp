@@ -80,6 +80,8 @@ struct tsc_ctx {
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int local_max_chunk = 256;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
+    int fused_apply = 1;                  // single-rank sieve passes: the pair kernel applies the verdicts tile by tile and closes the pass (sieve.hpp)
+    int open_lds_blocks = 1 << 30;        // k_open_rows stages the scan-block prefix in LDS up to this many blocks (tests lower it to take the other path)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback
     int pass_timing = 0;                  // HIP events per pass: 0 none, 1 on the pair kernel's dispatch, 2 also around the whole pass
     // basis estimated by tsc_embed_clash_compact_dev beside its clash kernel, for the tsc_prune_create that follows (consumed once)

@@ -3,8 +3,8 @@
 // A pass only ever compares structures of the same chunk (tscode/rmsd_pruning.py:136-147), so when the longest chunk of
 // a pass holds at most LP_MAX_ROWS structures a workgroup can own a chunk end to end: it ranks the chunk's active
 // structures (the mask bits, by ballot), finds every row's stop column in the cache view, screens and evaluates the
-// pairs, and applies the verdicts (mask, cache keys, scan counts, statistics) -- the work of k_open_pass, k_stop_scan,
-// k_rmsd_sieve and k_apply_pass without the three kernel boundaries in between.  The host takes this path for passes
+// pairs, and applies the verdicts (mask, cache keys, scan counts, statistics) -- the work of k_open_rows, k_rmsd_sieve and the
+// tile-wise apply without the kernel boundary in between.  The host takes this path for passes
 // whose chunks are a few row tiles long and for small ensembles (see tsc_prune_pass_local), where a pass is bound by
 // launch latency, not by work.
 //
@@ -39,9 +39,10 @@ struct LocalPassArgs {
     const unsigned *dmax_bits;
 };
 
-struct LocalTickets {  // zeroed by k_init_run and again by the block that closes a pass
+struct LocalTickets {  // zeroed by k_init_run and again by the wavefront that closes a pass
     unsigned group[LP_TICKET_GROUPS][32];  // one counter per 128-byte line
     unsigned top;
+    unsigned pad[31];
 };
 
 __device__ inline unsigned long long lds_extract64(const unsigned long long *bits, int start) {
@@ -52,13 +53,11 @@ __device__ inline unsigned long long lds_extract64(const unsigned long long *bit
 }
 
 __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
-                                                             const unsigned long long *__restrict__ mbit,
+                                                             unsigned long long *__restrict__ bits, int bit_words,
                                                              const unsigned long long *__restrict__ dbit, const double *__restrict__ heavy,
                                                              const double *__restrict__ Gall, const float *__restrict__ D,
-                                                             int32_t *__restrict__ key_a, int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
-                                                             PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items,
-                                                             PassRecord *__restrict__ rec, StepArgs next, unsigned long long *__restrict__ dbit_rw,
-                                                             LocalTickets *__restrict__ tickets) {
+                                                             CacheViews cv, PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items,
+                                                             StepCtx sc, StepArgs next, LocalTickets *__restrict__ tickets) {
     __shared__ unsigned long long s_mb[LP_WORDS + 2], s_db[LP_WORDS + 2];
     __shared__ unsigned short s_wpre[LP_WORDS + 2];
     __shared__ unsigned short s_act[LP_MAX_ROWS], s_cend[LP_MAX_ROWS];
@@ -66,13 +65,16 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
     __shared__ unsigned short s_queue[LP_WAVES][LP_QCAP], s_exq[LP_WAVES][128];
     __shared__ __attribute__((aligned(16))) float s_rowdesc[LP_WAVES][LP_TI * DW];
     __shared__ unsigned long long s_stat[8];  // block totals of the five statistics
-    __shared__ unsigned long long s_sum[32];
     __shared__ int s_A, s_anydb, s_last;
     static_assert(DW == 16 && LP_TI * DW == 256, "row staging: 4 rows x 16 components per 64 lanes");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool pass_on = st->pass_on != 0;
+    // the pass reads one bit copy of the mask and clears the rows it removes in the other (every row of a pass sees the mask
+    // as it was when the pass began, rmsd_pruning.py:151-157, whatever order the workgroups run in)
+    const unsigned long long *mbit = bits + size_t(st->bitsel) * bit_words;
+    unsigned long long *mbit_next = bits + size_t(st->bitsel ^ 1) * bit_words;
     // which chunk, and which share of its row tiles
     int c, j, nb;
     {
@@ -90,9 +92,11 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0, n_evaluated = 0, n_removed = 0;
 
     if (pass_on) {
-        // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures.  The mask comes from the snapshot
-        // k_dbit_build took before this launch (mbit), NOT from the byte mask: other workgroups -- of this very chunk when it
-        // is shared -- clear bytes of it in step 4, and they may be done before this one starts
+        // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures.  The other bit copy may lag one pass
+        // behind (a superset of this one): and-ing this chunk's words into it brings it up to date, and commutes with the
+        // bits other workgroups -- of this very chunk when it is shared -- clear there in step 4
+        if (j == 0)
+            for (int w = (first >> 6) + tid; w <= ((first + L - 1) >> 6); w += LP_THREADS) atomicAnd(&mbit_next[w], mbit[w]);
         for (int w = tid; w < nw; w += LP_THREADS) {
             unsigned long long m = extract64(mbit, int64_t(first) + 64 * w);
             unsigned long long v = a.use_cache ? extract64(dbit, int64_t(first) + 64 * w) : 0ull;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                 if (b != INT_MAX) {
                     const int t_r = s_act[r], t_b = s_act[b];
                     mask[first + t_r] = 0;
+                    atomicAnd(&mbit_next[(first + t_r) >> 6], ~(1ull << ((first + t_r) & 63)));
                     my_block = (first + t_r) / block_items;
                     delta = t_b - t_r;
                     removed = true;
@@ -315,18 +320,8 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                 if (lane == l) atomicSub(&bsum[blk], __popcll(same));
                 left &= ~same;
             }
-            const unsigned long long rm = __builtin_amdgcn_ballot_w64(removed);
-            const int n_rm = __popcll(rm);
-            if (n_rm) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(n_keys, n_rm);
-                base = __shfl(base, 0);
-                if (removed) {
-                    const int slot = base + __popcll(rm & lt_mask);
-                    key_a[slot] = first;
-                    key_b[slot] = first + delta;
-                }
-            }
+            const int n_rm = __popcll(__builtin_amdgcn_ballot_w64(removed));
+            views_insert_wave(cv, removed, first, first + delta);  // the cache keys (:69-73), where later passes will look for them
             for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
             n_evaluated += ev, n_removed += (unsigned long long)n_rm;
         }
@@ -356,10 +351,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
         s_last = last;
     }
     __syncthreads();
-    if (!s_last) return;
-    pass_step_block(st, cnt, rec, next, dbit_rw, s_sum);
-    if (tid < LP_TICKET_GROUPS) tickets->group[tid][0] = 0;
-    if (tid == 0) tickets->top = 0;
+    if (s_last && tid < 64) pass_step_wave(sc, next);  // (zeroes the tickets as well)
 }
 
 }  // namespace tsc

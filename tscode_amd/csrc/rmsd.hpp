@@ -298,119 +298,256 @@ __device__ inline void count_add(PassCounters *c, unsigned bucket, int what, uns
 }
 
 // Device-resident control block of a prune run.  The host enqueues every pass that COULD run (20 k < N) without
-// waiting for counts; k_pass_step evaluates the reference's gate `k == 1 or 20*k < count_nonzero(mask)`
-// (rmsd_pruning.py:192) on the device and the kernels of a pass that is gated off return immediately.
+// waiting for counts; the kernel that closes a pass evaluates the reference's gate `k == 1 or 20*k < count_nonzero(mask)`
+// (rmsd_pruning.py:192) for the next one on the device, and the kernels of a pass that is gated off return immediately.
 struct PruneState {
     int n_active;  // count_nonzero(mask) after the last finished pass
     int pass_on;   // gate of the pass in flight
     int A;         // active structures entering the pass in flight (== n_active at its start)
     unsigned ticket;  // blocks of k_apply_pass that have finished (the last one closes the pass)
+    int bitsel;    // which of the two bit copies of the mask the pass in flight READS (it clears the rows it removes in the other)
 };
 struct PassRecord {  // one per schedule slot, read back once at the end of the run
     long long k, n_before, n_after, formed, exact, screened, evaluated, removed;
     int on, algo;
 };
 
-// Initial state of a run: out_mask = ones (rmsd_pruning.py:182), empty cache (:183), zeroed bitmaps, records and counters.
-__global__ __launch_bounds__(256) void k_init_run(int64_t n, uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit,
-                                                   unsigned long long *__restrict__ dbit, int bit_words, int32_t *__restrict__ n_keys,
-                                                   PruneState *__restrict__ st, PassRecord *__restrict__ rec, int n_rec,
-                                                   PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int n_blocks, int block_items,
-                                                   unsigned *__restrict__ dmax_bits, unsigned *__restrict__ zero_words, int n_zero_words,
-                                                   int32_t *__restrict__ act, int first_slot, long long first_k, int first_algo, int dbit_extra_words) {
+// "Every unit of this pass has finished": two-level arrival counter (same-address atomics serialise at ~12 ns each, so
+// thousands of arrivals go to PT_GROUPS counters on separate 128-byte lines and only the last of a group to the top).
+constexpr int PT_GROUPS = 64;
+struct PassTickets {  // zeroed by k_init_run and again by the wavefront that closes a pass
+    unsigned group[PT_GROUPS][32];
+    unsigned top;
+    unsigned pad[31];
+};
+// one lane calls this for unit `unit` of `n_units`; true for the arrival that completes the pass
+__device__ inline bool tickets_arrive(PassTickets *tk, unsigned unit, unsigned n_units, unsigned n_groups) {
+    const unsigned grp = unit % n_groups;
+    const unsigned in_group = (n_units - grp + n_groups - 1) / n_groups;
+    if (atomicAdd(&tk->group[grp][0], 1u) != in_group - 1) return false;
+    const unsigned groups = n_units < n_groups ? n_units : n_groups;
+    return atomicAdd(&tk->top, 1u) == groups - 1;
+}
+
+// The similarity cache of the reference (rmsd_pruning.py:65-76, :204) as one bitmap PER FUTURE PASS.  A row removed in a
+// pass leaves the key (a, b) = (first, first + (j - i)); a later pass hits that key only where `a` is the start of one of
+// ITS chunks and `b` lies inside that chunk -- and then exactly for the pairs with first + (j - i) == b.  The schedule of
+// a run is known when it starts, so the kernel that removes a row sets bit b in the view of every later pass the key
+// applies to (a handful of integer divisions per removed row; few keys apply anywhere) and no pass has to walk the key
+// list before it can start.  Behind the n-bit view of a pass sits its summary, one bit per 1024 view bits: the stop-column
+// search walks only non-empty blocks.
+constexpr int MAX_SLOTS = 18;
+struct ViewPass {  // one view's pass: k chunks of cs = n // k structures; a / cs == (a * magic) >> shift for every a < 2^31
+    int k, cs;
+    unsigned magic;
+    int shift;
+};
+struct CacheViews {
+    unsigned long long *views;  // [count][stride] words
+    long long stride;           // words per view: bit_words + summary words
+    int bit_words;
+    int n;                      // structures of the run
+    int first, count;           // views first .. count - 1 belong to the passes after the one in flight
+    const ViewPass *pass;       // [count]
+};
+// Division by an invariant: m = floor(2^(31+L) / d) + 1 with L = ceil(log2 d) divides every 31-bit dividend exactly
+// (Granlund & Montgomery 1994, theorem 4.2 with N = 31); m < 2^32.
+inline ViewPass view_pass(int n, int k) {
+    ViewPass v;
+    v.k = k, v.cs = n / k;
+    int L = 0;
+    while ((1ll << L) < (long long)v.cs) ++L;
+    v.magic = unsigned(((1ull << (31 + L)) / (unsigned long long)v.cs) + 1ull);
+    v.shift = 31 + L;
+    return v;
+}
+// A whole wavefront calls this with one removed row per lane (or none): key (a, b) of lane `removed`.  The loop over the later
+// passes is wave-uniform (their parameters come by scalar loads); the summary words, which every key of a chunk shares, take
+// one atomic per wavefront and word instead of one per key (same-address atomics serialise at ~12 ns each).
+__device__ inline void views_insert_wave(const CacheViews &cv, bool removed, int a, int b) {
+    if (__ballot(removed) == 0) return;
+    const int lane = threadIdx.x & 63;
+    for (int j = cv.first; j < cv.count; ++j) {
+        const ViewPass vp = cv.pass[j];
+        bool ok = false;
+        if (removed) {
+            const int c = int(((unsigned long long)unsigned(a) * vp.magic) >> vp.shift);
+            if (c * vp.cs == a && c < vp.k) ok = b < ((c == vp.k - 1) ? cv.n : vp.cs * (c + 1));
+        }
+        unsigned long long left = __ballot(ok);
+        if (!left) continue;
+        unsigned long long *v = cv.views + int64_t(j) * cv.stride;
+        if (ok) atomicOr(&v[b >> 6], 1ull << (b & 63));
+        while (left) {
+            const int leader = __ffsll((long long)left) - 1;
+            const int word = __shfl(b >> 16, leader);
+            const bool same = ok && (b >> 16) == word;
+            unsigned long long sb = same ? 1ull << ((b >> 10) & 63) : 0ull;
+            for (int off = 32; off > 0; off >>= 1) sb |= __shfl_xor(sb, off);
+            if (lane == leader) {
+                unsigned long long *ds = v + cv.bit_words + word;
+                if ((__hip_atomic_load(ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & sb) != sb) atomicOr(ds, sb);
+            }
+            left &= ~__ballot(same);
+        }
+    }
+}
+
+// Initial state of a run: out_mask = ones (rmsd_pruning.py:182), empty cache (:183), zeroed records, counters, tickets.
+struct InitArgs {
+    int64_t n;
+    uint8_t *mask;
+    unsigned long long *bits;  // two copies of the mask as bits, bit_words each
+    int bit_words;
+    unsigned long long *views;  // cache views of every pass of the schedule + their summaries
+    int64_t view_words;
+    ViewPass *view_pass;        // device copy of the schedule
+    int n_views;
+    ViewPass sched[MAX_SLOTS];
+    PruneState *st;
+    PassRecord *rec;
+    int n_rec;
+    PassCounters *cnt;
+    int32_t *bsum, *boff;       // per scan block: active structures in it / before it
+    int n_blocks, block_items;
+    unsigned *dmax_bits;
+    unsigned *zero_words;       // arrival counters of the kernels that close a pass
+    int64_t n_zero_words;
+    int32_t *tile_done;         // arrivals per row tile of the fused pair kernel
+    int64_t n_tile_done;
+    int32_t *act;
+    int first_slot;
+    long long first_k;
+    int first_algo;
+};
+__global__ __launch_bounds__(256) void k_init_run(InitArgs a) {
     // first_slot >= 0: the first pass of the schedule is opened here as well (gate of rmsd_pruning.py:192 on the full count,
     // its record), which is all a k_pass_step launch would do at this point
+    const int64_t n = a.n;
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
-    unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mask);  // scratch blocks are 256-byte aligned
+    unsigned long long *m8 = reinterpret_cast<unsigned long long *>(a.mask);  // scratch blocks are 256-byte aligned
     for (int64_t e = tid; e < n / 8; e += stride) m8[e] = 0x0101010101010101ull;
-    for (int64_t e = (n / 8) * 8 + tid; e < n; e += stride) mask[e] = 1;
+    for (int64_t e = (n / 8) * 8 + tid; e < n; e += stride) a.mask[e] = 1;
     // every entry of the active list is a valid structure index from the start: the pair kernel gathers through
-    // act[x] for x up to n without knowing the active count, and the first global pass may come after chunk-local ones
-    for (int64_t e = tid; e < n; e += stride) act[e] = int32_t(e);
-    for (int64_t e = tid; e < bit_words; e += stride) mbit[e] = 0, dbit[e] = 0;
-    for (int64_t e = tid; e < dbit_extra_words; e += stride) dbit[bit_words + e] = 0;  // the summary bitmap behind dbit
-    unsigned long long *c = &cnt->w[0][0];
-    for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
-    for (int64_t e = tid; e < n_zero_words; e += stride) zero_words[e] = 0;  // tickets of the chunk-local pass kernel
-    char *r = reinterpret_cast<char *>(rec);
-    for (int64_t e = tid; e < int64_t(n_rec) * int64_t(sizeof(PassRecord)); e += stride)
-        if (int(e / int64_t(sizeof(PassRecord))) != first_slot) r[e] = 0;  // (the first pass's record is written whole below)
-    // per-block counts of the mask for the exclusive scan of every pass; k_apply_pass keeps them current
-    for (int64_t e = tid; e < n_blocks; e += stride) {
-        const int64_t lo = e * block_items;
-        bsum[e] = int32_t(lo >= n ? 0 : (n - lo < block_items ? n - lo : block_items));
+    // act[x] for x up to n without knowing the active count
+    for (int64_t e = tid; e < n; e += stride) a.act[e] = int32_t(e);
+    for (int64_t e = tid; e < a.bit_words; e += stride) {  // n ones, zeros behind them, in both copies
+        const int64_t lo = e * 64;
+        const unsigned long long w = lo + 64 <= n ? ~0ull : (lo >= n ? 0ull : ((1ull << (n - lo)) - 1ull));
+        a.bits[e] = w, a.bits[a.bit_words + e] = w;
     }
+    for (int64_t e = tid; e < a.view_words; e += stride) a.views[e] = 0;
+    unsigned long long *c = &a.cnt->w[0][0];
+    for (int64_t e = tid; e < CNT_BUCKETS * CNT_WORDS; e += stride) c[e] = 0;
+    for (int64_t e = tid; e < a.n_zero_words; e += stride) a.zero_words[e] = 0;
+    for (int64_t e = tid; e < a.n_tile_done; e += stride) a.tile_done[e] = 0;
+    char *r = reinterpret_cast<char *>(a.rec);
+    for (int64_t e = tid; e < int64_t(a.n_rec) * int64_t(sizeof(PassRecord)); e += stride)
+        if (int(e / int64_t(sizeof(PassRecord))) != a.first_slot) r[e] = 0;  // (the first pass's record is written whole below)
+    // per-block counts of the mask and their exclusive prefix: what ranks an active structure (k_open_rows); the kernels
+    // that remove rows keep the counts current, the one that closes a pass the prefix
+    for (int64_t e = tid; e <= a.n_blocks; e += stride) {
+        const int64_t lo = e * a.block_items;
+        if (e < a.n_blocks) a.bsum[e] = int32_t(lo >= n ? 0 : (n - lo < a.block_items ? n - lo : a.block_items));
+        a.boff[e] = int32_t(lo >= n ? n : lo);
+    }
+    if (tid < a.n_views) a.view_pass[tid] = a.sched[tid];
     if (tid == 0) {
-        n_keys[0] = 0;
-        if (dmax_bits) *dmax_bits = 0;  // running maximum of the descriptor build (sieve.hpp)
-        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0;
-        if (first_slot >= 0) {
-            const int on = (first_k == 1 || 20 * first_k < (long long)n) ? 1 : 0;
-            PassRecord &fr = rec[first_slot];
-            fr.k = first_k, fr.n_before = fr.n_after = (long long)n, fr.on = on, fr.algo = first_algo;
+        if (a.dmax_bits) *a.dmax_bits = 0;  // running maximum of the descriptor build (sieve.hpp)
+        PruneState *st = a.st;
+        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0, st->bitsel = 0;
+        if (a.first_slot >= 0) {
+            const int on = (a.first_k == 1 || 20 * a.first_k < (long long)n) ? 1 : 0;
+            PassRecord &fr = a.rec[a.first_slot];
+            fr.k = a.first_k, fr.n_before = fr.n_after = (long long)n, fr.on = on, fr.algo = a.first_algo;
             fr.formed = fr.exact = fr.screened = fr.evaluated = fr.removed = 0;
             st->pass_on = on;
         }
     }
 }
 
-// Closes the pass in slot `prev` (sums its counters, updates n_active) and opens the pass in slot `cur` (gate, A,
-// zeroed counters and cache-view bitmap).  prev / cur = -1: nothing to close / open.  Runs in ONE block of 256
-// threads: the last block of k_apply_pass (below) or, for the first pass of a run, k_pass_step.
+// Closes the pass in slot `prev` (sums its counters, updates n_active, re-ranks the scan blocks, flips the bit copy) and
+// opens the pass in slot `cur` (gate, A, zeroed counters).  prev / cur = -1: nothing to close / open.  Runs in ONE
+// WAVEFRONT: of the last unit of the closing pass to finish -- a row tile of the pair kernel, a block of k_apply_pass or of
+// k_pass_chunks -- or, where no pass precedes, of k_pass_step.
 struct StepArgs {
     int prev, cur;
     long long k_cur;
     int algo_cur;
-    int bit_words;
     int prev_algo;  // >= 0: the kernel that really ran the closing pass (recorded in its PassRecord), -1: as opened
 };
+struct StepCtx {
+    PruneState *st;
+    PassCounters *cnt;
+    PassRecord *rec;
+    int32_t *bsum, *boff;
+    int n_blocks;
+    unsigned *tickets;  // every arrival counter of the run (PassTickets and the chunk-local kernel's: one per 128-byte line), zeroed on the way out
+    int ticket_lines;
+};
 
-__device__ inline void pass_step_block(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec, const StepArgs &sa,
-                                       unsigned long long *__restrict__ dbit, unsigned long long *s_sum /* 32 words of LDS */) {
-    const bool closing = sa.prev >= 0 && st->pass_on != 0;
+__device__ inline void pass_step_wave(const StepCtx &sc, const StepArgs &sa) {
+    PruneState *st = sc.st;
+    const int lane = threadIdx.x & 63;
+    static_assert(CNT_BUCKETS == 64 && CNT_REMOVED == 4, "one bucket per lane, five statistics");
+    // the buckets and block counts were written by other CUs' atomics: read at the L2, not through this CU's cache.  All
+    // loads of the step are issued before the first is used (one memory round trip, not seven)
+    const int pass_on = st->pass_on, n_before = st->n_active, bitsel = st->bitsel;
+    unsigned long long v0 = __hip_atomic_load(&sc.cnt->w[lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v1 = __hip_atomic_load(&sc.cnt->w[lane][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v2 = __hip_atomic_load(&sc.cnt->w[lane][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v3 = __hip_atomic_load(&sc.cnt->w[lane][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v4 = __hip_atomic_load(&sc.cnt->w[lane][4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int c_first = lane < sc.n_blocks ? __hip_atomic_load(&sc.bsum[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const bool closing = sa.prev >= 0 && pass_on != 0;
+    unsigned long long sum[CNT_REMOVED + 1] = {v0, v1, v2, v3, v4};
     if (closing) {
-        // 256 threads, two loads each (word t % 8 of buckets t / 8 and t / 8 + 32), all in flight together; the buckets
-        // were written by other blocks' atomics, so they are read at the L2, not through this CU's cache
-        static_assert(CNT_BUCKETS == 64 && CNT_REMOVED < 8, "layout of the parallel counter sum");
-        const int w = threadIdx.x & 7, b0 = threadIdx.x >> 3;
-        unsigned long long v = __hip_atomic_load(&cnt->w[b0][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                               __hip_atomic_load(&cnt->w[b0 + 32][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) < 8) s_sum[8 * (threadIdx.x >> 6) + w] = v;  // s_sum[4][8]: one partial per wavefront
+#pragma unroll
+        for (int w = 0; w <= CNT_REMOVED; ++w)
+            for (int off = 32; off > 0; off >>= 1) sum[w] += __shfl_xor(sum[w], off);
+        int run = 0;
+        for (int b0 = 0; b0 < sc.n_blocks; b0 += 64) {
+            const int b = b0 + lane;
+            const int c = b0 == 0 ? c_first : (b < sc.n_blocks ? __hip_atomic_load(&sc.bsum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+            int incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (b < sc.n_blocks) sc.boff[b] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) sc.boff[sc.n_blocks] = run;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
+        int n_active = n_before;
         if (closing) {
-            PassRecord &r = rec[sa.prev];
-            for (int w = 0; w < 8; ++w) s_sum[w] += s_sum[8 + w] + s_sum[16 + w] + s_sum[24 + w];
-            r.formed = (long long)s_sum[CNT_FORMED], r.exact = (long long)s_sum[CNT_EXACT], r.screened = (long long)s_sum[CNT_SCREENED];
-            r.evaluated = (long long)s_sum[CNT_EVALUATED], r.removed = (long long)s_sum[CNT_REMOVED];
-            st->n_active -= int(s_sum[CNT_REMOVED]);
-            r.n_after = st->n_active;
+            PassRecord &r = sc.rec[sa.prev];
+            r.formed = (long long)sum[CNT_FORMED], r.exact = (long long)sum[CNT_EXACT], r.screened = (long long)sum[CNT_SCREENED];
+            r.evaluated = (long long)sum[CNT_EVALUATED], r.removed = (long long)sum[CNT_REMOVED];
+            n_active -= int(sum[CNT_REMOVED]);
+            st->n_active = n_active;
+            r.n_after = n_active;
             if (sa.prev_algo >= 0) r.algo = sa.prev_algo;
+            st->bitsel = bitsel ^ 1;  // the copy the closing pass cleared its removed rows in is the current one now
         }
         int on = 0;
         if (sa.cur >= 0) {
-            on = (sa.k_cur == 1 || 20 * sa.k_cur < (long long)st->n_active) ? 1 : 0;  // rmsd_pruning.py:192
-            PassRecord &r = rec[sa.cur];
-            r.k = sa.k_cur, r.n_before = st->n_active, r.n_after = st->n_active, r.on = on, r.algo = sa.algo_cur;
+            on = (sa.k_cur == 1 || 20 * sa.k_cur < (long long)n_active) ? 1 : 0;  // rmsd_pruning.py:192
+            PassRecord &r = sc.rec[sa.cur];
+            r.k = sa.k_cur, r.n_before = n_active, r.n_after = n_active, r.on = on, r.algo = sa.algo_cur;
             r.formed = r.exact = r.screened = r.evaluated = r.removed = 0;
         }
-        st->A = st->n_active;
+        st->A = n_active;
         st->pass_on = on;
+        st->ticket = 0;
     }
-    __syncthreads();
-    unsigned long long *c = &cnt->w[0][0];
-    for (int e = threadIdx.x; e < CNT_BUCKETS * CNT_WORDS; e += 256) c[e] = 0;
-    if (sa.cur >= 0)
-        for (int e = threadIdx.x; e < sa.bit_words; e += 256) dbit[e] = 0;
+    // counters back to zero (only the words in use); the arrival counters: the first word of every 128-byte line
+    for (int e = lane; e < CNT_BUCKETS * 8; e += 64) sc.cnt->w[e >> 3][e & 7] = 0;
+    for (int e = lane; e < sc.ticket_lines; e += 64) sc.tickets[32 * e] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_pass_step(PruneState *__restrict__ st, PassCounters *__restrict__ cnt, PassRecord *__restrict__ rec,
-                                                    StepArgs sa, unsigned long long *__restrict__ dbit) {
-    __shared__ unsigned long long s_sum[32];
-    pass_step_block(st, cnt, rec, sa, dbit, s_sum);
-}
+__global__ __launch_bounds__(64) void k_pass_step(StepCtx sc, StepArgs sa) { pass_step_wave(sc, sa); }
 
 // ---------------------------------------------------------------------------------------------------
 // per-pass helper kernels (the pass sequence is in tscode_hip.hip, tsc_prune_pass_local / tsc_prune_pass_finish)
@@ -428,79 +565,6 @@ __device__ inline void chunk_of(const PassGeom &g, int64_t i, int64_t &first, in
     last = (c == g.k - 1) ? g.n : first + g.cs;       // :141-144
 }
 
-// Cache view of one pass: a key (a, b) = (first, first + (j - i)) (:65) can be hit only where a is a chunk
-// start of this pass and b lies inside that chunk; then it is hit by exactly the pairs with a + (j-i) == b.
-// Cache view of a pass from the key list, shared by k_dbit_build and k_open_pass: key (a, b) sets bit b of dbit when a is a
-// chunk start of this pass and b lies in that chunk, and the bit of b's 1024-bit block in the summary dsum (k_stop_scan
-// walks only the non-empty blocks).  The summary of a run of 57k structures is ONE word: its bits are OR-ed across the
-// wavefront first and sent by one lane, or every applicable key would queue on the same address.
-__device__ inline void build_cache_view(const PassGeom &g, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b, int nk,
-                                        unsigned long long *__restrict__ dbit, unsigned long long *__restrict__ dsum) {
-    const int lane = threadIdx.x & 63;
-    const int stride = gridDim.x * blockDim.x;
-    for (int q0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; q0 < nk; q0 += stride) {  // wave-uniform bounds
-        const int q = q0 + lane;
-        bool ok = false;
-        int b = 0;
-        if (q < nk) {
-            const int a = key_a[q];
-            b = key_b[q];
-            const int c = a / g.cs;
-            if (c * g.cs == a && c < g.k) {
-                const int last = (c == g.k - 1) ? g.n : g.cs * (c + 1);
-                ok = b < last;
-            }
-        }
-        if (ok) atomicOr(&dbit[b >> 6], 1ull << (b & 63));
-        for (unsigned long long left = __ballot(ok); left;) {
-            const int word = __shfl(b >> 16, __ffsll((long long)left) - 1);
-            const bool same = ok && (b >> 16) == word;
-            unsigned long long bits = same ? 1ull << ((b >> 10) & 63) : 0ull;
-            for (int off = 32; off > 0; off >>= 1) bits |= __shfl_xor(bits, off);
-            const unsigned long long grp = __ballot(same);
-            if (lane == __ffsll((long long)grp) - 1) atomicOr(&dsum[word], bits);
-            left &= ~grp;
-        }
-    }
-}
-
-// Cache view of a pass on its own (the chunk-local pass kernel, local_pass.hpp, needs nothing else from k_open_pass):
-// key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
-// It also takes the SNAPSHOT of the mask that the pass reads (mbit, one bit per structure): the workgroups of the chunk-local
-// kernel remove rows from the byte mask while others, possibly of the same chunk, have not started yet -- every row of a
-// pass must see the mask as it was when the pass began (rmsd_pruning.py:151-157), whatever order the workgroups run in.
-__global__ __launch_bounds__(256) void k_dbit_build(PassGeom g, int use_cache, const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
-                                                     const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
-                                                     const PruneState *__restrict__ st, unsigned long long *__restrict__ dsum,
-                                                     const uint8_t *__restrict__ mask, unsigned long long *__restrict__ mbit) {
-    if (st->pass_on == 0) return;
-    const int n64 = (g.n + 63) & ~63;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n64; t += gridDim.x * blockDim.x) {  // (wave-uniform bounds)
-        const unsigned long long w = __builtin_amdgcn_ballot_w64(t < g.n && mask[t] != 0);
-        if ((threadIdx.x & 63) == 0) mbit[t >> 6] = w;
-    }
-    if (use_cache) build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
-}
-
-// Opens the data of a pass in one launch: ranks of the active structures, their index list and the mask as bits
-// (the second phase of the exclusive scan, scan.hpp; k_apply_pass keeps the per-block counts current), and the
-// cache view of the pass: key (a, b) sets bit b when a is a chunk start of this pass and b lies in that chunk.
-// Grid: scan_grid_blocks(n) blocks of SCAN_THREADS.
-__global__ __launch_bounds__(SCAN_THREADS) void k_open_pass(PassGeom g, int use_cache, const PruneState *__restrict__ st,
-                                                             const uint8_t *__restrict__ mask, const int32_t *__restrict__ bsum,
-                                                             int32_t *__restrict__ pos, int32_t *__restrict__ act_idx,
-                                                             uint8_t *__restrict__ mbit_bytes, int32_t *__restrict__ total_out,
-                                                             const int32_t *__restrict__ key_a, const int32_t *__restrict__ key_b,
-                                                             const int32_t *__restrict__ n_keys, unsigned long long *__restrict__ dbit,
-                                                             unsigned long long *__restrict__ dsum) {
-    __shared__ int s_w[SCAN_THREADS / WAVE];
-    __shared__ int s_o[SCAN_THREADS / WAVE];
-    if (st->pass_on == 0) return;
-    scan_write_block(mask, g.n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o);
-    if (!use_cache) return;
-    build_cache_view(g, key_a, key_b, *n_keys, dbit, dsum);
-}
-
 __device__ inline unsigned long long extract64(const unsigned long long *__restrict__ bits, int64_t start) {
     int64_t w = start >> 6;
     int sh = int(start & 63);
@@ -509,90 +573,270 @@ __device__ inline unsigned long long extract64(const unsigned long long *__restr
     return lo | hi;
 }
 
-// One 16-lane group per active row i (4 rows per wavefront): cend[r] = rank of the first active column j in (i, last) with
-// (first + (j - i)) in the cache view (the row returns "not similar" there, :66-67), else rank of `last`.
-// Columns of compacted rank in (r, cend[r]) are the ones the reference may still evaluate for row r.
-// The same group also initialises best[r]; the block (16 rows = one row tile of the pair kernel) records the tile's largest
-// stop column.
-__global__ __launch_bounds__(256) void k_stop_scan(PassGeom g, int use_cache, const PruneState *__restrict__ st,
-                                                    const int32_t *__restrict__ act_idx, const int32_t *__restrict__ pos,
-                                                    const unsigned long long *__restrict__ mbit, const unsigned long long *__restrict__ dbit,
-                                                    const unsigned long long *__restrict__ dsum, int32_t *__restrict__ cend,
-                                                    int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
-                                                    const float *__restrict__ D, float *__restrict__ Dc) {
-    // 16 lanes per row, 4 rows per wavefront: a lane tests 64 deltas at a time, a group 1024 per step
-    // D (optional): the 16 descriptor components of the row's structure are copied to position r of Dc on the way (one
-    // float per lane), so that the pair kernel reads rows and columns by position -- no gather through the active list
-    // in front of every column tile (a dependent round trip per tile)
-    if (st->pass_on == 0) return;
-    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
-    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
-    const bool mine = r < st->A;
-    int64_t i = 0, first = 0, last = 0;
-    float dval = 0.0f;
-    if (mine) {
-        i = act_idx[r];
-        chunk_of(g, i, first, last);
-        if (D) dval = D[i * 16 + sl];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SCAN_BLOCK_WORDS = 32;  // a scan block (scan.hpp: SCAN_TILE = 2048 structures) as 64-bit words of the mask's bit copy
+constexpr int DESC_WORDS = 16;        // floats per descriptor (sieve.hpp: DW)
+
+// position of the k-th (0-based) set bit of w (k < popcount(w))
+__device__ inline int select64(unsigned long long w, int k) {
+    int p = 0;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const int c = __popcll((w >> p) & ((1ull << s) - 1ull));
+        if (k >= c) k -= c, p += s;
     }
-    int64_t found = last;
-    if (use_cache) {
-        // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
-        // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
-        // blocks of it, found through the summary bitmap dsum, instead of every block of its chunk
-        const int64_t len = mine ? last - i - 1 : 0;
-        const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
-        int64_t B = p_lo >> 10;
-        const int64_t B_hi = p_hi >> 10;
-        bool scanning = len > 0;
-        while (__ballot(scanning) != 0) {
-            if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
-                bool any = false;
-                while (B <= B_hi) {
-                    const unsigned long long sw = dsum[B >> 6] >> (B & 63);
-                    if (sw) {
-                        B += __ffsll((long long)sw) - 1;
-                        any = B <= B_hi;
-                        break;
-                    }
-                    B = ((B >> 6) + 1) << 6;
+    return p;
+}
+
+// Everything a pass needs per ROW, in one launch with no kernel in front of it: OPEN_LPR lanes per active row r, one
+// wavefront per 16 rows = one row tile of the pair kernel, four tiles per block.
+//   * which structure is the r-th active one: the scan block from the prefix of the block counts (boff, kept current by
+//     the kernel that closed the previous pass), the bit inside the block from the 32 words of the mask's bit copy --
+//     an ordered compaction without a scan pass over the whole mask;
+//   * cend[r] = rank of the first active column j in (i, last) with (first + (j - i)) in the cache view of this pass (the
+//     row returns "not similar" there, :66-67), else rank of `last`.  Columns of compacted rank in (r, cend[r]) are the
+//     ones the reference may still evaluate for row r;
+//   * act[r], best[r] = none, the row's descriptor copied to position r of Dc (the pair kernel reads rows and columns by
+//     position), the largest stop column of the tile;
+//   * the other bit copy of the mask brought up to date (the rows this pass removes are cleared THERE, so that every row of
+//     the pass sees the mask as it was when the pass began, rmsd_pruning.py:151-157, whatever order the tiles finish in).
+// fused != 0: the pair kernel applies the verdicts of a row tile itself when the tile's last work item finishes, and the
+// last tile closes the pass.  A tile without work (no row with columns to look at; beyond the active count; the pass gated
+// off) has nothing to apply and arrives here.
+constexpr int OPEN_LDS_BLOCKS = 2048;  // scan blocks whose prefix is staged in LDS (4 M structures); beyond: read from memory
+constexpr int OPEN_LPR = 4;            // lanes per row (measured: with 16, a million structures need 30 000 blocks that each
+                                       // wait out the same three memory round trips -- 86 us per pass)
+constexpr int OPEN_WPL = 32 / OPEN_LPR;  // words of a 2048-bit scan block per lane
+struct OpenArgs {
+    int use_cache, fused, lds_cap;
+    const unsigned long long *view;  // cache view of this pass and its summary (bit_words behind it)
+    unsigned long long *bits;        // the two bit copies of the mask
+    int bit_words;
+    const int32_t *boff;
+    int n_blocks, block_items;
+    unsigned n_tiles;                // row tiles of the pass (arrival count of a fused pass)
+    PassTickets *tickets;
+};
+__global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
+                                                    int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
+                                                    const float *__restrict__ D, float *__restrict__ Dc) {
+    static_assert(SCAN_BLOCK_WORDS == 32 && 64 / OPEN_LPR == 16 && DESC_WORDS == 4 * OPEN_LPR, "one wavefront = one row tile; a float4 of the descriptor per lane");
+    __shared__ int s_boff[OPEN_LDS_BLOCKS + 1];
+    const PruneState *st = sc.st;
+    const int lane = threadIdx.x & 63, sub = lane / OPEN_LPR, sl = lane % OPEN_LPR;
+    // (the first 256 entries of the prefix are requested together with the state block: one round trip for both)
+    const bool in_lds = oa.n_blocks <= oa.lds_cap;
+    const int boff_mine = (in_lds && int(threadIdx.x) <= oa.n_blocks) ? oa.boff[threadIdx.x] : 0;
+    const int pass_on = st->pass_on, A = st->A, sel = st->bitsel;
+    const unsigned long long *X = oa.bits + size_t(sel) * oa.bit_words;
+    const unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = int(tile) * 16;
+    if (pass_on) {
+        unsigned long long *Xo = oa.bits + size_t(sel ^ 1) * oa.bit_words;
+        for (int w = blockIdx.x * 256 + threadIdx.x; w < oa.bit_words; w += gridDim.x * 256) Xo[w] = X[w];
+    }
+    if (pass_on && in_lds && int(blockIdx.x) * 64 < A) {  // (block-uniform)
+        if (int(threadIdx.x) <= oa.n_blocks) s_boff[threadIdx.x] = boff_mine;
+        for (int e = threadIdx.x + 256; e <= oa.n_blocks; e += 256) s_boff[e] = oa.boff[e];
+        __syncthreads();
+    }
+    if (tile >= oa.n_tiles) return;  // (padding of the last block)
+    bool dead = true;
+    if (pass_on && r0 < A) {
+        auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
+        const int r_true = r0 + sub;
+        const bool mine = r_true < A;
+        const int r = mine ? r_true : A - 1;  // (idle groups walk along with the last row: the shuffles below stay convergent)
+        // scan block of rank r: the last b with boff[b] <= r  (boff[0] = 0, boff[n_blocks] = A > r)
+        int lo = 0, hi = oa.n_blocks;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (before(mid) <= r) lo = mid;
+            else hi = mid;
+        }
+        int64_t i;
+        {
+            const int rem = r - before(lo);
+            unsigned long long w[OPEN_WPL];
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) w[u] = X[size_t(lo) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u], c += __popcll(w[u]);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < OPEN_LPR; off <<= 1) {
+                const int t = __shfl_up(incl, off, OPEN_LPR);
+                if (sl >= off) incl += t;
+            }
+            int t = rem - (incl - c);  // index of the wanted bit among this lane's; exactly one lane of the row holds it
+            const bool here = t >= 0 && t < c;
+            int pos = 0;
+            if (here) {
+#pragma unroll
+                for (int u = 0; u < OPEN_WPL; ++u) {
+                    const int cu = __popcll(w[u]);
+                    if (t >= 0 && t < cu) pos = 64 * (OPEN_WPL * sl + u) + select64(w[u], t);
+                    t -= cu;  // (negative from here on, or still to come)
                 }
-                scanning = any;
             }
-            unsigned long long w = 0;
-            const int64_t p0 = (B * 16 + sl) * 64;  // first position of this lane's word of the block
-            if (scanning && p0 <= p_hi && p0 + 63 >= p_lo) {
-                w = dbit[B * 16 + sl] & extract64(mbit, p0 + shift);
-                if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
-                if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
+            const unsigned hit = unsigned(__ballot(here) >> (OPEN_LPR * sub)) & ((1u << OPEN_LPR) - 1u);
+            pos = __shfl(pos, OPEN_LPR * sub + (__ffs(hit) - 1));
+            i = int64_t(lo) * oa.block_items + pos;
+        }
+        int64_t first, last;
+        chunk_of(g, i, first, last);
+        f32x4 dval = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (D) dval = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * sl);
+        // rank of a position = active structures before it: the prefix of its scan block + the set bits of the block below it
+        // (OPEN_WPL words per lane, summed over the row's lanes)
+        auto block_words = [&](int64_t pos, unsigned long long (&w)[OPEN_WPL]) {
+            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) {
+                const int wlo = 64 * (OPEN_WPL * sl + u);
+                w[u] = (bf < oa.n_blocks && wlo < off) ? X[size_t(bf) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u] : 0ull;
             }
-            const unsigned hit = unsigned(__ballot(w != 0) >> (16 * sub)) & 0xffffu;  // this row's 16 lanes
-            if (scanning && hit) {
-                const int fl = __ffs(hit) - 1;
-                const unsigned long long wl = __shfl(w, 16 * sub + fl);
-                found = (B * 16 + fl) * 64 + (__ffsll((long long)wl) - 1) + shift;  // mask position of the first cached column
-                scanning = false;
-            } else {
-                (void)__shfl(w, 16 * sub);  // keep the shuffle convergent for every lane
-                ++B;
-                if (B > B_hi) scanning = false;
+        };
+        auto rank_of = [&](int64_t pos, const unsigned long long (&w)[OPEN_WPL]) {
+            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) {
+                const int below = off - 64 * (OPEN_WPL * sl + u);  // bits of this word that lie below the position
+                const unsigned long long m = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1ull : 0ull);
+                cnt += __popcll(w[u] & m);
+            }
+#pragma unroll
+            for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            return (bf < oa.n_blocks ? before(bf) : A) + cnt;
+        };
+        // the stop column is the end of the chunk unless the cache view has a hit (rare): its words are requested now, with
+        // the descriptor and the view's summary, not after the walk through the view
+        unsigned long long wr[OPEN_WPL];
+        block_words(last, wr);
+        int64_t found = last;
+        if (oa.use_cache) {
+            // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
+            // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
+            // blocks of it, found through the summary bitmap, instead of every block of its chunk
+            const unsigned long long *dbit = oa.view, *dsum = oa.view + oa.bit_words;
+            const int64_t len = mine ? last - i - 1 : 0;
+            const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
+            int64_t B = p_lo >> 10;
+            const int64_t B_hi = p_hi >> 10;
+            bool scanning = len > 0;
+            while (__ballot(scanning) != 0) {
+                if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
+                    bool any = false;
+                    while (B <= B_hi) {
+                        const unsigned long long sw = dsum[B >> 6] >> (B & 63);
+                        if (sw) {
+                            B += __ffsll((long long)sw) - 1;
+                            any = B <= B_hi;
+                            break;
+                        }
+                        B = ((B >> 6) + 1) << 6;
+                    }
+                    scanning = any;
+                }
+                // the 16 words of the block, 16 / OPEN_LPR per lane: first cached column this lane sees (mask position), or none
+                int64_t cand = INT64_MAX;
+                if (scanning) {
+#pragma unroll
+                    for (int u = 16 / OPEN_LPR - 1; u >= 0; --u) {
+                        const int64_t p0 = (B * 16 + (16 / OPEN_LPR) * sl + u) * 64;  // first position of this word
+                        if (p0 <= p_hi && p0 + 63 >= p_lo) {
+                            unsigned long long w = dbit[p0 >> 6] & extract64(X, p0 + shift);
+                            if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
+                            if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
+                            if (w) cand = p0 + (__ffsll((long long)w) - 1) + shift;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cand = min(cand, (int64_t)__shfl_xor((long long)cand, o));
+                if (scanning && cand != INT64_MAX) {
+                    found = cand;
+                    scanning = false;
+                } else {
+                    ++B;
+                    if (B > B_hi) scanning = false;
+                }
             }
         }
+        if (found != last) block_words(found, wr);  // (the lanes of a row agree)
+        int my_c = rank_of(found, wr);
+        if (mine && D) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * sl) = dval;
+        if (mine && sl == 0) {
+            act[r] = int32_t(i);
+            cend[r] = my_c;
+            best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
+        }
+        // largest stop column of the 16 rows of this tile: lets a work item of the pair kernel whose column segment lies
+        // beyond it leave after one scalar load
+        if (!mine) my_c = 0;
+        for (int off = 32; off > 0; off >>= 1) my_c = max(my_c, __shfl_xor(my_c, off));
+        if (lane == 0) tile_cmax[tile] = my_c;
+        dead = my_c <= ((r0 + 1) & ~63);  // no work item of the pair kernel will find a column for this tile
+    } else if (lane == 0) {
+        tile_cmax[tile] = 0;  // every work item of this tile leaves at its first test
     }
-    if (mine && D) Dc[int64_t(r) * 16 + sl] = dval;
-    int my_c = 0;
-    if (mine && sl == 0) {
-        my_c = pos[found];
-        cend[r] = my_c;
-        best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
+    if (!oa.fused || !dead) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int fin = 0;
+    if (lane == 0) fin = tickets_arrive(oa.tickets, tile, oa.n_tiles, PT_GROUPS) ? 1 : 0;
+    if (__builtin_amdgcn_readfirstlane(fin)) pass_step_wave(sc, next);
+}
+
+// The verdicts of up to 64 rows of a finished pass, one row per lane (a whole wavefront calls this): rows with a similar
+// column are removed (:113) -- mask byte, the bit in the copy the NEXT pass reads, the count of their scan block -- and
+// leave one cache key each (:76, appended after the pass at :204), entered into the views of the later passes; counts what
+// the reference's sequential scan would have evaluated.  best[] was written by other CUs' atomics: read at the L2.
+struct ApplyArgs {
+    PassGeom g;
+    const int32_t *act, *cend;
+    const int32_t *best;
+    uint8_t *mask;
+    unsigned long long *bits;
+    int bit_words;
+    int32_t *bsum;
+    int block_items;
+    CacheViews cv;
+};
+__device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool valid, unsigned long long &ev_total, unsigned long long &rm_total) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long ev = 0;
+    bool removed = false;
+    int my_block = -1;
+    int64_t first = 0, delta = 0;
+    if (valid) {
+        const int b = __hip_atomic_load(&a.best[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != INT_MAX) {
+            const int64_t i = a.act[r], j = a.act[b];
+            int64_t last;
+            chunk_of(a.g, i, first, last);
+            a.mask[i] = 0;
+            atomicAnd(&a.bits[size_t(sel ^ 1) * a.bit_words + (i >> 6)], ~(1ull << (i & 63)));
+            my_block = int(i / a.block_items);
+            delta = j - i;
+            removed = true;
+            ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
+        } else {
+            ev = (unsigned long long)(a.cend[r] - r - 1);  // every active column before the stop column
+        }
     }
-    // largest stop column of the 16 rows of this block = one row tile of the pair kernel: lets a work item whose column
-    // segment lies beyond it leave after two scalar loads
-    __shared__ int s_cmax[4];
-    for (int off = 32; off > 0; off >>= 1) my_c = max(my_c, __shfl_xor(my_c, off));
-    if (lane == 0) s_cmax[threadIdx.x >> 6] = my_c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cmax[blockIdx.x] = max(max(s_cmax[0], s_cmax[1]), max(s_cmax[2], s_cmax[3]));
+    // the per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a wavefront fall
+    // into one or two blocks, and thousands of single decrements of two cache lines would serialise
+    for (unsigned long long left = __ballot(removed); left;) {
+        const int l = __ffsll((long long)left) - 1;
+        const int blk = __shfl(my_block, l);
+        const unsigned long long same = __ballot(removed && my_block == blk);
+        if (lane == l) atomicSub(&a.bsum[blk], __popcll(same));
+        left &= ~same;
+    }
+    views_insert_wave(a.cv, removed, int(first), int(first + delta));
+    const int n_rm = __popcll(__ballot(removed));
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+    ev_total += ev, rm_total += (unsigned long long)n_rm;
 }
 
 // Gather the active structures into the two layouts the tile kernel reads:
@@ -836,76 +1080,31 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
     }
 }
 
-// Apply a finished pass: rows with a similar column are removed (:113) and leave one cache key each
-// (:76, appended after the pass at :204); counts what the reference's sequential scan would have evaluated.
-__global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, PruneState *__restrict__ st, const int32_t *__restrict__ act_idx,
-                                                     const int32_t *__restrict__ cend, const int32_t *__restrict__ best,
-                                                     uint8_t *__restrict__ mask, int32_t *__restrict__ key_a,
-                                                     int32_t *__restrict__ key_b, int32_t *__restrict__ n_keys,
-                                                     PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items, PassRecord *__restrict__ rec,
-                                                     StepArgs next, unsigned long long *__restrict__ dbit) {
-    __shared__ unsigned long long s_sum[32];
+// Apply a finished pass as a launch of its own (the register-tiled kernel's passes, and passes whose rows were searched by
+// several ranks: best[] is complete only after the exchange).  The sieve kernel of a single-rank run does this itself, tile
+// by tile (sieve.hpp).
+__global__ __launch_bounds__(256) void k_apply_pass(ApplyArgs a, StepCtx sc, StepArgs next) {
     __shared__ int s_last;
+    PruneState *st = sc.st;
     const bool pass_on = st->pass_on != 0;
     const int n_active = pass_on ? st->A : 0;  // a pass that is gated off has no rows; its blocks still take a ticket
+    const int sel = st->bitsel;
     const int lane = threadIdx.x & 63;
     unsigned long long ev_total = 0, rm_total = 0;
     // a capped grid walks the rows tile by tile (block-uniform bounds: every wavefront keeps all its lanes for the ballots)
     for (int row0 = blockIdx.x * 256; row0 < n_active; row0 += gridDim.x * 256) {
         const int r = row0 + threadIdx.x;
-        unsigned long long ev = 0;
-        bool removed = false;
-        int my_block = -1;
-        int64_t first = 0, delta = 0;
-        if (r < n_active) {
-            const int b = best[r];
-            if (b != INT_MAX) {
-                const int64_t i = act_idx[r], j = act_idx[b];
-                int64_t last;
-                chunk_of(g, i, first, last);
-                mask[i] = 0;
-                my_block = int(i / block_items);
-                delta = j - i;
-                removed = true;
-                ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
-            } else {
-                ev = (unsigned long long)(cend[r] - r - 1);  // every active column before the stop column
-            }
-        }
-        // the scan's per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a
-        // wavefront fall into one or two blocks, and thousands of single decrements of two cache lines would serialise
-        for (unsigned long long left = __ballot(removed); left;) {
-            const int l = __ffsll((long long)left) - 1;
-            const int blk = __shfl(my_block, l);
-            const unsigned long long same = __ballot(removed && my_block == blk);
-            if (lane == l) atomicSub(&bsum[blk], __popcll(same));
-            left &= ~same;
-        }
-        // one slot reservation per wavefront for the keys of its removed rows (order inside the cache is irrelevant)
-        const unsigned long long rm = __ballot(removed);
-        const int n_rm = __popcll(rm);
-        int base = 0;
-        if (n_rm) {
-            if (lane == 0) base = atomicAdd(n_keys, n_rm);
-            base = __shfl(base, 0);
-            if (removed) {
-                const int slot = base + __popcll(rm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                key_a[slot] = int32_t(first);
-                key_b[slot] = int32_t(first + delta);
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
-        ev_total += ev, rm_total += (unsigned long long)n_rm;
+        apply_wave_rows(a, sel, r, r < n_active, ev_total, rm_total);
     }
     if (lane == 0) {
         const unsigned bucket = blockIdx.x * 4 + (threadIdx.x >> 6);
-        count_add(cnt, bucket, CNT_EVALUATED, ev_total);
-        count_add(cnt, bucket, CNT_REMOVED, rm_total);
+        count_add(sc.cnt, bucket, CNT_EVALUATED, ev_total);
+        count_add(sc.cnt, bucket, CNT_REMOVED, rm_total);
     }
     // The last block to get here closes this pass and opens the next one (what a separate one-block launch would do).
-    // The only data handed from block to block are the statistics buckets, and those are written by agent-scope
-    // atomics and read with agent-scope (sc1) loads -- so no cache fence is needed (a __threadfence() per block costs
-    // an L2 write-back each: measured 14 us per pass): every wave drains its atomics, the block's barrier, ONE lane's
+    // The only data handed from block to block are the statistics buckets and block counts, and those are written by
+    // agent-scope atomics and read with agent-scope (sc1) loads -- so no cache fence is needed (a __threadfence() per block
+    // costs an L2 write-back each: measured 14 us per pass): every wave drains its atomics, the block's barrier, ONE lane's
     // ticket add, and the block whose add came last reads (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -914,9 +1113,7 @@ __global__ __launch_bounds__(256) void k_apply_pass(PassGeom g, PruneState *__re
         s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_last) return;
-    pass_step_block(st, cnt, rec, next, dbit, s_sum);
-    if (threadIdx.x == 0) st->ticket = 0;
+    if (s_last && threadIdx.x < 64) pass_step_wave(sc, next);
 }
 
 // End of a run: the pass records and (optionally) the survivor mask go to host-visible memory from ONE small launch instead

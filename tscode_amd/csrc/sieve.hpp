@@ -21,15 +21,17 @@
 // lower bound certainly exceeds h thr^2.  Pairs in the sliver between the two limits are simply not dropped.
 //
 // Pass kernel (k_rmsd_sieve): one wavefront = 16 rows x one column segment, lane = CPL columns of a tile.
-//   screen : descriptors are read by position from a copy in active order that k_stop_scan writes on its way (one float
-//            per lane of its 16 lanes per row), so no index load stands in front of a column tile; the two families of a
+//   screen : descriptors are read by position from a copy in active order that k_open_rows writes on its way (one float4
+//            per lane of its 4 lanes per row), so no index load stands in front of a column tile; the two families of a
 //            component sit side by side, so one v_pk_add_f32 + one v_pk_fma_f32 advance both
 //            distances; the 16 row descriptors sit in LDS and are read as broadcasts; ONE compare per (row, tile) decides
 //            whether any column is within the limit; survivors go to a per-wavefront LDS queue (ballot + prefix popcount);
 //   drain  : stage 1, whenever the queue holds 64 pairs (or at the end, spread over several lanes per pair): H from the
 //            two structures in memory, the quartic tests (reject / accept near-duplicates / undecided);
 //            stage 2, the explicit rotation for the undecided, when 64 have gathered or at the end;
-//            atomicMin(best[row], column).
+//            atomicMin(best[row], column);
+//   apply  : (single-rank runs) the work item that finishes a row tile last removes the tile's rows that found a similar
+//            column and enters their cache keys into the views of the later passes; the last tile of the pass closes it.
 // Any number of heavy atoms is supported (no register-resident structure).
 #pragma once
 #include "common.hpp"
@@ -456,7 +458,7 @@ struct SieveArgs {
     double half_h_thr2;   // h * thr^2 / 2
     double two_thr2;      // 2 thr^2 when the near-duplicate test applies (h >= 4), else -1
     int drain_min;        // queue length that triggers a drain between column tiles (1..64)
-    const int32_t *tile_cmax;   // device: per row tile, the largest stop column of its 16 rows (k_stop_scan)
+    const int32_t *tile_cmax;   // device: per row tile, the largest stop column of its 16 rows (k_open_rows)
     const unsigned *dmax_bits;  // device: largest |descriptor component| of the run (bit pattern of a float), see screen_limit32
     double desc_limit;          // h thr^2: exact squared descriptor distance above which a pair is certainly dissimilar
 };
@@ -501,12 +503,25 @@ __device__ inline bool pair_is_similar(const double *__restrict__ p, const doubl
 #ifndef TSC_SIEVE_OCC1
 #define TSC_SIEVE_OCC1 6
 #endif
-template <int TI, int CPL, bool TRIM = false>
-__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                        const double *__restrict__ Gall, const float *__restrict__ D,
-                                                        const int32_t *__restrict__ cend,
-                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                        const PruneState *__restrict__ st, SieveArgs a) {
+// What the pair kernel of a single-rank run does when the LAST work item of a row tile finishes: it applies the tile's
+// verdicts (apply_wave_rows, rmsd.hpp) and, if the tile was the last of the pass, closes the pass and opens the next one
+// (pass_step_wave) -- no k_apply_pass launch behind the pair kernel.  Work items of a tile = its column segments that start
+// below the tile's largest stop column (the others leave at their first test and do not count).
+struct FusedApply {
+    ApplyArgs ap;
+    int32_t *tile_done;  // arrivals per row tile (zero between passes)
+    PassTickets *tickets;
+    unsigned n_tiles;    // blocks of k_open_rows = row tiles that arrive, here or there
+    StepCtx sc;
+    StepArgs next;
+};
+
+template <int TI, int CPL, bool TRIM>
+__device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                           const double *__restrict__ Gall, const float *__restrict__ D,
+                                           const int32_t *__restrict__ cend,
+                                           int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                           const PruneState *__restrict__ st, const SieveArgs a) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
     static_assert(DW == 2 * KD, "two families of KD components");
     constexpr int QCAP = TI * 64 * CPL + 64;  // one column tile can add TI * 64 * CPL pairs on top of a remainder below 64
@@ -526,9 +541,6 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     const int r0 = tile * TI;
     const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
     const int seg_hi = seg_lo + a.seg_cols;
-    if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
-    // most items of a pass with long chunks start beyond every stop column of their row tile: two scalar loads and out
-    if (st->pass_on == 0 || a.tile_cmax[tile] <= seg_lo) return;
 
     // ---- prologue in one memory round trip: the state, this item's 16 stop columns / best columns (they decide whether
     // it has work at all: most items of a late pass have none) and the descriptors of its rows and first column tile.
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static_assert(DW == 16 && TI * DW == 256, "row staging: 4 rows x 16 components per 64 lanes");
-    // D holds the descriptors in ACTIVE order (position r = the r-th active structure; k_stop_scan copies them there every
+    // D holds the descriptors in ACTIVE order (position r = the r-th active structure; k_open_rows copies them there every
     // pass): rows and columns are read by position, nothing is gathered through act[] in front of the screen.  Positions
     // up to n - 1 are readable; those beyond the active count hold stale values that no row's range admits.
     int row_src[4];
@@ -864,6 +876,47 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
         count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+    }
+}
+
+template <int TI, int CPL, bool TRIM = false, bool FUSED = false>
+__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                                        const double *__restrict__ Gall, const float *__restrict__ D,
+                                                        const int32_t *__restrict__ cend,
+                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                        const PruneState *__restrict__ st, SieveArgs a, FusedApply fa) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = a.tile_begin + slot * a.tile_stride;
+    const int r0 = tile * TI;
+    const int seg_base = (r0 + 1) & ~63;
+    const int seg_lo = seg_base + int(blockIdx.y) * a.seg_cols;
+    if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
+    // most items of a pass with long chunks start beyond every stop column of their row tile (0 for a tile without rows or
+    // a pass that is gated off: k_open_rows): one scalar load and out
+    const int tcm = a.tile_cmax[tile];
+    if (tcm <= seg_lo) return;
+    sieve_item<TI, CPL, TRIM>(heavy, act, Gall, D, cend, best, counters, st, a);
+    if constexpr (FUSED) {
+        // this item's atomicMin's on best[] are at the L2 before its arrival is
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int lim = min(a.n, tcm);
+        const int n_live = min(int(gridDim.y), (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
+        int last = 0;
+        if (lane == 0) last = (atomicAdd(&fa.tile_done[tile], 1) == n_live - 1) ? 1 : 0;
+        if (!__builtin_amdgcn_readfirstlane(last)) return;
+        if (lane == 0) fa.tile_done[tile] = 0;
+        unsigned long long ev_total = 0, rm_total = 0;
+        const int A = st->A;
+        apply_wave_rows(fa.ap, st->bitsel, r0 + lane, lane < TI && r0 + lane < A, ev_total, rm_total);
+        int fin = 0;
+        if (lane == 0) {
+            count_add(counters, unsigned(slot), CNT_EVALUATED, ev_total);
+            count_add(counters, unsigned(slot), CNT_REMOVED, rm_total);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) fin = tickets_arrive(fa.tickets, unsigned(tile), fa.n_tiles, PT_GROUPS) ? 1 : 0;
+        if (__builtin_amdgcn_readfirstlane(fin)) pass_step_wave(fa.sc, fa.next);
     }
 }
 

@@ -495,6 +495,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c,
 
 static const double KS[TSC_MAX_PASSES] = {5e5, 2e5, 1e5, 5e4, 2e4, 1e4, 5000, 2000, 1000, 500, 200, 100, 50, 20, 10, 5, 2, 1};  // :186-188
 
+static_assert(MAX_SLOTS == TSC_MAX_PASSES, "one cache view per schedule slot");
 constexpr int TILE_ROWS = 16;
 constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel takes any h
 
@@ -510,15 +511,24 @@ struct tsc_prune {
     int algo = ALGO_SIEVE;  // pair kernel of this run
     // device state
     uint8_t *mask = nullptr;
-    int32_t *pos = nullptr, *act = nullptr, *cend = nullptr, *best = nullptr, *key_a = nullptr, *key_b = nullptr, *n_keys = nullptr;
-    int32_t *bsum = nullptr, *total = nullptr, *tile_cmax = nullptr;
-    unsigned long long *mbit = nullptr, *dbit = nullptr;
+    int32_t *act = nullptr, *cend = nullptr, *best = nullptr;
+    int32_t *bsum = nullptr, *boff = nullptr, *tile_cmax = nullptr, *tile_done = nullptr;
+    int n_blocks = 0;                      // scan blocks (SCAN_TILE structures each) the mask is ranked by
+    unsigned long long *bits = nullptr;    // two bit copies of the mask (the pass in flight reads one, clears removed rows in the other)
+    unsigned long long *views = nullptr;   // cache view of every pass of the schedule, each followed by its summary (rmsd.hpp, CacheViews)
+    ViewPass *view_pass = nullptr;         // device: the pass of each view (chunk count, chunk size, its division constants)
+    int view_of_slot[TSC_MAX_PASSES];      // schedule slot -> view index (-1: the pass can never run)
+    int n_views = 0;
     size_t bit_words = 0, dsum_words = 0;
+    bool cur_fused = false;                // the open pass is applied by the pair kernel itself
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
-    float *Dc = nullptr;     // ... in active order, rewritten by k_stop_scan every pass: what the pair kernel reads
+    float *Dc = nullptr;     // ... in active order, rewritten by k_open_rows every pass: what the pair kernel reads
     double *Gall = nullptr;
-    LocalTickets *tickets = nullptr;  // chunk-local pass kernel
+    struct Tickets {
+        PassTickets pass;
+        LocalTickets local;
+    } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
     uint8_t *export_mask_host = nullptr;  // set by prune_run: pinned host buffer that receives the mask with the statistics
     unsigned *dmax_bits = nullptr;  // device scalar: largest |descriptor component| as float bits (zeroed by k_init_run)
@@ -675,25 +685,29 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     p->thr = rmsd_thr;
     p->mode = mode;
     p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
-    p->bit_words = size_t(n / 64 + 4);
+    p->bit_words = size_t(n / 64 + 40);  // (k_open_rows reads the 32 words of a whole scan block, also of the last, partial one)
+    p->n_blocks = int(scan_bsum_count(n));
     int rc = 0;
     if (mask_buffer)
         p->mask = mask_buffer;  // the caller's verdict buffer serves as the working mask (8-byte aligned, n bytes)
     else if (!rc)
         rc = palloc(p, size_t(n), &p->mask);
-    if (!rc) rc = palloc(p, size_t(n) + 1, &p->pos);
     if (!rc) rc = palloc(p, size_t(n), &p->act);
     if (!rc) rc = palloc(p, size_t(n), &p->cend);
     if (!rc) rc = palloc(p, size_t(n), &p->best);
-    if (!rc) rc = palloc(p, size_t(n), &p->key_a);
-    if (!rc) rc = palloc(p, size_t(n), &p->key_b);
-    if (!rc) rc = palloc(p, 4, &p->n_keys);
-    if (!rc) rc = palloc(p, scan_bsum_count(n), &p->bsum);
-    if (!rc) rc = palloc(p, 4, &p->total);
-    if (!rc) rc = palloc(p, size_t(n) / 16 + 2, &p->tile_cmax);
-    if (!rc) rc = palloc(p, p->bit_words, &p->mbit);
-    p->dsum_words = p->bit_words / 1024 + 4;  // one summary bit per 1024 cache-view bits, kept right behind dbit
-    if (!rc) rc = palloc(p, p->bit_words + p->dsum_words, &p->dbit);
+    if (!rc) rc = palloc(p, size_t(p->n_blocks) + 1, &p->bsum);
+    if (!rc) rc = palloc(p, size_t(p->n_blocks) + 1, &p->boff);
+    if (!rc) rc = palloc(p, size_t(n) / 16 + 8, &p->tile_cmax);
+    if (!rc) rc = palloc(p, size_t(n) / 16 + 8, &p->tile_done);
+    if (!rc) rc = palloc(p, 2 * p->bit_words, &p->bits);
+    p->dsum_words = p->bit_words / 1024 + 4;  // one summary bit per 1024 cache-view bits, kept right behind the view
+    p->n_views = 0;
+    for (int slot = 0; slot < TSC_MAX_PASSES; ++slot) {
+        const bool can_run = int64_t(KS[slot]) == 1 || 20 * int64_t(KS[slot]) < n;  // (tsc_prune_next_pass)
+        p->view_of_slot[slot] = (can_run && mode == 0) ? p->n_views++ : -1;
+    }
+    if (!rc) rc = palloc(p, std::max<size_t>(1, size_t(p->n_views) * (p->bit_words + p->dsum_words)), &p->views);
+    if (!rc) rc = palloc(p, TSC_MAX_PASSES, &p->view_pass);
     if (!rc) rc = palloc(p, 1, &p->counters);
     if (!rc) rc = palloc(p, 1, &p->state);
     if (!rc) rc = palloc(p, TSC_MAX_PASSES, &p->records);
@@ -706,9 +720,9 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         } else {
             p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
         }
-        if (!rc) rc = palloc(p, 1, &p->tickets);
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
     }
+    if (!rc) rc = palloc(p, 1, &p->tickets);
     if (!rc && p->algo == ALGO_TILE) {
         const size_t hp3 = size_t(p->hp) * 3;
         rc = palloc(p, size_t(p->npad) * hp3, &p->Xr);
@@ -721,11 +735,20 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         for (int slot = 0; slot < TSC_MAX_PASSES && first_slot < 0; ++slot)
             if (int64_t(KS[slot]) == 1 || 20 * int64_t(KS[slot]) < n) first_slot = slot;
         p->opened_slot = first_slot;
-        hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, n, p->mask, p->mbit, p->dbit, int(p->bit_words),
-                           p->n_keys, p->state, p->records, TSC_MAX_PASSES, p->counters, p->bsum, int(scan_bsum_count(n)), SCAN_TILE,
-                           own_desc ? p->dmax_bits : nullptr,
-                           reinterpret_cast<unsigned *>(p->tickets), p->tickets ? int(sizeof(LocalTickets) / sizeof(unsigned)) : 0, p->act,
-                           first_slot, first_slot >= 0 ? (long long)KS[first_slot] : 0ll, p->algo, int(p->dsum_words));
+        InitArgs ia;
+        memset(&ia, 0, sizeof(ia));
+        ia.n = n, ia.mask = p->mask, ia.bits = p->bits, ia.bit_words = int(p->bit_words);
+        ia.views = p->views, ia.view_words = int64_t(p->n_views) * int64_t(p->bit_words + p->dsum_words), ia.view_pass = p->view_pass, ia.n_views = p->n_views;
+        for (int slot = 0; slot < TSC_MAX_PASSES; ++slot)
+            if (p->view_of_slot[slot] >= 0) ia.sched[p->view_of_slot[slot]] = view_pass(int(n), int(KS[slot]));
+        ia.st = p->state, ia.rec = p->records, ia.n_rec = TSC_MAX_PASSES, ia.cnt = p->counters;
+        ia.bsum = p->bsum, ia.boff = p->boff, ia.n_blocks = p->n_blocks, ia.block_items = SCAN_TILE;
+        ia.dmax_bits = own_desc ? p->dmax_bits : nullptr;
+        // the arrival counters and the per-tile ones lie in two blocks: the tickets are zeroed here, tile_done by its own loop below
+        ia.zero_words = reinterpret_cast<unsigned *>(p->tickets), ia.n_zero_words = int64_t(sizeof(*p->tickets) / sizeof(unsigned));
+        ia.act = p->act, ia.first_slot = first_slot, ia.first_k = first_slot >= 0 ? (long long)KS[first_slot] : 0ll, ia.first_algo = p->algo;
+        ia.tile_done = p->tile_done, ia.n_tile_done = n / 16 + 8;
+        hipLaunchKernelGGL(k_init_run, dim3(grid_for(n / 8 + 1, 256, 512)), dim3(256), 0, st, ia);
         hipError_t e = hipGetLastError();
         // padded columns of the compacted layouts are read by the last column tile of a segment but never used; the
         // register-tiled kernel's buffers are zeroed once so that those reads see finite numbers
@@ -803,7 +826,34 @@ static StepArgs next_step_args(const tsc_prune *p, int *next_slot) {
         }
     }
     *next_slot = nxt;
-    return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, nxt >= 0 ? int(p->bit_words + p->dsum_words) : 0, p->cur_local ? ALGO_LOCAL : -1};
+    return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, p->cur_local ? ALGO_LOCAL : -1};
+}
+
+static StepCtx step_ctx(const tsc_prune *p) {
+    return StepCtx{p->state, p->counters, p->records, p->bsum, p->boff, p->n_blocks, reinterpret_cast<unsigned *>(p->tickets),
+                   int(sizeof(*p->tickets) / 128)};
+}
+
+// Views of the passes AFTER the open one (where the rows it removes leave their cache keys); none in cache-free mode.
+static CacheViews later_views(const tsc_prune *p) {
+    CacheViews cv;
+    cv.views = p->views, cv.stride = (long long)(p->bit_words + p->dsum_words), cv.bit_words = int(p->bit_words), cv.n = int(p->n);
+    cv.first = p->mode == 0 ? p->view_of_slot[p->cur_slot] + 1 : 0;
+    cv.count = p->mode == 0 ? p->n_views : 0;
+    cv.pass = p->view_pass;
+    return cv;
+}
+
+static const unsigned long long *view_of_open_pass(const tsc_prune *p) {
+    return p->mode == 0 ? p->views + size_t(p->view_of_slot[p->cur_slot]) * (p->bit_words + p->dsum_words) : p->views;
+}
+
+static ApplyArgs apply_args(const tsc_prune *p) {
+    ApplyArgs a;
+    a.g = PassGeom{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
+    a.act = p->act, a.cend = p->cend, a.best = p->best, a.mask = p->mask, a.bits = p->bits, a.bit_words = int(p->bit_words);
+    a.bsum = p->bsum, a.block_items = SCAN_TILE, a.cv = later_views(p);
+    return a;
 }
 
 // The pair search of one rank's row tiles of the open pass (step 3 of a pass; steps 1-2 have run).
@@ -856,22 +906,34 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
         a.tile_cmax = p->tile_cmax;
         a.drain_min = c->drain_min;
-        if (c->sieve_cpl == 1)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 1>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else if (c->sieve_cpl == 2 && c->sieve_trim)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2, true>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else if (c->sieve_cpl == 2)
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 2>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
-        else
-            hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, 4>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                                  (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,
-                                  (const PruneState *)p->state, a);
+        FusedApply fa;
+        memset(&fa, 0, sizeof(fa));
+        if (p->cur_fused) {
+            fa.ap = apply_args(p);
+            fa.tile_done = p->tile_done, fa.tickets = &p->tickets->pass, fa.n_tiles = unsigned(ceil_div(A, TILE_ROWS));
+            fa.sc = step_ctx(p);
+            int nxt = -1;
+            fa.next = next_step_args(p, &nxt);
+            p->opened_slot = nxt;
+            p->last_slot = -1;  // closed on the device, by the pair kernel's last tile
+        }
+#define TSC_LAUNCH_SIEVE(CPL, TRIM, FUSED)                                                                                                        \
+    hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, CPL, TRIM, FUSED>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,     \
+                          (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,                          \
+                          (const PruneState *)p->state, a, fa)
+        const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
+        if (p->cur_fused) {
+            if (c->sieve_cpl == 1) TSC_LAUNCH_SIEVE(1, false, true);
+            else if (trim) TSC_LAUNCH_SIEVE(2, true, true);
+            else if (c->sieve_cpl == 2) TSC_LAUNCH_SIEVE(2, false, true);
+            else TSC_LAUNCH_SIEVE(4, false, true);
+        } else {
+            if (c->sieve_cpl == 1) TSC_LAUNCH_SIEVE(1, false, false);
+            else if (trim) TSC_LAUNCH_SIEVE(2, true, false);
+            else if (c->sieve_cpl == 2) TSC_LAUNCH_SIEVE(2, false, false);
+            else TSC_LAUNCH_SIEVE(4, false, false);
+        }
+#undef TSC_LAUNCH_SIEVE
     }
     TSC_HIP(hipGetLastError());
     return 0;
@@ -894,8 +956,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     // 0. open this pass: gate (:192), counters, cache-view bitmap -- already done by the apply kernel of the pass before
     //    it (its last block), by a one-block launch for the first pass of a run
     if (p->opened_slot != slot) {
-        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, int(p->bit_words + p->dsum_words), -1};  // (zeroes dbit and its summary)
-        hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
+        StepArgs sa{p->last_slot, slot, (long long)k, p->algo, -1};
+        hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(64), 0, st, step_ctx(p), sa);
     }
     p->last_slot = slot;
     p->slot_used[slot] = true;
@@ -903,13 +965,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
     // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
-    // chunks are a few row tiles long -- at 57k structures the passes k = 1000 and 500 take 33 and 39 us instead of about
-    // 50 -- and is no better than the four-launch path beyond; "local_max_chunk" moves the limit)
+    // chunks are a few row tiles long -- at 57k structures the passes k = 1000 and 500 take 40 and 45 us instead of about
+    // 50 -- and loses beyond: k = 200, 100 take 59 and 75 us there against 52 on the two-launch path; "local_max_chunk"
+    // moves the limit)
     p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= std::min(LP_MAX_ROWS, c->local_max_chunk);
+    p->cur_fused = false;
     if (p->cur_local) {
-        // the pass's view of the mask (a bit snapshot: the kernel below clears bytes of the mask while it runs) and of the cache
-        hipLaunchKernelGGL(k_dbit_build, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, g, use_cache, (const int32_t *)p->key_a, (const int32_t *)p->key_b,
-                           (const int32_t *)p->n_keys, p->dbit, (const PruneState *)p->state, p->dbit + p->bit_words, (const uint8_t *)p->mask, p->mbit);
         LocalPassArgs a;
         a.h = p->h, a.use_cache = use_cache;
         a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
@@ -923,22 +984,29 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         const StepArgs sa = next_step_args(p, &nxt);
         const int64_t blocks = (k - 1) * a.nb_regular + a.nb_last;
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
-        hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask,
-                              (const unsigned long long *)p->mbit, (const unsigned long long *)p->dbit, p->heavy, (const double *)p->Gall, (const float *)p->Dall, p->key_a, p->key_b,
-                              p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit, p->tickets);
+        hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask, p->bits, int(p->bit_words),
+                              view_of_open_pass(p), p->heavy, (const double *)p->Gall, (const float *)p->Dall, later_views(p), p->counters, p->bsum,
+                              SCAN_TILE, step_ctx(p), sa, &p->tickets->local);
         TSC_HIP(hipGetLastError());
         p->opened_slot = nxt;
         p->last_slot = -1;  // closed on the device
         p->local_done = true;
         return 0;
     }
-    // 1. ranks of the active structures, their index list, the mask as bits, the cache view of this pass
-    hipLaunchKernelGGL(k_open_pass, dim3(scan_grid_blocks(n)), dim3(SCAN_THREADS), 0, st, g, use_cache, (const PruneState *)p->state,
-                       (const uint8_t *)p->mask, (const int32_t *)p->bsum, p->pos, p->act, reinterpret_cast<uint8_t *>(p->mbit), p->total,
-                       (const int32_t *)p->key_a, (const int32_t *)p->key_b, (const int32_t *)p->n_keys, p->dbit, p->dbit + p->bit_words);
-    // 2. stop column, best[] and compacted descriptor of every row
-    hipLaunchKernelGGL(k_stop_scan, dim3(ceil_div(A, 16)), dim3(256), 0, st, g, use_cache, (const PruneState *)p->state, p->act, p->pos, p->mbit,
-                       p->dbit, (const unsigned long long *)(p->dbit + p->bit_words), p->cend, p->best, p->tile_cmax, (const float *)p->Dall, p->Dc);
+    // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
+    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && c->fused_apply != 0;
+    {
+        OpenArgs oa;
+        oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
+        oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
+        oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
+        oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
+        int nxt = -1;
+        const StepArgs sa = p->cur_fused ? next_step_args(p, &nxt) : StepArgs{-1, -1, 0ll, 0, -1};
+        static_assert(SCAN_TILE == 64 * SCAN_BLOCK_WORDS && DW == DESC_WORDS, "k_open_rows");
+        hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 4)), dim3(256), 0, st, g, oa, step_ctx(p), sa, p->act, p->cend, p->best, p->tile_cmax,
+                           (const float *)p->Dall, p->Dc);
+    }
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
@@ -953,7 +1021,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_rows(tsc_prune *p, int rank, int world) {
     TSC_REQUIRE(p != nullptr, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
-    if (p->cur_k == 0 || !p->local_done || p->cur_local)
+    if (p->cur_k == 0 || !p->local_done || p->cur_local || p->cur_fused)
         return fail(TSC_ERR_STATE, "tsc_prune_pass_rows: needs an open pass whose tsc_prune_pass_local ran with world_size > 1");
     DeviceGuard guard(p->ctx->device);
     return launch_pair_search(p, rank, world);
@@ -979,13 +1047,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
-    if (!p->cur_local) {  // (a chunk-local pass has applied its verdicts already)
-        PassGeom g{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
+    if (!p->cur_local && !p->cur_fused) {  // (a chunk-local pass, and the pair kernel of a fused one, have applied the verdicts already)
         int nxt = -1;
         const StepArgs sa = next_step_args(p, &nxt);
         const int blocks = int(std::min<int64_t>(ceil_div<int64_t>(p->n, 256), 512));
-        hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, c->stream, g, p->state, p->act, p->cend, p->best, p->mask, p->key_a, p->key_b,
-                           p->n_keys, p->counters, p->bsum, SCAN_TILE, p->records, sa, p->dbit);
+        hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, c->stream, apply_args(p), step_ctx(p), sa);
         p->opened_slot = nxt;
         p->last_slot = -1;  // closed on the device
         TSC_HIP(hipGetLastError());
@@ -1037,8 +1103,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     if (!p->collected) {
         hipStream_t st = c->stream;
         if (p->last_slot >= 0) {
-            StepArgs sa{p->last_slot, -1, 0ll, 0, 0, -1};
-            hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(256), 0, st, p->state, p->counters, p->records, sa, p->dbit);
+            StepArgs sa{p->last_slot, -1, 0ll, 0, -1};
+            hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(64), 0, st, step_ctx(p), sa);
             p->last_slot = -1;
         }
         static_assert(sizeof(PassRecord) * TSC_MAX_PASSES <= 4096 && sizeof(PassRecord) % 8 == 0, "records fit the pinned staging buffer");
@@ -1217,6 +1283,16 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "local_max_chunk") == 0) {
         TSC_REQUIRE(value >= 16 && value <= LP_MAX_ROWS, "local_max_chunk must be in [16, %d]", LP_MAX_ROWS);
         c->local_max_chunk = int(value);
+        return 0;
+    }
+    if (strcmp(name, "fused_apply") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "fused_apply must be 0 or 1");
+        c->fused_apply = int(value);
+        return 0;
+    }
+    if (strcmp(name, "open_lds_blocks") == 0) {
+        TSC_REQUIRE(value >= 0, "open_lds_blocks must not be negative");
+        c->open_lds_blocks = int(std::min(value, 1073741824.0));
         return 0;
     }
     if (strcmp(name, "local_pass") == 0) {
