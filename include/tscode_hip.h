@@ -80,7 +80,11 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * "pca_min_n": ensembles smaller than this (default 6000) take the identity basis for their descriptors instead of estimated
  * principal axes (three launches and about 45 us less per run; any basis gives the same verdicts).
  * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 256, up to 2048) structures
- * run in the one-launch chunk-local kernel; "clash_fp32": 1 (default)
+ * run in the one-launch chunk-local kernel; "sieve_trim": 1 (default) = the screen's shorter instruction sequence;
+ * "fused_apply": 1 (default) lets the sieve kernel of a single-rank pass apply a row tile's verdicts itself when the tile's last
+ * work item finishes and close the pass (two launches per pass); 0 = tsc_prune_pass_finish launches k_apply_pass (always so for the
+ * register-tiled kernel and for passes searched by several ranks);  "open_lds_blocks": scan blocks (2048 structures each) up to which
+ * the per-row kernel stages their prefix in LDS (default: its capacity, 2048; 0 = always read it from memory; tests);  "clash_fp32": 1 (default)
  * decides verdict-only clash masks by a packed-fp32 minimum with fp64 fallback;
  * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
  * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms),
@@ -335,10 +339,12 @@ int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs);        /* upper bound
  * every rank) and returns with the first pass that does left open (*k = its k) or *k = 0 at the end of the schedule
  * (rmsd_pruning.py:186-204).  One host call instead of three per small pass. */
 int tsc_prune_run_replicated(tsc_prune *run, int world, int64_t min_pairs, int64_t *k);
-int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous.  With world_size == 1 a pass whose chunks
-                                                                      are short runs whole in here (chunk-local kernel, option
-                                                                      "local_pass"): best[] is then not produced and
-                                                                      tsc_prune_pass_finish only does the bookkeeping */
+int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous.  With world_size == 1 the verdicts are applied
+                                                                      in here as well -- by the pair kernel itself, tile by tile
+                                                                      (option "fused_apply"; best[] stays readable), or, for a pass
+                                                                      whose chunks are short, by the chunk-local kernel (option
+                                                                      "local_pass"; best[] is then not produced) -- and
+                                                                      tsc_prune_pass_finish only does the host's bookkeeping */
 int tsc_prune_pass_rows(tsc_prune *p, int rank, int world_size);  /* after tsc_prune_pass_local: the pair search of ANOTHER rank's row
                                                                      tiles of the same pass, into the same best[] (atomicMin).  Lets
                                                                      one GPU stand in for several ranks (tools/predict_scaling.py times
