@@ -23,4 +23,7 @@ def load_golden(name):
 def oracle():
     import oracle as orc
     orc.build()
+    # no more threads than CPUs this process may run on (an OpenMP runtime that sizes its team by the machine, on a box that
+    # grants 16 of 256 hardware threads, turns every small parallel region into milliseconds)
+    orc.set_num_threads(max(1, min(orc.num_threads(), len(os.sched_getaffinity(0)), 32)))
     return orc

@@ -607,6 +607,38 @@ def test_prune_random_small_ensembles(eng, oracle, algo):
     assert checked > 100
 
 
+def _blocks_of_near_duplicates(n_parents, children, h, seed):
+    rng = np.random.default_rng(seed)
+    parents = rng.normal(size=(n_parents, h, 3)) * 3.0
+    return np.ascontiguousarray(np.repeat(parents, children, axis=0) + rng.normal(size=(n_parents * children, h, 3)) * 0.02)
+
+
+_BIG_REF = {}
+
+
+@pytest.mark.parametrize("lds_blocks", [2 ** 30, 128])
+def test_prune_beyond_256_scan_blocks(eng, oracle, lds_blocks):
+    """640 000 structures (313 scan blocks of 2048: more than one entry of the block prefix per thread of k_open_rows; with
+    open_lds_blocks = 128 the prefix is read from memory instead of LDS), in runs of 200 near-duplicates so that the early
+    passes remove almost everything and the oracle finishes in seconds.  Masks, schedule and evaluation counts equal the
+    oracle's, in both modes."""
+    heavy = _blocks_of_near_duplicates(3200, 200, 6, seed=77)
+    eng.set_option("open_lds_blocks", lds_blocks)
+    try:
+        for mode in (0, 1):
+            if mode not in _BIG_REF:              # (seconds of oracle time per mode: shared by the two parametrisations;
+                # chunk-parallel: the first pass has 20 000 chunks, one parallel region each if rows were spread instead)
+                _BIG_REF[mode] = oracle.prune_heavy(heavy, 0.5, mode=mode)
+            ref = _BIG_REF[mode]
+            mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+            assert np.array_equal(mask, ref["mask"]), (mode, int(mask.sum()), int(ref["mask"].sum()))
+            assert [s["k"] for s in stats] == [s["k"] for s in ref["stats"]]
+            assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+        assert int(mask.sum()) == 3200
+    finally:
+        eng.set_option("open_lds_blocks", 2 ** 30)
+
+
 def test_prune_children_spread_around_the_threshold(eng, oracle, algo):
     """A mid-size ensemble whose children scatter AROUND the threshold (rotations of several degrees, 0.12 A shifts): many
     pairs the quartic tests cannot decide, long walks of the exact path, every large-pass code path of the pair kernels.
