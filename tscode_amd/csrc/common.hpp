@@ -80,6 +80,9 @@ struct tsc_ctx {
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int local_max_chunk = 256;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
+    void *dbg_buf = nullptr;              // -DTSC_DBG_STAMPS builds: time stamps of the pair kernel's wavefronts
+    size_t dbg_bytes = 0;
+    int64_t dbg_waves = 0, dbg_stamp_k = -1;
     int fused_apply = 1;                  // single-rank sieve passes: the pair kernel applies the verdicts tile by tile and closes the pass (sieve.hpp)
     int open_lds_blocks = 1 << 30;        // k_open_rows stages the scan-block prefix in LDS up to this many blocks (tests lower it to take the other path)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback

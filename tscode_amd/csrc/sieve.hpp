@@ -461,7 +461,21 @@ struct SieveArgs {
     const int32_t *tile_cmax;   // device: per row tile, the largest stop column of its 16 rows (k_open_rows)
     const unsigned *dmax_bits;  // device: largest |descriptor component| of the run (bit pattern of a float), see screen_limit32
     double desc_limit;          // h thr^2: exact squared descriptor distance above which a pair is certainly dissimilar
+    unsigned long long *dbg;    // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront of the launch (tools/stamps.py), else null
 };
+
+#ifdef TSC_DBG_STAMPS   // measurement hook: where a wavefront of the pair kernel spends its time (100 MHz wall clock)
+#define TSC_STAMP(i)                                                                                                                  \
+    do {                                                                                                                              \
+        if (a.dbg) {                                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                               \
+            if ((threadIdx.x & 63) == 0)                                                                                              \
+                a.dbg[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 32 + (threadIdx.x >> 6) * 8 + (i)] = wall_clock64();             \
+        }                                                                                                                             \
+    } while (0)
+#else
+#define TSC_STAMP(i) do { } while (0)
+#endif
 
 // H = p^T q of one pair read from memory.  `lpp` consecutive lanes (a power of two) share the pair: lane `sub` takes
 // atoms sub, sub + lpp, ... and the group sums H with a butterfly, so a batch of few pairs has a short critical path
@@ -618,6 +632,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     }
     __builtin_amdgcn_wave_barrier();
 
+    TSC_STAMP(1);  // prologue data has arrived
     const int h3 = a.h * 3;
     unsigned short *queue = s_queue[wid];
     int qn = 0;
@@ -864,6 +879,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
         load_tile();
 #endif
     }
+    TSC_STAMP(2);  // screen done
 #ifdef TSC_DBG_NODRAIN
     qn = 0;
 #endif
@@ -872,6 +888,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     qe = 0;
 #endif
     if (qe > 0) exact_stage(0, qe);
+    TSC_STAMP(3);  // candidates evaluated
     if (lane == 0) {
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
@@ -891,6 +908,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     const int r0 = tile * TI;
     const int seg_base = (r0 + 1) & ~63;
     const int seg_lo = seg_base + int(blockIdx.y) * a.seg_cols;
+    TSC_STAMP(0);  // the wavefront has started
     if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
     // most items of a pass with long chunks start beyond every stop column of their row tile (0 for a tile without rows or
     // a pass that is gated off: k_open_rows): one scalar load and out
@@ -904,6 +922,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
         const int n_live = min(int(gridDim.y), (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
         int last = 0;
         if (lane == 0) last = (atomicAdd(&fa.tile_done[tile], 1) == n_live - 1) ? 1 : 0;
+        TSC_STAMP(4);  // arrived at the tile's counter
         if (!__builtin_amdgcn_readfirstlane(last)) return;
         if (lane == 0) fa.tile_done[tile] = 0;
         unsigned long long ev_total = 0, rm_total = 0;
@@ -915,8 +934,13 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
             count_add(counters, unsigned(slot), CNT_REMOVED, rm_total);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSC_STAMP(5);  // tile applied
         if (lane == 0) fin = tickets_arrive(fa.tickets, unsigned(tile), fa.n_tiles, PT_GROUPS) ? 1 : 0;
-        if (__builtin_amdgcn_readfirstlane(fin)) pass_step_wave(fa.sc, fa.next);
+        TSC_STAMP(6);  // arrived at the pass's counter
+        if (__builtin_amdgcn_readfirstlane(fin)) {
+            pass_step_wave(fa.sc, fa.next);
+            TSC_STAMP(7);  // pass closed
+        }
     }
 }
 

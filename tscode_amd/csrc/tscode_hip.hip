@@ -906,6 +906,20 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
         a.tile_cmax = p->tile_cmax;
         a.drain_min = c->drain_min;
+        a.dbg = nullptr;
+#ifdef TSC_DBG_STAMPS
+        if (c->dbg_stamp_k == k) {
+            const size_t bytes = size_t(grid.x) * grid.y * 32 * sizeof(unsigned long long);
+            if (c->dbg_bytes < bytes) {
+                if (c->dbg_buf) (void)hipFree(c->dbg_buf);
+                TSC_HIP(hipMalloc(&c->dbg_buf, bytes));
+                c->dbg_bytes = bytes;
+            }
+            TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
+            c->dbg_waves = int64_t(grid.x) * grid.y * 4;
+            a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
+        }
+#endif
         FusedApply fa;
         memset(&fa, 0, sizeof(fa));
         if (p->cur_fused) {
@@ -1079,6 +1093,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(t
         TSC_TRY(tsc_prune_pass_finish(p));
     }
 }
+
+#ifdef TSC_DBG_STAMPS
+// measurement builds only: the time stamps of the last stamped pair-kernel launch, 8 per wavefront (tools/stamps.py)
+extern "C" __attribute__((visibility("default"))) int tsc_debug_stamps(tsc_ctx *c, unsigned long long *dst, int64_t max_waves, int64_t *n_waves) {
+    DeviceGuard guard(c->device);
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    const int64_t n = std::min(max_waves, c->dbg_waves);
+    if (n > 0) TSC_HIP(hipMemcpy(dst, c->dbg_buf, size_t(n) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_waves = n;
+    return 0;
+}
+#endif
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev) {
     TSC_REQUIRE(p && mask_dev, "null argument");
@@ -1285,6 +1311,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->local_max_chunk = int(value);
         return 0;
     }
+#ifdef TSC_DBG_STAMPS
+    if (strcmp(name, "dbg_stamp_k") == 0) {
+        c->dbg_stamp_k = int64_t(value);
+        return 0;
+    }
+#endif
     if (strcmp(name, "fused_apply") == 0) {
         TSC_REQUIRE(value == 0 || value == 1, "fused_apply must be 0 or 1");
         c->fused_apply = int(value);
