@@ -11,8 +11,10 @@ fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_c
 N = 1: the one-call pipeline (tsc_pipeline_dev).
 
 N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): the line's `value` is ONE ensemble sharded over the
-ranks, `"scaling": "strong"` -- pose blocks for embed/clash, one RCCL all-gather of the surviving heavy-atom shards, the row
-tiles of every large prune pass dealt round-robin with an all-reduce(MIN) over best[] per pass
+ranks, `"scaling": "strong"` -- the row tiles of every large prune pass dealt round-robin with an all-reduce(MIN) over best[]
+per pass, and in front of it either pose blocks for embed/clash + one RCCL all-gather of the surviving heavy-atom shards
+(`"front": "shard"`) or every rank embedding all poses itself so that no coordinates travel (`"front": "replicate"`): both are
+timed on the node before the warm-up and the faster one runs (`front_tuning`; `--front` forces one)
 (tscode_amd/pipeline.py::sharded_step); `rccl_world`, `allgather_bytes_per_step` and `allreduce_bytes_per_step` say what
 crossed xGMI.  `replicas` beside it (`"scaling": "weak"`): every GPU runs the whole pipeline on its own ensemble, no
 data-path collective -- how a batch of independent embeds uses a node.  The 100k x 50 pipeline is a 0.9 ms chain of dependent
@@ -67,6 +69,9 @@ def parse():
                          "collective (weak scaling).  The other one is timed too and reported beside it.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one GPU to rehearse "
                                                       "(device tensors then travel over the host)")
+    ap.add_argument("--front", choices=("auto", "shard", "replicate"), default="auto",
+                    help="multi-rank front half: pose blocks + all-gather of the survivors' coordinates, every rank computing all "
+                         "poses itself (nothing but best[] travels), or whichever is faster on this node (timed before the warm-up)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--pass-timing", type=int, default=1,
@@ -244,10 +249,12 @@ def main():
             pipe = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, device_index=local_rank, mode=args.mode, seed=7)
         elif sharded:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
-                                  force_sharded=args.force_sharded or world == 1)
+                                  force_sharded=args.force_sharded or world == 1, front=args.front)
         else:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
         configure(pipe, args.pass_timing)
+        if sharded and world > 1 and pipe.front == "auto":
+            pipe.tune_front()                                  # both forms of the front half timed on this node, before the warm-up
         for _ in range(args.warmup):
             pipe.step()
         dt, res, acc = timed_loop(pipe, args.steps)           # THE timed region (library events as --pass-timing says)
@@ -278,8 +285,9 @@ def main():
                "events_off": leg["events_off"], "what": what}
         return out
 
-    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: pose blocks, one RCCL all-gather of the surviving heavy-atom shards, "
-                    "all-reduce(MIN) over best[] per large pass")
+    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: all-reduce(MIN) over best[] per large pass (row tiles dealt to the ranks); the "
+                    "front half as `front` says -- 'shard': pose blocks + one RCCL all-gather of the surviving heavy-atom shards, "
+                    "'replicate': every rank embeds and clash-filters all poses itself -- whichever `front_tuning` measured faster on this node")
     REPLICAS_WHAT = "one whole ensemble per GPU (the same ensemble on every rank), no data-path collective"
 
     main_sharded = (world > 1 and args.multi == "sharded") or args.force_sharded
@@ -460,9 +468,12 @@ def main():
             out["rccl_world"] = dist.get_world_size() if use_dist else 1
             out["collective_backend"] = dist.get_backend() if use_dist else None
             out["allgather_bytes_per_step"] = res.get("allgather_bytes")
+            out["front"] = res.get("front")                    # "shard" or "replicate": what the line was measured with
+            out["front_tuning"] = getattr(leg["pipe"], "front_tuning", None)
             out["allreduce_bytes_per_step"] = res.get("allreduce_bytes")
             out["sharded_passes"] = [{"k": k, "best_entries": nb} for k, nb in res.get("exchanges", [])]
-            out["collectives_per_step"] = 2 + len(res.get("exchanges", []))           # counts all-reduce, coordinates all-gather, one per sharded pass
+            # counts all-reduce and coordinates all-gather (front = shard only), one all-reduce per sharded pass
+            out["collectives_per_step"] = (2 if res.get("front") == "shard" else 0) + len(res.get("exchanges", []))
         if side is not None:
             out[side[0]] = side[1]
         if error is not None:
@@ -523,6 +534,8 @@ def main():
             c4["workload"] = f"C4: {ens4.n_poses} conformers x {ens4.n_atoms} atoms ({ens4.n_heavy} heavy), seed {ens4.seed}"
             c4["n_pass_clash"] = int(leg4["res"]["n_pass"])
             if world > 1:
+                c4["front"] = leg4["res"].get("front")
+                c4["front_tuning"] = getattr(leg4["pipe"], "front_tuning", None)
                 c4["allgather_bytes_per_step"] = leg4["res"].get("allgather_bytes")
                 c4["allreduce_bytes_per_step"] = leg4["res"].get("allreduce_bytes")
                 c4["sharded_passes"] = [k for k, _ in leg4["res"].get("exchanges", [])]

@@ -22,7 +22,8 @@
  *   - MULTI-GPU, a deliberate deviation from SURVEY.md 8(b): that sketch has "multi-GPU variants take a device list / an RCCL
  *     communicator held in tsc_ctx".  This library opens no communicator and spawns no process.  The path shards as one
  *     process per GPU, each with a context of its own, and the exchange steps (one all-gather of the surviving heavy-atom
- *     shards, one all-reduce(MIN) over best[] per sharded pass) belong to the HOST that owns the process group: in this
+ *     shards -- or none, when every rank embeds all poses itself: the host times both forms on its node -- and one
+ *     all-reduce(MIN) over best[] per sharded pass) belong to the HOST that owns the process group: in this
  *     repository torch.distributed over RCCL (tscode_amd/pipeline.py::sharded_step), in a C host ncclAllGather /
  *     ncclAllReduce on the same device pointers.  What the C ABI provides for it is the part only the library can do: a
  *     rank's block of poses (tsc_embed_clash_compact_dev), the stepping form of the prune with the row tiles of a pass dealt to

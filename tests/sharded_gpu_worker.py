@@ -31,13 +31,23 @@ def main():
         d = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
         unstable += digest is not None and d != digest
         digest = digest or d
+    # the pipeline chose a form of the front half by timing both (tune_front, inside the first step); either form, forced, must
+    # give the same survivors and the same evaluation counts
+    forms_agree, evals = True, [s["pairs_evaluated"] for s in res["stats"]]
+    for form in ("shard", "replicate"):
+        pipe.front = form
+        r2 = pipe.step()
+        torch.cuda.synchronize()
+        d2 = hashlib.sha256(np.packbits(pipe.h_keep[:r2["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
+        forms_agree = forms_agree and r2["front"] == form and d2 == digest and [s["pairs_evaluated"] for s in r2["stats"]] == evals
     flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64)
     gathered = [torch.zeros_like(flags) for _ in range(world)]
     dist.all_gather(gathered, flags)
     if rank == 0:
         sharded_passes = [s["k"] for s in res["stats"] if s["algo"] in (1, 2)]
         print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "keep_sha256_16": digest, "steps_that_differ": unstable,
-                          "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"],
+                          "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"], "forms_agree": forms_agree,
+                          "front_tuning": pipe.front_tuning,
                           "pairs_evaluated": [s["pairs_evaluated"] for s in res["stats"]], "global_path_passes": sharded_passes}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

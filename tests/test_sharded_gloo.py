@@ -103,6 +103,16 @@ class OracleShardBackend:
         self.heavy_local[:len(heavy)].copy_(torch.from_numpy(heavy))
         return len(heavy)
 
+    def embed_clash_all(self):
+        """front="replicate": every rank computes the whole pose list itself."""
+        import torch
+        e = self.ens
+        poses = self.o.transform_batch(e.frag_coords, e.conf_idx, e.rot, e.pos)
+        cm = self.o.compenetration_mask(poses, e.ids, 1.5, 0)
+        heavy = np.ascontiguousarray(poses[cm][:, e.atomnos != 1])
+        self.heavy_all[:len(heavy)].copy_(torch.from_numpy(heavy))
+        return len(heavy)
+
     def make_stepper(self, n_pass):
         return OracleStepper(self.o, self.heavy_all[:n_pass].numpy(), self.best, self.thr, self.mode, self.tile_rows)
 
@@ -113,7 +123,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_poses, mode, out_dir):
+def _worker(rank, world, port, n_poses, mode, out_dir, front="shard"):
     import torch
     import torch.distributed as dist
 
@@ -127,19 +137,21 @@ def _worker(rank, world, port, n_poses, mode, out_dir):
     try:
         ens = make_config("C2", n_poses)
         backend = OracleShardBackend(oracle, ens, rank, world, mode=mode)
-        res = sharded_step(backend, rank, world, dist)
+        res = sharded_step(backend, rank, world, dist, front=front)
+        assert res["front"] == front and (res["allgather_bytes"] > 0) == (front == "shard")
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keep=backend.keep[:res["n_pass"]].numpy(), n_pass=res["n_pass"],
                  n_keep=res["n_keep"], counts=np.array(res["counts"]), ks=np.array([s["k"] for s in res["stats"]]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_poses,mode", [(2, 3000, 0), (3, 2001, 0), (2, 1500, 1)])
-def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode):
+@pytest.mark.parametrize("world,n_poses,mode,front", [(2, 3000, 0, "shard"), (3, 2001, 0, "shard"), (2, 1500, 1, "shard"), (2, 2500, 0, "replicate"),
+                                                      (3, 1201, 1, "replicate")])
+def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front):
     import torch.multiprocessing as mp
 
     from tscode_amd.synthetic import make_config
-    mp.spawn(_worker, args=(world, _free_port(), n_poses, mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_poses, mode, str(tmp_path), front), nprocs=world, join=True)
     ens = make_config("C2", n_poses)
     poses = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
     cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
@@ -147,7 +159,7 @@ def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode):
     for rank in range(world):
         got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert int(got["n_pass"]) == int(cm.sum())
-        assert got["counts"].sum() == cm.sum() and len(got["counts"]) == world
+        assert got["counts"].sum() == cm.sum() and len(got["counts"]) == (world if front == "shard" else 1)
         assert np.array_equal(got["keep"].astype(bool), ref["mask"]), f"rank {rank}"
         assert int(got["n_keep"]) == int(ref["mask"].sum())
         assert got["ks"].tolist() == [s["k"] for s in ref["stats"]]

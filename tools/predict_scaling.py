@@ -11,7 +11,9 @@ and combines them as the protocol would run:  max_r front(r) + counts all-reduce
 sum over passes [replicated part + max_r local(r) + all-reduce(best[])] .  The collectives are MODELLED, not measured:
 per-link xGMI bandwidth 153 GB/s x 0.7 efficiency, 20 us fixed cost per collective, and two readings of the mesh -- ring
 collectives bound by ONE link (conservative) and every shard sent straight to its N - 1 peers over all links at once
-(what the fully connected xGMI mesh allows) -- both stated in the output.
+(what the fully connected xGMI mesh allows) -- both stated in the output.  Beside it, for every N, the other form of the front
+half (`front_replicate`: every rank embeds all poses itself, no coordinates travel; pipeline.py times both on the node and
+keeps the faster).
 
 usage (GPU box): python tools/predict_scaling.py [C3 C4] > profiles/r02_predicted_scaling.json
 """
@@ -60,7 +62,7 @@ def allreduce_ms(nbytes, n, all_links=False):
     return 2.0 * (nbytes / n) * steps / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
 
 
-def measure(cfg, n_ranks, reps=3):
+def measure(cfg, n_ranks, reps=3, front_all_ms=None):
     ens = make_config(cfg)
     # front half: every rank's block
     front, counts = [], []
@@ -114,7 +116,14 @@ def measure(cfg, n_ranks, reps=3):
                 + sum(allreduce_ms(4 * p["best_entries"], n_ranks, all_links) for p in best["passes"]))
     comm, comm_fast = comm_ms(False), comm_ms(True)
     compute = max(front) + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
-    return {"n_ranks": n_ranks, "front_ms_per_rank": front, "replicated_ms": best["replicated_ms"],
+    # the other form of the front half (pipeline.py, front="replicate"): every rank embeds and clash-filters ALL poses, no counts
+    # all-reduce, no all-gather -- only the all-reduces of best[] remain
+    front_all = max(front) if n_ranks == 1 or front_all_ms is None else front_all_ms
+    rep_comm = [sum(allreduce_ms(4 * p["best_entries"], n_ranks, al) for p in best["passes"]) for al in (False, True)]
+    rep_compute = front_all + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
+    replicate = {"front_ms": front_all, "compute_ms": rep_compute, "modelled_comm_ms": rep_comm[0], "modelled_comm_ms_all_links": rep_comm[1],
+                 "predicted_ms_per_step": rep_compute + rep_comm[0], "predicted_ms_per_step_all_links": rep_compute + rep_comm[1]}
+    return {"n_ranks": n_ranks, "front_replicate": replicate, "front_ms_per_rank": front, "replicated_ms": best["replicated_ms"],
             "sharded_passes": [{"k": p["k"], "best_entries": p["best_entries"], "max_local_ms": max(p["local_ms_per_rank"]),
                                 "sum_local_ms": sum(p["local_ms_per_rank"]), "imbalance": max(p["local_ms_per_rank"]) * n_ranks / max(sum(p["local_ms_per_rank"]), 1e-9)}
                                for p in best["passes"]],
@@ -134,15 +143,22 @@ def main():
            "measured_on": torch.cuda.get_device_name(0), "configs": {}}
     for cfg in cfgs:
         rows = []
+        front_all = None
         for n in (1, 2, 4, 8):
             t0 = time.time()
-            rows.append(measure(cfg, n))
-            print(f"{cfg} N={n}: predicted {rows[-1]['predicted_ms_per_step']:.3f} ms/step "
-                  f"(compute {rows[-1]['compute_ms']:.3f}, modelled comm {rows[-1]['modelled_comm_ms']:.3f}) [{time.time() - t0:.0f} s]", file=sys.stderr)
+            rows.append(measure(cfg, n, front_all_ms=front_all))
+            if n == 1:
+                front_all = max(rows[0]["front_ms_per_rank"])          # one rank's front half IS the whole pose list
+            rp = rows[-1]["front_replicate"]
+            print(f"{cfg} N={n}: front sharded {rows[-1]['predicted_ms_per_step']:.3f} ms/step (compute {rows[-1]['compute_ms']:.3f}, modelled comm "
+                  f"{rows[-1]['modelled_comm_ms']:.3f}; all links {rows[-1]['predicted_ms_per_step_all_links']:.3f}) | front replicated "
+                  f"{rp['predicted_ms_per_step']:.3f} (all links {rp['predicted_ms_per_step_all_links']:.3f}) [{time.time() - t0:.0f} s]", file=sys.stderr)
         base = rows[0]["predicted_ms_per_step"]
         for r in rows:
             r["speedup_vs_1_rank_protocol"] = base / r["predicted_ms_per_step"]
             r["speedup_vs_1_rank_protocol_all_links"] = base / r["predicted_ms_per_step_all_links"]
+            r["front_replicate"]["speedup_vs_1_rank_protocol"] = base / r["front_replicate"]["predicted_ms_per_step"]
+            r["front_replicate"]["speedup_vs_1_rank_protocol_all_links"] = base / r["front_replicate"]["predicted_ms_per_step_all_links"]
         out["configs"][cfg] = rows
     print(json.dumps(out, indent=1))
 

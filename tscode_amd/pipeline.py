@@ -14,6 +14,12 @@ N GPUs:    one process per GPU, ``sharded_step``:
               an all-reduce(MIN) over best[] merges them, and every rank applies the identical mask and
               cache update, so no rank ever needs another rank's mask.
 
+           Step 1-2 have a second form, ``front="replicate"``: every rank embeds and clash-filters ALL poses itself and
+           nothing but best[] ever travels.  Moving the survivors' coordinates costs 24 B per heavy atom over xGMI;
+           recomputing them costs a few flops and no bytes -- which is faster depends on the node (the all-gather of 350 MB at
+           1M conformers is modelled at 0.4-2.9 ms, the embed of all 1M poses measures 0.87 ms), so ``DevicePipeline`` times
+           both forms on the node it runs on and keeps the faster one (``tune_front``).
+
 ``sharded_step`` only talks to a small backend interface, so the same protocol code runs under gloo on
 CPU tensors in the tests (with a test-only backend) and under RCCL on the GPU (``HipShardBackend``).
 """
@@ -61,26 +67,22 @@ def _all_gather(dist, out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=None):
+def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=None, front="shard"):
     """One step of the hot path over an ensemble sharded across ``world`` ranks, run inside ``backend.stream_context()`` when the
     backend has one (the HIP backend makes its own torch stream current, so that its kernels, torch's copies and the
-    collectives are ordered on one stream)."""
+    collectives are ordered on one stream).  ``front``: "shard" = pose blocks + all-gather of the survivors' coordinates,
+    "replicate" = every rank computes the whole front half, no coordinates travel (module docstring)."""
+    if front not in ("shard", "replicate"):
+        raise ValueError(f"front must be 'shard' or 'replicate', got {front!r}")
     enter = getattr(backend, "stream_context", None)
     if enter is None:
-        return _sharded_step(backend, rank, world, dist, group, min_pairs)
+        return _sharded_step(backend, rank, world, dist, group, min_pairs, front)
     with enter():
-        return _sharded_step(backend, rank, world, dist, group, min_pairs)
+        return _sharded_step(backend, rank, world, dist, group, min_pairs, front)
 
 
-def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
-    """The protocol itself.
-
-    backend interface (all tensors live where the backend computes):
-        embed_clash_block() -> n_pass_local      fills backend.heavy_local[:n_pass_local]  (h, 3 per row)
-        heavy_pad, gather, heavy_all, counts, keep, max_local, best      preallocated tensors / int
-        make_stepper(n_pass) -> stepper with next_pass(), pass_estimate(), pass_local(rank, world), n_active(), pass_finish(),
-                                stats(), copy_mask(dst), close(); it keeps best[] in backend.best
-    """
+def _front_sharded(backend, rank, world, dist, group):
+    """Pose blocks -> counts -> all-gather of the heavy-atom shards; returns (n_pass, n_pass_local, counts, all-gathered bytes)."""
     n_pass_local = int(backend.embed_clash_block())
     # how many poses of every block passed the clash check
     backend.counts.zero_()
@@ -101,7 +103,24 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
     for r, c in enumerate(counts):
         backend.heavy_all[off:off + c].copy_(gathered[r, :c])
         off += c
-    n_pass = off
+    return off, n_pass_local, counts, int(world * rows * row_elems * backend.gather.element_size())
+
+
+def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front="shard"):
+    """The protocol itself.
+
+    backend interface (all tensors live where the backend computes):
+        embed_clash_block() -> n_pass_local      fills backend.heavy_local[:n_pass_local]  (h, 3 per row)
+        embed_clash_all() -> n_pass              (front="replicate" only) fills backend.heavy_all[:n_pass] from ALL poses
+        heavy_pad, gather, heavy_all, counts, keep, max_local, best      preallocated tensors / int
+        make_stepper(n_pass) -> stepper with next_pass(), pass_estimate(), pass_local(rank, world), n_active(), pass_finish(),
+                                stats(), copy_mask(dst), close(); it keeps best[] in backend.best
+    """
+    if front == "replicate":
+        n_pass = int(backend.embed_clash_all())
+        n_pass_local, counts, gathered_bytes = n_pass, [n_pass], 0
+    else:
+        n_pass, n_pass_local, counts, gathered_bytes = _front_sharded(backend, rank, world, dist, group)
     stats = []
     exchanges = []                                      # (k, entries of best[] all-reduced) of every pass that was sharded
     if n_pass > 0:
@@ -135,7 +154,8 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs):
             st.close()
     n_keep = stats[-1]["n_active_after"] if stats else 0
     return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts, "exchanges": exchanges,
-            "allgather_bytes": int(world * rows * row_elems * backend.gather.element_size()), "allreduce_bytes": 4 * sum(n for _, n in exchanges) + 8 * world}
+            "front": front, "allgather_bytes": gathered_bytes,
+            "allreduce_bytes": 4 * sum(n for _, n in exchanges) + (8 * world if front == "shard" else 0)}
 
 
 class _HipStepper:
@@ -224,6 +244,19 @@ class HipShardBackend:
         return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.heavy_idx,
                                                 self.clash_thresh, self.max_clashes, self.clash, self.structures, self.heavy_local)
 
+    def embed_clash_all(self):
+        """front="replicate": the whole pose list on this rank; the survivors' heavy atoms land in heavy_all directly.  The
+        full-size inputs and outputs (clash_all, structures_all) are set up on first use."""
+        if getattr(self, "d_ci_all", None) is None:
+            torch, ens = self.torch, self.ens
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+            self.d_ci_all, self.d_rot_all, self.d_pos_all = t(ens.conf_idx), t(ens.rot), t(ens.pos)
+            self.clash_all = torch.empty(ens.n_poses, dtype=torch.uint8, device=self.dev)
+            self.structures_all = torch.empty((ens.n_poses, ens.n_atoms, 3), dtype=torch.float64, device=self.dev)
+        return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci_all, self.d_rot_all, self.d_pos_all, self.ens.n_poses,
+                                                self.heavy_idx, self.clash_thresh, self.max_clashes, self.clash_all, self.structures_all,
+                                                self.heavy_all)
+
     def make_stepper(self, n_pass):
         st = self.eng.prune_stepper(self.heavy_all, n_pass, self.h, self.rmsd_thr, self.mode)
         st.use_best_buffer(self.best)
@@ -232,7 +265,10 @@ class HipShardBackend:
 
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
-                 process_group=None, force_sharded=False, shard_min_pairs=None):
+                 process_group=None, force_sharded=False, shard_min_pairs=None, front="auto"):
+        """``front`` (multi-rank runs): "shard" = pose blocks + all-gather of the survivors' coordinates, "replicate" = every rank
+        computes the whole front half and only best[] travels, "auto" = ``tune_front()`` decides on the node at hand (called by
+        the first ``step()`` unless the caller did; one rank: "shard", there is nothing to choose)."""
         import torch
         self.torch, self.ens = torch, ens
         self.rank, self.world, self.pg = int(rank), int(world), process_group
@@ -240,6 +276,10 @@ class DevicePipeline:
         self._run = None
         self.sharded = self.world > 1 or force_sharded
         self.shard_min_pairs = shard_min_pairs                  # None: SHARD_MIN_PAIRS (tests lower it to shard small passes too)
+        if front not in ("auto", "shard", "replicate"):
+            raise ValueError(f"front must be 'auto', 'shard' or 'replicate', got {front!r}")
+        self.front = front if self.world > 1 or front != "auto" else "shard"
+        self.front_tuning = None
         if self.sharded:
             self.backend = HipShardBackend(ens, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
             self.d_keep, self.d_clash, self.d_structures = self.backend.keep, self.backend.clash, self.backend.structures
@@ -277,7 +317,38 @@ class DevicePipeline:
                                                           self.heavy_idx, c, m, r, mode, self.d_clash, self.d_structures, self.d_keep,
                                                           self.h_keep)
             return self._run()
-        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs)
+        if self.front == "auto":
+            self.tune_front()
+        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs, self.front)
+
+    def tune_front(self, steps=2):
+        """Times both forms of the front half on this node -- one untimed step each (buffers, communicators), then ``steps`` timed
+        ones each, the slowest rank's time counting (all-reduce MAX) -- and keeps the faster.  Every rank reaches the same
+        decision.  Both forms give the same result, so the tuning steps are ordinary steps."""
+        import time
+        dist, torch = self.torch.distributed, self.torch
+        if not self.sharded:
+            return None
+        times = {}
+        for form in ("shard", "replicate"):
+            sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form)
+            torch.cuda.synchronize(self.backend.dev)
+            dist.barrier(group=self.pg)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form)
+            torch.cuda.synchronize(self.backend.dev)
+            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
+            if dist.get_backend(self.pg) == "gloo":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            else:                                   # nccl (= RCCL) reduces device tensors
+                td = t.to(self.backend.dev)
+                dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.pg)
+                t = td.cpu()
+            times[form] = float(t[0])
+        self.front = min(times, key=times.get)
+        self.front_tuning = {"ms_per_step": times, "chosen": self.front}
+        return self.front_tuning
 
 
 class CsearchChain:
