@@ -4,6 +4,7 @@ Build a second library with -DTSC_DBG_STAMPS next to the product one (it must li
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -DTSC_DBG_STAMPS \
           -o tscode_amd/libtscode_hip_stamps.so tscode_amd/csrc/tscode_hip.hip
 and run   TSCODE_AMD_LIB=$PWD/tscode_amd/libtscode_hip_stamps.so python tools/stamps.py C3 100 [opt=value ...]
+(a negative k stamps k_open_rows of that pass instead of the pair kernel)
 The kernel stamps the 100 MHz wall clock (after draining its outstanding memory operations: the stamps perturb it a little) at:
 0 wavefront started, 1 prologue data arrived, 2 screen done, 3 candidates evaluated, 4 arrived at the tile's counter, 5 tile applied,
 6 arrived at the pass's counter, 7 pass closed.  Printed: percentiles of every phase over the wavefronts that went through it, in us.
@@ -48,6 +49,8 @@ print("phase (us)                                    min     p50     p90     p99
 print("wavefront start after the first one        ", pct(s[started, 0] - t_start))
 names = ["prologue (start -> data arrived)", "screen", "drains (candidates evaluated)", "-> arrived at the tile counter", "apply the tile",
          "-> arrived at the pass counter", "close the pass"]
+if k < 0:      # k_open_rows of pass -k: 0 started, 1 bit copy made and prefix staged, 2 structure of the row found, 3 stop column and rank, 4 written
+    names = ["bit copy, prefix -> LDS", "search + select (the row's structure)", "descriptor, cache view, rank of the stop column", "stores"]
 for i, nm in enumerate(names, start=1):
     m = (s[:, i] > 0) & (s[:, i - 1] > 0)
     if m.any():

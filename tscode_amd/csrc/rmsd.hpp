@@ -616,7 +616,19 @@ struct OpenArgs {
     int n_blocks, block_items;
     unsigned n_tiles;                // row tiles of the pass (arrival count of a fused pass)
     PassTickets *tickets;
+    unsigned long long *dbg;         // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront (tools/stamps.py), else null
 };
+#ifdef TSC_DBG_STAMPS
+#define TSC_OPEN_STAMP(i)                                                                                                     \
+    do {                                                                                                                      \
+        if (oa.dbg) {                                                                                                         \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                       \
+            if ((threadIdx.x & 63) == 0) oa.dbg[size_t(blockIdx.x) * 32 + (threadIdx.x >> 6) * 8 + (i)] = wall_clock64();       \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define TSC_OPEN_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
                                                     int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
                                                     const float *__restrict__ D, float *__restrict__ Dc) {
@@ -627,6 +639,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
     // (the first 256 entries of the prefix are requested together with the state block: one round trip for both)
     const bool in_lds = oa.n_blocks <= oa.lds_cap;
     const int boff_mine = (in_lds && int(threadIdx.x) <= oa.n_blocks) ? oa.boff[threadIdx.x] : 0;
+    TSC_OPEN_STAMP(0);  // started (and the first loads have come back)
     const int pass_on = st->pass_on, A = st->A, sel = st->bitsel;
     const unsigned long long *X = oa.bits + size_t(sel) * oa.bit_words;
     const unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -641,6 +654,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
         __syncthreads();
     }
     if (tile >= oa.n_tiles) return;  // (padding of the last block)
+    TSC_OPEN_STAMP(1);  // bit copy made, prefix staged
     bool dead = true;
     if (pass_on && r0 < A) {
         auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
@@ -685,6 +699,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
         int64_t first, last;
         chunk_of(g, i, first, last);
         f32x4 dval = {0.0f, 0.0f, 0.0f, 0.0f};
+        TSC_OPEN_STAMP(2);  // the row's structure found
         if (D) dval = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * sl);
         // rank of a position = active structures before it: the prefix of its scan block + the set bits of the block below it
         // (OPEN_WPL words per lane, summed over the row's lanes)
@@ -765,6 +780,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
         }
         if (found != last) block_words(found, wr);  // (the lanes of a row agree)
         int my_c = rank_of(found, wr);
+        TSC_OPEN_STAMP(3);  // stop column and its rank
         if (mine && D) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * sl) = dval;
         if (mine && sl == 0) {
             act[r] = int32_t(i);
@@ -777,6 +793,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
         for (int off = 32; off > 0; off >>= 1) my_c = max(my_c, __shfl_xor(my_c, off));
         if (lane == 0) tile_cmax[tile] = my_c;
         dead = my_c <= ((r0 + 1) & ~63);  // no work item of the pair kernel will find a column for this tile
+        TSC_OPEN_STAMP(4);  // everything written
     } else if (lane == 0) {
         tile_cmax[tile] = 0;  // every work item of this tile leaves at its first test
     }

@@ -1015,6 +1015,20 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
+        oa.dbg = nullptr;
+#ifdef TSC_DBG_STAMPS
+        if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
+            const size_t bytes = size_t(ceil_div(ceil_div(A, 16), 4)) * 32 * sizeof(unsigned long long);
+            if (c->dbg_bytes < bytes) {
+                if (c->dbg_buf) (void)hipFree(c->dbg_buf);
+                TSC_HIP(hipMalloc(&c->dbg_buf, bytes));
+                c->dbg_bytes = bytes;
+            }
+            TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
+            c->dbg_waves = int64_t(ceil_div(ceil_div(A, 16), 4)) * 4;
+            oa.dbg = static_cast<unsigned long long *>(c->dbg_buf);
+        }
+#endif
         int nxt = -1;
         const StepArgs sa = p->cur_fused ? next_step_args(p, &nxt) : StepArgs{-1, -1, 0ll, 0, -1};
         static_assert(SCAN_TILE == 64 * SCAN_BLOCK_WORDS && DW == DESC_WORDS, "k_open_rows");
