@@ -13,7 +13,9 @@ import shutil
 import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
-stats = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
+# (gpurun merges into an existing gpurun_out/: take the newest run of each kind)
+newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
+stats = newest(f"{src}/trace/**/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{prefix}_kernel_stats.csv")
 shutil.copy(f"{src}/bench_trace.json", f"profiles/{prefix}_bench_under_rocprof.json")
 # digest of the HIP sources the profile was taken from (bench.py prints `traffic` only while it still matches)
@@ -23,7 +25,7 @@ for _p in sorted(glob.glob("tscode_amd/csrc/*")):
     _h.update(open(_p, "rb").read())
 out = {"csrc_sha256_16": _h.hexdigest()[:16]}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(f"{src}/{name}/**/*counter_collection.csv", recursive=True)[0]
+    f = newest(f"{src}/{name}/**/*counter_collection.csv")
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
