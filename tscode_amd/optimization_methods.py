@@ -22,6 +22,9 @@ _MASS = {1: 1.00794, 3: 6.941, 5: 10.811, 6: 12.0107, 7: 14.0067, 8: 15.9994, 9:
          34: 78.96, 35: 79.904, 46: 106.42, 53: 126.90447}
 
 
+_WARNED_MASSES = False
+
+
 def get_inertia_moments(coords, masses):
     """tscode/algebra.py:165-186 for one structure: (3,) moments, ordered by absolute value (the input is not shifted)."""
     return get_engine().inertia_moments(np.asarray(coords, dtype=np.float64)[None], masses)[0]
@@ -47,6 +50,13 @@ def prune_by_moment_of_inertia(structures, atomnos, max_deviation=1e-2, masses=N
     atomnos = np.asarray(atomnos)
     heavy = atomnos != 1
     if masses is None:
+        global _WARNED_MASSES
+        if not _WARNED_MASSES:                                           # said once, loudly: the table is this package's, not periodictable's
+            import warnings
+            warnings.warn("prune_by_moment_of_inertia: masses= not given; using tscode_amd's built-in table of standard atomic weights, "
+                          "which has not been checked against the `periodictable` package the reference reads its masses from "
+                          "(tscode/pt.py).  Pass masses=[pt[z].mass for z in atomnos] to use the reference's own values.", stacklevel=2)
+            _WARNED_MASSES = True
         try:
             heavy_masses = np.array([_MASS[int(a)] for a in atomnos[heavy]])
         except KeyError as exc:
