@@ -21,7 +21,12 @@ constexpr int LP_MAX_ROWS = 2048;  // longest chunk (structures) the chunk-local
 constexpr int LP_WAVES = 4;
 constexpr int LP_THREADS = LP_WAVES * 64;
 constexpr int LP_TI = 16;                       // rows per work item
-constexpr int LP_TILES_PER_BLOCK = 2 * LP_WAVES;  // row tiles one block is sized for
+#ifndef TSC_LP_TPB
+#define TSC_LP_TPB 4
+#endif
+// row tiles one block is sized for: one per wavefront (measured against two: a wavefront walks its tiles one after the other, and
+// a pass of this kernel is as long as its slowest wavefront -- C3's k = 500 pass 44 -> 39 us, a 20 000-structure call 0.71 -> 0.64 ms)
+constexpr int LP_TILES_PER_BLOCK = TSC_LP_TPB;
 constexpr int LP_QCAP = LP_TI * 64 + 64;
 constexpr int LP_WORDS = LP_MAX_ROWS / 64;
 constexpr int LP_TICKET_GROUPS = 16;  // two-level ticket: same-address atomics serialise (~12 ns each)

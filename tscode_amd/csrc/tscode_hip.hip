@@ -979,9 +979,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
     const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
     // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
     // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
-    // chunks are a few row tiles long -- at 57k structures the passes k = 1000 and 500 take 40 and 45 us instead of about
-    // 50 -- and loses beyond: k = 200, 100 take 59 and 75 us there against 52 on the two-launch path; "local_max_chunk"
-    // moves the limit)
+    // chunks are a few row tiles long -- at 57k structures the passes k = 1000, 500 and 200 take 37, 39 and 50 us instead of
+    // 52-58 -- and loses beyond: k = 100 takes 58 us there against 53 on the two-launch path; "local_max_chunk" moves the limit)
     p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= std::min(LP_MAX_ROWS, c->local_max_chunk);
     p->cur_fused = false;
     if (p->cur_local) {
