@@ -80,7 +80,7 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * descriptors as well (poses of up to about 80 heavy atoms; otherwise and with 0 a separate launch reads the coordinates back).
  * "pca_min_n": ensembles smaller than this (default 6000) take the identity basis for their descriptors instead of estimated
  * principal axes (three launches and about 45 us less per run; any basis gives the same verdicts).
- * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 320, up to 2048) structures
+ * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 384, up to 2048) structures
  * run in the one-launch chunk-local kernel; "sieve_trim": 1 (default) = the screen's shorter instruction sequence;
  * "fused_apply": 1 (default) lets the sieve kernel of a single-rank pass apply a row tile's verdicts itself when the tile's last
  * work item finishes and close the pass (two launches per pass); 0 = tsc_prune_pass_finish launches k_apply_pass (always so for the
