@@ -23,7 +23,7 @@ for f in glob.glob(f"{P}/p*/**/*counter_collection.csv", recursive=True):
         key = (f, k, r["Dispatch_Id"])
         if key not in seen:
             seen.add(key)
-out = {k: dict(v) for k, v in agg.items() if "sieve" in k or "stop_scan" in k or "apply" in k or "open_pass" in k}
+out = {k: dict(v) for k, v in agg.items() if "sieve" in k or "open_rows" in k or "apply" in k or "pass_chunks" in k}
 json.dump(out, open(f"{P}/sq_counters.json", "w"), indent=1)
 for k, v in out.items():
     print(k)
