@@ -636,7 +636,8 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     const int h3 = a.h * 3;
     unsigned short *queue = s_queue[wid];
     int qn = 0;
-    unsigned long long n_screened = 0, n_eval = 0, n_exact = 0;
+    unsigned long long n_eval = 0, n_exact = 0;
+    int my_screened = 0;  // lanes 0..15: pairs of this item's rows that went through the screen (<= 16 x segment)
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // Queue entries are evaluated in two stages, each over batches of up to 64 pairs with lpp = 64 / pow2ceil(batch) lanes
@@ -758,15 +759,18 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
         {   // ---- screen one tile against every live row
             const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + TILE_COLS - 1;
             unsigned rows = unsigned(__ballot(here));
+            // columns of this tile inside every live row's range (r, cend): counted once per tile by the rows' own lanes (a few
+            // vector instructions per tile; as seven scalar ones per (row, tile) it was a quarter of the row loop's instructions)
+            my_screened += here ? max(0, min(my_cend, c0 + TILE_COLS) - max(r0 + lane + 1, c0)) : 0;
             if constexpr (TRIM) {
+                // rows whose range (r, cend) holds the WHOLE tile need no column mask: one bit per row, tested by the row loop
+                const unsigned full = unsigned(__ballot(here && r0 + lane < c0 && my_cend >= c0 + TILE_COLS));
                 // the same screen with fewer vector instructions per (row, tile): one LDS record per row (components and norms
                 // behind one address), the norms folded into the dot-product chain, and the two families compared with the limit
                 // separately instead of max / max / min / compare (NaN handling unchanged: a NaN component never rejects)
                 while (rows) {
                     const int t = __ffs(rows) - 1;
                     rows &= rows - 1;
-                    const int r = r0 + t;
-                    const int ce = __builtin_amdgcn_readlane(my_cend, t);
 #ifdef TSC_DBG_NOROWLOAD      // (measurement hook: every row of a tile uses row 0's record -- wrong verdicts, the screen without its per-row LDS reads)
                     const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc);
 #else
@@ -776,34 +780,37 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
 #pragma unroll
                     for (int k = 0; k < KD; ++k) rd[k] = rec[k];
                     const f32x2 nr = rec[KD];
-                    n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
                     // Both family distances against the limit as INTEGER compares of the bit patterns (for a positive limit the
                     // order of non-negative floats; a negative sum -- rounding -- is below it either way; a NaN with a clear sign
-                    // bit now counts as beyond the limit where the float compare let it through to H, which rejects it: :75):
-                    // two v_cmp per column straight into lane masks, no canonicalising max, nothing materialised per lane.
-                    unsigned long long pm[CPL];
+                    // bit counts as beyond the limit where a float compare would let it through to H, which rejects it: :75).
+                    // The larger of a column's two families, the smaller of that over the lane's columns, ONE compare and one
+                    // branch on it per (row, tile): the scalar side of this loop (27 instructions per trip against 24 vector ones
+                    // before: each family's compare into a lane mask, the masks combined and tested there) was what a wavefront
+                    // spent its trip on.
+                    int worst[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
                         f32x2 acc = cn[u];                         // -|c|^2 / 2
 #pragma unroll
                         for (int k = 0; k < KD; ++k) acc = __builtin_elementwise_fma(rd[k], dq[u][k], acc);
                         const f32x2 s2 = __builtin_elementwise_fma(acc, f32x2{-2.0f, -2.0f}, nr);
-                        pm[u] = ~(__builtin_amdgcn_ballot_w64(__float_as_int(s2.x) > limit_bits) | __builtin_amdgcn_ballot_w64(__float_as_int(s2.y) > limit_bits));
+                        worst[u] = max(__float_as_int(s2.x), __float_as_int(s2.y));
                     }
-                    if (!(r < c0 && ce >= c0 + TILE_COLS)) {  // the tile crosses an end of the row's range: only the columns inside count
+                    if (!((full >> t) & 1u)) {  // the tile crosses an end of the row's range: only the columns inside count
+                        const int r = r0 + t, ce = __builtin_amdgcn_readlane(my_cend, t);
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
                             const int col = c0 + 64 * u + lane;
-                            pm[u] &= __builtin_amdgcn_ballot_w64(col > r && col < ce);
+                            worst[u] = (col > r && col < ce) ? worst[u] : INT_MAX;
                         }
                     }
-                    unsigned long long any = pm[0];
+                    int nearest = worst[0];
 #pragma unroll
-                    for (int u = 1; u < CPL; ++u) any |= pm[u];
-                    if (any) {
+                    for (int u = 1; u < CPL; ++u) nearest = min(nearest, worst[u]);
+                    if (__builtin_amdgcn_ballot_w64(nearest <= limit_bits)) {   // (rare) some column of the tile is within the limit
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
-                            const unsigned long long m = pm[u];
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(worst[u] <= limit_bits);
                             if (m) {
                                 if ((m >> lane) & 1ull) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
                                 qn += __popcll(m);
@@ -821,8 +828,6 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
                 f32x2 rd[KD];
 #pragma unroll
                 for (int k = 0; k < KD; ++k) rd[k] = dr[k];
-                // columns of this tile inside the row's range (r, ce): counted without a ballot
-                n_screened += (unsigned long long)max(0, min(ce, c0 + TILE_COLS) - max(r + 1, c0));
                 // larger of the two family distances for the lane's CPL columns, as |r|^2 + |c|^2 - 2 r.c in packed fp32 (one
                 // v_pk_fma_f32 per component advances both families; 10 instructions per column, screen_limit32_dot has
                 // the error bound)
@@ -889,10 +894,11 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
 #endif
     if (qe > 0) exact_stage(0, qe);
     TSC_STAMP(3);  // candidates evaluated
+    for (int off = 8; off > 0; off >>= 1) my_screened += __shfl_xor(my_screened, off);
     if (lane == 0) {
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
-        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+        count_add(counters, unsigned(slot), CNT_SCREENED, (unsigned long long)my_screened);
     }
 }
 
