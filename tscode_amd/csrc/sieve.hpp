@@ -763,61 +763,67 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
             // vector instructions per tile; as seven scalar ones per (row, tile) it was a quarter of the row loop's instructions)
             my_screened += here ? max(0, min(my_cend, c0 + TILE_COLS) - max(r0 + lane + 1, c0)) : 0;
             if constexpr (TRIM) {
-                // rows whose range (r, cend) holds the WHOLE tile need no column mask: one bit per row, tested by the row loop
+                // rows whose range (r, cend) holds the WHOLE tile need no column mask: one bit per row
                 const unsigned full = unsigned(__ballot(here && r0 + lane < c0 && my_cend >= c0 + TILE_COLS));
                 // the same screen with fewer vector instructions per (row, tile): one LDS record per row (components and norms
                 // behind one address), the norms folded into the dot-product chain, and the two families compared with the limit
-                // separately instead of max / max / min / compare (NaN handling unchanged: a NaN component never rejects)
-                while (rows) {
-                    const int t = __ffs(rows) - 1;
-                    rows &= rows - 1;
+                // separately instead of max / max / min / compare (NaN handling unchanged: a NaN component never rejects).
+                // Two loops over the same body: first the rows that hold the whole tile (no column mask, no test for it),
+                // then the few whose range ends or begins inside it.
+                auto screen_rows = [&](unsigned todo, auto partial) __attribute__((always_inline)) {
+                    while (todo) {
+                        const int t = __ffs(todo) - 1;
+                        todo &= todo - 1;
 #ifdef TSC_DBG_NOROWLOAD      // (measurement hook: every row of a tile uses row 0's record -- wrong verdicts, the screen without its per-row LDS reads)
-                    const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc);
+                        const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc);
 #else
-                    const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc + t * RS);
+                        const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc + t * RS);
 #endif
-                    f32x2 rd[KD];
+                        f32x2 rd[KD];
 #pragma unroll
-                    for (int k = 0; k < KD; ++k) rd[k] = rec[k];
-                    const f32x2 nr = rec[KD];
-                    // Both family distances against the limit as INTEGER compares of the bit patterns (for a positive limit the
-                    // order of non-negative floats; a negative sum -- rounding -- is below it either way; a NaN with a clear sign
-                    // bit counts as beyond the limit where a float compare would let it through to H, which rejects it: :75).
-                    // The larger of a column's two families, the smaller of that over the lane's columns, ONE compare and one
-                    // branch on it per (row, tile): the scalar side of this loop (27 instructions per trip against 24 vector ones
-                    // before: each family's compare into a lane mask, the masks combined and tested there) was what a wavefront
-                    // spent its trip on.
-                    int worst[CPL];
-#pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        f32x2 acc = cn[u];                         // -|c|^2 / 2
-#pragma unroll
-                        for (int k = 0; k < KD; ++k) acc = __builtin_elementwise_fma(rd[k], dq[u][k], acc);
-                        const f32x2 s2 = __builtin_elementwise_fma(acc, f32x2{-2.0f, -2.0f}, nr);
-                        worst[u] = max(__float_as_int(s2.x), __float_as_int(s2.y));
-                    }
-                    if (!((full >> t) & 1u)) {  // the tile crosses an end of the row's range: only the columns inside count
-                        const int r = r0 + t, ce = __builtin_amdgcn_readlane(my_cend, t);
+                        for (int k = 0; k < KD; ++k) rd[k] = rec[k];
+                        const f32x2 nr = rec[KD];
+                        // Both family distances against the limit as INTEGER compares of the bit patterns (for a positive limit the
+                        // order of non-negative floats; a negative sum -- rounding -- is below it either way; a NaN with a clear
+                        // sign bit counts as beyond the limit where a float compare would let it through to H, which rejects it:
+                        // :75).  The larger of a column's two families, the smaller of that over the lane's columns, ONE compare
+                        // and one branch on it per (row, tile): the scalar side of this loop (27 instructions per trip against 24
+                        // vector ones before: each family's compare into a lane mask, the masks combined and tested there) was
+                        // what a wavefront spent its trip on.
+                        int worst[CPL];
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
-                            const int col = c0 + 64 * u + lane;
-                            worst[u] = (col > r && col < ce) ? worst[u] : INT_MAX;
+                            f32x2 acc = cn[u];                         // -|c|^2 / 2
+#pragma unroll
+                            for (int k = 0; k < KD; ++k) acc = __builtin_elementwise_fma(rd[k], dq[u][k], acc);
+                            const f32x2 s2 = __builtin_elementwise_fma(acc, f32x2{-2.0f, -2.0f}, nr);
+                            worst[u] = max(__float_as_int(s2.x), __float_as_int(s2.y));
                         }
-                    }
-                    int nearest = worst[0];
+                        if constexpr (decltype(partial)::value) {  // the tile crosses an end of the row's range: only the columns inside count
+                            const int r = r0 + t, ce = __builtin_amdgcn_readlane(my_cend, t);
 #pragma unroll
-                    for (int u = 1; u < CPL; ++u) nearest = min(nearest, worst[u]);
-                    if (__builtin_amdgcn_ballot_w64(nearest <= limit_bits)) {   // (rare) some column of the tile is within the limit
+                            for (int u = 0; u < CPL; ++u) {
+                                const int col = c0 + 64 * u + lane;
+                                worst[u] = (col > r && col < ce) ? worst[u] : INT_MAX;
+                            }
+                        }
+                        int nearest = worst[0];
 #pragma unroll
-                        for (int u = 0; u < CPL; ++u) {
-                            const unsigned long long m = __builtin_amdgcn_ballot_w64(worst[u] <= limit_bits);
-                            if (m) {
-                                if ((m >> lane) & 1ull) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
-                                qn += __popcll(m);
+                        for (int u = 1; u < CPL; ++u) nearest = min(nearest, worst[u]);
+                        if (__builtin_amdgcn_ballot_w64(nearest <= limit_bits)) {   // (rare) some column of the tile is within the limit
+#pragma unroll
+                            for (int u = 0; u < CPL; ++u) {
+                                const unsigned long long m = __builtin_amdgcn_ballot_w64(worst[u] <= limit_bits);
+                                if (m) {
+                                    if ((m >> lane) & 1ull) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 12) | unsigned(c0 + 64 * u + lane - seg_lo));
+                                    qn += __popcll(m);
+                                }
                             }
                         }
                     }
-                }
+                };
+                screen_rows(rows & full, std::false_type{});
+                screen_rows(rows & ~full, std::true_type{});
             } else
             while (rows) {
                 const int t = __ffs(rows) - 1;
