@@ -95,6 +95,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
     const int nw = (L + 63) >> 6;
     if (tid < 8) s_stat[tid] = 0;
     unsigned long long n_screened = 0, n_eval = 0, n_exact = 0, n_evaluated = 0, n_removed = 0;
+    int my_screened = 0;  // lanes 0..15 of a wavefront: pairs of its tiles' rows that went through the screen
 
     if (pass_on) {
         // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures.  The other bit copy may lag one pass
@@ -265,13 +266,15 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                     if (c0 + 64 < cmax) load_cols(c0 + 64, dq_next);
                     const bool here = lane < nrows && ((alive >> lane) & 1u) && my_cend > c0 && r0 + lane < c0 + 63;
                     unsigned rows = unsigned(__builtin_amdgcn_ballot_w64(here));
+                    // (columns of this tile inside every live row's range: counted once per tile by the rows' own lanes, not by
+                    // seven scalar instructions per row -- sieve.hpp)
+                    my_screened += here ? max(0, min(my_cend, c0 + 64) - max(r0 + lane + 1, c0)) : 0;
                     while (rows) {
                         const int t = __ffs(rows) - 1;
                         rows &= rows - 1;
                         const int r = r0 + t;
                         const int ce = __builtin_amdgcn_readlane(my_cend, t);
                         const f32x2 *dr = reinterpret_cast<const f32x2 *>(rowdesc + t * DW);
-                        n_screened += (unsigned long long)max(0, min(ce, c0 + 64) - max(r + 1, c0));
                         f32x2 s2 = {0.0f, 0.0f};
 #pragma unroll
                         for (int k = 0; k < KD; ++k) {
@@ -295,6 +298,8 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
             if (qn > 0) sign_stage(0, qn);
             if (qe > 0) exact_stage(0, qe);
         }
+        for (int off = 8; off > 0; off >>= 1) my_screened += __shfl_xor(my_screened, off);
+        n_screened = (unsigned long long)my_screened;
         __syncthreads();
 
         // ---- 4. apply this block's rows: mask, one cache key per removed row (:69-73), scan counts, evaluation count
