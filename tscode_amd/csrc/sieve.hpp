@@ -770,10 +770,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
                 // separately instead of max / max / min / compare (NaN handling unchanged: a NaN component never rejects).
                 // Two loops over the same body: first the rows that hold the whole tile (no column mask, no test for it),
                 // then the few whose range ends or begins inside it.
-                auto screen_rows = [&](unsigned todo, auto partial) __attribute__((always_inline)) {
-                    while (todo) {
-                        const int t = __ffs(todo) - 1;
-                        todo &= todo - 1;
+                auto screen_row = [&](const int t, auto partial) __attribute__((always_inline)) {
 #ifdef TSC_DBG_NOROWLOAD      // (measurement hook: every row of a tile uses row 0's record -- wrong verdicts, the screen without its per-row LDS reads)
                         const f32x2 *rec = reinterpret_cast<const f32x2 *>(rowdesc);
 #else
@@ -820,10 +817,23 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
                                 }
                             }
                         }
+                };
+                auto screen_rows = [&](unsigned todo, auto partial) __attribute__((always_inline)) {
+                    while (todo) {
+                        const int t = __ffs(todo) - 1;
+                        todo &= todo - 1;
+                        screen_row(t, partial);
                     }
                 };
-                screen_rows(rows & full, std::false_type{});
-                screen_rows(rows & ~full, std::true_type{});
+                if ((rows & full) == 0xffffu) {
+                    // all 16 rows hold the whole tile (the usual tile of a large pass): the loop unrolled, every row's record at
+                    // a constant LDS offset, no index arithmetic and no loop control between the rows
+#pragma unroll
+                    for (int t = 0; t < TI; ++t) screen_row(t, std::false_type{});
+                } else {
+                    screen_rows(rows & full, std::false_type{});
+                    screen_rows(rows & ~full, std::true_type{});
+                }
             } else
             while (rows) {
                 const int t = __ffs(rows) - 1;
