@@ -1303,12 +1303,13 @@ def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
     assert (res2["n_conformers"], res2["n_pass"], res2["n_keep"]) == (res["n_conformers"], res["n_pass"], res["n_keep"])
 
 
-@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0)])
+@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0), (2, "C5", 0, 0)])
 def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     """The multi-rank protocol on the product backend (HIP kernels), several ranks sharing this box's one GPU: gloo as the
     transport (device tensors staged over the host), everything else as under RCCL -- pose blocks, all-gather of the
     survivors' heavy atoms, row tiles of the large passes dealt round-robin with all-reduce(MIN), small passes replicated.
-    C3 with two and four ranks and C4 (1M x 50) with three against the recorded oracle results; C2 with three ranks and the
+    C3 with two and four ranks, C4 (1M x 50) with three and C5 (500k x 200 atoms, three fragments) with two against the recorded
+    oracle results; C2 with three ranks and the
     sharding threshold lowered so that small passes are sharded too, against the oracle run here."""
     import json
     import os
@@ -1326,8 +1327,8 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     # both forms of the front half (pose blocks + all-gather / every rank embeds all poses) were timed, one was chosen by every
     # rank alike, and each of them, forced, gives the same survivors and evaluation counts
     assert got["forms_agree"] and got["front_tuning"]["chosen"] in ("shard", "replicate") and len(got["front_tuning"]["ms_per_step"]) == 2
-    if cfg in ("C3", "C4"):                              # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
-        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))[{"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0"}[cfg]]
+    if cfg in ("C3", "C4", "C5"):                        # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
+        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))[{"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0", "C5": "C5:500000:mode0"}[cfg]]
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
         assert got["pairs_evaluated"] == [p["pairs_evaluated"] for p in exp["passes"]]
     else:
