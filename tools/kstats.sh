@@ -8,7 +8,8 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-side-leg $* > "$P/bench.json" 2> "$P/trace.err"
 python3 - "$P" <<'PY'
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)   # (the newest run of this directory)
 rows = list(csv.DictReader(open(f)))
 steps = 12
 tot = 0
