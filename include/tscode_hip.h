@@ -72,7 +72,7 @@ int tsc_ctx_set_stream(tsc_ctx *ctx, void *hip_stream);
 int tsc_ctx_synchronize(tsc_ctx *ctx);
 /* Tunables.  "prune_algo": 0 = automatic (default), 1 = register-tiled all-pairs kernel (<= 32 heavy atoms),
  * 2 = descriptor sieve (any size);  "seg_cols": columns per pair-kernel work item (multiple of 256, at most 4096; 0 = automatic);
- * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64);
+ * "drain_min": queued pairs that trigger an evaluation batch in the sieve kernel (1..64, default 32);
  * "sieve_cpl": columns per lane of the sieve kernel's screen, 1, 2 (default) or 4 -- register footprint against occupancy;
  * "early_basis": 1 (default) lets tsc_pipeline_dev estimate the descriptor basis of the prune from a sample of the unfiltered
  * poses on a side stream while the clash kernel runs (the choice of basis never changes a verdict); 0 = from the filtered
