@@ -350,6 +350,34 @@ int tsc_prune_pass_rows(tsc_prune *p, int rank, int world_size);  /* after tsc_p
                                                                      tiles of the same pass, into the same best[] (atomicMin).  Lets
                                                                      one GPU stand in for several ranks (tools/predict_scaling.py times
                                                                      every rank's share this way; repeating a share changes nothing) */
+/* RANK-PARTITIONED passes ("early passes": whole chunks to GPUs).  The chunks of a pass are independent
+ * (tscode/rmsd_pruning.py:139-157: every chunk reads the same input mask and the same cache), so while a pass has at least
+ * min_chunks_per_rank chunks per rank each rank runs the WHOLE pass flow -- rows, stop columns, pair search, verdicts -- on the
+ * chunks that start inside its block [n rank / world, n (rank + 1) / world) of the structure axis and on nothing else: no
+ * per-row work is replicated, and what crosses the ranks is one bit per structure plus five counters.
+ *   tsc_prune_exchange_words(n, mode) -> words of the exchange buffer (int64: n / 64 + 40 removed-row bits, 8 statistics, then --
+ *                                mode 0 -- the storage of the run's cache views, which move into this buffer)
+ *   tsc_prune_set_partition      right after tsc_prune_create; exch_dev = caller-owned device buffer of that many int64 (e.g. a
+ *                                torch tensor that torch.distributed can all-reduce); zeroed here.  The per-pass exchange is over
+ *                                its first n / 64 + 48 words
+ *   per pass:  tsc_prune_next_pass;  tsc_prune_pass_partitioned -> 1:
+ *                  tsc_prune_pass_range;                       // this rank's chunks, asynchronous
+ *                  <all-reduce SUM over the exchange buffer>   // the ranks' bits are disjoint: the sum is their union
+ *                  tsc_prune_pass_merge;                       // mask, bit copy, scan counts, record, the gate of :192, the next
+ *                                                              // pass's rows -- identical on every rank; asynchronous
+ *              -> 0: the first such pass after partitioned ones needs the cache keys of every rank (a key (a, b) is only ever
+ *                  hit in the chunk that starts at a, which belongs to the same rank in every partitioned pass -- so the keys
+ *                  stayed where they were made):  tsc_prune_views_ptr -> words > 0:  <all-reduce SUM over that block> (views_dev,
+ *                  or exch_dev + offset_words: the views of the passes still to run), tsc_prune_views_merged;  then
+ *                  tsc_prune_pass_local / tsc_prune_pass_finish as above.
+ * The per-pass statistics of a partitioned pass (tsc_prune_stats) are the sums over all ranks. */
+int tsc_prune_exchange_words(int64_t n, int mode, int64_t *words);
+int tsc_prune_set_partition(tsc_prune *p, int rank, int world_size, int min_chunks_per_rank, void *exch_dev_i64, int64_t exch_words);
+int tsc_prune_pass_partitioned(tsc_prune *p, int *flag);
+int tsc_prune_pass_range(tsc_prune *p);
+int tsc_prune_pass_merge(tsc_prune *p);
+int tsc_prune_views_ptr(tsc_prune *p, void **views_dev_i64, int64_t *offset_words, int64_t *words);
+int tsc_prune_views_merged(tsc_prune *p);
 int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i32[n_entries], valid until finish */
 /* Make the run keep best[] in a caller-owned device buffer of n int32 (e.g. a torch tensor that
  * torch.distributed can all-reduce); call right after tsc_prune_create. */

@@ -332,6 +332,85 @@ def test_prune_sharded_rows_equal_single(eng, oracle):
     _lib.check(lib.tsc_free(eng._h, d_heavy))
 
 
+@pytest.mark.parametrize("world,min_chunks,n_poses,mode", [(2, 4, 12_000, 0), (3, 1, 12_000, 0), (8, 4, 40_000, 0), (3, 4, 9_000, 1), (5, 2, 700, 0)])
+def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_poses, mode):
+    """Rank-partitioned passes (tsc_prune_pass_range / tsc_prune_pass_merge): `world` prune runs over the same heavy-atom array stand
+    in for the ranks, each takes the chunks that start inside its block of the structure axis, and the all-reduce(SUM) of the
+    exchange buffers is done here with torch.  Every rank must end with the oracle's mask, and the per-pass statistics -- active
+    counts and the reference's own pair-evaluation counts -- must be the single-run ones on every rank."""
+    import torch
+
+    from tscode_amd.engine import PruneStepper
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", n_poses)
+    heavy = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
+    one_mask, one_stats = eng.prune_heavy(heavy, 0.5, mode)
+    assert np.array_equal(one_mask, ref["mask"])
+    dev = torch.device("cuda:0")
+    d_heavy = torch.from_numpy(heavy).to(dev)
+    n, h = heavy.shape[0], heavy.shape[1]
+    words = PruneStepper.exchange_words(eng.lib, n, mode)
+    steppers, exch = [], []
+    for r in range(world):
+        st = eng.prune_stepper(d_heavy, n, h, 0.5, mode)
+        ex = torch.zeros(words, dtype=torch.int64, device=dev)
+        st.set_partition(r, world, min_chunks, ex)
+        steppers.append(st), exch.append(ex)
+    per_pass = n // 64 + 48
+    n_part = n_views = 0
+    while True:
+        ks = {st.next_pass() for st in steppers}
+        assert len(ks) == 1
+        k = ks.pop()
+        if k == 0:
+            break
+        flags = {st.pass_partitioned() for st in steppers}
+        assert len(flags) == 1 and flags.pop() == (k >= min_chunks * world)
+        if k >= min_chunks * world:
+            for st in steppers:
+                st.pass_range()
+            eng.synchronize()
+            total = torch.stack([e[:per_pass] for e in exch]).sum(0)
+            # the ranks' removed rows are disjoint: no bit may be set twice
+            for a in range(world):
+                for b in range(a + 1, world):
+                    assert not bool((exch[a][:per_pass - 8] & exch[b][:per_pass - 8]).any()), (k, a, b)
+            for e, st in zip(exch, steppers):
+                e[:per_pass].copy_(total)
+                torch.cuda.synchronize()
+                st.pass_merge()
+            n_part += 1
+            continue
+        ranges = {st.views_range() for st in steppers}
+        assert len(ranges) == 1
+        off, w = ranges.pop()
+        if w:
+            torch.cuda.synchronize()
+            eng.synchronize()
+            total = torch.stack([e[off:off + w] for e in exch]).sum(0)
+            for e in exch:
+                e[off:off + w].copy_(total)
+            torch.cuda.synchronize()
+            n_views += 1
+        for st in steppers:
+            st.views_merged()
+            st.pass_local(0, 1)         # every rank runs the remaining passes whole (their sharding by row tiles is tested elsewhere)
+            st.pass_finish()
+    assert n_part >= 1 and n_views == (1 if mode == 0 else 0)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    for r, st in enumerate(steppers):
+        st.copy_mask(keep)
+        stats = st.stats()
+        assert np.array_equal(keep.cpu().numpy().astype(bool), ref["mask"]), f"rank {r}"
+        for a, b, c in zip(stats, one_stats, ref["stats"]):
+            assert (a["k"], a["n_active_before"], a["n_active_after"]) == (b["k"], b["n_active_before"], b["n_active_after"]), (r, a, b)
+            assert a["pairs_evaluated"] == c["pairs_evaluated"] == b["pairs_evaluated"], (r, a["k"], a["pairs_evaluated"], c["pairs_evaluated"])
+            assert a["new_keys"] == b["new_keys"]
+        assert len(stats) == len(one_stats)
+        st.close()
+
+
 def test_pipeline_c2_vs_oracle(eng, oracle):
     import torch
 

@@ -64,6 +64,80 @@ class OracleStepper:
         self._stats.append({"k": self.k, "n_active_before": before, "n_active_after": int(self.mask.sum())})
         self.k = 0
 
+    # ---- partitioned passes: the whole pass on the chunks that start inside this rank's block of the structure axis.  The oracle
+    # computes best[] with the keys THIS rank holds (its own removals only); rows outside the rank's chunks are discarded, so a
+    # wrong ownership rule (a key needed by another rank's chunk) would show as a wrong mask.
+    def set_partition(self, rank, world, min_chunks):
+        self.rank, self.world, self.min_chunks = rank, world, min_chunks
+        self.bit_words = self.n // 64 + 40
+        self.exch = self.backend_exch.numpy()
+        self.exch[:] = 0
+        self.views_split = False
+
+    def pass_partitioned(self):
+        return getattr(self, "world", 1) > 1 and self.k >= self.min_chunks * self.world
+
+    def exchange_words(self):
+        return self.bit_words + 8
+
+    def pass_range(self):
+        from tscode_amd.pipeline import partition_bounds
+        best = np.full(len(self.act), INT_MAX, dtype=np.int32)
+        self.o.prune_pass_rows(self.heavy, self.mask, self.keys, self.k, 0, 1, self.tile_rows, best, self.thr, self.mode)
+        _, _, s_lo, s_hi = partition_bounds(self.n, self.k, self.rank, self.world)
+        rows = np.flatnonzero((best != INT_MAX) & (self.act >= s_lo) & (self.act < s_hi))
+        i, j = self.act[rows], self.act[best[rows]]
+        cs = self.n // self.k
+        first = np.minimum(i // cs, self.k - 1) * cs
+        self.keys = np.concatenate([self.keys, np.stack([first, first + (j - i)], axis=1)])      # this rank's keys only
+        bits = np.zeros(self.bit_words * 64, dtype=np.uint8)
+        bits[i] = 1
+        self.exch[:self.bit_words] = np.packbits(bits, bitorder="little").view(np.int64)
+        self.exch[self.bit_words] = len(rows)                                                    # a statistic that must come out as the sum
+        self.views_split = True
+
+    def pass_merge(self):
+        removed = np.flatnonzero(np.unpackbits(self.exch[:self.bit_words].view(np.uint8), bitorder="little"))
+        assert int(self.exch[self.bit_words]) == len(removed)                                    # the ranks' removals are disjoint
+        before = int(self.mask.sum())
+        self.mask[removed] = 0
+        self.exch[:self.bit_words + 8] = 0
+        self._stats.append({"k": self.k, "n_active_before": before, "n_active_after": int(self.mask.sum())})
+        self.k = 0
+
+    def _remaining(self):
+        return [self.k] + [int(k) for k in self.ks if int(k) == 1 or 20 * int(k) < self.n]
+
+    def views_range(self):
+        if not getattr(self, "views_split", False) or self.mode != 0:
+            return 0, 0
+        # the keys of this rank as one row of n flags per remaining pass: flag b of pass k2 = a key (a, b) with a the start of the
+        # chunk of b in that pass (the only keys that pass can hit)
+        off = self.bit_words + 8
+        rem = self._remaining()
+        dense = np.zeros((len(rem), self.n), dtype=np.int64)
+        for q, k2 in enumerate(rem):
+            cs = self.n // k2
+            for a, b in self.keys:
+                if 0 <= b < self.n and np.minimum(b // cs, k2 - 1) * cs == a:
+                    dense[q, b] = 1
+        self.exch[off:off + dense.size] = dense.ravel()
+        return off, dense.size
+
+    def views_merged(self):
+        if getattr(self, "views_split", False) and self.mode == 0:
+            off = self.bit_words + 8
+            rem = self._remaining()
+            dense = self.exch[off:off + len(rem) * self.n].reshape(len(rem), self.n)
+            assert dense.max(initial=0) <= 1                                                     # disjoint between ranks
+            keys = set()
+            for q, k2 in enumerate(rem):
+                cs = self.n // k2
+                for b in np.flatnonzero(dense[q]):
+                    keys.add((int(np.minimum(b // cs, k2 - 1) * cs), int(b)))
+            self.keys = np.array(sorted(keys), dtype=np.int64).reshape(-1, 2)
+        self.views_split = False
+
     def stats(self):
         return self._stats
 
@@ -92,6 +166,7 @@ class OracleShardBackend:
         self.best = torch.zeros(n, dtype=torch.int32)
         self.keep = torch.zeros(n, dtype=torch.uint8)
         self.counts = torch.zeros(world, dtype=torch.int64)
+        self.exch = torch.zeros(n // 64 + 48 + 19 * n, dtype=torch.int64)
 
     def embed_clash_block(self):
         import torch
@@ -114,7 +189,9 @@ class OracleShardBackend:
         return len(heavy)
 
     def make_stepper(self, n_pass):
-        return OracleStepper(self.o, self.heavy_all[:n_pass].numpy(), self.best, self.thr, self.mode, self.tile_rows)
+        st = OracleStepper(self.o, self.heavy_all[:n_pass].numpy(), self.best, self.thr, self.mode, self.tile_rows)
+        st.backend_exch = self.exch
+        return st
 
 
 def _free_port():
@@ -123,7 +200,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_poses, mode, out_dir, front="shard"):
+def _worker(rank, world, port, n_poses, mode, out_dir, front="shard", partition_chunks=4):
     import torch
     import torch.distributed as dist
 
@@ -137,21 +214,26 @@ def _worker(rank, world, port, n_poses, mode, out_dir, front="shard"):
     try:
         ens = make_config("C2", n_poses)
         backend = OracleShardBackend(oracle, ens, rank, world, mode=mode)
-        res = sharded_step(backend, rank, world, dist, front=front)
+        res = sharded_step(backend, rank, world, dist, front=front, partition_chunks=partition_chunks)
         assert res["front"] == front and (res["allgather_bytes"] > 0) == (front == "shard")
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keep=backend.keep[:res["n_pass"]].numpy(), n_pass=res["n_pass"],
-                 n_keep=res["n_keep"], counts=np.array(res["counts"]), ks=np.array([s["k"] for s in res["stats"]]))
+                 n_keep=res["n_keep"], counts=np.array(res["counts"]), ks=np.array([s["k"] for s in res["stats"]]),
+                 partitioned=np.array([k for k, _ in res["partitioned"]], dtype=np.int64))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_poses,mode,front", [(2, 3000, 0, "shard"), (3, 2001, 0, "shard"), (2, 1500, 1, "shard"), (2, 2500, 0, "replicate"),
-                                                      (3, 1201, 1, "replicate")])
-def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front):
+# partition_chunks: 4 = the default (passes with >= 4 chunks per rank are partitioned by chunks, the rest sharded by row tiles or
+# replicated), 1 = every pass down to k = world partitioned (chunks as long as a rank's block: every block boundary is a seam
+# that a chunk straddles), 0 = no partitioned pass (the protocol of round 2)
+@pytest.mark.parametrize("world,n_poses,mode,front,partition_chunks", [
+    (2, 3000, 0, "shard", 4), (3, 2001, 0, "shard", 4), (2, 1500, 1, "shard", 4), (2, 2500, 0, "replicate", 4), (3, 1201, 1, "replicate", 4),
+    (2, 2999, 0, "replicate", 1), (3, 2503, 0, "shard", 1), (3, 1801, 0, "replicate", 0)])
+def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front, partition_chunks):
     import torch.multiprocessing as mp
 
     from tscode_amd.synthetic import make_config
-    mp.spawn(_worker, args=(world, _free_port(), n_poses, mode, str(tmp_path), front), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_poses, mode, str(tmp_path), front, partition_chunks), nprocs=world, join=True)
     ens = make_config("C2", n_poses)
     poses = oracle.transform_batch(ens.frag_coords, ens.conf_idx, ens.rot, ens.pos)
     cm = oracle.compenetration_mask(poses, ens.ids, 1.5, 0)
@@ -163,6 +245,28 @@ def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front):
         assert np.array_equal(got["keep"].astype(bool), ref["mask"]), f"rank {rank}"
         assert int(got["n_keep"]) == int(ref["mask"].sum())
         assert got["ks"].tolist() == [s["k"] for s in ref["stats"]]
+        want = [s["k"] for s in ref["stats"] if partition_chunks and s["k"] >= partition_chunks * world]
+        assert got["partitioned"].tolist() == want, (got["partitioned"].tolist(), want)
+
+
+def test_partition_bounds_are_whole_chunks_that_cover_the_pass():
+    from tscode_amd.pipeline import partition_bounds
+    for n in (57, 1000, 1003, 57046, 483472):
+        for k in (1, 2, 5, 10, 50, 200, 2000):
+            if k > n:
+                continue
+            cs = n // k
+            for world in (1, 2, 3, 8):
+                b = [partition_bounds(n, k, r, world) for r in range(world)]
+                assert b[0][0] == 0 and b[0][2] == 0 and b[-1][1] == k and b[-1][3] == n
+                for r in range(world):
+                    c_lo, c_hi, s_lo, s_hi = b[r]
+                    assert c_lo <= c_hi and s_lo == (c_lo * cs if c_lo < k else n) and s_hi == (c_hi * cs if c_hi < k else n)
+                    if r + 1 < world:
+                        assert b[r + 1][0] == c_hi and b[r + 1][2] == s_hi
+                    # a chunk belongs to the rank whose block [n r / W, n (r + 1) / W) holds its first structure
+                    for c in range(c_lo, c_hi):
+                        assert n * r // world <= c * cs and (r + 1 == world or c * cs < n * (r + 1) // world)
 
 
 def test_block_bounds_cover_the_pose_axis():

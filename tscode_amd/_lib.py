@@ -99,6 +99,13 @@ _SIGNATURES = {
     "tsc_prune_run_replicated": (C.c_int, [_vp, C.c_int, C.c_int64, c_i64p]),
     "tsc_prune_pass_local": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsc_prune_pass_rows": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "tsc_prune_exchange_words": (C.c_int, [C.c_int64, C.c_int, c_i64p]),
+    "tsc_prune_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
+    "tsc_prune_pass_partitioned": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "tsc_prune_pass_range": (C.c_int, [_vp]),
+    "tsc_prune_pass_merge": (C.c_int, [_vp]),
+    "tsc_prune_views_ptr": (C.c_int, [_vp, C.POINTER(_vp), c_i64p, c_i64p]),
+    "tsc_prune_views_merged": (C.c_int, [_vp]),
     "tsc_prune_best_ptr": (C.c_int, [_vp, C.POINTER(_vp), c_i64p]),
     "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),
     "tsc_prune_pass_finish": (C.c_int, [_vp]),

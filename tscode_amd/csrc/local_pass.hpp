@@ -40,6 +40,10 @@ struct LocalPassArgs {
     int use_cache;
     int nb_regular;  // blocks per chunk for chunks 0 .. k-2
     int nb_last;     // blocks of the last chunk (it takes the remainder, :141-142)
+    int c_lo;        // first chunk of this launch and how many regular chunks (not the last one of the pass) follow it: 0 and k - 1,
+    int n_reg;       // unless the pass is partitioned over ranks (rmsd.hpp, k_pass_merge): then this rank's chunks; blocks beyond
+                     // n_reg * nb_regular belong to the last chunk of the pass
+    unsigned long long *exch;  // rank-partitioned pass (else null): removed rows are noted here and applied by k_pass_merge
     double thr, maxdev_thr, half_h_thr2, two_thr2, desc_limit;
     const unsigned *dmax_bits;
 };
@@ -83,9 +87,10 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
     // which chunk, and which share of its row tiles
     int c, j, nb;
     {
-        const int reg_blocks = (g.k - 1) * a.nb_regular;
+        const int reg_blocks = a.n_reg * a.nb_regular;
         if (int(blockIdx.x) < reg_blocks) {
             c = int(blockIdx.x) / a.nb_regular, j = int(blockIdx.x) - c * a.nb_regular, nb = a.nb_regular;
+            c += a.c_lo;
         } else {
             c = g.k - 1, j = int(blockIdx.x) - reg_blocks, nb = a.nb_last;
         }
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
         // ---- 1. the chunk's mask and cache view as bits; ranks of the active structures.  The other bit copy may lag one pass
         // behind (a superset of this one): and-ing this chunk's words into it brings it up to date, and commutes with the
         // bits other workgroups -- of this very chunk when it is shared -- clear there in step 4
-        if (j == 0)
+        if (j == 0 && !a.exch)
             for (int w = (first >> 6) + tid; w <= ((first + L - 1) >> 6); w += LP_THREADS) atomicAnd(&mbit_next[w], mbit[w]);
         for (int w = tid; w < nw; w += LP_THREADS) {
             unsigned long long m = extract64(mbit, int64_t(first) + 64 * w);
@@ -313,9 +318,13 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                 const int b = s_best[r];
                 if (b != INT_MAX) {
                     const int t_r = s_act[r], t_b = s_act[b];
-                    mask[first + t_r] = 0;
-                    atomicAnd(&mbit_next[(first + t_r) >> 6], ~(1ull << ((first + t_r) & 63)));
-                    my_block = (first + t_r) / block_items;
+                    if (a.exch) {
+                        atomicOr(&a.exch[(first + t_r) >> 6], 1ull << ((first + t_r) & 63));
+                    } else {
+                        mask[first + t_r] = 0;
+                        atomicAnd(&mbit_next[(first + t_r) >> 6], ~(1ull << ((first + t_r) & 63)));
+                        my_block = (first + t_r) / block_items;
+                    }
                     delta = t_b - t_r;
                     removed = true;
                     ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGe
                     ev = (unsigned long long)(int(s_cend[r]) - r - 1);  // every active column before the stop column
                 }
             }
-            for (unsigned long long left = __builtin_amdgcn_ballot_w64(removed); left;) {
+            for (unsigned long long left = __builtin_amdgcn_ballot_w64(removed && my_block >= 0); left;) {
                 const int l = __ffsll((long long)left) - 1;
                 const int blk = __shfl(my_block, l);
                 const unsigned long long same = __builtin_amdgcn_ballot_w64(removed && my_block == blk);

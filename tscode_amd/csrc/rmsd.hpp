@@ -306,6 +306,9 @@ struct PruneState {
     int A;         // active structures entering the pass in flight (== n_active at its start)
     unsigned ticket;  // blocks of k_apply_pass that have finished (the last one closes the pass)
     int bitsel;    // which of the two bit copies of the mask the pass in flight READS (it clears the rows it removes in the other)
+    int row_lo;    // rank-partitioned pass (tsc_prune_pass_range): active rank of this rank's local row 0; 0 in every other pass.
+                   // In such a pass A counts only the active structures of this rank's chunks and act / cend / best / Dc are
+                   // indexed by LOCAL row (global active rank - row_lo): the pair kernel sees an ensemble of A rows
 };
 struct PassRecord {  // one per schedule slot, read back once at the end of the run
     long long k, n_before, n_after, formed, exact, screened, evaluated, removed;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void k_init_run(InitArgs a) {
     if (tid == 0) {
         if (a.dmax_bits) *a.dmax_bits = 0;  // running maximum of the descriptor build (sieve.hpp)
         PruneState *st = a.st;
-        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0, st->bitsel = 0;
+        st->n_active = int(n), st->pass_on = 0, st->A = int(n), st->ticket = 0, st->bitsel = 0, st->row_lo = 0;
         if (a.first_slot >= 0) {
             const int on = (a.first_k == 1 || 20 * a.first_k < (long long)n) ? 1 : 0;
             PassRecord &fr = a.rec[a.first_slot];
@@ -484,6 +487,9 @@ struct StepCtx {
     int n_blocks;
     unsigned *tickets;  // every arrival counter of the run (PassTickets and the chunk-local kernel's: one per 128-byte line), zeroed on the way out
     int ticket_lines;
+    unsigned long long *exch_tail;  // rank-partitioned pass only (else null): the last unit of this rank's share does not close the
+                                    // pass -- it leaves this rank's five statistics here, behind the removed-row bits of the exchange
+                                    // buffer, and k_pass_merge closes the pass after the ranks' buffers have been summed
 };
 
 __device__ inline void pass_step_wave(const StepCtx &sc, const StepArgs &sa) {
@@ -501,6 +507,18 @@ __device__ inline void pass_step_wave(const StepCtx &sc, const StepArgs &sa) {
     int c_first = lane < sc.n_blocks ? __hip_atomic_load(&sc.bsum[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool closing = sa.prev >= 0 && pass_on != 0;
     unsigned long long sum[CNT_REMOVED + 1] = {v0, v1, v2, v3, v4};
+    if (sc.exch_tail) {  // this rank's share of a rank-partitioned pass is done: statistics into the exchange buffer, counters cleared
+#pragma unroll
+        for (int w = 0; w <= CNT_REMOVED; ++w)
+            for (int off = 32; off > 0; off >>= 1) sum[w] += __shfl_xor(sum[w], off);
+        if (lane == 0 && pass_on != 0) {
+#pragma unroll
+            for (int w = 0; w <= CNT_REMOVED; ++w) sc.exch_tail[w] = sum[w];
+        }
+        for (int e = lane; e < CNT_BUCKETS * 8; e += 64) sc.cnt->w[e >> 3][e & 7] = 0;
+        for (int e = lane; e < sc.ticket_lines; e += 64) sc.tickets[32 * e] = 0;
+        return;
+    }
     if (closing) {
 #pragma unroll
         for (int w = 0; w <= CNT_REMOVED; ++w)
@@ -539,6 +557,7 @@ __device__ inline void pass_step_wave(const StepCtx &sc, const StepArgs &sa) {
             r.formed = r.exact = r.screened = r.evaluated = r.removed = 0;
         }
         st->A = n_active;
+        st->row_lo = 0;
         st->pass_on = on;
         st->ticket = 0;
     }
@@ -640,7 +659,9 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
     const bool in_lds = oa.n_blocks <= oa.lds_cap;
     const int boff_mine = (in_lds && int(threadIdx.x) <= oa.n_blocks) ? oa.boff[threadIdx.x] : 0;
     TSC_OPEN_STAMP(0);  // started (and the first loads have come back)
-    const int pass_on = st->pass_on, A = st->A, sel = st->bitsel;
+    // (row_lo / n_all differ from 0 / A only in a rank-partitioned pass: rows and ranks below are LOCAL except where the mask's
+    // own ranking -- the prefix of the scan blocks -- is consulted)
+    const int pass_on = st->pass_on, A = st->A, sel = st->bitsel, row_lo = st->row_lo, n_all = st->n_active;
     const unsigned long long *X = oa.bits + size_t(sel) * oa.bit_words;
     const unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r0 = int(tile) * 16;
@@ -661,16 +682,17 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
         const int r_true = r0 + sub;
         const bool mine = r_true < A;
         const int r = mine ? r_true : A - 1;  // (idle groups walk along with the last row: the shuffles below stay convergent)
-        // scan block of rank r: the last b with boff[b] <= r  (boff[0] = 0, boff[n_blocks] = A > r)
+        const int rg = r + row_lo;            // its rank among ALL active structures
+        // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg)
         int lo = 0, hi = oa.n_blocks;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (before(mid) <= r) lo = mid;
+            if (before(mid) <= rg) lo = mid;
             else hi = mid;
         }
         int64_t i;
         {
-            const int rem = r - before(lo);
+            const int rem = rg - before(lo);
             unsigned long long w[OPEN_WPL];
             int c = 0;
 #pragma unroll
@@ -722,7 +744,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
             }
 #pragma unroll
             for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-            return (bf < oa.n_blocks ? before(bf) : A) + cnt;
+            return (bf < oa.n_blocks ? before(bf) : n_all) + cnt - row_lo;
         };
         // the stop column is the end of the chunk unless the cache view has a hit (rare): its words are requested now, with
         // the descriptor and the view's summary, not after the walk through the view
@@ -818,6 +840,8 @@ struct ApplyArgs {
     int32_t *bsum;
     int block_items;
     CacheViews cv;
+    unsigned long long *exch;  // rank-partitioned pass (else null): removed rows are only NOTED here, one bit each; mask, bit copy and
+                               // block counts follow in k_pass_merge, from the sum of every rank's notes
 };
 __device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool valid, unsigned long long &ev_total, unsigned long long &rm_total) {
     const int lane = threadIdx.x & 63;
@@ -831,9 +855,13 @@ __device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool 
             const int64_t i = a.act[r], j = a.act[b];
             int64_t last;
             chunk_of(a.g, i, first, last);
-            a.mask[i] = 0;
-            atomicAnd(&a.bits[size_t(sel ^ 1) * a.bit_words + (i >> 6)], ~(1ull << (i & 63)));
-            my_block = int(i / a.block_items);
+            if (a.exch) {
+                atomicOr(&a.exch[i >> 6], 1ull << (i & 63));
+            } else {
+                a.mask[i] = 0;
+                atomicAnd(&a.bits[size_t(sel ^ 1) * a.bit_words + (i >> 6)], ~(1ull << (i & 63)));
+                my_block = int(i / a.block_items);
+            }
             delta = j - i;
             removed = true;
             ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
@@ -843,7 +871,7 @@ __device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool 
     }
     // the per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a wavefront fall
     // into one or two blocks, and thousands of single decrements of two cache lines would serialise
-    for (unsigned long long left = __ballot(removed); left;) {
+    for (unsigned long long left = __ballot(removed && my_block >= 0); left;) {
         const int l = __ffsll((long long)left) - 1;
         const int blk = __shfl(my_block, l);
         const unsigned long long same = __ballot(removed && my_block == blk);
@@ -1131,6 +1159,149 @@ __global__ __launch_bounds__(256) void k_apply_pass(ApplyArgs a, StepCtx sc, Ste
     }
     __syncthreads();
     if (s_last && threadIdx.x < 64) pass_step_wave(sc, next);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Rank-partitioned passes (one process per GPU, tscode_amd/pipeline.py).  The chunks of a pass are independent
+// (rmsd_pruning.py:139-157: every chunk reads the same input mask and the same cache), so while a pass has several chunks
+// per rank each rank takes the chunks that START inside its block [n r / W, n (r + 1) / W) of the structure axis and runs
+// the whole pass flow on them alone -- k_open_rows over its rows only, the pair kernel, the tile-wise apply.  What it learns
+// is which rows it removed: one bit each in an exchange buffer (n / 64 words + the pass's five statistics).  The host sums
+// the ranks' buffers (the bits are disjoint, so the sum is their union; NCCL / RCCL have no bitwise reduction) and
+// k_pass_merge makes the pass's outcome the state of every rank: mask bytes, the bit copy the next pass reads, the scan
+// blocks' counts and prefix, the record, the gate of rmsd_pruning.py:192 for the next pass and -- when that one is
+// rank-partitioned too -- which of the active structures are this rank's rows in it.
+// The cache keys of the removed rows stay with the rank that removed them: a key (a, b) can only be hit by a later pass in
+// the chunk that starts at a (rmsd.hpp, CacheViews), and the chunk that starts at a belongs to the same rank in every
+// rank-partitioned pass.  Before the first pass that is NOT partitioned this way the host sums the cache views of the
+// remaining passes over the ranks once (disjoint bits again) and k_views_summaries rebuilds their summary words.
+
+// Active structures before position pos (0 <= pos <= n) in the bit copy X: the prefix of its scan block + the set bits of
+// the block below it.  One wavefront calls this.
+__device__ inline int rank_below_wave(const int32_t *__restrict__ boff, const unsigned long long *__restrict__ X, int n_blocks, int n_active, int64_t pos) {
+    const int lane = threadIdx.x & 63;
+    const int bf = int(pos / (64 * SCAN_BLOCK_WORDS)), off = int(pos - int64_t(bf) * (64 * SCAN_BLOCK_WORDS));
+    int cnt = 0;
+    if (bf < n_blocks && lane < SCAN_BLOCK_WORDS) {
+        const int below = off - 64 * lane;
+        const unsigned long long m = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1ull : 0ull);
+        cnt = m ? __popcll(X[size_t(bf) * SCAN_BLOCK_WORDS + lane] & m) : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    return (bf < n_blocks ? boff[bf] : n_active) + cnt;
+}
+
+// The rows of this rank in the OPEN pass: the active structures of [s_lo, s_hi) (whole chunks of that pass).  Needed as a
+// launch of its own only where no k_pass_merge precedes the pass (the first pass of a run).
+__global__ __launch_bounds__(64) void k_range_open(PruneState *__restrict__ st, const int32_t *__restrict__ boff, const unsigned long long *__restrict__ bits,
+                                                    int bit_words, int n_blocks, int s_lo, int s_hi) {
+    const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
+    const int n_all = st->n_active;
+    const int lo = rank_below_wave(boff, X, n_blocks, n_all, s_lo), hi = rank_below_wave(boff, X, n_blocks, n_all, s_hi);
+    if ((threadIdx.x & 63) == 0) st->row_lo = lo, st->A = hi - lo;
+}
+
+struct MergeArgs {
+    int n, bit_words, n_blocks;
+    unsigned long long *bits;   // the two bit copies of the mask
+    unsigned long long *exch;   // bit_words words of removed rows, then the five statistics: summed over the ranks by the host
+    uint8_t *mask;
+    int next_s_lo, next_s_hi;   // the next pass is rank-partitioned: this rank's structures [s_lo, s_hi) in it; -1: it is not
+};
+__global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, StepArgs sa) {
+    __shared__ int s_part[16], s_run;
+    PruneState *st = sc.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pass_on = st->pass_on, sel = st->bitsel, n_before = st->n_active;
+    const bool closing = sa.prev >= 0 && pass_on != 0;
+    const unsigned long long *X = a.bits + size_t(sel) * a.bit_words;
+    unsigned long long *Xo = a.bits + size_t(sel ^ 1) * a.bit_words;
+    if (tid == 0) s_run = n_before;
+    if (closing) {
+        for (int w = tid; w < a.bit_words; w += 1024) {
+            unsigned long long rm = a.exch[w];
+            Xo[w] = X[w] & ~rm;
+            if (rm) {
+                a.exch[w] = 0;
+                for (rm &= X[w]; rm; rm &= rm - 1) a.mask[int64_t(w) * 64 + (__ffsll((long long)rm) - 1)] = 0;
+            }
+        }
+        __syncthreads();  // (one block: its global writes are visible to all its threads behind the barrier)
+        if (tid == 0) s_run = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < a.n_blocks; b0 += 1024) {
+            const int b = b0 + tid;
+            int c = 0;
+            if (b < a.n_blocks) {
+#pragma unroll 8
+                for (int u = 0; u < SCAN_BLOCK_WORDS; ++u) c += __popcll(Xo[size_t(b) * SCAN_BLOCK_WORDS + u]);
+                sc.bsum[b] = c;
+            }
+            int incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_part[wv] = incl;
+            __syncthreads();
+            int base = s_run;
+            for (int q = 0; q < wv; ++q) base += s_part[q];
+            if (b < a.n_blocks) sc.boff[b] = base + incl - c;
+            __syncthreads();
+            if (tid == 1023) s_run = base + incl;
+            __syncthreads();
+        }
+        if (tid == 0) sc.boff[a.n_blocks] = s_run;
+    }
+    __syncthreads();
+    const int n_active = s_run;
+    if (tid == 0) {
+        if (closing) {
+            PassRecord &r = sc.rec[sa.prev];
+            r.formed = (long long)a.exch[a.bit_words + CNT_FORMED], r.exact = (long long)a.exch[a.bit_words + CNT_EXACT];
+            r.screened = (long long)a.exch[a.bit_words + CNT_SCREENED], r.evaluated = (long long)a.exch[a.bit_words + CNT_EVALUATED];
+            r.removed = (long long)(n_before - n_active);
+            r.n_after = n_active;
+            if (sa.prev_algo >= 0) r.algo = sa.prev_algo;
+            st->n_active = n_active;
+            st->bitsel = sel ^ 1;
+        }
+        for (int w = 0; w < 8; ++w) a.exch[a.bit_words + w] = 0;
+        int on = 0;
+        if (sa.cur >= 0) {
+            on = (sa.k_cur == 1 || 20 * sa.k_cur < (long long)n_active) ? 1 : 0;  // rmsd_pruning.py:192
+            PassRecord &r = sc.rec[sa.cur];
+            r.k = sa.k_cur, r.n_before = n_active, r.n_after = n_active, r.on = on, r.algo = sa.algo_cur;
+            r.formed = r.exact = r.screened = r.evaluated = r.removed = 0;
+        }
+        st->pass_on = on;
+        st->ticket = 0;
+        if (a.next_s_lo < 0) st->A = n_active, st->row_lo = 0;
+    }
+    if (a.next_s_lo >= 0 && wv == 0) {  // (boff and the new bit copy were written by this block, before the barriers above)
+        const unsigned long long *Xn = closing ? Xo : X;
+        const int lo = rank_below_wave(sc.boff, Xn, a.n_blocks, n_active, a.next_s_lo), hi = rank_below_wave(sc.boff, Xn, a.n_blocks, n_active, a.next_s_hi);
+        if (lane == 0) st->row_lo = lo, st->A = hi - lo;
+    }
+}
+
+// Summary words of `count` cache views (one bit per 1024 view bits, CacheViews) rebuilt from their bits: after the host has
+// summed the views of the remaining passes over the ranks, the summed summary words mean nothing.
+__global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__restrict__ views, long long stride, int bit_words, int dsum_words, int count) {
+    for (int v = blockIdx.y; v < count; v += gridDim.y) {
+        unsigned long long *bits = views + int64_t(v) * stride, *ds = bits + bit_words;
+        for (int sw = blockIdx.x * blockDim.x + threadIdx.x; sw < dsum_words; sw += gridDim.x * blockDim.x) {
+            unsigned long long out = 0;
+            for (int b = 0; b < 64; ++b) {  // summary bit b of word sw: view words [16 (64 sw + b), + 16)
+                const int64_t w0 = (int64_t(sw) * 64 + b) * 16;
+                if (w0 >= bit_words) break;
+                unsigned long long any = 0;
+                for (int u = 0; u < 16 && w0 + u < bit_words; ++u) any |= bits[w0 + u];
+                if (any) out |= 1ull << b;
+            }
+            ds[sw] = out;
+        }
+    }
 }
 
 // End of a run: the pass records and (optionally) the survivor mask go to host-visible memory from ONE small launch instead

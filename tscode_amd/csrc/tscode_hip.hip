@@ -530,6 +530,12 @@ struct tsc_prune {
         LocalTickets local;
     } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
+    // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
+    int part_rank = 0, part_world = 1, part_min_chunks = 0;
+    unsigned long long *exch = nullptr;  // caller-owned exchange buffer: bit_words words of removed rows + 8 of statistics
+    bool cur_range = false;              // the open pass is run by tsc_prune_pass_range / tsc_prune_pass_merge
+    int range_ready_slot = -1;           // slot whose row range the device already holds (set by the k_pass_merge before it)
+    bool views_split = false;            // partitioned passes have run: the cache views of the remaining passes hold this rank's keys only
     uint8_t *export_mask_host = nullptr;  // set by prune_run: pinned host buffer that receives the mask with the statistics
     unsigned *dmax_bits = nullptr;  // device scalar: largest |descriptor component| as float bits (zeroed by k_init_run)
     PassCounters *counters = nullptr;
@@ -829,9 +835,23 @@ static StepArgs next_step_args(const tsc_prune *p, int *next_slot) {
     return StepArgs{p->cur_slot, nxt, nxt >= 0 ? (long long)KS[nxt] : 0ll, p->algo, p->cur_local ? ALGO_LOCAL : -1};
 }
 
-static StepCtx step_ctx(const tsc_prune *p) {
+// range_close: the context of the kernels of a rank-partitioned pass -- their last unit leaves the statistics in the exchange buffer
+// instead of closing the pass (pass_step_wave)
+static StepCtx step_ctx(const tsc_prune *p, bool range_close = false) {
     return StepCtx{p->state, p->counters, p->records, p->bsum, p->boff, p->n_blocks, reinterpret_cast<unsigned *>(p->tickets),
-                   int(sizeof(*p->tickets) / 128)};
+                   int(sizeof(*p->tickets) / 128), range_close ? p->exch + p->bit_words : nullptr};
+}
+
+// Chunks [c_lo, c_hi) of a pass of k chunks that START inside rank's block [n rank / world, n (rank + 1) / world) of the
+// structure axis, and the structures [s_lo, s_hi) they cover (the last chunk of the pass runs to n, rmsd_pruning.py:141-144).
+static void partition_bounds(int64_t n, int64_t k, int rank, int world, int64_t *c_lo, int64_t *c_hi, int64_t *s_lo, int64_t *s_hi) {
+    const int64_t cs = n / k;
+    auto first_chunk = [&](int r) { return r <= 0 ? int64_t(0) : (r >= world ? k : std::min<int64_t>(ceil_div<int64_t>(n * r / world, cs), k)); };
+    *c_lo = first_chunk(rank), *c_hi = first_chunk(rank + 1);
+    *s_lo = *c_lo < k ? *c_lo * cs : n, *s_hi = *c_hi < k ? *c_hi * cs : n;
+}
+static bool pass_is_partitioned(const tsc_prune *p, int64_t k) {
+    return p->part_world > 1 && p->exch && p->algo == ALGO_SIEVE && k >= int64_t(p->part_min_chunks) * p->part_world;
 }
 
 // Views of the passes AFTER the open one (where the rows it removes leave their cache keys); none in cache-free mode.
@@ -853,16 +873,18 @@ static ApplyArgs apply_args(const tsc_prune *p) {
     a.g = PassGeom{int(p->n), int(p->cur_k), int(p->n / p->cur_k)};
     a.act = p->act, a.cend = p->cend, a.best = p->best, a.mask = p->mask, a.bits = p->bits, a.bit_words = int(p->bit_words);
     a.bsum = p->bsum, a.block_items = SCAN_TILE, a.cv = later_views(p);
+    a.exch = p->cur_range ? p->exch : nullptr;
     return a;
 }
 
 // The pair search of one rank's row tiles of the open pass (step 3 of a pass; steps 1-2 have run).
-static int launch_pair_search(tsc_prune *p, int rank, int world) {
+// rows_ub: upper bound of the rows of the pass on this device (n; in a rank-partitioned pass the structures of this rank's chunks)
+static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub) {
     tsc_ctx *c = p->ctx;
     hipStream_t st = c->stream;
     const int64_t n = p->n, k = p->cur_k;
     const int slot = p->cur_slot;
-    const int A = int(n);
+    const int A = int(std::max<int64_t>(rows_ub, 1));
     PassGeom g{int(n), int(k), int(n / k)};
     const int64_t longest_chunk = n - (k - 1) * g.cs;
     // 3. pairs: rows dealt round-robin over ranks in tiles of 16, columns cut into segments for load balance
@@ -925,11 +947,13 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
         if (p->cur_fused) {
             fa.ap = apply_args(p);
             fa.tile_done = p->tile_done, fa.tickets = &p->tickets->pass, fa.n_tiles = unsigned(ceil_div(A, TILE_ROWS));
-            fa.sc = step_ctx(p);
+            fa.sc = step_ctx(p, p->cur_range);
             int nxt = -1;
             fa.next = next_step_args(p, &nxt);
-            p->opened_slot = nxt;
-            p->last_slot = -1;  // closed on the device, by the pair kernel's last tile
+            if (!p->cur_range) {
+                p->opened_slot = nxt;
+                p->last_slot = -1;  // closed on the device, by the pair kernel's last tile
+            }
         }
 #define TSC_LAUNCH_SIEVE(CPL, TRIM, FUSED)                                                                                                        \
     hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, CPL, TRIM, FUSED>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,     \
@@ -953,17 +977,20 @@ static int launch_pair_search(tsc_prune *p, int rank, int world) {
     return 0;
 }
 
-extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
-    TSC_REQUIRE(p != nullptr, "null argument");
-    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
-    if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_local: no pass open (call tsc_prune_next_pass)");
+// The launches of a pass on this device.  range = false: the rows dealt to (rank, world) by tiles, of all chunks (tsc_prune_pass_local).
+// range = true: every row of the chunks that belong to this rank (tsc_prune_pass_range); rank / world are then 0 / 1 for the
+// kernels -- they see an ensemble made of this rank's rows.
+static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
     hipStream_t st = c->stream;
     const int64_t n = p->n, k = p->cur_k;
     const int slot = p->cur_slot;
-    const int A = int(n);  // grids are sized for the upper bound; kernels read the true count from the state block
+    int64_t c_lo = 0, c_hi = k, s_lo = 0, s_hi = n;
+    if (range) partition_bounds(n, k, p->part_rank, p->part_world, &c_lo, &c_hi, &s_lo, &s_hi);
+    const int A = int(std::max<int64_t>(s_hi - s_lo, 1));  // grids are sized for the upper bound; kernels read the true count from the state block
     PassGeom g{int(n), int(k), int(n / k)};
+    p->cur_range = range;
     for (int i = 0; i < 4; ++i)
         if (!p->ev[slot][i]) TSC_TRY(get_event(c, &p->ev[slot][i]));
     if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[slot][0], st));
@@ -973,21 +1000,28 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         StepArgs sa{p->last_slot, slot, (long long)k, p->algo, -1};
         hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(64), 0, st, step_ctx(p), sa);
     }
+    if (range && p->range_ready_slot != slot)  // no k_pass_merge in front of this pass (the first of a run): which rows are this rank's
+        hipLaunchKernelGGL(k_range_open, dim3(1), dim3(64), 0, st, p->state, (const int32_t *)p->boff, (const unsigned long long *)p->bits, int(p->bit_words),
+                           p->n_blocks, int(s_lo), int(s_hi));
     p->last_slot = slot;
     p->slot_used[slot] = true;
     const int use_cache = (p->mode == 0);
-    const int64_t longest_chunk = n - (k - 1) * g.cs;  // the last chunk takes the remainder (:141-142)
+    // the last chunk takes the remainder (:141-142); of this rank's chunks, in a partitioned pass
+    const int64_t longest_chunk = c_hi == k ? n - (k - 1) * g.cs : g.cs;
     // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
     // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
     // chunks are a few row tiles long -- at 57k structures the passes k = 1000, 500 and 200 take 37, 39 and 50 us instead of
     // 52-58 -- and loses beyond: k = 100 takes 58 us there against 53 on the two-launch path; "local_max_chunk" moves the limit)
-    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && longest_chunk <= std::min(LP_MAX_ROWS, c->local_max_chunk);
+    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && std::max<int64_t>(longest_chunk, g.cs) <= std::min(LP_MAX_ROWS, c->local_max_chunk) &&
+                   c_hi > c_lo;
     p->cur_fused = false;
     if (p->cur_local) {
         LocalPassArgs a;
         a.h = p->h, a.use_cache = use_cache;
         a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
-        a.nb_last = std::max(1, ceil_div(ceil_div(int(longest_chunk), LP_TI), LP_TILES_PER_BLOCK));
+        a.nb_last = c_hi == k ? std::max(1, ceil_div(ceil_div(int(n - (k - 1) * g.cs), LP_TI), LP_TILES_PER_BLOCK)) : 0;
+        a.c_lo = int(c_lo), a.n_reg = int(std::min<int64_t>(c_hi, k - 1) - c_lo);
+        a.exch = range ? p->exch : nullptr;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
@@ -995,19 +1029,21 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         a.dmax_bits = p->dmax_bits;
         int nxt = -1;
         const StepArgs sa = next_step_args(p, &nxt);
-        const int64_t blocks = (k - 1) * a.nb_regular + a.nb_last;
+        const int64_t blocks = int64_t(a.n_reg) * a.nb_regular + a.nb_last;
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
         hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask, p->bits, int(p->bit_words),
                               view_of_open_pass(p), p->heavy, (const double *)p->Gall, (const float *)p->Dall, later_views(p), p->counters, p->bsum,
-                              SCAN_TILE, step_ctx(p), sa, &p->tickets->local);
+                              SCAN_TILE, step_ctx(p, range), sa, &p->tickets->local);
         TSC_HIP(hipGetLastError());
-        p->opened_slot = nxt;
-        p->last_slot = -1;  // closed on the device
+        if (!range) {
+            p->opened_slot = nxt;
+            p->last_slot = -1;  // closed on the device
+        }
         p->local_done = true;
         return 0;
     }
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
-    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && c->fused_apply != 0;
+    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
     {
         OpenArgs oa;
         oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
@@ -1031,7 +1067,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         int nxt = -1;
         const StepArgs sa = p->cur_fused ? next_step_args(p, &nxt) : StepArgs{-1, -1, 0ll, 0, -1};
         static_assert(SCAN_TILE == 64 * SCAN_BLOCK_WORDS && DW == DESC_WORDS, "k_open_rows");
-        hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 4)), dim3(256), 0, st, g, oa, step_ctx(p), sa, p->act, p->cend, p->best, p->tile_cmax,
+        hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 4)), dim3(256), 0, st, g, oa, step_ctx(p, range), sa, p->act, p->cend, p->best, p->tile_cmax,
                            (const float *)p->Dall, p->Dc);
     }
     if (p->algo == ALGO_TILE) {
@@ -1040,8 +1076,125 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, (const PruneState *)p->state,
                            p->Xr, p->Xc, p->npad, p->G);
     }
-    TSC_TRY(launch_pair_search(p, rank, world));
+    TSC_TRY(launch_pair_search(p, rank, world, A));
     p->local_done = true;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_local: no pass open (call tsc_prune_next_pass)");
+    if (p->views_split && p->mode == 0)
+        return fail(TSC_ERR_STATE, "tsc_prune_pass_local: rank-partitioned passes have run; sum the cache views over the ranks first "
+                                   "(tsc_prune_views_ptr, tsc_prune_views_merged)");
+    return pass_launch(p, rank, world, false);
+}
+
+// ---- rank-partitioned passes (rmsd.hpp, k_pass_merge) ----
+// words of the exchange buffer of a run over n structures: the removed-row bits of a pass (bit_words of prune_create_impl), eight
+// words of statistics, then -- reference-exact mode -- the storage of every cache view of the run (so that the host can sum the
+// views of the remaining passes over the ranks in place, as part of a buffer it owns)
+static int64_t views_words_of(int64_t n, int mode) {
+    if (mode != 0) return 0;
+    int n_views = 0;
+    for (int slot = 0; slot < TSC_MAX_PASSES; ++slot) n_views += (int64_t(KS[slot]) == 1 || 20 * int64_t(KS[slot]) < n) ? 1 : 0;
+    const int64_t bit_words = n / 64 + 40;
+    return int64_t(n_views) * (bit_words + bit_words / 1024 + 4);
+}
+extern "C" __attribute__((visibility("default"))) int tsc_prune_exchange_words(int64_t n, int mode, int64_t *words) {
+    TSC_REQUIRE(words && n > 0, "bad argument");
+    *words = n / 64 + 40 + 8 + views_words_of(n, mode);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_set_partition(tsc_prune *p, int rank, int world, int min_chunks_per_rank, void *exch_dev,
+                                                                              int64_t exch_words) {
+    TSC_REQUIRE(p && exch_dev, "null argument");
+    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world && min_chunks_per_rank >= 1, "bad rank %d / world %d / min_chunks_per_rank %d", rank, world,
+                min_chunks_per_rank);
+    const int64_t need = int64_t(p->bit_words) + 8 + views_words_of(p->n, p->mode);
+    TSC_REQUIRE(exch_words >= need, "exchange buffer of %lld words, %lld needed (tsc_prune_exchange_words)", (long long)exch_words, (long long)need);
+    if (p->cur_k != 0 || p->next_ks != 0) return fail(TSC_ERR_STATE, "tsc_prune_set_partition: call it right after tsc_prune_create");
+    DeviceGuard guard(p->ctx->device);
+    p->part_rank = rank, p->part_world = world, p->part_min_chunks = min_chunks_per_rank;
+    p->exch = static_cast<unsigned long long *>(exch_dev);
+    TSC_HIP(hipMemsetAsync(p->exch, 0, size_t(need) * sizeof(unsigned long long), p->ctx->stream));
+    if (p->mode == 0) p->views = p->exch + p->bit_words + 8;  // the cache views live in the caller's buffer from here on (still empty)
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_partitioned(tsc_prune *p, int *flag) {
+    TSC_REQUIRE(p && flag, "null argument");
+    if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_pass_partitioned: no pass open");
+    *flag = pass_is_partitioned(p, p->cur_k) ? 1 : 0;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_range(tsc_prune *p) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_range: no pass open (call tsc_prune_next_pass)");
+    if (!pass_is_partitioned(p, p->cur_k)) return fail(TSC_ERR_STATE, "tsc_prune_pass_range: the open pass (k = %lld) is not rank-partitioned", (long long)p->cur_k);
+    TSC_TRY(pass_launch(p, 0, 1, true));
+    p->views_split = true;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_merge(tsc_prune *p) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    if (p->cur_k == 0 || !p->local_done || !p->cur_range) return fail(TSC_ERR_STATE, "tsc_prune_pass_merge: tsc_prune_pass_range has not run");
+    tsc_ctx *c = p->ctx;
+    DeviceGuard guard(c->device);
+    int nxt = -1;
+    const StepArgs sa = next_step_args(p, &nxt);
+    MergeArgs ma;
+    ma.n = int(p->n), ma.bit_words = int(p->bit_words), ma.n_blocks = p->n_blocks, ma.bits = p->bits, ma.exch = p->exch, ma.mask = p->mask;
+    ma.next_s_lo = ma.next_s_hi = -1;
+    if (nxt >= 0 && pass_is_partitioned(p, int64_t(KS[nxt]))) {
+        int64_t c_lo, c_hi, s_lo, s_hi;
+        partition_bounds(p->n, int64_t(KS[nxt]), p->part_rank, p->part_world, &c_lo, &c_hi, &s_lo, &s_hi);
+        ma.next_s_lo = int(s_lo), ma.next_s_hi = int(s_hi);
+        p->range_ready_slot = nxt;
+    }
+    hipLaunchKernelGGL(k_pass_merge, dim3(1), dim3(1024), 0, c->stream, ma, step_ctx(p), sa);
+    TSC_HIP(hipGetLastError());
+    p->opened_slot = nxt;
+    p->last_slot = -1;  // closed on the device
+    if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[p->cur_slot][3], c->stream));
+    p->cur_k = 0;
+    p->cur_slot = -1;
+    p->cur_range = false;
+    p->collected = false;
+    return 0;
+}
+
+// The cache views of the passes that have not run yet (the open one included), as one block of 64-bit words: after partitioned
+// passes they hold the keys of this rank's removed rows only.  *words = 0: nothing to exchange (cache-free mode, or no partitioned
+// pass has run).  Otherwise: sum the block over the ranks (the ranks' bits are disjoint), then tsc_prune_views_merged.
+extern "C" __attribute__((visibility("default"))) int tsc_prune_views_ptr(tsc_prune *p, void **views_dev, int64_t *offset_words, int64_t *words) {
+    TSC_REQUIRE(p && views_dev && offset_words && words, "null argument");
+    if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_views_ptr: no pass open");
+    *views_dev = nullptr, *offset_words = 0, *words = 0;
+    if (!p->views_split || p->mode != 0) return 0;
+    const int v = p->view_of_slot[p->cur_slot];
+    *views_dev = p->views + size_t(v) * (p->bit_words + p->dsum_words);
+    *offset_words = int64_t(p->views - p->exch) + int64_t(v) * int64_t(p->bit_words + p->dsum_words);
+    *words = int64_t(p->n_views - v) * int64_t(p->bit_words + p->dsum_words);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_prune_views_merged(tsc_prune *p) {
+    TSC_REQUIRE(p != nullptr, "null argument");
+    if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_views_merged: no pass open");
+    if (p->views_split && p->mode == 0) {
+        DeviceGuard guard(p->ctx->device);
+        const int v = p->view_of_slot[p->cur_slot], count = p->n_views - v;
+        hipLaunchKernelGGL(k_views_summaries, dim3(std::max(1, ceil_div(int(p->dsum_words), 256)), unsigned(count)), dim3(256), 0, p->ctx->stream,
+                           p->views + size_t(v) * (p->bit_words + p->dsum_words), (long long)(p->bit_words + p->dsum_words), int(p->bit_words),
+                           int(p->dsum_words), count);
+        TSC_HIP(hipGetLastError());
+    }
+    p->views_split = false;
     return 0;
 }
 
@@ -1051,7 +1204,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_rows(tsc_pr
     if (p->cur_k == 0 || !p->local_done || p->cur_local || p->cur_fused)
         return fail(TSC_ERR_STATE, "tsc_prune_pass_rows: needs an open pass whose tsc_prune_pass_local ran with world_size > 1");
     DeviceGuard guard(p->ctx->device);
-    return launch_pair_search(p, rank, world);
+    return launch_pair_search(p, rank, world, p->n);
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries) {
@@ -1072,6 +1225,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_use_best_buffer(
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_prune *p) {
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
+    if (p->cur_range) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: a rank-partitioned pass is closed by tsc_prune_pass_merge");
     tsc_ctx *c = p->ctx;
     DeviceGuard guard(c->device);
     if (!p->cur_local && !p->cur_fused) {  // (a chunk-local pass, and the pair kernel of a fused one, have applied the verdicts already)
@@ -1101,7 +1255,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(t
         TSC_TRY(tsc_prune_next_pass(p, &k));
         *k_out = k;
         if (k == 0) return 0;
-        if (world > 1 && p->n * (p->n / k) / 2 >= min_pairs) return 0;
+        // (a partitioned pass, or the first pass after partitioned ones -- the cache views must be summed over the ranks first --
+        // goes back to the caller as well)
+        if (world > 1 && (pass_is_partitioned(p, k) || (p->views_split && p->mode == 0) || p->n * (p->n / k) / 2 >= min_pairs)) return 0;
         TSC_TRY(tsc_prune_pass_local(p, 0, 1));
         TSC_TRY(tsc_prune_pass_finish(p));
     }

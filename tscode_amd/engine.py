@@ -500,6 +500,40 @@ class PruneStepper:
         """The pair search of another rank's row tiles of the open pass (after pass_local), into the same best[]."""
         check(self.e.lib.tsc_prune_pass_rows(self._p, C.c_int(rank), C.c_int(world)))
 
+    # ---- rank-partitioned passes (include/tscode_hip.h) ----
+    @staticmethod
+    def exchange_words(lib, n, mode) -> int:
+        w = C.c_int64()
+        check(lib.tsc_prune_exchange_words(C.c_int64(int(n)), C.c_int(mode), C.byref(w)))
+        return w.value
+
+    def set_partition(self, rank, world, min_chunks_per_rank, exch_dev):
+        """exch_dev: device tensor of at least exchange_words(n) int64 that the caller can all-reduce."""
+        check(self.e.lib.tsc_prune_set_partition(self._p, C.c_int(rank), C.c_int(world), C.c_int(min_chunks_per_rank), ptr(exch_dev),
+                                                 C.c_int64(exch_dev.numel())))
+        self._keep_exch = exch_dev
+
+    def pass_partitioned(self) -> bool:
+        f = C.c_int()
+        check(self.e.lib.tsc_prune_pass_partitioned(self._p, C.byref(f)))
+        return bool(f.value)
+
+    def pass_range(self):
+        check(self.e.lib.tsc_prune_pass_range(self._p))
+
+    def pass_merge(self):
+        check(self.e.lib.tsc_prune_pass_merge(self._p))
+
+    def views_range(self):
+        """(offset, words) of the block of the exchange buffer that holds the cache views of the passes still to run, to be summed
+        over the ranks before the open (not partitioned) pass; words = 0: nothing to exchange."""
+        p, off, n = C.c_void_p(), C.c_int64(), C.c_int64()
+        check(self.e.lib.tsc_prune_views_ptr(self._p, C.byref(p), C.byref(off), C.byref(n)))
+        return off.value, n.value
+
+    def views_merged(self):
+        check(self.e.lib.tsc_prune_views_merged(self._p))
+
     def best_ptr(self):
         p, n = C.c_void_p(), C.c_int64()
         check(self.e.lib.tsc_prune_best_ptr(self._p, C.byref(p), C.byref(n)))

@@ -30,12 +30,31 @@ import numpy as np
 
 from .engine import Engine, FragmentSet
 
-__all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "sharded_step", "block_bounds", "SHARD_MIN_PAIRS"]
+__all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "sharded_step", "block_bounds", "partition_bounds", "SHARD_MIN_PAIRS",
+           "PARTITION_MIN_CHUNKS"]
 
 # A pass smaller than this many pairs (estimate n * (n / k) / 2, identical on every rank) is not worth a collective:
 # every rank runs it whole and reaches the same verdicts on its own.  On MI355X such a pass takes tens of
 # microseconds, the same as one small all-reduce over xGMI.
 SHARD_MIN_PAIRS = 50_000_000
+
+
+# A pass with at least this many chunks per rank is PARTITIONED: every rank runs the whole pass on the chunks that start inside its
+# block of the structure axis (chunks are independent, tscode/rmsd_pruning.py:139-157) and the ranks exchange one bit per structure.
+# With fewer chunks per rank the ranks' shares would differ by more than 1 / PARTITION_MIN_CHUNKS (a rank gets a whole chunk more or
+# less than another): those passes deal their ROW TILES round-robin instead and exchange best[].
+PARTITION_MIN_CHUNKS = 4
+
+
+def partition_bounds(n: int, k: int, rank: int, world: int):
+    """Chunks [c_lo, c_hi) of a pass of k chunks that start inside rank's block of the structure axis and the structures
+    [s_lo, s_hi) they cover (mirror of the library's partition_bounds, tscode_hip.hip)."""
+    cs = n // k
+
+    def first_chunk(r):
+        return 0 if r <= 0 else (k if r >= world else min(-(-(n * r // world) // cs), k))
+    c_lo, c_hi = first_chunk(rank), first_chunk(rank + 1)
+    return c_lo, c_hi, (c_lo * cs if c_lo < k else n), (c_hi * cs if c_hi < k else n)
 
 
 def block_bounds(n: int, rank: int, world: int):
@@ -67,7 +86,7 @@ def _all_gather(dist, out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=None, front="shard"):
+def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=None, front="shard", partition_chunks=PARTITION_MIN_CHUNKS):
     """One step of the hot path over an ensemble sharded across ``world`` ranks, run inside ``backend.stream_context()`` when the
     backend has one (the HIP backend makes its own torch stream current, so that its kernels, torch's copies and the
     collectives are ordered on one stream).  ``front``: "shard" = pose blocks + all-gather of the survivors' coordinates,
@@ -76,9 +95,9 @@ def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=Non
         raise ValueError(f"front must be 'shard' or 'replicate', got {front!r}")
     enter = getattr(backend, "stream_context", None)
     if enter is None:
-        return _sharded_step(backend, rank, world, dist, group, min_pairs, front)
+        return _sharded_step(backend, rank, world, dist, group, min_pairs, front, partition_chunks)
     with enter():
-        return _sharded_step(backend, rank, world, dist, group, min_pairs, front)
+        return _sharded_step(backend, rank, world, dist, group, min_pairs, front, partition_chunks)
 
 
 def _front_sharded(backend, rank, world, dist, group):
@@ -106,7 +125,7 @@ def _front_sharded(backend, rank, world, dist, group):
     return off, n_pass_local, counts, int(world * rows * row_elems * backend.gather.element_size())
 
 
-def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front="shard"):
+def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front="shard", partition_chunks=PARTITION_MIN_CHUNKS):
     """The protocol itself.
 
     backend interface (all tensors live where the backend computes):
@@ -114,7 +133,10 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
         embed_clash_all() -> n_pass              (front="replicate" only) fills backend.heavy_all[:n_pass] from ALL poses
         heavy_pad, gather, heavy_all, counts, keep, max_local, best      preallocated tensors / int
         make_stepper(n_pass) -> stepper with next_pass(), pass_estimate(), pass_local(rank, world), n_active(), pass_finish(),
-                                stats(), copy_mask(dst), close(); it keeps best[] in backend.best
+                                stats(), copy_mask(dst), close(); it keeps best[] in backend.best.  Optional (partitioned passes,
+                                ``partition_chunks`` > 0): set_partition(rank, world, min_chunks) -- the stepper then keeps its
+                                exchange buffer in backend.exch (int64) --, pass_partitioned(), pass_range(), exchange_words(),
+                                pass_merge(), views_range() -> (offset, words) into backend.exch, views_merged()
     """
     if front == "replicate":
         n_pass = int(backend.embed_clash_all())
@@ -122,22 +144,42 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
     else:
         n_pass, n_pass_local, counts, gathered_bytes = _front_sharded(backend, rank, world, dist, group)
     stats = []
-    exchanges = []                                      # (k, entries of best[] all-reduced) of every pass that was sharded
+    exchanges = []                                      # (k, entries of best[] all-reduced) of every pass that was sharded by row tiles
+    partitioned = []                                    # (k, int64 words summed) of every pass that was partitioned by chunks
+    views_words = 0
     if n_pass > 0:
         st = backend.make_stepper(n_pass)
         limit = SHARD_MIN_PAIRS if min_pairs is None else min_pairs
+        can_partition = world > 1 and partition_chunks > 0 and hasattr(st, "set_partition")
+        if can_partition:
+            st.set_partition(rank, world, partition_chunks)
         try:
             while True:
                 if hasattr(st, "run_replicated"):       # the small passes in one library call; back here for an exchange
                     k = st.run_replicated(world, limit)
                     if k == 0:
                         break
-                    shard = True
+                    shard = st.pass_estimate() >= limit
                 else:
                     k = st.next_pass()
                     if k == 0:
                         break
                     shard = world > 1 and st.pass_estimate() >= limit
+                if can_partition and st.pass_partitioned():
+                    # the whole pass on this rank's chunks; what the ranks tell each other is which rows they removed
+                    st.pass_range()
+                    words = st.exchange_words()
+                    _all_reduce(dist, backend.exch[:words], dist.ReduceOp.SUM, group)
+                    st.pass_merge()
+                    partitioned.append((int(k), int(words)))
+                    continue
+                if can_partition:
+                    # first pass after the partitioned ones: every rank needs every rank's cache keys from here on
+                    off, words = st.views_range()
+                    if words:
+                        _all_reduce(dist, backend.exch[off:off + words], dist.ReduceOp.SUM, group)
+                        views_words += int(words)
+                    st.views_merged()
                 if shard:
                     st.pass_local(rank, world)          # this rank's row tiles only ...
                     n_best = st.n_active()
@@ -154,13 +196,14 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
             st.close()
     n_keep = stats[-1]["n_active_after"] if stats else 0
     return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts, "exchanges": exchanges,
-            "front": front, "allgather_bytes": gathered_bytes,
-            "allreduce_bytes": 4 * sum(n for _, n in exchanges) + (8 * world if front == "shard" else 0)}
+            "partitioned": partitioned, "front": front, "allgather_bytes": gathered_bytes,
+            "allreduce_bytes": 4 * sum(n for _, n in exchanges) + 8 * sum(w for _, w in partitioned) + 8 * views_words
+                               + (8 * world if front == "shard" else 0)}
 
 
 class _HipStepper:
-    def __init__(self, stepper):
-        self.s = stepper
+    def __init__(self, stepper, exch=None):
+        self.s, self.exch = stepper, exch
 
     def next_pass(self):
         return self.s.next_pass()
@@ -176,6 +219,27 @@ class _HipStepper:
 
     def pass_rows(self, rank, world):
         self.s.pass_rows(rank, world)
+
+    def set_partition(self, rank, world, min_chunks):
+        self.s.set_partition(rank, world, min_chunks, self.exch)
+
+    def pass_partitioned(self):
+        return self.s.pass_partitioned()
+
+    def pass_range(self):
+        self.s.pass_range()
+
+    def exchange_words(self):
+        return self.s.n // 64 + 48
+
+    def pass_merge(self):
+        self.s.pass_merge()
+
+    def views_range(self):
+        return self.s.views_range()
+
+    def views_merged(self):
+        self.s.views_merged()
 
     def n_active(self):
         return self.s.best_ptr()[1]
@@ -232,6 +296,9 @@ class HipShardBackend:
         self.best = torch.empty(n, dtype=torch.int32, device=self.dev)
         self.keep = torch.empty(n, dtype=torch.uint8, device=self.dev)
         self.counts = torch.zeros(world, dtype=torch.int64, device=self.dev)
+        # exchange buffer of the partitioned passes (removed-row bits + statistics, then the run's cache views), sized for all n poses
+        from .engine import PruneStepper
+        self.exch = torch.zeros(PruneStepper.exchange_words(self.eng.lib, max(n, 1), 0), dtype=torch.int64, device=self.dev)
         self.keep_host = torch.empty(n, dtype=torch.uint8).pin_memory()
         torch.cuda.synchronize(self.dev)
 
@@ -260,12 +327,12 @@ class HipShardBackend:
     def make_stepper(self, n_pass):
         st = self.eng.prune_stepper(self.heavy_all, n_pass, self.h, self.rmsd_thr, self.mode)
         st.use_best_buffer(self.best)
-        return _HipStepper(st)
+        return _HipStepper(st, self.exch)
 
 
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
-                 process_group=None, force_sharded=False, shard_min_pairs=None, front="auto"):
+                 process_group=None, force_sharded=False, shard_min_pairs=None, front="auto", partition_chunks=PARTITION_MIN_CHUNKS):
         """``front`` (multi-rank runs): "shard" = pose blocks + all-gather of the survivors' coordinates, "replicate" = every rank
         computes the whole front half and only best[] travels, "auto" = ``tune_front()`` decides on the node at hand (called by
         the first ``step()`` unless the caller did; one rank: "shard", there is nothing to choose)."""
@@ -276,6 +343,7 @@ class DevicePipeline:
         self._run = None
         self.sharded = self.world > 1 or force_sharded
         self.shard_min_pairs = shard_min_pairs                  # None: SHARD_MIN_PAIRS (tests lower it to shard small passes too)
+        self.partition_chunks = int(partition_chunks)           # chunks per rank from which a pass is partitioned by chunks (0: never)
         if front not in ("auto", "shard", "replicate"):
             raise ValueError(f"front must be 'auto', 'shard' or 'replicate', got {front!r}")
         self.front = front if self.world > 1 or front != "auto" else "shard"
@@ -319,7 +387,8 @@ class DevicePipeline:
             return self._run()
         if self.front == "auto":
             self.tune_front()
-        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs, self.front)
+        return sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs, self.front,
+                            self.partition_chunks)
 
     def tune_front(self, steps=2):
         """Times both forms of the front half on this node -- one untimed step each (buffers, communicators), then ``steps`` timed
@@ -331,12 +400,12 @@ class DevicePipeline:
             return None
         times = {}
         for form in ("shard", "replicate"):
-            sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form)
+            sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form, self.partition_chunks)
             torch.cuda.synchronize(self.backend.dev)
             dist.barrier(group=self.pg)
             t0 = time.perf_counter()
             for _ in range(steps):
-                sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form)
+                sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form, self.partition_chunks)
             torch.cuda.synchronize(self.backend.dev)
             t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
             if dist.get_backend(self.pg) == "gloo":
