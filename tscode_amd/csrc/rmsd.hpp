@@ -1234,7 +1234,8 @@ __global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, St
             int c = 0;
             if (b < a.n_blocks) {
 #pragma unroll 8
-                for (int u = 0; u < SCAN_BLOCK_WORDS; ++u) c += __popcll(Xo[size_t(b) * SCAN_BLOCK_WORDS + u]);
+                for (int u = 0; u < SCAN_BLOCK_WORDS; ++u)  // (the block list is padded beyond the last word of a bit copy)
+                    c += b * SCAN_BLOCK_WORDS + u < a.bit_words ? __popcll(Xo[size_t(b) * SCAN_BLOCK_WORDS + u]) : 0;
                 sc.bsum[b] = c;
             }
             int incl = c;

@@ -920,7 +920,9 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
         }
     } else {
         SieveArgs a;
-        a.n = int(n), a.h = p->h;
+        // (the bound the grid was sized for: tiles of the last block beyond it must leave before they read a stale tile_cmax[] entry
+        // and arrive at the pass's counter as a tile that does not exist)
+        a.n = A, a.h = p->h;
         a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
