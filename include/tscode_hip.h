@@ -157,6 +157,23 @@ int tsc_embed_clash_compact_dev(tsc_ctx *ctx, const double *frags, const int64_t
                                 const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, uint8_t *clash_mask,
                                 double *structures, double *heavy, int64_t *n_pass_host);
 
+/* The two halves of the above as calls of their own, for a front half that is spread over ranks differently (tscode_amd/pipeline.py,
+ * front = "hybrid": every rank takes the clash verdicts of ITS block of poses -- tsc_embed_clash_mask_dev --, the verdicts are
+ * summed over the ranks, one byte per pose, and every rank then embeds the heavy atoms of ALL passing poses itself: recomputing a
+ * pose from its 100 bytes of parameters costs less than moving its 24 n_heavy bytes of coordinates over xGMI).
+ * tsc_basis_from_poses_dev: forks the estimate of the prune's descriptor basis from a sample of these poses onto the context's side
+ *   stream (about 50 us that whatever is enqueued next on the main stream hides); consumed once, by tsc_embed_masked_dev or
+ *   tsc_prune_create on this context.
+ * tsc_embed_masked_dev: the poses selected by mask u8[n_poses] (device), embedded in order: structures f64[n_sel, n_atoms, 3]
+ *   and / or heavy f64[n_sel, n_heavy, 3] (either may be NULL).  With `heavy` and a pending basis the kernel writes the prune's
+ *   descriptors as well, and the next tsc_prune_create on this context over the same `heavy` takes them instead of reading the
+ *   coordinates back.  n_sel_host (optional): count of selected poses (the call then synchronises for it while the embed runs). */
+int tsc_basis_from_poses_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols,
+                             const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy);
+int tsc_embed_masked_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols,
+                         const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses, const uint8_t *mask,
+                         const int32_t *heavy_idx, int n_heavy, double *structures, double *heavy, int64_t *n_sel_host);
+
 /* ---- K3: Kabsch RMSD (no centring) ------------------------------------------------------------
  * Replaces rmsd_and_max_numba (tscode/rmsd_pruning.py:6-41) on listed pairs of one heavy-atom array:
  * (rmsd[k], maxdev[k]) = rmsd_and_max_numba(heavy[pairs[k,0]], heavy[pairs[k,1]]).

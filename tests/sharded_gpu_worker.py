@@ -34,7 +34,7 @@ def main():
     # the pipeline chose a form of the front half by timing both (tune_front, inside the first step); either form, forced, must
     # give the same survivors and the same evaluation counts
     forms_agree, evals = True, [s["pairs_evaluated"] for s in res["stats"]]
-    for form in ("shard", "replicate"):
+    for form in ("shard", "replicate", "hybrid"):
         pipe.front = form
         r2 = pipe.step()
         torch.cuda.synchronize()

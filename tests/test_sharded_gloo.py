@@ -188,6 +188,25 @@ class OracleShardBackend:
         self.heavy_all[:len(heavy)].copy_(torch.from_numpy(heavy))
         return len(heavy)
 
+    def clash_block_into_all(self):
+        """front="hybrid": this block's verdicts into the all-poses mask (zero elsewhere)."""
+        import torch
+        e = self.ens
+        sl = slice(self.lo, self.hi)
+        poses = self.o.transform_batch(e.frag_coords, e.conf_idx[sl], e.rot[sl], e.pos[sl])
+        self.clash_all = torch.zeros(e.n_poses, dtype=torch.uint8)
+        self.clash_all[sl] = torch.from_numpy(self.o.compenetration_mask(poses, e.ids, 1.5, 0).astype(np.uint8))
+
+    def embed_masked_all(self):
+        import torch
+        e = self.ens
+        cm = self.clash_all.numpy().astype(bool)
+        assert self.clash_all.max() <= 1                      # the blocks' verdicts do not overlap
+        poses = self.o.transform_batch(e.frag_coords, e.conf_idx[cm], e.rot[cm], e.pos[cm])
+        heavy = np.ascontiguousarray(poses[:, e.atomnos != 1])
+        self.heavy_all[:len(heavy)].copy_(torch.from_numpy(heavy))
+        return len(heavy)
+
     def make_stepper(self, n_pass):
         st = OracleStepper(self.o, self.heavy_all[:n_pass].numpy(), self.best, self.thr, self.mode, self.tile_rows)
         st.backend_exch = self.exch
@@ -228,7 +247,7 @@ def _worker(rank, world, port, n_poses, mode, out_dir, front="shard", partition_
 # that a chunk straddles), 0 = no partitioned pass (the protocol of round 2)
 @pytest.mark.parametrize("world,n_poses,mode,front,partition_chunks", [
     (2, 3000, 0, "shard", 4), (3, 2001, 0, "shard", 4), (2, 1500, 1, "shard", 4), (2, 2500, 0, "replicate", 4), (3, 1201, 1, "replicate", 4),
-    (2, 2999, 0, "replicate", 1), (3, 2503, 0, "shard", 1), (3, 1801, 0, "replicate", 0)])
+    (2, 2999, 0, "replicate", 1), (3, 2503, 0, "shard", 1), (3, 1801, 0, "replicate", 0), (2, 2200, 0, "hybrid", 4), (3, 1901, 1, "hybrid", 2)])
 def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front, partition_chunks):
     import torch.multiprocessing as mp
 

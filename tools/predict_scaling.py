@@ -1,21 +1,22 @@
 """Predicted strong-scaling curve of the sharded single-ensemble protocol, from ONE GPU.
 
 The builder has one MI355X at a time; the N = 2, 4, 8 line of bench.py can only run on the driver's node.  What one GPU can
-measure is every rank's SHARE of the work: for N in {1, 2, 4, 8} and every rank r < N this script times, with HIP events,
-  * the embed + clash + compaction of rank r's pose block (HipShardBackend.embed_clash_block),
-  * for every pass that the protocol shards: tsc_prune_pass_local(r, N) -- rank r's row tiles -- one rank after the other on
-    the same card (best[] accumulates by atomicMin, so after the last rank the pass is complete and the run continues with
-    the true verdicts),
-  * everything the ranks replicate (the small passes, the per-pass bookkeeping around a sharded pass, the export),
-and combines them as the protocol would run:  max_r front(r) + counts all-reduce + coordinates all-gather +
-sum over passes [replicated part + max_r local(r) + all-reduce(best[])] .  The collectives are MODELLED, not measured:
-per-link xGMI bandwidth 153 GB/s x 0.7 efficiency, 20 us fixed cost per collective, and two readings of the mesh -- ring
-collectives bound by ONE link (conservative) and every shard sent straight to its N - 1 peers over all links at once
-(what the fully connected xGMI mesh allows) -- both stated in the output.  Beside it, for every N, the other form of the front
-half (`front_replicate`: every rank embeds all poses itself, no coordinates travel; pipeline.py times both on the node and
-keeps the faster).
+measure is every rank's SHARE of the work.  For N in {1, 2, 4, 8} this script keeps N prune runs ("ranks") over the same
+survivor list in lockstep, exactly as tscode_amd/pipeline.py::sharded_step drives them, and times every library call of every
+rank with HIP events:
+  * the front half in its three forms -- rank r's pose block (embed + clash + compaction; `shard`), all poses on every rank
+    (`replicate`), rank r's clash verdicts + the embed of ALL survivors on every rank (`hybrid`);
+  * a PARTITIONED pass (k >= PARTITION_MIN_CHUNKS x N chunks): tsc_prune_pass_range of every rank (its own chunks: rows, stop
+    columns, pair search, verdicts), the exchange buffers summed here with torch as the all-reduce would, tsc_prune_pass_merge
+    of every rank;
+  * a pass SHARDED BY ROW TILES: tsc_prune_pass_local(r, N) of every rank, best[] min-merged here, tsc_prune_pass_finish;
+  * a small pass that every rank runs whole.
+A pass costs  max_r(local part) + collective + max_r(closing part);  the collectives are MODELLED, not measured: per-link xGMI
+bandwidth 153 GB/s x 0.7 efficiency, 20 us fixed cost per collective, and two readings of the mesh -- ring collectives bound by
+ONE link (conservative) and every shard sent straight to its N - 1 peers over all links at once (what the fully connected xGMI
+mesh allows) -- both stated in the output.
 
-usage (GPU box): python tools/predict_scaling.py [C3 C4] > profiles/r02_predicted_scaling.json
+usage (GPU box): python tools/predict_scaling.py [C3 C4] [--chunks M] > profiles/r03_predicted_scaling.json
 """
 import json
 import sys
@@ -25,7 +26,8 @@ sys.path.insert(0, ".")
 import numpy as np
 import torch
 
-from tscode_amd.pipeline import SHARD_MIN_PAIRS, HipShardBackend
+from tscode_amd.engine import PruneStepper
+from tscode_amd.pipeline import PARTITION_MIN_CHUNKS, SHARD_MIN_PAIRS, HipShardBackend
 from tscode_amd.synthetic import make_config
 
 LINK_GBS, LINK_EFF, COLL_FIXED_US = 153.0, 0.7, 20.0
@@ -62,10 +64,9 @@ def allreduce_ms(nbytes, n, all_links=False):
     return 2.0 * (nbytes / n) * steps / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
 
 
-def measure(cfg, n_ranks, reps=3, front_all_ms=None):
-    ens = make_config(cfg)
-    # front half: every rank's block
-    front, counts = [], []
+def measure_front(ens, n_ranks, reps):
+    """(slowest rank of `shard`, pass counts per rank, slowest rank's clash verdicts alone)"""
+    front, counts, clash_only = [], [], []
     for r in range(n_ranks):
         be = HipShardBackend(ens, 0, r, n_ranks, 1.5, 0, 0.5, 0)
         be.eng.set_option("pass_timing", 0)
@@ -73,8 +74,15 @@ def measure(cfg, n_ranks, reps=3, front_all_ms=None):
         runs_r = [tm(be.embed_clash_block) for _ in range(reps + 1)]
         front.append(min(t for t, _ in runs_r))
         counts.append(int(runs_r[-1][1]))
+        clash_only.append(min(tm(be.clash_block_into_all)[0] for _ in range(reps + 1)))    # hybrid: everything in front of the mask exchange
         del be
         torch.cuda.empty_cache()
+    return front, counts, clash_only
+
+
+def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
+    ens = make_config(cfg)
+    front, counts, clash_only = measure_front(ens, n_ranks, reps)
     # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
     be = HipShardBackend(ens, 0, 0, 1, 1.5, 0, 0.5, 0)
     be.eng.set_option("pass_timing", 0)
@@ -82,83 +90,150 @@ def measure(cfg, n_ranks, reps=3, front_all_ms=None):
     n_pass = int(be.embed_clash_block())
     with torch.cuda.stream(be.stream):
         be.heavy_all[:n_pass].copy_(be.heavy_local[:n_pass])
+    if n_ranks == 1:                  # hybrid, behind the exchange: every survivor's heavy atoms + descriptors on every rank (the same at every N)
+        ts = []
+        for _ in range(reps + 1):
+            be.clash_block_into_all()
+            ts.append(tm(be.embed_masked_all)[0])
+        embed_all_ms = min(ts)
+        n_pass = int(be.embed_clash_block())
+        with torch.cuda.stream(be.stream):
+            be.heavy_all[:n_pass].copy_(be.heavy_local[:n_pass])
     h = be.h
+    words = PruneStepper.exchange_words(be.eng.lib, n_pass, 0)
+    per_pass_words = n_pass // 64 + 48
+    exch = [torch.zeros(words, dtype=torch.int64, device=be.dev) for _ in range(n_ranks)]
+    bests = [torch.empty(n_pass, dtype=torch.int32, device=be.dev) for _ in range(n_ranks)]
     runs = []
     for rep in range(reps):
-        passes, replicated = [], 0.0
-        t_create, st = tm(lambda: be.make_stepper(n_pass))
-        replicated += t_create
+        passes, setup = [], 0.0
+        sts = []
+        for r in range(n_ranks):
+            t, st = tm(lambda r=r: be.eng.prune_stepper(be.heavy_all, n_pass, h, 0.5, 0))
+            setup = max(setup, t)
+            st.use_best_buffer(bests[r])
+            if n_ranks > 1 and chunks > 0:
+                with torch.cuda.stream(be.stream):
+                    st.set_partition(r, n_ranks, chunks, exch[r])
+            sts.append(st)
         while True:
-            t_rep, k = tm(lambda: st.run_replicated(n_ranks, SHARD_MIN_PAIRS))
-            replicated += t_rep
+            ks = {st.next_pass() for st in sts}
+            assert len(ks) == 1
+            k = ks.pop()
             if k == 0:
                 break
-            # rank 0's call opens the pass (scan, cache view, stop columns: replicated work) and searches rank 0's rows; the
-            # other ranks' rows follow one by one (tsc_prune_pass_rows), rank 0's once more alone (idempotent) to separate its
-            # pair search from the opening
-            t_open0, _ = tm(lambda: st.pass_local(0, n_ranks))
-            local = [tm(lambda r=r: st.pass_rows(r, n_ranks))[0] for r in range(n_ranks)]
-            replicated += max(t_open0 - local[0], 0.0)
-            n_best = st.n_active()
-            t_fin, _ = tm(st.pass_finish)
-            replicated += t_fin
-            passes.append({"k": int(k), "best_entries": int(n_best), "local_ms_per_rank": local})
-        t_tail, _ = tm(lambda: st.copy_mask(be.keep))
-        replicated += t_tail
-        stats = st.stats()
-        st.close()
-        runs.append({"replicated_ms": replicated, "passes": passes, "n_keep": int(stats[-1]["n_active_after"])})
-    best = min(runs, key=lambda r: r["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in r["passes"]))
+            est = sts[0].pass_estimate()
+            if n_ranks > 1 and chunks > 0 and sts[0].pass_partitioned():
+                t_range = [tm(st.pass_range)[0] for st in sts]
+                with torch.cuda.stream(be.stream):
+                    total = torch.stack([e[:per_pass_words] for e in exch]).sum(0)
+                    for e in exch:
+                        e[:per_pass_words].copy_(total)
+                t_merge = [tm(st.pass_merge)[0] for st in sts]
+                passes.append({"k": int(k), "kind": "partitioned", "local_ms_per_rank": t_range, "close_ms": max(t_merge), "bytes": 8 * per_pass_words})
+                continue
+            extra = 0
+            if n_ranks > 1 and chunks > 0:
+                off, w = sts[0].views_range()
+                for st in sts[1:]:
+                    st.views_range()
+                if w:
+                    with torch.cuda.stream(be.stream):
+                        total = torch.stack([e[off:off + w] for e in exch]).sum(0)
+                        for e in exch:
+                            e[off:off + w].copy_(total)
+                    extra = 8 * w
+                t_v = [tm(st.views_merged)[0] for st in sts]
+                if w:
+                    passes.append({"k": int(k), "kind": "views", "local_ms_per_rank": [0.0] * n_ranks, "close_ms": max(t_v), "bytes": extra})
+            if n_ranks > 1 and est >= SHARD_MIN_PAIRS:
+                t_loc = [tm(lambda r=r, st=st: st.pass_local(r, n_ranks))[0] for r, st in enumerate(sts)]
+                n_best = sts[0].best_ptr()[1]
+                with torch.cuda.stream(be.stream):
+                    merged = torch.stack(bests).amin(0)
+                    for b in bests:
+                        b.copy_(merged)
+                t_fin = [tm(st.pass_finish)[0] for st in sts]
+                passes.append({"k": int(k), "kind": "row_tiles", "local_ms_per_rank": t_loc, "close_ms": max(t_fin), "bytes": 4 * n_best})
+            else:
+                t_all = [tm(lambda st=st: (st.pass_local(0, 1), st.pass_finish()))[0] for st in sts]
+                passes.append({"k": int(k), "kind": "replicated", "local_ms_per_rank": t_all, "close_ms": 0.0, "bytes": 0})
+        t_tail = max(tm(lambda st=st: st.copy_mask(be.keep))[0] for st in sts)
+        stats = sts[0].stats()
+        for st in sts:
+            st.close()
+        runs.append({"setup_ms": setup, "tail_ms": t_tail, "passes": passes, "n_keep": int(stats[-1]["n_active_after"])})
+
+    def compute(run):
+        return run["setup_ms"] + run["tail_ms"] + sum(max(p["local_ms_per_rank"]) + p["close_ms"] for p in run["passes"])
+    best = min(runs, key=compute)
     gather_bytes = n_ranks * max(counts) * h * 24             # shards padded to the largest count (pipeline.py)
 
-    def comm_ms(all_links):
-        return (allreduce_ms(8 * n_ranks, n_ranks, all_links) + allgather_ms(gather_bytes, n_ranks, all_links)
-                + sum(allreduce_ms(4 * p["best_entries"], n_ranks, all_links) for p in best["passes"]))
-    comm, comm_fast = comm_ms(False), comm_ms(True)
-    compute = max(front) + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
-    # the other form of the front half (pipeline.py, front="replicate"): every rank embeds and clash-filters ALL poses, no counts
-    # all-reduce, no all-gather -- only the all-reduces of best[] remain
-    front_all = max(front) if n_ranks == 1 or front_all_ms is None else front_all_ms
-    rep_comm = [sum(allreduce_ms(4 * p["best_entries"], n_ranks, al) for p in best["passes"]) for al in (False, True)]
-    rep_compute = front_all + best["replicated_ms"] + sum(max(p["local_ms_per_rank"]) for p in best["passes"])
-    replicate = {"front_ms": front_all, "compute_ms": rep_compute, "modelled_comm_ms": rep_comm[0], "modelled_comm_ms_all_links": rep_comm[1],
-                 "predicted_ms_per_step": rep_compute + rep_comm[0], "predicted_ms_per_step_all_links": rep_compute + rep_comm[1]}
-    return {"n_ranks": n_ranks, "front_replicate": replicate, "front_ms_per_rank": front, "replicated_ms": best["replicated_ms"],
-            "sharded_passes": [{"k": p["k"], "best_entries": p["best_entries"], "max_local_ms": max(p["local_ms_per_rank"]),
-                                "sum_local_ms": sum(p["local_ms_per_rank"]), "imbalance": max(p["local_ms_per_rank"]) * n_ranks / max(sum(p["local_ms_per_rank"]), 1e-9)}
-                               for p in best["passes"]],
-            "compute_ms": compute, "modelled_comm_ms": comm, "modelled_comm_ms_all_links": comm_fast, "allgather_bytes": gather_bytes,
-            "pass_counts_per_rank": counts, "predicted_ms_per_step": compute + comm, "predicted_ms_per_step_all_links": compute + comm_fast,
-            "predicted_conformers_per_s": ens.n_poses / (compute + comm) * 1e3,
-            "predicted_conformers_per_s_all_links": ens.n_poses / (compute + comm_fast) * 1e3, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}
+    def pass_comm(all_links):
+        return sum(allreduce_ms(p["bytes"], n_ranks, all_links) for p in best["passes"] if p["bytes"])
+    prune_ms = compute(best)
+    fronts = {}
+    # shard: pose blocks + counts all-reduce + all-gather of the survivors' heavy atoms
+    fronts["shard"] = {"compute_ms": max(front), "comm_ms": [allreduce_ms(8 * n_ranks, n_ranks, al) + allgather_ms(gather_bytes, n_ranks, al) for al in (False, True)]}
+    # replicate: every rank embeds and clash-filters all poses
+    fa = max(front) if n_ranks == 1 or front_all_ms is None else front_all_ms
+    fronts["replicate"] = {"compute_ms": fa, "comm_ms": [0.0, 0.0]}
+    # hybrid: this rank's clash verdicts, the mask summed over the ranks (one byte per pose), every survivor embedded on every rank
+    if embed_all_ms is not None:
+        fronts["hybrid"] = {"compute_ms": max(clash_only) + embed_all_ms,
+                            "comm_ms": [allreduce_ms(ens.n_poses, n_ranks, al) for al in (False, True)] if n_ranks > 1 else [0.0, 0.0]}
+    out_fronts = {}
+    for name, f in fronts.items():
+        ring, fast = f["compute_ms"] + f["comm_ms"][0] + prune_ms + pass_comm(False), f["compute_ms"] + f["comm_ms"][1] + prune_ms + pass_comm(True)
+        out_fronts[name] = {"front_compute_ms": f["compute_ms"], "front_comm_ms_ring": f["comm_ms"][0], "front_comm_ms_all_links": f["comm_ms"][1],
+                            "predicted_ms_per_step": ring, "predicted_ms_per_step_all_links": fast}
+    by_kind = {}
+    for p in best["passes"]:
+        d = by_kind.setdefault(p["kind"], {"passes": 0, "local_ms": 0.0, "close_ms": 0.0, "comm_ms_ring": 0.0, "comm_ms_all_links": 0.0})
+        d["passes"] += 1
+        d["local_ms"] += max(p["local_ms_per_rank"])
+        d["close_ms"] += p["close_ms"]
+        d["comm_ms_ring"] += allreduce_ms(p["bytes"], n_ranks, False) if p["bytes"] else 0.0
+        d["comm_ms_all_links"] += allreduce_ms(p["bytes"], n_ranks, True) if p["bytes"] else 0.0
+    return {"n_ranks": n_ranks, "partition_min_chunks": chunks, "fronts": out_fronts, "front_ms_per_rank": front, "clash_only_ms_per_rank": clash_only,
+            "embed_all_survivors_ms": embed_all_ms, "setup_ms": best["setup_ms"], "tail_ms": best["tail_ms"], "prune_compute_ms": prune_ms,
+            "pass_comm_ms_ring": pass_comm(False), "pass_comm_ms_all_links": pass_comm(True), "by_kind": by_kind,
+            "passes": [{"k": p["k"], "kind": p["kind"], "max_local_ms": max(p["local_ms_per_rank"]), "sum_local_ms": sum(p["local_ms_per_rank"]),
+                        "close_ms": p["close_ms"], "bytes": p["bytes"]} for p in best["passes"]],
+            "allgather_bytes": gather_bytes, "pass_counts_per_rank": counts, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}, embed_all_ms
 
 
 def main():
-    cfgs = [a for a in sys.argv[1:] if a.startswith("C")] or ["C3", "C4"]
+    args = sys.argv[1:]
+    chunks = PARTITION_MIN_CHUNKS
+    if "--chunks" in args:
+        i = args.index("--chunks")
+        chunks = int(args[i + 1])
+        del args[i:i + 2]
+    cfgs = [a for a in args if a.startswith("C")] or ["C3", "C4"]
     out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
            "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
                      "ring (predicted_ms_per_step)": "per-link bound: all-gather = (N-1) steps of one shard over one link; all-reduce = reduce-scatter + all-gather of that pattern",
                      "all_links (predicted_ms_per_step_all_links)": "the fully connected xGMI mesh used at once: every shard straight to its N-1 peers, one link each",
-                     "shard_min_pairs": SHARD_MIN_PAIRS},
+                     "shard_min_pairs": SHARD_MIN_PAIRS, "partition_min_chunks": chunks},
            "measured_on": torch.cuda.get_device_name(0), "configs": {}}
     for cfg in cfgs:
         rows = []
-        front_all = None
+        front_all = embed_all = None
         for n in (1, 2, 4, 8):
             t0 = time.time()
-            rows.append(measure(cfg, n, front_all_ms=front_all))
+            row, embed_all = measure(cfg, n, chunks, front_all_ms=front_all, embed_all_ms=embed_all)
+            rows.append(row)
             if n == 1:
                 front_all = max(rows[0]["front_ms_per_rank"])          # one rank's front half IS the whole pose list
-            rp = rows[-1]["front_replicate"]
-            print(f"{cfg} N={n}: front sharded {rows[-1]['predicted_ms_per_step']:.3f} ms/step (compute {rows[-1]['compute_ms']:.3f}, modelled comm "
-                  f"{rows[-1]['modelled_comm_ms']:.3f}; all links {rows[-1]['predicted_ms_per_step_all_links']:.3f}) | front replicated "
-                  f"{rp['predicted_ms_per_step']:.3f} (all links {rp['predicted_ms_per_step_all_links']:.3f}) [{time.time() - t0:.0f} s]", file=sys.stderr)
-        base = rows[0]["predicted_ms_per_step"]
+            print(f"{cfg} N={n}: " + " | ".join(f"{name} {f['predicted_ms_per_step']:.3f} (all links {f['predicted_ms_per_step_all_links']:.3f})"
+                                                for name, f in row["fronts"].items()) + f"  prune compute {row['prune_compute_ms']:.3f} [{time.time() - t0:.0f} s]",
+                  file=sys.stderr)
+        base = min(f["predicted_ms_per_step"] for f in rows[0]["fronts"].values())
         for r in rows:
-            r["speedup_vs_1_rank_protocol"] = base / r["predicted_ms_per_step"]
-            r["speedup_vs_1_rank_protocol_all_links"] = base / r["predicted_ms_per_step_all_links"]
-            r["front_replicate"]["speedup_vs_1_rank_protocol"] = base / r["front_replicate"]["predicted_ms_per_step"]
-            r["front_replicate"]["speedup_vs_1_rank_protocol_all_links"] = base / r["front_replicate"]["predicted_ms_per_step_all_links"]
+            for f in r["fronts"].values():
+                f["speedup_vs_1_rank_protocol"] = base / f["predicted_ms_per_step"]
+                f["speedup_vs_1_rank_protocol_all_links"] = base / f["predicted_ms_per_step_all_links"]
         out["configs"][cfg] = rows
     print(json.dumps(out, indent=1))
 

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "tsc_rmsd_pairs_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "tsc_embed_clash_compact_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_double, C.c_int64,
                                                _vp, _vp, _vp, _vp]),
+    "tsc_basis_from_poses_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_int]),
+    "tsc_embed_masked_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, c_i64p]),
     "tsc_inertia_moments": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
     "tsc_moi_first_similar": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp]),
     "tsc_embed_scores": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),

@@ -92,6 +92,15 @@ struct tsc_ctx {
     double *eb_block = nullptr;           // [sample coordinates | moment accumulators | basis]
     int eb_h = 0, eb_samples = 0;
     bool eb_valid = false;
+    // descriptors written by tsc_embed_masked_dev with the poses it embeds, for the tsc_prune_create that follows on the same
+    // structures (consumed once; the run borrows the buffers until it is destroyed)
+    float *xd_D = nullptr;
+    double *xd_G = nullptr;
+    unsigned *xd_dmax = nullptr;
+    int64_t xd_cap = 0;                   // structures the buffers hold
+    int xd_h = 0;
+    const double *xd_heavy = nullptr;     // the heavy-atom array they describe
+    bool xd_valid = false;
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
     std::vector<int32_t> slot_host;       // heavy-atom slot table of the last tsc_pipeline_dev call and its device copy

@@ -772,14 +772,23 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     return 0;
 }
 
+static const double *pending_basis(const tsc_ctx *c, int h);  // (with the pipeline's helpers, below)
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
     TSC_REQUIRE(c != nullptr, "tsc_prune_create: null argument");
-    // a basis that tsc_embed_clash_compact_dev estimated beside its clash kernel is used once, by the run created next
-    const double *basis = nullptr;
-    if (c->eb_valid && c->eb_h == h && c->prune_algo != ALGO_TILE) {
+    // descriptors that tsc_embed_masked_dev wrote with this very array are used once, by the run created next ...
+    if (c->xd_valid && c->xd_h == h && c->xd_heavy == heavy_dev && n <= c->xd_cap && c->prune_algo != ALGO_TILE) {
+        ExternalDescriptors ext;
+        ext.D = c->xd_D, ext.G = c->xd_G, ext.dmax_bits = c->xd_dmax;
+        c->xd_valid = false;
+        return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, nullptr, &ext);
+    }
+    c->xd_valid = false;
+    // ... and so is a basis that tsc_embed_clash_compact_dev / tsc_basis_from_poses_dev estimated on the side stream
+    const double *basis = pending_basis(c, h);
+    if (basis) {
         DeviceGuard guard(c->device);
         TSC_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        basis = c->eb_block + size_t(c->eb_samples) * h * 3 + moment_doubles(h);
     }
     c->eb_valid = false;
     return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, basis);
@@ -2106,6 +2115,130 @@ static int basis_sample_table(tsc_ctx *c, int64_t n_poses, int *n_samples_out) {
     return 0;
 }
 
+// The descriptor basis of a prune from a sample of unfiltered poses, on the side stream: begin() records the fork point on the main
+// stream (the inputs are ordered there) and makes room in the context's persistent block; launch() enqueues the chain -- sample
+// embed, moments, basis: about 50 us -- on the side stream and marks the basis valid for the next consumer (tsc_prune_create or
+// tsc_embed_masked_dev on this context, which wait for ev_join).  Work enqueued on the main stream between the two hides the chain.
+struct BasisFork {
+    int n_samples = 0;
+    double *sample = nullptr, *moments = nullptr, *basis = nullptr;
+};
+static int basis_fork_begin(tsc_ctx *c, int64_t n_poses, int n_heavy, BasisFork *bf) {
+    *bf = BasisFork();
+    if (!(c->early_basis && c->prune_algo != ALGO_TILE)) return 0;
+    TSC_TRY(basis_sample_table(c, n_poses, &bf->n_samples));
+    const size_t need = size_t(bf->n_samples) * n_heavy * 3 + moment_doubles(n_heavy) + basis_doubles(n_heavy);
+    if (!(c->eb_block && c->eb_h == n_heavy && c->eb_samples == bf->n_samples)) {
+        TSC_HIP(hipStreamSynchronize(c->basis_stream));
+        if (c->eb_block) c->release(c->eb_block);
+        c->eb_block = nullptr;
+        void *q = nullptr;
+        TSC_TRY(c->alloc(need * sizeof(double), &q));
+        c->eb_block = static_cast<double *>(q), c->eb_h = n_heavy, c->eb_samples = bf->n_samples;
+    }
+    bf->sample = c->eb_block, bf->moments = bf->sample + size_t(bf->n_samples) * n_heavy * 3, bf->basis = bf->moments + moment_doubles(n_heavy);
+    TSC_HIP(hipEventRecord(c->ev_fork, c->stream));
+    return 0;
+}
+static int basis_fork_launch(tsc_ctx *c, const BasisFork &bf, Scratch &s, const double *frags, const FragTable &ft, const int32_t *conf_idx, const double *rot,
+                             const double *pos, const int32_t *d_slot, int n_heavy) {
+    if (!bf.basis) return 0;
+    TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(bf.n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
+                       rot, pos, (const int32_t *)c->sample_dev, int64_t(bf.n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, bf.sample,
+                       (const int32_t *)nullptr, bf.moments, int(moment_doubles(n_heavy)));
+    TSC_TRY(build_basis(c, c->basis_stream, s, bf.sample, n_heavy, bf.n_samples, 1, bf.basis, nullptr, bf.moments));
+    TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
+    c->eb_valid = true;
+    return 0;
+}
+static const double *pending_basis(const tsc_ctx *c, int h) {
+    return (c->eb_valid && c->eb_h == h && c->prune_algo != ALGO_TILE) ? c->eb_block + size_t(c->eb_samples) * h * 3 + moment_doubles(h) : nullptr;
+}
+
+// Fork the descriptor basis of the prune that will follow from a sample of these poses (all device pointers, as
+// tsc_transform_batch_dev) -- a call of its own for hosts that run the clash verdicts and the embedding as separate steps
+// (the multi-rank front half of tscode_amd/pipeline.py): enqueue it first, and the chain runs beside whatever follows.
+extern "C" __attribute__((visibility("default"))) int tsc_basis_from_poses_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                                                               const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                                                               const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx, "tsc_basis_from_poses_dev: null argument");
+    TSC_REQUIRE(n_poses > 0 && n_poses < INT32_MAX, "bad n_poses");
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    TSC_REQUIRE(n_heavy > 0 && n_heavy <= ft.n_total, "bad n_heavy");
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    int32_t *d_slot;
+    TSC_TRY(heavy_slot_table(c, ft, heavy_idx, n_heavy, &d_slot));
+    BasisFork bf;
+    TSC_TRY(basis_fork_begin(c, n_poses, n_heavy, &bf));
+    return basis_fork_launch(c, bf, s, frags, ft, conf_idx, rot, pos, d_slot, n_heavy);
+}
+
+// The poses selected by a mask that is ALREADY on the device (clash verdicts gathered from every rank, say), embedded in order:
+// structures f64[n_sel, n_atoms, 3] and / or heavy f64[n_sel, n_heavy, 3] (either may be NULL, not both).  With `heavy`, and a
+// basis pending on this context (tsc_basis_from_poses_dev), the kernel also writes the descriptors of the prune that follows; the
+// next tsc_prune_create on this context over the same `heavy` array takes them instead of reading the coordinates back.
+// n_sel_host (optional): the number of selected poses; the call synchronises for it while the embed runs.
+extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
+                                                                           const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
+                                                                           const double *pos, int64_t n_poses, const uint8_t *mask, const int32_t *heavy_idx,
+                                                                           int n_heavy, double *structures, double *heavy, int64_t *n_sel_host) {
+    TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && mask && (structures || heavy), "tsc_embed_masked_dev: null argument");
+    TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX, "bad n_poses");
+    if (n_sel_host) *n_sel_host = 0;
+    if (n_poses == 0) return 0;
+    FragTable ft;
+    TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
+    TSC_REQUIRE(n_heavy > 0 && n_heavy <= ft.n_total, "bad n_heavy");
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->stream;
+    Scratch s(c);
+    int32_t *d_slot, *bsum, *act, *total;
+    TSC_TRY(heavy_slot_table(c, ft, heavy_idx, n_heavy, &d_slot));
+    TSC_TRY(s.get(scan_bsum_count(n_poses), &bsum));
+    TSC_TRY(s.get(size_t(n_poses), &act));
+    TSC_TRY(s.get(1, &total));
+    TSC_TRY(scan_mask(st, mask, n_poses, bsum, nullptr, act, nullptr, total));
+    if (n_sel_host) TSC_TRY(read_i32_begin(c, total));
+    const double *basis = heavy ? pending_basis(c, n_heavy) : nullptr;
+    c->xd_valid = false;
+    if (basis && c->fuse_descriptors && transform_describe_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024) {
+        if (!(c->xd_D && c->xd_cap >= n_poses)) {
+            for (void *q : {static_cast<void *>(c->xd_D), static_cast<void *>(c->xd_G), static_cast<void *>(c->xd_dmax)})
+                if (q) c->release(q);
+            c->xd_D = nullptr, c->xd_G = nullptr, c->xd_dmax = nullptr, c->xd_cap = 0;
+            void *q = nullptr;
+            TSC_TRY(c->alloc(size_t(n_poses) * DW * sizeof(float), &q));
+            c->xd_D = static_cast<float *>(q);
+            TSC_TRY(c->alloc(size_t(n_poses) * sizeof(double), &q));
+            c->xd_G = static_cast<double *>(q);
+            TSC_TRY(c->alloc(4 * sizeof(unsigned), &q));
+            c->xd_dmax = static_cast<unsigned *>(q);
+            c->xd_cap = n_poses;
+        }
+        const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
+        TSC_HIP(hipMemsetAsync(c->xd_dmax, 0, sizeof(unsigned), st));
+        TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));  // the basis from the side stream
+        hipLaunchKernelGGL(k_transform_describe, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_describe_lds_bytes(ft.n_mols, n_heavy), st,
+                           frags, ft, conf_idx, rot, pos, (const int32_t *)act, structures, (const int32_t *)d_slot, n_heavy, heavy, (const int32_t *)total,
+                           nf0, nf1, basis, (const double *)(basis + size_t(KD) * (nf0 + nf1)), c->xd_D, c->xd_G, c->xd_dmax);
+        c->xd_valid = true, c->xd_h = n_heavy, c->xd_heavy = heavy;
+        c->eb_valid = false;  // (the basis went into the descriptors)
+    } else {
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos,
+                           (const int32_t *)act, int64_t(0), structures, (const int32_t *)d_slot, heavy ? n_heavy : 0, heavy, (const int32_t *)total);
+    }
+    TSC_HIP(hipGetLastError());
+    if (n_sel_host) {
+        int32_t n_sel = 0;
+        TSC_TRY(read_i32_finish(c, &n_sel));
+        *n_sel_host = n_sel;
+    }
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                                                                   const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                                                                   const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy,
@@ -2129,32 +2262,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_de
     // The descriptor basis of the prune that follows (tsc_prune_create on the gathered survivors), from a sample of THIS block's
     // unfiltered poses, on the side stream beside the clash kernel -- as tsc_pipeline_dev does.  Every rank of a sharded run
     // ends up with a basis of its own; any basis gives the same verdicts.
-    int n_samples = 0;
-    double *eb_sample = nullptr, *eb_moments = nullptr, *eb_basis = nullptr;
-    if (c->early_basis && c->prune_algo != ALGO_TILE) {
-        TSC_TRY(basis_sample_table(c, n_poses, &n_samples));
-        const size_t need = size_t(n_samples) * n_heavy * 3 + moment_doubles(n_heavy) + basis_doubles(n_heavy);
-        if (!(c->eb_block && c->eb_h == n_heavy && c->eb_samples == n_samples)) {
-            TSC_HIP(hipStreamSynchronize(c->basis_stream));
-            if (c->eb_block) c->release(c->eb_block);
-            c->eb_block = nullptr;
-            void *q = nullptr;
-            TSC_TRY(c->alloc(need * sizeof(double), &q));
-            c->eb_block = static_cast<double *>(q), c->eb_h = n_heavy, c->eb_samples = n_samples;
-        }
-        eb_sample = c->eb_block, eb_moments = eb_sample + size_t(n_samples) * n_heavy * 3, eb_basis = eb_moments + moment_doubles(n_heavy);
-        TSC_HIP(hipEventRecord(c->ev_fork, st));
-    }
+    BasisFork bf;
+    TSC_TRY(basis_fork_begin(c, n_poses, n_heavy, &bf));
     TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes, clash_mask, nullptr));
-    if (eb_basis) {
-        TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
-        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
-                           rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, eb_sample,
-                           (const int32_t *)nullptr, eb_moments, int(moment_doubles(n_heavy)));
-        TSC_TRY(build_basis(c, c->basis_stream, s, eb_sample, n_heavy, n_samples, 1, eb_basis, nullptr, eb_moments));
-        TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
-        c->eb_valid = true;
-    }
+    TSC_TRY(basis_fork_launch(c, bf, s, frags, ft, conf_idx, rot, pos, d_slot, n_heavy));
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     TSC_TRY(read_i32_begin(c, total));
     hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos, (const int32_t *)act,

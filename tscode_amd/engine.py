@@ -187,6 +187,22 @@ class Engine:
                                                    C.byref(n_pass)))
         return n_pass.value
 
+    def basis_from_poses_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, heavy_idx):
+        """Fork the estimate of the prune's descriptor basis from a sample of these poses onto the side stream."""
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        check(self.lib.tsc_basis_from_poses_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos), C.c_int64(n_poses),
+                                                heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx))))
+
+    def embed_masked_dev(self, frags: FragmentSet, frags_dev, conf_idx, rot, pos, n_poses, mask, heavy_idx, structures, heavy, want_count=True):
+        """The poses selected by a device mask, embedded in order into ``structures`` and / or ``heavy`` (either may be None).
+        Returns how many were selected (None with want_count=False: the call then does not synchronise)."""
+        heavy_idx = np.ascontiguousarray(heavy_idx, dtype=np.int32)
+        n_sel = C.c_int64()
+        check(self.lib.tsc_embed_masked_dev(self._h, ptr(frags_dev), *frags.table_args(), ptr(conf_idx), ptr(rot), ptr(pos), C.c_int64(n_poses),
+                                            ptr(mask), heavy_idx.ctypes.data_as(_lib.c_i32p), C.c_int(len(heavy_idx)), ptr(structures), ptr(heavy),
+                                            C.byref(n_sel) if want_count else None))
+        return n_sel.value if want_count else None
+
     def all_dists(self, a, b) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -57,6 +57,9 @@ def partition_bounds(n: int, k: int, rank: int, world: int):
     return c_lo, c_hi, (c_lo * cs if c_lo < k else n), (c_hi * cs if c_hi < k else n)
 
 
+FRONTS = ("shard", "replicate", "hybrid")
+
+
 def block_bounds(n: int, rank: int, world: int):
     """Contiguous block [lo, hi) of the pose axis owned by ``rank``."""
     return (n * rank) // world, (n * (rank + 1)) // world
@@ -91,8 +94,8 @@ def sharded_step(backend, rank: int, world: int, dist, group=None, min_pairs=Non
     backend has one (the HIP backend makes its own torch stream current, so that its kernels, torch's copies and the
     collectives are ordered on one stream).  ``front``: "shard" = pose blocks + all-gather of the survivors' coordinates,
     "replicate" = every rank computes the whole front half, no coordinates travel (module docstring)."""
-    if front not in ("shard", "replicate"):
-        raise ValueError(f"front must be 'shard' or 'replicate', got {front!r}")
+    if front not in FRONTS:
+        raise ValueError(f"front must be one of {FRONTS}, got {front!r}")
     enter = getattr(backend, "stream_context", None)
     if enter is None:
         return _sharded_step(backend, rank, world, dist, group, min_pairs, front, partition_chunks)
@@ -125,12 +128,22 @@ def _front_sharded(backend, rank, world, dist, group):
     return off, n_pass_local, counts, int(world * rows * row_elems * backend.gather.element_size())
 
 
+def _front_hybrid(backend, rank, world, dist, group):
+    """Clash verdicts of this rank's block -> the verdicts of all blocks (one byte per pose: all-reduce SUM of a mask that is zero
+    outside the rank's block) -> every rank embeds the heavy atoms of ALL passing poses itself.  Returns (n_pass, mask bytes moved)."""
+    backend.clash_block_into_all()            # (also forks the descriptor basis onto the side stream, embeds this block's survivors)
+    _all_reduce(dist, backend.clash_all, dist.ReduceOp.SUM, group)
+    return int(backend.embed_masked_all()), int(backend.clash_all.numel())
+
+
 def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front="shard", partition_chunks=PARTITION_MIN_CHUNKS):
     """The protocol itself.
 
     backend interface (all tensors live where the backend computes):
         embed_clash_block() -> n_pass_local      fills backend.heavy_local[:n_pass_local]  (h, 3 per row)
         embed_clash_all() -> n_pass              (front="replicate" only) fills backend.heavy_all[:n_pass] from ALL poses
+        clash_block_into_all(), clash_all, embed_masked_all() -> n_pass   (front="hybrid" only): verdicts of this rank's block into
+                                                 the all-poses mask (zero elsewhere); heavy_all[:n_pass] from the summed mask
         heavy_pad, gather, heavy_all, counts, keep, max_local, best      preallocated tensors / int
         make_stepper(n_pass) -> stepper with next_pass(), pass_estimate(), pass_local(rank, world), n_active(), pass_finish(),
                                 stats(), copy_mask(dst), close(); it keeps best[] in backend.best.  Optional (partitioned passes,
@@ -138,8 +151,12 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
                                 exchange buffer in backend.exch (int64) --, pass_partitioned(), pass_range(), exchange_words(),
                                 pass_merge(), views_range() -> (offset, words) into backend.exch, views_merged()
     """
+    mask_bytes = 0
     if front == "replicate":
         n_pass = int(backend.embed_clash_all())
+        n_pass_local, counts, gathered_bytes = n_pass, [n_pass], 0
+    elif front == "hybrid":
+        n_pass, mask_bytes = _front_hybrid(backend, rank, world, dist, group)
         n_pass_local, counts, gathered_bytes = n_pass, [n_pass], 0
     else:
         n_pass, n_pass_local, counts, gathered_bytes = _front_sharded(backend, rank, world, dist, group)
@@ -198,7 +215,7 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
     return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts, "exchanges": exchanges,
             "partitioned": partitioned, "front": front, "allgather_bytes": gathered_bytes,
             "allreduce_bytes": 4 * sum(n for _, n in exchanges) + 8 * sum(w for _, w in partitioned) + 8 * views_words
-                               + (8 * world if front == "shard" else 0)}
+                               + (8 * world if front == "shard" else 0) + mask_bytes}
 
 
 class _HipStepper:
@@ -324,6 +341,38 @@ class HipShardBackend:
                                                 self.heavy_idx, self.clash_thresh, self.max_clashes, self.clash_all, self.structures_all,
                                                 self.heavy_all)
 
+    def _all_inputs(self):
+        if getattr(self, "d_ci_all", None) is None:
+            torch, ens = self.torch, self.ens
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+            self.d_ci_all, self.d_rot_all, self.d_pos_all = t(ens.conf_idx), t(ens.rot), t(ens.pos)
+            self.clash_all = torch.zeros(ens.n_poses, dtype=torch.uint8, device=self.dev)
+
+    def clash_block(self):
+        """The clash verdicts of this rank's block alone (no pose is written)."""
+        self.eng.embed_clash_mask_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.clash_thresh, self.max_clashes,
+                                      self.clash)
+
+    def clash_block_into_all(self):
+        """front="hybrid", before the exchange: the descriptor basis forked onto the side stream (from a sample of ALL poses), this
+        block's verdicts written into the all-poses mask, which is zero elsewhere, and this block's passing poses embedded with all
+        their atoms (``structures``: what the caller gets back; only the heavy atoms of the OTHER blocks' poses are ever needed here)."""
+        self._all_inputs()
+        self.eng.basis_from_poses_dev(self.fs, self.d_frags, self.d_ci_all, self.d_rot_all, self.d_pos_all, self.ens.n_poses, self.heavy_idx)
+        self.clash_all.zero_()
+        block = self.clash_all[self.lo:self.hi]
+        if self.n_local:
+            self.eng.embed_clash_mask_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.clash_thresh, self.max_clashes,
+                                          block)
+            self.eng.embed_masked_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, block, self.heavy_idx, self.structures,
+                                      None, want_count=False)
+
+    def embed_masked_all(self):
+        """front="hybrid", after the exchange: the heavy atoms (and the prune's descriptors) of every passing pose, on this rank."""
+        self._all_inputs()
+        return self.eng.embed_masked_dev(self.fs, self.d_frags, self.d_ci_all, self.d_rot_all, self.d_pos_all, self.ens.n_poses, self.clash_all,
+                                         self.heavy_idx, None, self.heavy_all)
+
     def make_stepper(self, n_pass):
         st = self.eng.prune_stepper(self.heavy_all, n_pass, self.h, self.rmsd_thr, self.mode)
         st.use_best_buffer(self.best)
@@ -344,8 +393,8 @@ class DevicePipeline:
         self.sharded = self.world > 1 or force_sharded
         self.shard_min_pairs = shard_min_pairs                  # None: SHARD_MIN_PAIRS (tests lower it to shard small passes too)
         self.partition_chunks = int(partition_chunks)           # chunks per rank from which a pass is partitioned by chunks (0: never)
-        if front not in ("auto", "shard", "replicate"):
-            raise ValueError(f"front must be 'auto', 'shard' or 'replicate', got {front!r}")
+        if front != "auto" and front not in FRONTS:
+            raise ValueError(f"front must be 'auto' or one of {FRONTS}, got {front!r}")
         self.front = front if self.world > 1 or front != "auto" else "shard"
         self.front_tuning = None
         if self.sharded:
@@ -399,7 +448,7 @@ class DevicePipeline:
         if not self.sharded:
             return None
         times = {}
-        for form in ("shard", "replicate"):
+        for form in FRONTS:
             sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form, self.partition_chunks)
             torch.cuda.synchronize(self.backend.dev)
             dist.barrier(group=self.pg)
