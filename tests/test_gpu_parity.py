@@ -1403,9 +1403,10 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     got = json.loads(line)
     assert got["world"] == world and got["ranks_agree"] and got["steps_that_differ"] == 0
-    # both forms of the front half (pose blocks + all-gather / every rank embeds all poses) were timed, one was chosen by every
+    # the three forms of the front half (pose blocks + all-gather / every rank embeds all poses / clash verdicts per block, survivors
+    # embedded everywhere) were timed, one was chosen by every
     # rank alike, and each of them, forced, gives the same survivors and evaluation counts
-    assert got["forms_agree"] and got["front_tuning"]["chosen"] in ("shard", "replicate") and len(got["front_tuning"]["ms_per_step"]) == 2
+    assert got["forms_agree"] and got["front_tuning"]["chosen"] in ("shard", "replicate", "hybrid") and len(got["front_tuning"]["ms_per_step"]) == 3
     if cfg in ("C3", "C4", "C5"):                        # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
         exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))[{"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0", "C5": "C5:500000:mode0"}[cfg]]
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])

@@ -1208,34 +1208,45 @@ struct MergeArgs {
     uint8_t *mask;
     int next_s_lo, next_s_hi;   // the next pass is rank-partitioned: this rank's structures [s_lo, s_hi) in it; -1: it is not
 };
+constexpr int MERGE_LDS_BLOCKS = 8192;  // scan blocks counted in LDS (16.7 M structures); beyond: every thread counts whole blocks from memory
 __global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, StepArgs sa) {
+    __shared__ int s_cnt[MERGE_LDS_BLOCKS];
     __shared__ int s_part[16], s_run;
     PruneState *st = sc.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pass_on = st->pass_on, sel = st->bitsel, n_before = st->n_active;
     const bool closing = sa.prev >= 0 && pass_on != 0;
+    const bool in_lds = a.n_blocks <= MERGE_LDS_BLOCKS;
     const unsigned long long *X = a.bits + size_t(sel) * a.bit_words;
     unsigned long long *Xo = a.bits + size_t(sel ^ 1) * a.bit_words;
-    if (tid == 0) s_run = n_before;
+    if (tid == 0) s_run = closing ? 0 : n_before;
     if (closing) {
+        if (in_lds)
+            for (int b = tid; b < a.n_blocks; b += 1024) s_cnt[b] = 0;
+        __syncthreads();
+        // the pass's outcome: the bit copy the next pass reads, the mask bytes of the removed rows, the scan blocks' counts
         for (int w = tid; w < a.bit_words; w += 1024) {
+            const unsigned long long old = X[w];
             unsigned long long rm = a.exch[w];
-            Xo[w] = X[w] & ~rm;
+            const unsigned long long now = old & ~rm;
+            Xo[w] = now;
+            if (in_lds && now) atomicAdd(&s_cnt[w / SCAN_BLOCK_WORDS], __popcll(now));  // (words behind the last block's are zero)
             if (rm) {
                 a.exch[w] = 0;
-                for (rm &= X[w]; rm; rm &= rm - 1) a.mask[int64_t(w) * 64 + (__ffsll((long long)rm) - 1)] = 0;
+                for (rm &= old; rm; rm &= rm - 1) a.mask[int64_t(w) * 64 + (__ffsll((long long)rm) - 1)] = 0;
             }
         }
-        __syncthreads();  // (one block: its global writes are visible to all its threads behind the barrier)
-        if (tid == 0) s_run = 0;
-        __syncthreads();
+        __syncthreads();  // (one block: its global and LDS writes are visible to all its threads behind the barrier)
         for (int b0 = 0; b0 < a.n_blocks; b0 += 1024) {
             const int b = b0 + tid;
             int c = 0;
             if (b < a.n_blocks) {
-#pragma unroll 8
-                for (int u = 0; u < SCAN_BLOCK_WORDS; ++u)  // (the block list is padded beyond the last word of a bit copy)
-                    c += b * SCAN_BLOCK_WORDS + u < a.bit_words ? __popcll(Xo[size_t(b) * SCAN_BLOCK_WORDS + u]) : 0;
+                if (in_lds) {
+                    c = s_cnt[b];
+                } else {
+                    for (int u = 0; u < SCAN_BLOCK_WORDS; ++u)  // (the block list is padded beyond the last word of a bit copy)
+                        c += b * SCAN_BLOCK_WORDS + u < a.bit_words ? __popcll(Xo[size_t(b) * SCAN_BLOCK_WORDS + u]) : 0;
+                }
                 sc.bsum[b] = c;
             }
             int incl = c;
@@ -1289,19 +1300,19 @@ __global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, St
 // Summary words of `count` cache views (one bit per 1024 view bits, CacheViews) rebuilt from their bits: after the host has
 // summed the views of the remaining passes over the ranks, the summed summary words mean nothing.
 __global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__restrict__ views, long long stride, int bit_words, int dsum_words, int count) {
-    for (int v = blockIdx.y; v < count; v += gridDim.y) {
-        unsigned long long *bits = views + int64_t(v) * stride, *ds = bits + bit_words;
-        for (int sw = blockIdx.x * blockDim.x + threadIdx.x; sw < dsum_words; sw += gridDim.x * blockDim.x) {
-            unsigned long long out = 0;
-            for (int b = 0; b < 64; ++b) {  // summary bit b of word sw: view words [16 (64 sw + b), + 16)
-                const int64_t w0 = (int64_t(sw) * 64 + b) * 16;
-                if (w0 >= bit_words) break;
-                unsigned long long any = 0;
-                for (int u = 0; u < 16 && w0 + u < bit_words; ++u) any |= bits[w0 + u];
-                if (any) out |= 1ull << b;
-            }
-            ds[sw] = out;
+    // one thread per summary BIT (16 view words); the 64 bits of a summary word sit in one wavefront and meet by ballot
+    const int per_view = dsum_words * 64;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < int64_t(count) * per_view; e += int64_t(gridDim.x) * blockDim.x) {
+        const int v = int(e / per_view), sb = int(e - int64_t(v) * per_view);
+        unsigned long long *bits = views + int64_t(v) * stride;
+        const int64_t w0 = int64_t(sb) * 16;
+        unsigned long long any = 0;
+        if (w0 < bit_words) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) any |= (w0 + u < bit_words) ? bits[w0 + u] : 0ull;
         }
+        const unsigned long long word = __ballot(any != 0);
+        if ((threadIdx.x & 63) == 0) bits[bit_words + (sb >> 6)] = word;
     }
 }
 

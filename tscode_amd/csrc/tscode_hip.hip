@@ -1200,7 +1200,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_views_merged(tsc
     if (p->views_split && p->mode == 0) {
         DeviceGuard guard(p->ctx->device);
         const int v = p->view_of_slot[p->cur_slot], count = p->n_views - v;
-        hipLaunchKernelGGL(k_views_summaries, dim3(std::max(1, ceil_div(int(p->dsum_words), 256)), unsigned(count)), dim3(256), 0, p->ctx->stream,
+        hipLaunchKernelGGL(k_views_summaries, dim3(unsigned(std::min<int64_t>(ceil_div<int64_t>(int64_t(count) * p->dsum_words * 64, 256), 2048))), dim3(256), 0, p->ctx->stream,
                            p->views + size_t(v) * (p->bit_words + p->dsum_words), (long long)(p->bit_words + p->dsum_words), int(p->bit_words),
                            int(p->dsum_words), count);
         TSC_HIP(hipGetLastError());
