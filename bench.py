@@ -11,12 +11,15 @@ fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_c
 N = 1: the one-call pipeline (tsc_pipeline_dev).
 
 N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): the line's `value` is ONE ensemble sharded over the
-ranks, `"scaling": "strong"` -- the row tiles of every large prune pass dealt round-robin with an all-reduce(MIN) over best[]
-per pass, and in front of it either pose blocks for embed/clash + one RCCL all-gather of the surviving heavy-atom shards
-(`"front": "shard"`) or every rank embedding all poses itself so that no coordinates travel (`"front": "replicate"`): both are
-timed on the node before the warm-up and the faster one runs (`front_tuning`; `--front` forces one)
-(tscode_amd/pipeline.py::sharded_step); `rccl_world`, `allgather_bytes_per_step` and `allreduce_bytes_per_step` say what
-crossed xGMI.  `replicas` beside it (`"scaling": "weak"`): every GPU runs the whole pipeline on its own ensemble, no
+ranks, `"scaling": "strong"` -- every prune pass with at least 4 chunks per rank PARTITIONED BY CHUNKS (a rank runs the whole pass
+on the chunks that start inside its block of the structure axis; one bit per structure + statistics summed per pass,
+`partitioned_passes`), the later passes with their row tiles dealt round-robin and an all-reduce(MIN) over best[]
+(`sharded_passes`), and in front of it one of three forms of the embed / clash half: pose blocks + one RCCL all-gather of the
+surviving heavy-atom shards (`"front": "shard"`), every rank embedding and clash-filtering all poses itself (`"replicate"`), or
+clash verdicts per pose block, one byte per pose summed over the ranks, and every rank embedding the heavy atoms of all passing
+poses itself (`"hybrid"`): the three are timed on the node before the warm-up and the fastest runs (`front_tuning`; `--front`
+forces one) (tscode_amd/pipeline.py::sharded_step); `rccl_world`, `allgather_bytes_per_step` and `allreduce_bytes_per_step` say
+what crossed xGMI.  `replicas` beside it (`"scaling": "weak"`): every GPU runs the whole pipeline on its own ensemble, no
 data-path collective -- how a batch of independent embeds uses a node.  The 100k x 50 pipeline is a 0.9 ms chain of dependent
 launches of which about 0.5 ms shards (the Amdahl ceiling of C3 is stated there); `--config C4` (1M x 50)
 is the workload on which sharding one ensemble pays.  Should the sharded leg fail or hang (180 s watchdog), the line falls
@@ -69,9 +72,10 @@ def parse():
                          "collective (weak scaling).  The other one is timed too and reported beside it.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one GPU to rehearse "
                                                       "(device tensors then travel over the host)")
-    ap.add_argument("--front", choices=("auto", "shard", "replicate"), default="auto",
+    ap.add_argument("--front", choices=("auto", "shard", "replicate", "hybrid"), default="auto",
                     help="multi-rank front half: pose blocks + all-gather of the survivors' coordinates, every rank computing all "
-                         "poses itself (nothing but best[] travels), or whichever is faster on this node (timed before the warm-up)")
+                         "poses itself, clash verdicts per block + every rank embedding all survivors (hybrid), or whichever is fastest on "
+                         "this node (timed before the warm-up)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--pass-timing", type=int, default=1,
@@ -285,9 +289,11 @@ def main():
                "events_off": leg["events_off"], "what": what}
         return out
 
-    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: all-reduce(MIN) over best[] per large pass (row tiles dealt to the ranks); the "
-                    "front half as `front` says -- 'shard': pose blocks + one RCCL all-gather of the surviving heavy-atom shards, "
-                    "'replicate': every rank embeds and clash-filters all poses itself -- whichever `front_tuning` measured faster on this node")
+    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: passes with >= 4 chunks per rank partitioned by chunks (all-reduce SUM of one bit "
+                    "per structure + statistics), the later ones by row tiles (all-reduce MIN over best[]); the front half as `front` says -- "
+                    "'shard': pose blocks + one RCCL all-gather of the surviving heavy-atom shards, 'replicate': every rank embeds and "
+                    "clash-filters all poses itself, 'hybrid': clash verdicts per block (one byte per pose summed over the ranks), all "
+                    "survivors' heavy atoms embedded on every rank -- whichever `front_tuning` measured fastest on this node")
     REPLICAS_WHAT = "one whole ensemble per GPU (the same ensemble on every rank), no data-path collective"
 
     main_sharded = (world > 1 and args.multi == "sharded") or args.force_sharded
@@ -420,7 +426,7 @@ def main():
                        "parity_vs_recorded_oracle": leg["parity"],
                        "chain": (f"csearch_rotate of fragment 0 ({CHAIN_CANDIDATES} angle sets x 8 torsions, walk-back included) -> {res.get('n_conformers')} kept "
                                  f"candidates = its conformers -> embed -> clash -> prune; the candidate array stays on the device") if chain else None,
-                       "parallelism": (f"one ensemble sharded over {world} rank(s): pose blocks, all-gather, per-pass all-reduce" if sharded_mode else
+                       "parallelism": (f"one ensemble sharded over {world} rank(s): front half per `front`, passes partitioned by chunks or sharded by row tiles, one all-reduce per pass" if sharded_mode else
                                        f"{world} x (one whole ensemble per GPU), no data-path collective"),
                        "conformers_per_step_all_ranks": units_per_step,
                        "library_events_in_timed_region": args.pass_timing},
@@ -472,8 +478,11 @@ def main():
             out["front_tuning"] = getattr(leg["pipe"], "front_tuning", None)
             out["allreduce_bytes_per_step"] = res.get("allreduce_bytes")
             out["sharded_passes"] = [{"k": k, "best_entries": nb} for k, nb in res.get("exchanges", [])]
-            # counts all-reduce and coordinates all-gather (front = shard only), one all-reduce per sharded pass
-            out["collectives_per_step"] = (2 if res.get("front") == "shard" else 0) + len(res.get("exchanges", []))
+            out["partitioned_passes"] = [{"k": k, "int64_words": w} for k, w in res.get("partitioned", [])]
+            # counts all-reduce and coordinates all-gather (front = shard), the clash mask (front = hybrid), one all-reduce per pass that
+            # is partitioned by chunks or sharded by row tiles, one for the cache views between the two kinds
+            out["collectives_per_step"] = ({"shard": 2, "hybrid": 1}.get(res.get("front"), 0) + len(res.get("exchanges", []))
+                                           + len(res.get("partitioned", [])) + (1 if res.get("partitioned") and args.mode == 0 else 0))
         if side is not None:
             out[side[0]] = side[1]
         if error is not None:
@@ -539,6 +548,7 @@ def main():
                 c4["allgather_bytes_per_step"] = leg4["res"].get("allgather_bytes")
                 c4["allreduce_bytes_per_step"] = leg4["res"].get("allreduce_bytes")
                 c4["sharded_passes"] = [k for k, _ in leg4["res"].get("exchanges", [])]
+                c4["partitioned_passes"] = [k for k, _ in leg4["res"].get("partitioned", [])]
             del leg4, ens4
         except Exception as exc:
             c4 = {"error": f"{type(exc).__name__}: {exc}"}
