@@ -91,11 +91,14 @@ def parse():
 
 def csrc_digest():
     """SHA-256 (16 hex digits) over the HIP sources: ties a profile under profiles/ to the kernels it was taken from."""
-    h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "tscode_amd", "csrc", "*"))):
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
-    return h.hexdigest()[:16]
+    from tscode_amd.build import csrc_digest as d
+    return d()
+
+
+def binary_digest():
+    """The digest of the sources the LOADED libtscode_hip.so was built from (baked in by tscode_amd/build.py)."""
+    from tscode_amd import _lib
+    return _lib.load().tsc_build_digest().decode()
 
 
 def cpu_baseline(cfg_name, n_sample, n_full, mode):
@@ -371,8 +374,11 @@ def main():
         # separate runs, KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- and only if that profile was
         # taken from the kernels that run now (digest of tscode_amd/csrc recorded in it); otherwise null, labelled stale
         traffic, traffic_src = None, None
-        now = csrc_digest()
-        if args.config == "C3" and args.n_poses is None and world == 1:
+        now, built = csrc_digest(), binary_digest()
+        if built != now:
+            traffic_src = (f"the loaded libtscode_hip.so was built from csrc {built}, the sources beside it are {now}: traffic withheld; "
+                           f"rebuild (python -m tscode_amd.build --force)")
+        elif args.config == "C3" and args.n_poses is None and world == 1:
             for name in PMC_PROFILES:
                 pmc_path = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(pmc_path):
@@ -440,6 +446,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "csrc_sha256_16": now,
+                "binary_csrc_sha256_16": built,
                 "algorithmic_bytes_per_launch": b_launch,
                 "avg_launch_us": avg_launch_s * 1e6 if avg_launch_s else None,
                 "launches_per_step": n_launch,

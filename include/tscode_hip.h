@@ -62,6 +62,9 @@ typedef struct tsc_prune tsc_prune; /* state of one prune_conformers_rmsd run (s
 /* ---- library / context ------------------------------------------------------------------ */
 int tsc_version(void);
 const char *tsc_last_error(void);
+/* SHA-256 (16 hex digits) of the kernel sources this binary was built from (tscode_amd/build.py passes it to the compiler;
+ * "unrecorded" for a build by other means): lets a measurement tie its numbers to the binary that ran, not to the sources beside it. */
+const char *tsc_build_digest(void);
 int tsc_device_count(void); /* >= 0, or a negative tsc_status */
 int tsc_ctx_create(int device, tsc_ctx **out);
 int tsc_ctx_destroy(tsc_ctx *ctx);
@@ -253,7 +256,7 @@ int tsc_torsion_comp_check(tsc_ctx *ctx, const double *coords, int64_t n_structs
 /* Greedy per-group filter of the embed loops (tscode/embeds.py:715, :843): inside each group a pose is accepted iff
  * it is not similar (tscode/rmsd_pruning.py:208-224, all atoms, rmsd < thr and maxdev < 2 thr) to any pose accepted
  * before it in that group.  poses f64[n_poses, n_atoms, 3]; group g is poses[group_off[g] : group_off[g+1]]
- * (group_off i32[n_groups + 1], group sizes <= 1024); accepted u8[n_poses]. */
+ * (group_off i32[n_groups + 1], group sizes <= 8192); accepted u8[n_poses]. */
 int tsc_greedy_group_filter(tsc_ctx *ctx, const double *poses, const int32_t *group_off, int n_groups, int n_atoms,
                             double rmsd_thr, uint8_t *accepted);
 int tsc_greedy_group_filter_dev(tsc_ctx *ctx, const double *poses, const int32_t *group_off_dev, int n_groups, int64_t n_poses,
@@ -279,7 +282,7 @@ int tsc_greedy_group_filter_dev(tsc_ctx *ctx, const double *poses, const int32_t
  * tsc_cyclical_embed: the inner loops of tscode/embeds.py:657-717 and :785-847 for any number of (conformers, pivots,
  *   polygon orientation) groups at once.  One row per (pose, molecule), row = pose * n_mols + m, with the inputs of
  *   tsc_cyclical_embed_params plus conf_idx i32[rows]; group_off i32[n_groups + 1] cuts the poses into the reference's
- *   `angular_poses` groups (consecutive, sizes <= 1024); compenetration_check (:714) and then, inside each group and in
+ *   `angular_poses` groups (consecutive, sizes <= 8192); compenetration_check (:714) and then, inside each group and in
  *   order, `not _rmsd_similarity(pose, kept poses of the group, rmsd_thr)` (:715; the reference passes 1). */
 int tsc_tfd_greedy_filter(tsc_ctx *ctx, const float *tf, int64_t n_structs, int n_quads, double thresh, uint8_t *accepted,
                           int64_t *n_kept);

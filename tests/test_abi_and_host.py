@@ -129,3 +129,16 @@ def test_synthetic_configs_are_deterministic():
     p = a.poses(0, 10)
     assert p.shape == (10, 30, 3)
     assert np.allclose(p[:, :15], a.frag_coords[0][0])                       # fragment 0 is fixed
+
+
+def test_pairing_filter_reads_internal_constraints_like_the_reference():
+    """tscode/embeds.py:642 evaluates `pair in embedder.internal_constraints` on an ndarray of index pairs: NumPy's `in` is
+    (array == pair).any() -- one matching index in its column is enough."""
+    import numpy as np
+
+    from tscode_amd.embeds import _in_constraints
+    ic = np.array([[3, 7], [10, 12]])
+    for pair in ([3, 7], [3, 99], [99, 12], [7, 3], [1, 2]):
+        assert _in_constraints(pair, ic) == (pair in ic), pair               # the reference's own expression
+    assert _in_constraints([3, 99], ic) and not _in_constraints([7, 3], ic)
+    assert not _in_constraints([3, 7], []) and not _in_constraints([3, 7], None)

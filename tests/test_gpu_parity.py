@@ -1269,6 +1269,28 @@ def test_cyclical_embed_golden(eng, oracle):
         tscode_amd.cyclical_embed_batch(_cyclical_case(g, 0) * 2, g["angles_0"])           # not two molecules
 
 
+def test_cyclical_embed_wide_groups(eng, oracle):
+    """STEPS = 36: (36 + 1)^2 = 1369 poses per (conformers, pivots, orientation) group -- beyond the 1024 the group filter took in round 2
+    (ADVICE r2).  The product driver against the oracle's loop on the molecules of G12's first case."""
+    import tscode_amd
+    from tscode_amd.utils import cartesian_product
+    g = load_golden("G12_cyclical_embed")
+    mols = _cyclical_case(g, 0)
+    steps = np.linspace(-40.0, 40.0, 37)
+    angles = cartesian_product(steps, steps)                                                # embedder.py:714-715
+    assert len(angles) == 1369
+    thresh = float(g["clash_thresh_0"])
+    poses, cons, tr = tscode_amd.cyclical_embed_batch(mols, angles, clash_thresh=thresh, rigid_shortcut=bool(g["rigid_0"]), return_trace=True)
+    get = lambda m, k: m[k] if isinstance(m, dict) else getattr(m, k)
+    cands, group_of, ok, kept, gids = oracle.cyclical_embed([np.asarray(get(m, "coords")) for m in mols], [np.atleast_1d(get(m, "reactive_indices")) for m in mols],
+                                                            [get(m, "pivots") for m in mols], angles, thresh, rigid_shortcut=bool(g["rigid_0"]))
+    assert np.array_equal(tr.group_of, group_of) and np.bincount(group_of).max() == 1369
+    assert np.array_equal(tr.clash_ok, ok) and np.array_equal(tr.kept, kept), (tr.kept.sum(), kept.sum())
+    assert np.abs(poses - cands[kept]).max() < VAL_TOL
+    with pytest.raises(ValueError):
+        tscode_amd.cyclical_embed_batch(mols, np.zeros((8193, 2)))                          # beyond the library's group size
+
+
 def test_embed_dropins_with_the_reference_signatures(eng):
     """tscode_amd.embeds.string_embed(embedder) / cyclical_embed(embedder): what install() puts in place of the reference's
     functions.  Duck-typed Embedder and molecules carrying exactly the recorded inputs of G11 / G12 (the reference's own

@@ -11,7 +11,10 @@ import csv, glob, sys
 import os
 f = max(glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)   # (the newest run of this directory)
 rows = list(csv.DictReader(open(f)))
-steps = 12
+# steps really executed under the profiler: warm-up + the timed loop + bench.py's events-off and detail loops -- counted, not assumed:
+# k_init_run runs exactly once per prune run, i.e. once per step
+steps = max([int(r["Calls"]) for r in rows if r["Name"].startswith("tsc::k_init_run") or "k_init_run" in r["Name"]] or [12])
+print("steps under the profiler:", steps)
 tot = 0
 for r in rows:
     tot += int(r["TotalDurationNs"])

@@ -45,6 +45,7 @@ _vp = C.c_void_p
 _SIGNATURES = {
     "tsc_version": (C.c_int, []),
     "tsc_last_error": (C.c_char_p, []),
+    "tsc_build_digest": (C.c_char_p, []),
     "tsc_device_count": (C.c_int, []),
     "tsc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "tsc_ctx_destroy": (C.c_int, [_vp]),

@@ -26,20 +26,41 @@ def _hipcc():
 def needs_build():
     if not os.path.exists(OUT):
         return True
+    # the digest of the sources the binary was built from is kept beside it (and inside it: tsc_build_digest); file times alone
+    # say nothing after a checkout or a copy to another machine
+    try:
+        if open(OUT + ".digest").read().strip() != csrc_digest():
+            return True
+    except OSError:
+        return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def csrc_digest():
+    """SHA-256 (16 hex digits) over the HIP sources, file names included: baked into the library (tsc_build_digest) so that a
+    measurement can say which kernels the BINARY it ran was built from, not only which sources lie next to it."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(CSRC, "*"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", f'-DTSC_CSRC_DIGEST="{csrc_digest()}"', "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(OUT + ".digest", "w") as f:
+        f.write(csrc_digest() + "\n")
     return OUT
 
 

@@ -11,7 +11,8 @@
 
 namespace tsc {
 
-constexpr int GF_MAX_GROUP = 1024;  // poses per group (the reference's groups hold (steps+1)^n_mols <= 216 by default)
+constexpr int GF_MAX_GROUP = 8192;  // poses per group: the reference's groups hold (rotation_steps + 1)^n_mols poses -- 36 or 216 by
+                                    // default, 8100 at STEPS = 89 for two molecules; the list of kept poses sits in LDS (32 KB)
 
 // One workgroup per group.  Groups of up to 64 poses (the reference's are 36 or 216 wide before the clash filter, usually far
 // fewer after it): all P (P - 1) / 2 pair tests run at once, one per thread, into a P x P bit matrix in LDS, and one thread

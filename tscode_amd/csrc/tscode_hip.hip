@@ -22,6 +22,10 @@ using namespace tsc;
 
 extern "C" __attribute__((visibility("default"))) int tsc_version(void) { return TSC_VERSION; }
 extern "C" __attribute__((visibility("default"))) const char *tsc_last_error(void) { return g_err; }
+#ifndef TSC_CSRC_DIGEST
+#define TSC_CSRC_DIGEST "unrecorded"
+#endif
+extern "C" __attribute__((visibility("default"))) const char *tsc_build_digest(void) { return TSC_CSRC_DIGEST; }
 
 extern "C" __attribute__((visibility("default"))) int tsc_device_count(void) {
     int n = 0;
@@ -1925,6 +1929,12 @@ static int embed_filter_run(tsc_ctx *c, Scratch &s, const double *d_frags, const
                             int64_t *n_kept_out, Filter filter) {
     hipStream_t st = c->stream;
     const int n = ft.n_total;
+    // copies into the CALLER's host arrays are enqueued long before this function returns: whatever path leaves it -- an error
+    // included -- the stream is idle first, so that no copy lands in memory the caller has meanwhile freed
+    struct SyncOnExit {
+        hipStream_t st;
+        ~SyncOnExit() { (void)hipStreamSynchronize(st); }
+    } sync_on_exit{st};
     uint8_t *d_mask, *d_kept_full, *d_acc;
     int32_t *bsum, *act, *pos_scan, *total, *act2, *total2;
     TSC_TRY(s.get(size_t(N), &d_mask));

@@ -134,6 +134,18 @@ def _reactive_pair_indices(pivot_cumnums, v):
     return [[oriented[0][0], oriented[1][0]], [oriented[0][1], oriented[1][1]]]
 
 
+MAX_GROUP_POSES = 8192      # poses per (conformers, pivots, orientation) group that tsc_cyclical_embed takes (GF_MAX_GROUP, group_filter.hpp)
+
+
+def _in_constraints(pair, internal_constraints):
+    """``pair in embedder.internal_constraints`` as the reference evaluates it (tscode/embeds.py:642, :777): the constraints are an
+    ndarray of index pairs (tscode/embedder.py:499) or an empty list, and ``in`` on an ndarray is ``(array == pair).any()`` -- true as
+    soon as ONE index matches in its column, not only for a whole pair."""
+    if internal_constraints is None or len(internal_constraints) == 0:
+        return False
+    return bool((np.asarray(internal_constraints) == np.asarray(pair)).any())
+
+
 def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=0, rigid_shortcut=True, max_norm_delta=5, pairings=None,
                          internal_constraints=(), rmsd_thr=1, return_trace=False):
     """The loops of a BImolecular ``cyclical_embed`` (tscode/embeds.py:470-732, rigid shortcut :734-860) in one GPU call.
@@ -171,6 +183,8 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
     pivots = [get(m, "pivots") for m in mols]
     angles = np.asarray(systematic_angles, dtype=np.float64).reshape(-1, 2)
     A = len(angles)
+    if A > MAX_GROUP_POSES:
+        raise ValueError(f"{A} angle pairs per group: tsc_cyclical_embed takes groups of up to {MAX_GROUP_POSES} poses (rotation steps up to 89)")
     directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])                                      # _get_directions for two, :252-253 / :768
     conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])                           # :470-471
     blocks, groups = [], []
@@ -207,7 +221,7 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
         for q in range(n_pi):
             for v in range(2):
                 ids = _reactive_pair_indices([cum[m][pi[q, m]] for m in range(2)], v)
-                if pairings and not all((list(pair) in ids) or (list(pair) in [list(c) for c in internal_constraints]) for pair in pairings):
+                if pairings and not all((list(pair) in ids) or _in_constraints(pair, internal_constraints) for pair in pairings):
                     continue                                                                         # :642 / :777
                 blocks.append(rec[q, v])
                 groups.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi[q]), v, ids))
@@ -287,7 +301,7 @@ def cyclical_embed(embedder, max_norm_delta=5):
             raise RuntimeError("this embed needs the reference's own cyclical_embed (three molecules, or a pivot pair it would bend): "
                                "tscode_amd.install() records it")
         return original(embedder, max_norm_delta) if max_norm_delta != 5 else original(embedder)
-    if len(mols) != 2:
+    if len(mols) != 2 or len(embedder.systematic_angles) > MAX_GROUP_POSES:       # (groups beyond the library's size: STEPS > 89)
         return theirs()
     packed = []
     for mol in mols:
