@@ -321,7 +321,9 @@ typedef struct {
     double gpu_ms;           /* HIP-event time of the whole pass on this device (0 unless "pass_timing" is 2) */
     double tile_ms;          /* HIP-event time of the pass's pair kernel alone (0 unless "pass_timing" >= 1) */
     int32_t algo;            /* kernel that ran the pass: 1 = register-tiled all-pairs, 2 = descriptor sieve, 3 = chunk-local kernel */
-    int32_t reserved;
+    int32_t nonfinite_input; /* 1: the run met a structure with a NaN or infinite coordinate (the same in every entry of a run; descriptor-sieve
+                                runs only).  Such a structure is similar to nothing -- every comparison of :75 with a NaN is false -- and is
+                                kept; the reference itself raises LinAlgError there (np.linalg.svd, :19), and so does the Python drop-in */
 } tsc_pass_stats;
 
 #define TSC_MAX_PASSES 18

@@ -332,6 +332,52 @@ def test_prune_sharded_rows_equal_single(eng, oracle):
     _lib.check(lib.tsc_free(eng._h, d_heavy))
 
 
+def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
+    """NaN / infinite coordinates: the reference's np.linalg.svd raises LinAlgError on such a pair (rmsd_pruning.py:19).
+    The library neither hangs nor faults: a non-finite structure is similar to nothing (every comparison of :75 with a NaN is false)
+    and is kept, every finite structure gets the verdict it gets from the oracle on the same input, the run reports that it met
+    one (tsc_pass_stats.nonfinite_input) -- and the Python drop-in turns that report into the reference's exception.  The clash
+    mask treats a NaN distance as 'not below the threshold', exactly as count(D < thresh) does (numba_functions.py:77-103)."""
+    import tscode_amd
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 6000)
+    poses = ens.poses()
+    heavy = np.ascontiguousarray(poses[:, ens.atomnos != 1])
+    clean_mask, clean_stats = eng.prune_heavy(heavy, 0.5, 0)
+    assert all(s["nonfinite_input"] == 0 for s in clean_stats)
+    bad = heavy.copy()
+    bad[17, 3, 1] = np.nan
+    bad[2500] = np.inf
+    bad[5999, 0, 0] = -np.inf
+    for mode in (0, 1):
+        ref = oracle.prune_heavy(bad, 0.5, mode=mode)
+        for local_pass in (1, 0):
+            eng.set_option("local_pass", local_pass)
+            try:
+                mask, stats = eng.prune_heavy(bad, 0.5, mode)
+            finally:
+                eng.set_option("local_pass", 1)
+            assert mask[[17, 2500, 5999]].all() and np.array_equal(mask, ref["mask"]), (mode, local_pass)
+            assert all(s["nonfinite_input"] == 1 for s in stats)
+            assert [s["n_active_after"] for s in stats] == [s["n_active_after"] for s in ref["stats"]]
+    all_atoms = poses.copy()
+    all_atoms[17, np.flatnonzero(ens.atomnos != 1)[3], 1] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        tscode_amd.prune_conformers_rmsd(all_atoms, ens.atomnos, 0.5)
+    h_only = poses.copy()
+    h_only[17, np.flatnonzero(ens.atomnos == 1)[0], 1] = np.nan            # a hydrogen: never enters the prune (:178-179)
+    kept, m = tscode_amd.prune_conformers_rmsd(h_only, ens.atomnos, 0.5)
+    assert np.array_equal(m, clean_mask)
+    # clash mask
+    cp = poses[:3000].copy()
+    cp[5, 2, 0] = np.nan
+    cp[77] = np.inf
+    cp[1234, -1, 2] = -np.inf
+    for max_clashes in (0, 2):
+        got = tscode_amd.compenetration_mask(cp, ens.ids, 1.5, max_clashes)
+        assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
+
+
 @pytest.mark.parametrize("world,min_chunks,n_poses,mode", [(2, 4, 12_000, 0), (3, 1, 12_000, 0), (8, 4, 40_000, 0), (3, 4, 9_000, 1), (5, 2, 700, 0)])
 def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_poses, mode):
     """Rank-partitioned passes (tsc_prune_pass_range / tsc_prune_pass_merge): `world` prune runs over the same heavy-atom array stand

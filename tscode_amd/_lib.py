@@ -34,7 +34,7 @@ class PassStats(C.Structure):
     _fields_ = [("k", C.c_int64), ("n_active_before", C.c_int64), ("n_active_after", C.c_int64),
                 ("pairs_evaluated", C.c_int64), ("pairs_computed", C.c_int64), ("candidates", C.c_int64),
                 ("pairs_screened", C.c_int64), ("new_keys", C.c_int64), ("gpu_ms", C.c_double), ("tile_ms", C.c_double),
-                ("algo", C.c_int32), ("reserved", C.c_int32)]
+                ("algo", C.c_int32), ("nonfinite_input", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -1326,9 +1326,10 @@ __global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__r
 // of two copy commands.  `rec_host` and `mask_host` are pinned host allocations mapped into the device's address space.
 __global__ __launch_bounds__(256) void k_export_run(const unsigned long long *__restrict__ rec, int rec_words, unsigned long long *__restrict__ rec_host,
                                                      const unsigned long long *__restrict__ mask, int64_t mask_words, const uint8_t *__restrict__ mask_bytes,
-                                                     int64_t n, unsigned long long *__restrict__ mask_host) {
+                                                     int64_t n, unsigned long long *__restrict__ mask_host, const unsigned *__restrict__ dmax_bits) {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = tid; e < rec_words; e += stride) rec_host[e] = rec[e];
+    if (tid == 0) rec_host[rec_words] = dmax_bits ? (unsigned long long)*dmax_bits : 0ull;  // (behind the records: did the descriptor build meet a non-finite structure)
     if (mask_host) {
         for (int64_t e = tid; e < mask_words; e += stride) mask_host[e] = mask[e];
         uint8_t *tail = reinterpret_cast<uint8_t *>(mask_host);

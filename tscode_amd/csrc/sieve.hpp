@@ -48,6 +48,7 @@ constexpr int NFAM = 2;            // feature families
 constexpr int DW = KD * NFAM;      // doubles per structure descriptor
 constexpr int DESC_SAMPLE = 4096;  // structures used to estimate the principal axes
 constexpr int DESC_MAX_FEAT = 256; // features per family that enter the descriptor (any subset keeps the bound valid)
+constexpr unsigned NONFINITE_BITS = 0x7fc00000u;  // what the running maximum of |descriptor| reads once a non-finite structure was seen
 
 // feature a of family fam of the structure at x (h atoms, xyz triples)
 __device__ inline double feature(const double *__restrict__ x, int h, int fam, int a) {
@@ -178,6 +179,11 @@ __device__ inline void describe_from_lds(const double *s_q, const double *s_x, i
     // same-address atomics serialise (about 12 ns each): only a wavefront that would raise the maximum sends one
     if ((threadIdx.x & 63) == 0 && mx > __uint_as_float(__hip_atomic_load(dmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         atomicMax(dmax_bits, __float_as_uint(mx));
+    // A structure with a NaN or infinite coordinate (its squared norm is not finite) raises the running maximum to the bit pattern of
+    // a NaN: the screen's limit then drops nothing (screen_limit32*), the evaluation stages find such a structure similar to nothing
+    // (every comparison with a NaN is false, rmsd_pruning.py:75), and the run reports that it saw one (tsc_pass_stats.nonfinite_input;
+    // the reference's np.linalg.svd raises LinAlgError on such input, rmsd_pruning.py:19)
+    if (__ballot(mine && sub == 0 && !(g < 1.7976931348623157e308)) != 0 && (threadIdx.x & 63) == 0) atomicMax(dmax_bits, NONFINITE_BITS);
 }
 
 // D[i][2k + fam] = sum_a Q_fam[k][a] * f_fam,a(x_i) - bias[fam*KD + k]   (fp32, original index space, the two families

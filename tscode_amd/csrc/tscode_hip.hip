@@ -1324,12 +1324,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             hipLaunchKernelGGL(k_export_run, dim3(grid_for(std::max<int64_t>(mask_words, rec_words), 256, 64)), dim3(256), 0, st,
                                reinterpret_cast<const unsigned long long *>(p->records), rec_words, static_cast<unsigned long long *>(c->pinned),
                                reinterpret_cast<const unsigned long long *>(p->mask), mask_words, (const uint8_t *)p->mask, p->n,
-                               reinterpret_cast<unsigned long long *>(p->export_mask_host));
+                               reinterpret_cast<unsigned long long *>(p->export_mask_host), (const unsigned *)p->dmax_bits);
             TSC_HIP(hipGetLastError());
             p->export_mask_host = nullptr;
         }
         TSC_HIP(hipStreamSynchronize(st));
         const PassRecord *rec = static_cast<const PassRecord *>(c->pinned);
+        const bool nonfinite = unsigned(static_cast<const unsigned long long *>(c->pinned)[sizeof(PassRecord) * TSC_MAX_PASSES / 8]) >= 0x7f800000u;
         p->n_passes = 0;
         for (int slot = 0; slot < TSC_MAX_PASSES; ++slot) {
             if (!p->slot_used[slot] || !rec[slot].on) continue;
@@ -1338,6 +1339,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             s.k = rec[slot].k, s.n_active_before = rec[slot].n_before, s.n_active_after = rec[slot].n_after;
             s.pairs_evaluated = rec[slot].evaluated, s.pairs_computed = rec[slot].formed, s.candidates = rec[slot].exact;
             s.pairs_screened = rec[slot].screened, s.new_keys = rec[slot].removed, s.algo = rec[slot].algo;
+            s.nonfinite_input = nonfinite ? 1 : 0;
             float ms = 0;
             if (c->pass_timing >= 2 && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
             if (c->pass_timing >= 1 && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;

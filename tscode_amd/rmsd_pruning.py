@@ -44,6 +44,10 @@ def prune_conformers_rmsd(structures, atomnos, rmsd_thr=0.5, mode=0, **_ignored)
     else:
         heavy = np.ascontiguousarray(structures[:, heavy_idx], dtype=np.float64)    # :179
         mask, _last_stats = get_engine().prune_heavy(heavy, float(rmsd_thr), int(mode))
+    if n > 1 and _last_stats and _last_stats[0].get("nonfinite_input"):
+        # the reference's np.linalg.svd (rmsd_pruning.py:19) raises on such a structure as soon as a pair with it is evaluated; the
+        # library itself defines the verdict (similar to nothing, kept) and only reports that it met one
+        raise np.linalg.LinAlgError("Array must not contain infs or NaNs")
     return structures[mask], mask                                                   # :206
 
 

@@ -25,32 +25,37 @@ def cartesian_product(*arrays):
     return np.stack(np.meshgrid(*arrays), -1).reshape(-1, len(arrays))
 
 
-def polygonize(lengths):
-    """tscode/utils.py:210-261: vertices of the polygon a cyclical embed arranges its pivots on.
+# Which sides of the triangle run backwards (end -> start) in each of the reference's eight orientation patterns, in its order
+# (tscode/utils.py:253: the enumeration every trimolecular loop walks; data, pinned by fixture G10)
+_TRIANGLE_REVERSED = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 1, 0], [1, 0, 1], [1, 1, 1]], dtype=bool)
+_SEGMENT_REVERSED = np.array([[0, 0], [0, 1]], dtype=bool)          # two pivots: the second orientation turns the second segment round
 
-    Two lengths: the two orientations of two centred, superposed segments -> f64[2, 2, 2, 3].
-    Three lengths: the eight orientation patterns of the triangle's sides -> f64[8, 3, 2, 3]; TriangleError when the lengths
-    violate the triangle inequality."""
-    assert len(lengths) in (2, 3)
-    arr = np.zeros((len(lengths), 2, 3))
-    if len(lengths) == 2:
-        arr[0, 0] = np.array([-lengths[0] / 2, 0, 0])
-        arr[0, 1] = np.array([+lengths[0] / 2, 0, 0])
-        arr[1, 0] = np.array([-lengths[1] / 2, 0, 0])
-        arr[1, 1] = np.array([+lengths[1] / 2, 0, 0])
-        out = np.vstack(([arr], [arr]))
-        out[1, 1] *= -1
-        return out
-    if not all(lengths[i] < lengths[i - 1] + lengths[i - 2] for i in (0, 1, 2)):
+
+def _oriented(sides, reversed_):
+    """sides f64[S, 2, 3] (start, end) under every orientation pattern reversed_[T, S] -> f64[T, S, 2, 3]."""
+    return np.where(reversed_[:, :, None, None], sides[None, :, ::-1, :], sides[None])
+
+
+def polygonize(lengths):
+    """tscode/utils.py:210-261: where a cyclical embed puts its pivots -- per orientation pattern, per pivot, a (start, end) pair.
+
+    Two lengths: two segments centred on the origin along x, superposed; the second pattern reverses the second -> f64[2, 2, 2, 3].
+    Three lengths: the sides of the triangle (0,0,0) - (L0,0,0) - (x,y,0) walked head to tail, under the reference's eight
+    reversal patterns -> f64[8, 3, 2, 3]; TriangleError when the lengths violate the triangle inequality."""
+    L = [float(v) for v in lengths]
+    if len(L) == 2:
+        sides = np.zeros((2, 2, 3))
+        sides[:, 0, 0], sides[:, 1, 0] = [-L[0] / 2, -L[1] / 2], [L[0] / 2, L[1] / 2]
+        return _oriented(sides, _SEGMENT_REVERSED)
+    if len(L) != 3:
+        raise AssertionError("polygonize takes two or three lengths")
+    if not (L[0] < L[1] + L[2] and L[1] < L[0] + L[2] and L[2] < L[0] + L[1]):
         raise TriangleError(f"Impossible to build a triangle with sides {lengths}")
-    arr[0, 1] = np.array([lengths[0], 0, 0])
-    arr[1, 0] = np.array([lengths[0], 0, 0])
-    a, b, c = np.power(lengths[0], 2), np.power(lengths[1], 2), np.power(lengths[2], 2)
+    # third vertex from the law of cosines, sides 1 and 2 meeting there (the operations and their order are the reference's:
+    # the fixture compares the vertices to the last bit)
+    a, b, c = np.power(L[0], 2), np.power(L[1], 2), np.power(L[2], 2)
     x = (a - b + c) / (2 * a ** 0.5)
     y = (c - x ** 2) ** 0.5
-    arr[1, 1] = np.array([x, y, 0])
-    arr[2, 0] = np.array([x, y, 0])
-    out = np.vstack([[arr]] * 8)
-    for t, v in ((1, 2), (2, 1), (3, 1), (3, 2), (4, 0), (5, 0), (5, 1), (6, 0), (6, 2), (7, 0), (7, 1), (7, 2)):
-        out[t, v][[0, 1]] = out[t, v][[1, 0]]                       # triangle t: start and end of side v swapped
-    return out
+    corners = np.array([[0.0, 0.0, 0.0], [L[0], 0.0, 0.0], [x, y, 0.0]])
+    sides = np.stack([corners, np.roll(corners, -1, axis=0)], axis=1)                        # side s: corner s -> corner s + 1
+    return _oriented(sides, _TRIANGLE_REVERSED)
