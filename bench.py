@@ -562,6 +562,25 @@ def main():
         watchdog4.cancel()
         if rank == 0:
             out["c4"] = c4
+    # beside the favourable C3: the workloads on which the prune's descriptor sieve has the least to offer (tools/hard_workloads.py) --
+    # children scattered around the threshold, and structures whose descriptors all coincide (reference-exact and cache-free mode),
+    # each with the automatic kernel choice, the sieve and the all-pairs kernel, and the CPU port on a bounded sample.  Side
+    # figures, never `value`.
+    if world == 1 and rank == 0 and args.config == "C3" and args.n_poses is None and not args.no_side_leg and not chain and exit_code == 0:
+        try:
+            leg["pipe"] = None
+            from tools.hard_workloads import measure as hard_measure
+            hw = hard_measure(100_000, 12_000 if not args.no_cpu else 0, steps=5)
+            out["hard_workloads"] = {name: {"workload": l["workload"],
+                                            "ms_per_step": {a: round(v["ms_per_step"], 4) for a, v in l["gpu"].items()},
+                                            "conformers_per_s": l["n"] / l["gpu"]["auto"]["ms_per_step"] * 1e3,
+                                            "kernels_of_the_automatic_choice": l["gpu"]["auto"]["kernels"],
+                                            "screen_pass_rate": l["gpu"]["sieve"]["screen_pass_rate"], "H_formed": l["gpu"]["sieve"]["H_formed"],
+                                            "pairs_screened": l["gpu"]["sieve"]["pairs_screened"], "n_survivors": l["gpu"]["auto"]["n_survivors"],
+                                            "kernels_agree": len({v["n_survivors"] for v in l["gpu"].values()}) == 1, "cpu": l.get("cpu")}
+                                     for name, l in hw["legs"].items()}
+        except Exception as exc:
+            out["hard_workloads"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         if world == 1 and not args.no_cpu and not chain:
             n_cpu = args.cpu_sample if args.cpu_sample else (ens.n_poses if args.config == "C3" else 40000)

@@ -948,6 +948,46 @@ def test_prune_when_descriptors_cannot_separate(eng, oracle):
     assert 30 < ref["mask"].sum() < 400
 
 
+def test_automatic_choice_takes_the_all_pairs_kernel_when_the_screen_separates_nothing(eng, oracle):
+    """40 000 structures whose descriptors all coincide (synthetic.make_unscreenable): from the spread of the sample's descriptors
+    the automatic choice (prune_algo 0) sees that the screen would let every pair through and runs the register-tiled all-pairs
+    kernel instead -- in a prune of its own (one synchronisation after the basis) and inside the pipeline (the spread arrives with the
+    side chain).  An ordinary ensemble keeps the sieve.  Verdicts and evaluation counts equal the oracle's either way."""
+    import torch
+
+    from tscode_amd.pipeline import DevicePipeline
+    from tscode_amd.synthetic import make_config, make_unscreenable
+    heavy = make_unscreenable(40_000)
+    for mode in (1, 0):
+        ref = oracle.prune_heavy(heavy, 0.5, mode=mode, row_parallel=True)
+        mask, stats = eng.prune_heavy(heavy, 0.5, mode)
+        assert np.array_equal(mask, ref["mask"]), mode
+        assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
+        assert {s["algo"] for s in stats} == {1}, [s["algo"] for s in stats]           # every pass by k_rmsd_tile
+    ens = make_config("C2", 40_000)                                                    # an ordinary ensemble: the sieve stays
+    ordinary = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    _, stats = eng.prune_heavy(ordinary, 0.5, 0)
+    assert 1 not in {s["algo"] for s in stats}
+    # inside the pipeline: fragment 0 is the 30-atom composite itself, with 4 000 such structures as its conformers (the poses pick one
+    # each: many exact repeats), fragment 1 a lone hydrogen far away -- every pose passes the clash check, the heavy atoms of a pose
+    # are one of the unscreenable structures
+    from tscode_amd.synthetic import Ensemble
+    n_poses = 40_000
+    rng = np.random.default_rng(5)
+    confs = make_unscreenable(4000, seed=7)
+    ens = Ensemble(frag_coords=[confs, np.array([[[50.0, 0.0, 0.0]]])], conf_idx=np.stack([rng.integers(0, 4000, n_poses), np.zeros(n_poses, np.int64)], 1).astype(np.int32),
+                   rot=np.ascontiguousarray(np.broadcast_to(np.eye(3), (n_poses, 2, 3, 3))), pos=np.zeros((n_poses, 2, 3)), ids=np.array([30, 1]),
+                   atomnos=np.array([6] * 30 + [1]), seed=5)
+    pipe = DevicePipeline(ens, device_index=0, mode=1)
+    res = pipe.step()
+    torch.cuda.synchronize()
+    poses = ens.poses()
+    ref = oracle.prune_heavy(np.ascontiguousarray(poses[:, :30]), 0.5, mode=1, row_parallel=True)
+    assert res["n_pass"] == n_poses and np.array_equal(pipe.h_keep[:n_poses].numpy().astype(bool), ref["mask"])
+    assert {s["algo"] for s in res["stats"]} == {1}
+    assert [s["pairs_evaluated"] for s in res["stats"]] == [s["pairs_evaluated"] for s in ref["stats"]]
+
+
 def test_clash_fp32_band_falls_back_to_fp64(eng, oracle):
     """Verdict-only clash masks use a packed-fp32 minimum with a rigorous band; poses whose closest inter-fragment
     distance sits within 1e-9 .. 1e-4 of the threshold must come out exactly like the fp64 reference."""

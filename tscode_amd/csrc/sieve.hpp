@@ -291,6 +291,7 @@ __global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, doubl
         Q[e] = (r / nf == r % nf) ? 1.0 : 0.0;
     }
     for (int e = threadIdx.x; e < DW; e += blockDim.x) bias[e] = 0.0;
+    if (threadIdx.x < NFAM) bias[DW + threadIdx.x] = __builtin_inf();  // (no estimate of the descriptors' spread: k_descriptor_basis)
 }
 
 // Device-side descriptor basis: one wavefront per feature family.  Orthonormal rows spanning the leading principal
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
     double *bout = bias + fam * KD;
     if (nf == 0) {
         if (lane < KD) bout[lane] = 0.0;
+        if (lane == 0) bias[DW + fam] = 0.0;  // (a family without features separates nothing)
         return;
     }
     const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
@@ -451,6 +453,23 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
         for (int a = 0; a < nf; ++a) b = fma(V[lane][a], mu[a], b);
         bout[lane] = b;
     }
+    // How far apart two structures of the sample lie in this family's descriptor, on average: E |V (f(p) - f(q))|^2 = 2 sum_k V_k^T C V_k.
+    // The host compares it with the screen's limit h thr^2: where both families stay below it the screen can separate (almost)
+    // nothing -- every pair would reach H anyway -- and an all-pairs kernel without a screen is the faster route (tscode_hip.hip,
+    // screen_is_useless).  Only worked out where that kernel exists (up to 32 heavy atoms); +inf otherwise.
+    double spread = __builtin_inf();
+    if (nf <= 32) {
+        double lam = 0.0;
+        if (lane < KD)
+            for (int a = 0; a < nf; ++a) {
+                double z = 0.0;
+                for (int b = 0; b < nf; ++b) z = fma(c_in_lds ? Cs[a][b] : ((a <= b ? M[size_t(a) * m + b] : M[size_t(b) * m + a]) * inv - mu[a] * mu[b]), V[lane][b], z);
+                lam = fma(V[lane][a], z, lam);
+            }
+        for (int off = 32; off > 0; off >>= 1) lam += __shfl_xor(lam, off);
+        spread = 2.0 * lam;
+    }
+    if (lane == 0) bias[DW + fam] = spread;
 }
 
 

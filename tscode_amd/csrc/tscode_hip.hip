@@ -581,7 +581,21 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
 }
 
 // Doubles of a descriptor basis: KD rows per feature family, then the DW projections of the mean feature vector (+ 1 spare)
-static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW + 1; }
+// ... and, behind the DW projections, the two families' mean squared descriptor distance over the sample (k_descriptor_basis)
+static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW + NFAM + 1; }
+static size_t basis_spread_offset(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW; }
+constexpr size_t PINNED_SPREAD_OFFSET = 8192;  // where a basis' two spread values land in the context's pinned buffer
+constexpr int64_t AUTO_TILE_MIN_N = 30000;     // a prune of its own (no pipeline around it) spends a synchronisation on the question from here on
+
+// "Would the screen let (almost) every pair through?"  Two structures of the sample lie 2 sum_k lambda_k apart, on average, in a
+// family's squared descriptor distance; the screen drops a pair only where a family's distance exceeds h thr^2.  Where BOTH families'
+// averages stay below that limit most pairs reach H = p^T q whatever the screen does, and the register-tiled all-pairs kernel, which
+// forms H for every pair at 2.5e10 pairs/s, beats the sieve's evaluation stage at 5e9 (profiles/r03_hard_workloads.json: 8 ms
+// against 46 on 100 000 structures whose descriptors coincide, cache-free mode).  Either kernel gives the same verdicts.
+static bool screen_is_useless(const double *spread, int h, double thr) {
+    const double limit = double(h) * thr * thr;
+    return spread[0] < limit && spread[1] < limit;  // (false for NaN / +inf: no estimate)
+}
 
 // Basis of the descriptors: leading principal axes of the two feature families (sieve.hpp) over `n_samples` structures
 // heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
@@ -675,7 +689,7 @@ static int get_event(tsc_ctx *c, hipEvent_t *e) {
 }
 
 static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask_buffer, tsc_prune **out,
-                             const double *basis = nullptr, const ExternalDescriptors *ext = nullptr) {
+                             const double *basis = nullptr, const ExternalDescriptors *ext = nullptr, int force_algo = -1) {
     TSC_REQUIRE(c && heavy_dev && out, "tsc_prune_create: null argument");
     TSC_REQUIRE(n > 0 && n < INT32_MAX - 4096, "n = %lld not supported", (long long)n);
     TSC_REQUIRE(h > 0, "no heavy atoms: the reference divides by zero here (rmsd_pruning.py:35)");
@@ -695,6 +709,29 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     p->thr = rmsd_thr;
     p->mode = mode;
     p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
+    Scratch s_basis(c);
+    if (force_algo >= 0) {
+        p->algo = force_algo;
+    } else if (c->prune_algo == ALGO_AUTO && h <= MAX_HP && n >= AUTO_TILE_MIN_N && !basis && !(ext && ext->D)) {
+        // automatic choice, no basis from a pipeline around this run: estimate it now and ask whether the screen can separate
+        // anything (one synchronisation, some 20 us, on a run of at least 30 000 structures)
+        const int n_samples = int(std::min<int64_t>(n, DESC_SAMPLE));
+        double *q = nullptr;
+        int rc0 = s_basis.get(basis_doubles(h), &q);
+        if (!rc0) rc0 = build_basis(c, c->stream, s_basis, heavy_dev, h, n_samples, std::max<int64_t>(1, n / n_samples), q);
+        if (!rc0) {
+            double *host = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET);
+            hipError_t e = hipMemcpyAsync(host, q + basis_spread_offset(h), NFAM * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc0 = fail(TSC_ERR_HIP, "descriptor spread read-back failed: %s", hipGetErrorString(e));
+            else if (screen_is_useless(host, h, rmsd_thr)) p->algo = ALGO_TILE;
+            else basis = q;  // (the sieve's descriptors are built from it further down)
+        }
+        if (rc0) {
+            delete p;
+            return rc0;
+        }
+    }
     p->bit_words = size_t(n / 64 + 40);  // (k_open_rows reads the 32 words of a whole scan block, also of the last, partial one)
     p->n_blocks = int(scan_bsum_count(n));
     int rc = 0;
@@ -1354,10 +1391,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
 // One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
 // synchronisation (the statistics read-back).
 static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
-                     tsc_pass_stats *stats, int *n_passes, const double *basis = nullptr, const ExternalDescriptors *ext = nullptr) {
+                     tsc_pass_stats *stats, int *n_passes, const double *basis = nullptr, const ExternalDescriptors *ext = nullptr, int force_algo = -1) {
     tsc_prune *p = nullptr;
     const bool in_place = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;  // run on the caller's buffer: no copy at the end
-    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis, ext));
+    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis, ext, force_algo));
     int rc = 0;
     for (;;) {
         int64_t k = 0;
@@ -2361,6 +2398,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
                            rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
                            (const int32_t *)nullptr, d_moments, int(moment_doubles(n_heavy)));
         TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments));
+        // (the two families' descriptor spread goes to the host with the chain: the host looks at it when it fetches the count below)
+        TSC_HIP(hipMemcpyAsync(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET, d_basis + basis_spread_offset(n_heavy), NFAM * sizeof(double),
+                               hipMemcpyDeviceToHost, c->basis_stream));
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
@@ -2386,9 +2426,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     int64_t n_keep = 0;
     int np = 0;
     if (d_basis) TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+    // automatic kernel choice: where the sample's descriptors hardly differ the screen separates nothing and the all-pairs kernel is the
+    // faster route (screen_is_useless).  The side chain finished long ago (it runs beside the clash kernel): no wait in practice
+    int force_algo = -1;
+    if (d_basis && c->prune_algo == ALGO_AUTO && n_heavy <= MAX_HP) {
+        TSC_HIP(hipEventSynchronize(c->ev_join));
+        if (screen_is_useless(reinterpret_cast<const double *>(static_cast<const char *>(c->pinned) + PINNED_SPREAD_OFFSET), n_heavy, rmsd_thr)) force_algo = ALGO_TILE;
+    }
+    const bool sieve_run = force_algo != ALGO_TILE;
     if (n_pass > 0) {
         if (timed) TSC_HIP(hipEventRecord(ev[2], st));
-        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np, d_basis, ext.D ? &ext : nullptr));
+        TSC_TRY(prune_run(c, d_heavy, n_pass, n_heavy, rmsd_thr, mode, keep_mask, keep_mask_host, stats, &np, sieve_run ? d_basis : nullptr,
+                          (sieve_run && ext.D) ? &ext : nullptr, force_algo));
         for (int i = 0; i < np; ++i) n_keep = stats ? stats[i].n_active_after : 0;
         if (!stats) {  // count survivors without the stats array
             TSC_TRY(scan_mask(st, keep_mask, n_pass, bsum, nullptr, nullptr, nullptr, total));

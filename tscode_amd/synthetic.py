@@ -23,7 +23,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ["Ensemble", "make_fragment", "make_ensemble", "CONFIGS", "make_config", "quat_to_mat"]
+__all__ = ["Ensemble", "make_fragment", "make_ensemble", "make_unscreenable", "CONFIGS", "make_config", "quat_to_mat"]
 
 
 def make_fragment(rng: np.random.Generator, n_atoms: int, step: float = 1.5, min_dist: float = 1.2) -> np.ndarray:
@@ -153,6 +153,28 @@ def make_ensemble(n_poses: int, atoms_per_frag, seed: int, children: int = 10,
         meta={"children": children, "sigma_rot_deg": sigma_rot_deg, "sigma_t": sigma_t,
               "shell": tuple(shell), "parent_of": parent_of},
     )
+
+
+def make_unscreenable(n: int, seed: int = 99, h: int = 30, children: int = 10, jitter: float = 0.004) -> np.ndarray:
+    """Heavy-atom array f64[n, h, 3] on which the descriptor sieve of the prune can drop NOTHING: two rigid bodies about the
+    origin, the first fixed, the second turned by one of n / children random rotations (+ a tiny jitter) ABOUT THE ORIGIN.  Every
+    atom keeps its distance from the origin and every atom pair (a, a + h / 2) lies inside one body and keeps its length, so the
+    rotation-invariant descriptors of all n structures coincide, while structures of different parents are far apart in RMSD.
+    Every pair a pass looks at therefore reaches H = p^T q (tools/worstcase.py, bench.py's `unscreenable` leg)."""
+    rng = np.random.default_rng(seed)
+    half = h // 2
+    na = half // 2
+    ia = list(range(0, na)) + list(range(half, half + na))                   # body A: atoms a and a + h / 2 for a < na
+    ib = [a for a in range(h) if a not in set(ia)]                           # body B: the other pairs (and an unpaired last atom)
+    A, B = rng.normal(size=(len(ia), 3)) * 3, rng.normal(size=(len(ib), 3)) * 3
+    n_par = max(1, n // children)
+    rots = quat_to_mat(rng.normal(size=(n_par, 4)))
+    which = rng.integers(0, n_par, size=n)
+    jit = quat_to_mat(np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 3)) * jitter], axis=1))
+    heavy = np.empty((n, h, 3))
+    heavy[:, ia] = A
+    heavy[:, ib] = np.einsum("nij,njk,ak->nai", rots[which], jit, B)
+    return np.ascontiguousarray(heavy)
 
 
 # BASELINE.json configs -> (N, atoms per fragment, seed); thresholds are fixed for all of them.
