@@ -664,10 +664,14 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
     // One read of the state per WORKGROUP: in a fused pass that is gated off the last tile to arrive -- possibly a wavefront of this
     // very launch -- opens the NEXT pass and rewrites the state block, and a wavefront of this block that started late would then
     // see the next pass's gate while its siblings saw this one's (a barrier below is conditional on it)
+#ifndef TSC_DBG_NO_STATE_LDS
     __shared__ int s_state[5];
     if (threadIdx.x == 0) s_state[0] = st->pass_on, s_state[1] = st->A, s_state[2] = st->bitsel, s_state[3] = st->row_lo, s_state[4] = st->n_active;
     __syncthreads();
     const int pass_on = s_state[0], A = s_state[1], sel = s_state[2], row_lo = s_state[3], n_all = s_state[4];
+#else   // (measurement hook: every wavefront reads the state block itself, as in round 2)
+    const int pass_on = st->pass_on, A = st->A, sel = st->bitsel, row_lo = st->row_lo, n_all = st->n_active;
+#endif
     const unsigned long long *X = oa.bits + size_t(sel) * oa.bit_words;
     const unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r0 = int(tile) * 16;

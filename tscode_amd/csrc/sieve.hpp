@@ -310,7 +310,9 @@ constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
 __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
                                                           int n_samples, double *__restrict__ Q, double *__restrict__ bias,
-                                                          unsigned *__restrict__ zero_word) {
+                                                          unsigned *__restrict__ zero_word, double *__restrict__ spread_host = nullptr) {
+    // spread_host (optional): host-visible copy of the two spread values written at the end (pinned memory; the host pre-sets +inf
+    // and looks without waiting: whatever finite values it finds are this kernel's)
     // zero_word (optional): the running max |D| of a descriptor build that follows this kernel, cleared here
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
     __shared__ double V[KD][DESC_MAX_FEAT], Z[KD][DESC_MAX_FEAT], mu[DESC_MAX_FEAT];
@@ -323,7 +325,10 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
     double *bout = bias + fam * KD;
     if (nf == 0) {
         if (lane < KD) bout[lane] = 0.0;
-        if (lane == 0) bias[DW + fam] = 0.0;  // (a family without features separates nothing)
+        if (lane == 0) {
+            bias[DW + fam] = 0.0;  // (a family without features separates nothing)
+            if (spread_host) spread_host[fam] = 0.0;
+        }
         return;
     }
     const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
@@ -458,18 +463,25 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
     // nothing -- every pair would reach H anyway -- and an all-pairs kernel without a screen is the faster route (tscode_hip.hip,
     // screen_is_useless).  Only worked out where that kernel exists (up to 32 heavy atoms); +inf otherwise.
     double spread = __builtin_inf();
-    if (nf <= 32) {
+    if (nf <= 32) {  // (c_in_lds) lane = (row k of V, an eighth of the features a): 64 lanes share the nf^2 KD products
+        static_assert(KD == 8 && BASIS_LDS_C >= 32, "lane layout of the spread estimate");
+        const int k = lane & 7;
         double lam = 0.0;
-        if (lane < KD)
-            for (int a = 0; a < nf; ++a) {
-                double z = 0.0;
-                for (int b = 0; b < nf; ++b) z = fma(c_in_lds ? Cs[a][b] : ((a <= b ? M[size_t(a) * m + b] : M[size_t(b) * m + a]) * inv - mu[a] * mu[b]), V[lane][b], z);
-                lam = fma(V[lane][a], z, lam);
-            }
+        for (int a = lane >> 3; a < nf; a += 8) {
+            double z = 0.0;
+            for (int b = 0; b < nf; ++b) z = fma(Cs[a][b], V[k][b], z);
+            lam = fma(V[k][a], z, lam);
+        }
         for (int off = 32; off > 0; off >>= 1) lam += __shfl_xor(lam, off);
         spread = 2.0 * lam;
     }
-    if (lane == 0) bias[DW + fam] = spread;
+    if (lane == 0) {
+        bias[DW + fam] = spread;
+        if (spread_host) {
+            spread_host[fam] = spread;
+            __threadfence_system();
+        }
+    }
 }
 
 

@@ -606,7 +606,7 @@ static size_t moment_doubles(int h) {
 
 // d_moments (optional): moment_doubles(h) doubles already zeroed on `st` by the caller; otherwise taken from `s` and cleared here
 static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *heavy, int h, int n_samples, int64_t stride, double *d_Q,
-                       unsigned *zero_word = nullptr, double *d_moments = nullptr) {
+                       unsigned *zero_word = nullptr, double *d_moments = nullptr, double *spread_host = nullptr) {
     const int nf[NFAM] = {n_features(h, 0), n_features(h, 1)};
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
     double *d_M[NFAM], *d_zero;
@@ -627,7 +627,7 @@ static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *hea
                            d_M[1]);
     }
     hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
-                       d_Q + q_doubles, zero_word);
+                       d_Q + q_doubles, zero_word, spread_host);
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -2397,10 +2397,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
                            rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
                            (const int32_t *)nullptr, d_moments, int(moment_doubles(n_heavy)));
-        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments));
-        // (the two families' descriptor spread goes to the host with the chain: the host looks at it when it fetches the count below)
-        TSC_HIP(hipMemcpyAsync(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET, d_basis + basis_spread_offset(n_heavy), NFAM * sizeof(double),
-                               hipMemcpyDeviceToHost, c->basis_stream));
+        // (the two families' descriptor spread is written to pinned host memory by the basis kernel itself: no copy, no wait -- the host
+        // pre-sets "no estimate" and looks after it has fetched the count below, long after the chain has finished)
+        double *spread_host = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET);
+        spread_host[0] = spread_host[1] = __builtin_inf();
+        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments, spread_host));
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
@@ -2430,8 +2431,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // faster route (screen_is_useless).  The side chain finished long ago (it runs beside the clash kernel): no wait in practice
     int force_algo = -1;
     if (d_basis && c->prune_algo == ALGO_AUTO && n_heavy <= MAX_HP) {
-        TSC_HIP(hipEventSynchronize(c->ev_join));
-        if (screen_is_useless(reinterpret_cast<const double *>(static_cast<const char *>(c->pinned) + PINNED_SPREAD_OFFSET), n_heavy, rmsd_thr)) force_algo = ALGO_TILE;
+        const volatile double *sh = reinterpret_cast<const volatile double *>(static_cast<const char *>(c->pinned) + PINNED_SPREAD_OFFSET);
+        const double spread[NFAM] = {sh[0], sh[1]};
+        if (screen_is_useless(spread, n_heavy, rmsd_thr)) force_algo = ALGO_TILE;
     }
     const bool sieve_run = force_algo != ALGO_TILE;
     if (n_pass > 0) {
