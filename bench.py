@@ -184,9 +184,8 @@ def main():
 
     # every rank draws the SAME ensemble, also for the replicas leg: per-GPU work is then exactly fixed as N grows, and every
     # rank's survivor set is checked against the recorded oracle mask (parity_vs_recorded_oracle = all ranks agree)
-    chain = args.config == "C5chain"          # config 5 as a chain: csearch rotations feed the pipeline's conformers (one GPU)
-    if chain and world > 1:
-        raise SystemExit("--config C5chain runs on one GPU")
+    chain = args.config == "C5chain"          # config 5 as a chain: csearch rotations feed the pipeline's conformers (N > 1: the search
+                                              # cut into blocks of the angle table, the kept candidates all-gathered in table order)
     ens = make_config("C5" if chain else args.config, args.n_poses)
     expected = None
     exp_path = os.path.join(ROOT, "tests", "golden", "expected_full.json")
@@ -238,7 +237,8 @@ def main():
         digest = hashlib.sha256(np.packbits(keep.astype(bool)).tobytes()).hexdigest()[:16]
         parity = None
         if expected is not None:
-            parity = bool(expected["n_pass"] == res["n_pass"] and expected["n_keep"] == res["n_keep"] and expected["keep_sha256_16"] == digest)
+            parity = bool(expected["n_pass"] == res["n_pass"] and expected["n_keep"] == res["n_keep"] and expected["keep_sha256_16"] == digest
+                          and expected.get("n_conformers", res.get("n_conformers")) == res.get("n_conformers"))
             if world > 1:                                       # every rank checks its own result
                 flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=red_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -249,11 +249,15 @@ def main():
         """One leg: its own pipeline, warm-up, THE timed region, then (detail) the same steps with the library's events off and
         three steps with all of them on.  Returns a dict of everything measured."""
         if chain:
-            from tscode_amd.pipeline import CsearchChain
+            from tscode_amd.pipeline import CsearchChain, ShardedCsearchChain
             n0 = ens.frag_coords[0].shape[1]
             torsions, tmasks = CsearchChain.chain_torsions(n0, 8, seed=5)
             angle_table = np.random.default_rng(6).choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(CHAIN_CANDIDATES, 8)).astype(np.int32)
-            pipe = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, device_index=local_rank, mode=args.mode, seed=7)
+            if sharded:
+                pipe = ShardedCsearchChain(ens, torsions, tmasks, angle_table, rank, world, process_group=pg, thresh=1.4, device_index=local_rank,
+                                           mode=args.mode, seed=7, front=args.front)
+            else:
+                pipe = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, device_index=local_rank, mode=args.mode, seed=7)
         elif sharded:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
                                   force_sharded=args.force_sharded or world == 1, front=args.front)

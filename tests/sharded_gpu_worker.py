@@ -21,8 +21,17 @@ def main():
     torch.cuda.set_device(0)
     from tscode_amd.pipeline import DevicePipeline
     from tscode_amd.synthetic import make_config
-    ens = make_config(cfg, n_poses if n_poses > 0 else None)
-    pipe = DevicePipeline(ens, device_index=0, rank=rank, world=world, mode=0, shard_min_pairs=min_pairs if min_pairs > 0 else None)
+    if cfg == "C5chain":          # config 5 as a chain, with the inputs of bench.py --config C5chain (tools/record_c5chain.py recorded the oracle's run)
+        from tscode_amd.pipeline import CsearchChain, ShardedCsearchChain
+        ens = make_config("C5", n_poses if n_poses > 0 else None)
+        torsions, tmasks = CsearchChain.chain_torsions(ens.frag_coords[0].shape[1], 8, seed=5)
+        n_cand = 20000 if n_poses <= 0 else max(200, n_poses // 25)
+        angle_table = np.random.default_rng(6).choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(n_cand, 8)).astype(np.int32)
+        pipe = ShardedCsearchChain(ens, torsions, tmasks, angle_table, rank, world, thresh=1.4, device_index=0, mode=0, seed=7,
+                                   shard_min_pairs=min_pairs if min_pairs > 0 else None)
+    else:
+        ens = make_config(cfg, n_poses if n_poses > 0 else None)
+        pipe = DevicePipeline(ens, device_index=0, rank=rank, world=world, mode=0, shard_min_pairs=min_pairs if min_pairs > 0 else None)
     res, digest, unstable = None, None, 0
     for _ in range(int(os.environ.get("SHARD_STEPS", "2"))):   # more steps on the same state: buffers are reused; every step must agree
         res = pipe.step()
@@ -45,7 +54,8 @@ def main():
     dist.all_gather(gathered, flags)
     if rank == 0:
         sharded_passes = [s["k"] for s in res["stats"] if s["algo"] in (1, 2)]
-        print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "keep_sha256_16": digest, "steps_that_differ": unstable,
+        print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "n_conformers": res.get("n_conformers"),
+                          "keep_sha256_16": digest, "steps_that_differ": unstable,
                           "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"], "forms_agree": forms_agree,
                           "front_tuning": pipe.front_tuning,
                           "pairs_evaluated": [s["pairs_evaluated"] for s in res["stats"]], "global_path_passes": sharded_passes}), flush=True)

@@ -1490,7 +1490,8 @@ def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
     assert (res2["n_conformers"], res2["n_pass"], res2["n_keep"]) == (res["n_conformers"], res["n_pass"], res["n_keep"])
 
 
-@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0), (2, "C5", 0, 0)])
+@pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0), (2, "C5", 0, 0),
+                                                         (3, "C5chain", 30_000, 0), (2, "C5chain", 0, 0)])
 def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     """The multi-rank protocol on the product backend (HIP kernels), several ranks sharing this box's one GPU: gloo as the
     transport (device tensors staged over the host), everything else as under RCCL -- pose blocks, all-gather of the
@@ -1515,10 +1516,30 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     # embedded everywhere) were timed, one was chosen by every
     # rank alike, and each of them, forced, gives the same survivors and evaluation counts
     assert got["forms_agree"] and got["front_tuning"]["chosen"] in ("shard", "replicate", "hybrid") and len(got["front_tuning"]["ms_per_step"]) == 3
-    if cfg in ("C3", "C4", "C5"):                        # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
-        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json")))[{"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0", "C5": "C5:500000:mode0"}[cfg]]
+    if cfg == "C5chain" and n_poses > 0:
+        # config 5 as a chain over three ranks (the conformational search cut into blocks of the angle table, the kept candidates
+        # all-gathered in table order) against the one-GPU chain on the same inputs, which test_c5_chain_... checks against the oracle
+        import hashlib
+
+        from tscode_amd.pipeline import CsearchChain
+        from tscode_amd.synthetic import make_config
+        ens = make_config("C5", n_poses)
+        torsions, tmasks = CsearchChain.chain_torsions(ens.frag_coords[0].shape[1], 8, seed=5)
+        angle_table = np.random.default_rng(6).choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(max(200, n_poses // 25), 8)).astype(np.int32)
+        one = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, seed=7)
+        r1 = one.step()
+        one.torch.cuda.synchronize()
+        d1 = hashlib.sha256(np.packbits(one.h_keep[:r1["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
+        assert (got["n_conformers"], got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (r1["n_conformers"], r1["n_pass"], r1["n_keep"], d1)
+        assert got["pairs_evaluated"] == [s["pairs_evaluated"] for s in r1["stats"]] and 0 < r1["n_conformers"] < len(angle_table)
+    if cfg in ("C3", "C4", "C5", "C5chain") and n_poses == 0:   # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
+        key = {"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0", "C5": "C5:500000:mode0", "C5chain": "C5chain:500000:mode0"}[cfg]
+        exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json"))).get(key)
+        if exp is None:
+            pytest.skip(f"{key} is not recorded in tests/golden/expected_full.json (tools/record_c5chain.py)")
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
         assert got["pairs_evaluated"] == [p["pairs_evaluated"] for p in exp["passes"]]
+        assert exp.get("n_conformers", got.get("n_conformers")) == got.get("n_conformers")
     else:
         from tscode_amd.synthetic import make_config
         ens = make_config(cfg)

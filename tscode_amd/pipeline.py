@@ -30,7 +30,7 @@ import numpy as np
 
 from .engine import Engine, FragmentSet
 
-__all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "sharded_step", "block_bounds", "partition_bounds", "SHARD_MIN_PAIRS",
+__all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "ShardedCsearchChain", "sharded_step", "block_bounds", "partition_bounds", "SHARD_MIN_PAIRS",
            "PARTITION_MIN_CHUNKS"]
 
 # A pass smaller than this many pairs (estimate n * (n / k) / 2, identical on every rank) is not worth a collective:
@@ -379,6 +379,31 @@ class HipShardBackend:
         return _HipStepper(st, self.exch)
 
 
+def time_fronts(torch, dev, pg, steps, step):
+    """``step(form)`` timed for every form of the front half: one untimed call, then ``steps`` timed ones between a barrier and a
+    device synchronisation, the slowest rank's time counting.  Returns {"ms_per_step": {form: ms}, "chosen": fastest}."""
+    import time
+    dist = torch.distributed
+    times = {}
+    for form in FRONTS:
+        step(form)
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=pg)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(form)
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
+        if dist.get_backend(pg) == "gloo":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
+        else:                                   # nccl (= RCCL) reduces device tensors
+            td = t.to(dev)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX, group=pg)
+            t = td.cpu()
+        times[form] = float(t[0])
+    return {"ms_per_step": times, "chosen": min(times, key=times.get)}
+
+
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
                  process_group=None, force_sharded=False, shard_min_pairs=None, front="auto", partition_chunks=PARTITION_MIN_CHUNKS):
@@ -440,32 +465,15 @@ class DevicePipeline:
                             self.partition_chunks)
 
     def tune_front(self, steps=2):
-        """Times both forms of the front half on this node -- one untimed step each (buffers, communicators), then ``steps`` timed
-        ones each, the slowest rank's time counting (all-reduce MAX) -- and keeps the faster.  Every rank reaches the same
-        decision.  Both forms give the same result, so the tuning steps are ordinary steps."""
-        import time
-        dist, torch = self.torch.distributed, self.torch
+        """Times the forms of the front half on this node -- one untimed step each (buffers, communicators), then ``steps`` timed
+        ones each, the slowest rank's time counting (all-reduce MAX) -- and keeps the fastest.  Every rank reaches the same
+        decision.  All forms give the same result, so the tuning steps are ordinary steps."""
         if not self.sharded:
             return None
-        times = {}
-        for form in FRONTS:
-            sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form, self.partition_chunks)
-            torch.cuda.synchronize(self.backend.dev)
-            dist.barrier(group=self.pg)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                sharded_step(self.backend, self.rank, self.world, dist, self.pg, self.shard_min_pairs, form, self.partition_chunks)
-            torch.cuda.synchronize(self.backend.dev)
-            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
-            if dist.get_backend(self.pg) == "gloo":
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            else:                                   # nccl (= RCCL) reduces device tensors
-                td = t.to(self.backend.dev)
-                dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.pg)
-                t = td.cpu()
-            times[form] = float(t[0])
-        self.front = min(times, key=times.get)
-        self.front_tuning = {"ms_per_step": times, "chosen": self.front}
+        self.front_tuning = time_fronts(self.torch, self.backend.dev, self.pg, steps,
+                                        lambda form: sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg,
+                                                                  self.shard_min_pairs, form, self.partition_chunks))
+        self.front = self.front_tuning["chosen"]
         return self.front_tuning
 
 
@@ -574,3 +582,153 @@ class CsearchChain:
             res = self.eng.pipeline_dev(fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.ens.n_poses, self.heavy_idx, c, m, r, mode,
                                         self.d_clash, self.d_structures, self.d_keep, self.h_keep)
         return {"n_conformers": n_kept, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "stats": res["stats"]}
+
+
+class ShardedCsearchChain:
+    """BASELINE config 5 as a chain over SEVERAL ranks (one process per GPU): the conformational search is cut into blocks of the
+    angle table, the kept candidates of all blocks are put together IN TABLE ORDER -- the reference keeps candidates in the order it
+    generates them and stops at ``n_out`` (tscode/torsion_module.py:505-510), and a pose names its conformer by that position -- and
+    the poses then run through the sharded pipeline (``sharded_step``).
+
+        1. rank r rotates the angle sets [n_cand r / W, n_cand (r + 1) / W) (tsc_csearch_rotate_dev, walk-back loop included) and
+           packs the kept ones in order (tsc_compact_rows_dev);
+        2. counts all-reduce (8 B per rank) + ONE all-gather of the packed blocks, padded to the largest block (n_atoms x 24 B per
+           candidate: 34 MB for 20 000 candidates of a 70-atom fragment); every rank un-pads in rank order into the conformer stack
+           of the searched fragment, cut at n_out;
+        3. conformer index of every pose = draw % n_kept (as in CsearchChain);
+        4. sharded_step on the poses: front half as ``front`` says, prune passes partitioned by chunks / sharded by row tiles.
+
+    Same result as CsearchChain on one GPU by construction; tests/test_gpu_parity.py runs two ranks against the recorded oracle run."""
+
+    def __init__(self, ens, torsions, masks, angles, rank, world, process_group=None, n_out=None, fragment=0, thresh=1.5, device_index=0,
+                 clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0, seed=0, front="auto", shard_min_pairs=None,
+                 partition_chunks=PARTITION_MIN_CHUNKS):
+        import copy
+
+        import torch
+        self.torch, self.rank, self.world, self.pg = torch, int(rank), int(world), process_group
+        self.thresh, self.shard_min_pairs, self.partition_chunks = thresh, shard_min_pairs, int(partition_chunks)
+        if front != "auto" and front not in FRONTS:
+            raise ValueError(f"front must be 'auto' or one of {FRONTS}, got {front!r}")
+        self.front, self.front_tuning = front, None
+        # the searched fragment first (its conformer stack is rewritten every step), the others behind it: an ensemble in that order
+        order = [fragment] + [m for m in range(len(ens.frag_coords)) if m != fragment]
+        off = np.concatenate([[0], np.cumsum([f.shape[1] for f in ens.frag_coords])])
+        atom_order = np.concatenate([np.arange(off[m], off[m + 1]) for m in order])
+        e2 = copy.copy(ens)
+        e2.frag_coords = [ens.frag_coords[m] for m in order]
+        e2.conf_idx, e2.rot, e2.pos = (np.ascontiguousarray(a[:, order]) for a in (ens.conf_idx, ens.rot, ens.pos))
+        e2.ids, e2.atomnos = np.asarray(ens.ids)[order], np.asarray(ens.atomnos)[atom_order]
+        self.ens = e2
+        self.backend = be = HipShardBackend(e2, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
+        self.eng, self.dev, self.stream = be.eng, be.dev, be.stream
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        base = np.ascontiguousarray(e2.frag_coords[0][0], dtype=np.float64)
+        self.n0 = base.shape[0]
+        tors = np.ascontiguousarray(torsions, dtype=np.int32).reshape(-1, 4)
+        self.n_tors = len(tors)
+        angles = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, self.n_tors)
+        self.n_cand = len(angles)
+        self.n_out = self.n_cand if n_out is None else int(n_out)
+        self.c_lo, self.c_hi = block_bounds(self.n_cand, self.rank, self.world)
+        self.max_block = (self.n_cand + self.world - 1) // self.world + 1
+        self.d_base, self.d_tors, self.d_masks = t(base), t(tors), t(np.ascontiguousarray(masks, dtype=np.uint8).reshape(self.n_tors, self.n0))
+        self.d_angles = t(angles[self.c_lo:self.c_hi])
+        nb = max(self.c_hi - self.c_lo, 1)
+        self.d_cand = torch.empty((nb, self.n0, 3), dtype=torch.float64, device=self.dev)
+        self.d_rb = torch.empty(nb, dtype=torch.int32, device=self.dev)
+        self.d_send = torch.zeros((self.max_block, self.n0, 3), dtype=torch.float64, device=self.dev)
+        self.d_gather = torch.empty((self.world * self.max_block, self.n0, 3), dtype=torch.float64, device=self.dev)
+        self.d_counts = torch.zeros(self.world, dtype=torch.int64, device=self.dev)
+        # fragment buffer of the pipeline: room for every candidate as a conformer of the searched fragment, the others behind it
+        others = [np.ascontiguousarray(f, dtype=np.float64) for f in e2.frag_coords[1:]]
+        self.cap0 = self.n_cand * self.n0 * 3
+        other_flat = np.concatenate([f.ravel() for f in others]) if others else np.zeros(0)
+        be.d_frags = torch.empty(self.cap0 + len(other_flat), dtype=torch.float64, device=self.dev)
+        be.d_frags[self.cap0:].copy_(t(other_flat))
+        self._other_sizes = [(f.shape[0], f.shape[1], f.size) for f in others]
+        rng = np.random.default_rng(seed)
+        draw = rng.integers(0, 2 ** 30, size=e2.n_poses).astype(np.int64)       # which conformer a pose uses: draw % n_kept
+        self.d_draw_all = t(draw)
+        be._all_inputs()                                                          # (the all-poses inputs of the replicate / hybrid fronts)
+        self.d_keep, self.d_clash, self.d_structures, self.h_keep = be.keep, be.clash, be.structures, be.keep_host
+        torch.cuda.synchronize(self.dev)
+
+    @property
+    def engine(self):
+        return self.eng
+
+    def set_option(self, name, value):
+        self.eng.set_option(name, value)
+
+    def _search(self):
+        """Steps 1-3; returns the number of conformers (0: nothing was kept anywhere)."""
+        torch, be, dist = self.torch, self.backend, self.torch.distributed
+        nb = self.c_hi - self.c_lo
+        n_local = 0
+        if nb > 0:
+            self.eng.csearch_rotate_dev(self.d_base, self.n0, self.d_tors, self.d_masks, self.n_tors, self.d_angles, nb, self.thresh, 0, self.d_cand,
+                                        self.d_rb)
+            kept_mask = (self.d_rb[:nb] != 0).to(torch.uint8)                                  # torsion_module.py:505
+            n_local = self.eng.compact_rows_dev(self.d_cand, kept_mask, nb, self.n0 * 24, self.d_send)
+        self.d_counts.zero_()
+        self.d_counts[self.rank] = n_local
+        _all_reduce(dist, self.d_counts, dist.ReduceOp.SUM, self.pg)
+        counts = [int(c) for c in self.d_counts.cpu().tolist()]
+        rows = max(max(counts), 1)
+        row_elems = self.n0 * 3
+        if self.world > 1:
+            _all_gather(dist, self.d_gather.view(-1)[:self.world * rows * row_elems], self.d_send.view(-1)[:rows * row_elems], self.pg)
+            gathered = self.d_gather.view(-1)[:self.world * rows * row_elems].view(self.world, rows, self.n0, 3)
+        else:
+            gathered = self.d_send[:rows].view(1, rows, self.n0, 3)
+        n_kept = min(sum(counts), self.n_out)                                                  # :510: stop at n_out structures
+        stack = be.d_frags[:self.cap0].view(self.n_cand, self.n0, 3)
+        o = 0
+        for r, c in enumerate(counts):                                                         # rank order = table order
+            c = min(c, n_kept - o)
+            if c > 0:
+                stack[o:o + c].copy_(gathered[r, :c])
+            o += c
+        self.allgather_bytes = int(self.world * rows * row_elems * 8) if self.world > 1 else 0
+        if n_kept == 0:
+            return 0
+        which = (self.d_draw_all % n_kept).to(torch.int32)
+        be.d_ci_all[:, 0] = which
+        be.d_ci[:, 0] = which[be.lo:be.hi]
+        fs = FragmentSet.__new__(FragmentSet)
+        sizes = [(n_kept, self.n0)] + [(s[0], s[1]) for s in self._other_sizes]
+        fs.n_mols = len(sizes)
+        fs.n_atoms = np.array([s[1] for s in sizes], dtype=np.int32)
+        fs.n_conf = np.array([s[0] for s in sizes], dtype=np.int32)
+        offs, o2 = [0], self.cap0
+        for s in self._other_sizes:
+            offs.append(o2)
+            o2 += s[2]
+        fs.frag_off = np.array(offs[:fs.n_mols], dtype=np.int64)
+        fs.n_total = int(fs.n_atoms.sum())
+        be.fs = fs
+        return n_kept
+
+    def tune_front(self, steps=2):
+        with self.torch.cuda.stream(self.stream):
+            if self._search() == 0:
+                self.front = "hybrid"
+                return None
+        self.front_tuning = time_fronts(self.torch, self.dev, self.pg, steps,
+                                        lambda form: sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg,
+                                                                  self.shard_min_pairs, form, self.partition_chunks))
+        self.front = self.front_tuning["chosen"]
+        return self.front_tuning
+
+    def step(self):
+        if self.front == "auto":
+            self.tune_front()
+        with self.torch.cuda.stream(self.stream):
+            n_kept = self._search()
+        if n_kept == 0:
+            return {"n_conformers": 0, "n_pass": 0, "n_keep": 0, "stats": []}
+        res = sharded_step(self.backend, self.rank, self.world, self.torch.distributed, self.pg, self.shard_min_pairs, self.front, self.partition_chunks)
+        res["n_conformers"] = n_kept
+        res["allgather_bytes"] = res.get("allgather_bytes", 0) + self.allgather_bytes
+        return res
