@@ -1531,7 +1531,7 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
         one.torch.cuda.synchronize()
         d1 = hashlib.sha256(np.packbits(one.h_keep[:r1["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
         assert (got["n_conformers"], got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (r1["n_conformers"], r1["n_pass"], r1["n_keep"], d1)
-        assert got["pairs_evaluated"] == [s["pairs_evaluated"] for s in r1["stats"]] and 0 < r1["n_conformers"] < len(angle_table)
+        assert got["pairs_evaluated"] == [s["pairs_evaluated"] for s in r1["stats"]] and 0 < r1["n_conformers"] <= len(angle_table)
     if cfg in ("C3", "C4", "C5", "C5chain") and n_poses == 0:   # full size: against the recorded oracle run (1M x 50 with three ranks: 206 398 survivors)
         key = {"C3": "C3:100000:mode0", "C4": "C4:1000000:mode0", "C5": "C5:500000:mode0", "C5chain": "C5chain:500000:mode0"}[cfg]
         exp = json.load(open(os.path.join(root, "tests", "golden", "expected_full.json"))).get(key)

@@ -331,12 +331,9 @@ class HipShardBackend:
     def embed_clash_all(self):
         """front="replicate": the whole pose list on this rank; the survivors' heavy atoms land in heavy_all directly.  The
         full-size inputs and outputs (clash_all, structures_all) are set up on first use."""
-        if getattr(self, "d_ci_all", None) is None:
-            torch, ens = self.torch, self.ens
-            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
-            self.d_ci_all, self.d_rot_all, self.d_pos_all = t(ens.conf_idx), t(ens.rot), t(ens.pos)
-            self.clash_all = torch.empty(ens.n_poses, dtype=torch.uint8, device=self.dev)
-            self.structures_all = torch.empty((ens.n_poses, ens.n_atoms, 3), dtype=torch.float64, device=self.dev)
+        self._all_inputs()
+        if getattr(self, "structures_all", None) is None:
+            self.structures_all = self.torch.empty((self.ens.n_poses, self.ens.n_atoms, 3), dtype=self.torch.float64, device=self.dev)
         return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci_all, self.d_rot_all, self.d_pos_all, self.ens.n_poses,
                                                 self.heavy_idx, self.clash_thresh, self.max_clashes, self.clash_all, self.structures_all,
                                                 self.heavy_all)
