@@ -1540,7 +1540,7 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
         assert (got["n_pass"], got["n_keep"], got["keep_sha256_16"]) == (exp["n_pass"], exp["n_keep"], exp["keep_sha256_16"])
         assert got["pairs_evaluated"] == [p["pairs_evaluated"] for p in exp["passes"]]
         assert exp.get("n_conformers", got.get("n_conformers")) == got.get("n_conformers")
-    else:
+    elif cfg != "C5chain":
         from tscode_amd.synthetic import make_config
         ens = make_config(cfg)
         poses = ens.poses()
