@@ -635,6 +635,7 @@ struct OpenArgs {
     int n_blocks, block_items;
     unsigned n_tiles;                // row tiles of the pass (arrival count of a fused pass)
     PassTickets *tickets;
+    int32_t *rank_of;                // (optional) rank_of[structure] = its active rank: what a culled pass (cull.hpp) lays its sorted order out from
     unsigned long long *dbg;         // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront (tools/stamps.py), else null
 };
 #ifdef TSC_DBG_STAMPS
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
             act[r] = int32_t(i);
             cend[r] = my_c;
             best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
+            if (oa.rank_of) oa.rank_of[i] = r;
         }
         // largest stop column of the 16 rows of this tile: lets a work item of the pair kernel whose column segment lies
         // beyond it leave after one scalar load

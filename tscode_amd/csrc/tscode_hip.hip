@@ -7,6 +7,7 @@
 #include "scan.hpp"
 #include "sieve.hpp"
 #include "local_pass.hpp"
+#include "cull.hpp"
 #include "group_filter.hpp"
 #include "csearch.hpp"
 #include "tfd.hpp"
@@ -534,6 +535,9 @@ struct tsc_prune {
         LocalTickets local;
     } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
+    // culled passes (cull.hpp): allocated when the first one comes up
+    int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr;
+    float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
     int part_rank = 0, part_world = 1, part_min_chunks = 0;
     unsigned long long *exch = nullptr;  // caller-owned exchange buffer: bit_words words of removed rows + 8 of statistics
@@ -1094,14 +1098,40 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         p->local_done = true;
         return 0;
     }
+    // Large passes: the structures laid out along a Morton curve, tile pairs skipped by bounding box (cull.hpp); the verdicts are
+    // applied by k_apply_pass behind the pair kernel (tsc_prune_pass_finish), on one rank or several
+    const bool culled = p->algo == ALGO_SIEVE && !range && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS &&
+                        double(n) * double(n / k) * 0.5 >= c->cull_min_pairs;
+    if (culled && !p->morton_order) {
+        int rc = palloc(p, size_t(n), &p->morton_order);
+        if (!rc) rc = palloc(p, size_t(n), &p->rank_of);
+        if (!rc) rc = palloc(p, size_t(n) + 256, &p->crank);
+        if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cbase);
+        if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cfill);
+        if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
+        if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
+        if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
+        if (rc) return rc;
+        // once per run: the structures in coarse Morton order of their descriptors (a counting sort over 32 768 cells)
+        Scratch s(c);
+        int *cells;
+        TSC_TRY(s.get(size_t(CULL_BUCKETS), &cells));
+        TSC_HIP(hipMemsetAsync(cells, 0, size_t(CULL_BUCKETS) * sizeof(int), st));
+        hipLaunchKernelGGL(k_morton_count, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, (const float *)p->Dall, n, (const unsigned *)p->dmax_bits, cells);
+        hipLaunchKernelGGL(k_morton_scan, dim3(1), dim3(1024), 0, st, cells);
+        hipLaunchKernelGGL(k_morton_scatter, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, (const float *)p->Dall, n, (const unsigned *)p->dmax_bits, cells,
+                           p->morton_order);
+        TSC_HIP(hipGetLastError());
+    }
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
-    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
+    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range) && !culled;
     {
         OpenArgs oa;
         oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
         oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
+        oa.rank_of = culled ? p->rank_of : nullptr;
         oa.dbg = nullptr;
 #ifdef TSC_DBG_STAMPS
         if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
@@ -1127,6 +1157,34 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         size_t lds = size_t(64) * (hp3 + 1) * sizeof(double);
         hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, (const PruneState *)p->state,
                            p->Xr, p->Xc, p->npad, p->G);
+    }
+    if (culled) {
+        hipLaunchKernelGGL(k_chunk_bases, dim3(unsigned(k + 1)), dim3(64), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->boff,
+                           (const unsigned long long *)p->bits, int(p->bit_words), p->n_blocks, p->cbase, p->cfill);
+        hipLaunchKernelGGL(k_sorted_layout, dim3(unsigned(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS))), dim3(256), 0, st, g, (const PruneState *)p->state,
+                           (const int32_t *)p->morton_order, (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of,
+                           (const float *)p->Dc, (const int32_t *)p->cbase, p->cfill, p->Ds, p->crank);
+        hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
+                           p->cbox, p->rbox);
+        SieveArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = A, a.h = p->h;
+        a.tile_begin = rank, a.tile_stride = world, a.seg_cols = 4096;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
+        a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.drain_min = c->drain_min;
+        CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k)};
+        const int n_tiles = ceil_div(A, TILE_ROWS), my_tiles = (n_tiles - rank + world - 1) / world;
+        // columns of a row tile: from its own 128-aligned position to the end of its (last row's) chunk -- a chunk and a tile more at most
+        const int n_seg = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, a.seg_cols);
+        hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
+        hipExtLaunchKernelGGL(k_rmsd_sieve_sorted, dim3(std::max(1, ceil_div(my_tiles, 4)), n_seg), dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
+                              (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca);
+        TSC_HIP(hipGetLastError());
+        p->local_done = true;
+        return 0;
     }
     TSC_TRY(launch_pair_search(p, rank, world, A));
     p->local_done = true;
@@ -1540,6 +1598,15 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
 #endif
+    if (strcmp(name, "cull") == 0) {
+        c->cull = value != 0.0 ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(name, "cull_min_pairs") == 0) {
+        TSC_REQUIRE(value >= 0.0, "cull_min_pairs must not be negative");
+        c->cull_min_pairs = value;
+        return 0;
+    }
     if (strcmp(name, "fused_apply") == 0) {
         TSC_REQUIRE(value == 0 || value == 1, "fused_apply must be 0 or 1");
         c->fused_apply = int(value);
