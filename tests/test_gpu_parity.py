@@ -199,8 +199,10 @@ def algo(request, eng):
         eng.set_option("open_lds_blocks", 0)
     if request.param[3] == 3:           # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
         eng.set_option("cull_min_pairs", 0)
+        eng.set_option("cull", 2)
     yield request.param[0]
     eng.set_option("cull_min_pairs", 2.0e9)
+    eng.set_option("cull", 1)
     eng.set_option("prune_algo", 0)
     eng.set_option("local_pass", 1)
     eng.set_option("sieve_trim", SIEVE_TRIM_DEFAULT)

@@ -96,47 +96,143 @@ __global__ __launch_bounds__(64) void k_chunk_bases(PassGeom g, const PruneState
     if ((threadIdx.x & 63) == 0) cbase[c] = r, cfill[c] = 0;
 }
 
-// The active structures of the pass, chunk by chunk, each chunk in Morton order: a block walks 2048 entries of the run's Morton
-// order, counts its active structures per chunk, reserves their slots with ONE atomic per chunk (the block's structures stay
-// together; which block comes first inside a chunk is up to the hardware -- a column tile that straddles two blocks mixes two
-// places of the curve, one tile in sixteen) and moves what the pair kernel reads BY POSITION: the descriptor, the structure's
-// active rank (crank: what the verdicts are expressed in).
+// Culled or walked?  The ordered walk looks at the pairs inside the rows' ranges (r, cend[r]) -- W of them, summed by k_open_rows;
+// the culled kernel at the tile pairs whose boxes lie within the limit, whatever the ranges are: a share f of ALL pairs of the
+// chunks that falls with the chunk length (measured at 1M x 50: 0.27 at 22 000 active structures per chunk, 0.19 at 62 000,
+// 0.13 at 206 000: about 0.27 (22 000 / len)^(1/3)) at two thirds of the walk's rate per pair (what the boxes leave are the near
+// tiles, dense in candidates).  Where the reference's cache ends most rows early (W a few per cent of all pairs: C4's k = 5 and
+// k = 1 passes) the walk has little to do and keeps the pass.  One wavefront; the verdict goes to pinned host memory, the host
+// waits for it (a pass that large takes a millisecond or more; enqueueing both kernels and letting the loser's 10^5 workgroups
+// start and leave cost 0.1-0.2 ms a pass) and launches one flow or the other.
+__global__ __launch_bounds__(64) void k_cull_decide(PruneState *__restrict__ st, const PassCounters *__restrict__ cnt, const int32_t *__restrict__ cbase, int k,
+                                                     int force, int *__restrict__ flag_host) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long w = __hip_atomic_load(&cnt->w[lane][CNT_WALK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+    double all = 0.0, longest = 0.0;
+    if (lane < k) {
+        const double len = double(cbase[lane + 1] - cbase[lane]);
+        all = 0.5 * len * len, longest = len;
+    }
+    for (int off = 32; off > 0; off >>= 1) all += __shfl_xor(all, off), longest = fmax(longest, __shfl_xor(longest, off));
+    if (lane == 0) {
+        const double f = 0.27 * cbrt(22000.0 / fmax(longest, 1.0));
+        const int on = (w > 0 && (force || double(w) > 1.5 * f * all)) ? 1 : 0;  // (force: option "cull" = 2, tests; w = 0: a pass that is gated off, or whose rows have no columns left)
+        st->cull_on = on;
+        *flag_host = on;
+        __threadfence_system();
+    }
+}
+
+// The active structures of the pass, chunk by chunk, each chunk in the run's Morton order -- an ORDERED partition of that order by
+// chunk, so that 128 consecutive positions of a chunk are 128 neighbours on the curve (a layout that only kept a block's structures
+// together gave column tiles that mixed two distant places of the curve, and the boxes culled a quarter of the tiles instead of
+// three quarters).  Three launches: per block of 2048 entries the number of active structures per chunk; their exclusive prefix
+// over the blocks (one wavefront per chunk); the scatter, which ranks every structure inside its block by ballots -- entry order
+// is kept inside a block as well -- and moves what the pair kernel reads BY POSITION: the descriptor and the structure's active
+// rank (crank: what the verdicts are expressed in).
 constexpr int CULL_LAYOUT_ITEMS = 2048;
-__global__ __launch_bounds__(256) void k_sorted_layout(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
-                                                       const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
-                                                       const float *__restrict__ Dc, const int32_t *__restrict__ cbase, int32_t *__restrict__ cfill,
-                                                       float *__restrict__ Ds, int32_t *__restrict__ crank) {
-    __shared__ int s_cnt[CULL_MAX_CHUNKS], s_base[CULL_MAX_CHUNKS];
+constexpr int CULL_LAYOUT_SLOTS = CULL_LAYOUT_ITEMS / 64;   // (round, wavefront) slots of a block: 64 consecutive entries each
+
+// chunk of entry m of the Morton order if that structure is active, else -1
+__device__ inline int layout_chunk(const PassGeom &g, const int32_t *__restrict__ order, const unsigned long long *__restrict__ X, int64_t m, int &i) {
+    i = 0;
+    if (m >= g.n) return -1;
+    i = order[m];
+    if (!((X[i >> 6] >> (i & 63)) & 1ull)) return -1;
+    const int c = i / g.cs;
+    return c >= g.k ? g.k - 1 : c;
+}
+// s_cnt[slot][chunk] = active structures of chunk `chunk` among the 64 entries of slot `slot`; mine = this lane's chunk (-1: none);
+// returns the lane's rank among the lanes of its wavefront with the same chunk
+__device__ inline int layout_wave_rank(int mine, int *s_cnt_slot) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank = 0;
+    for (unsigned long long left = __ballot(mine >= 0); left;) {
+        const int c = __shfl(mine, __ffsll((long long)left) - 1);
+        const unsigned long long same = __ballot(mine == c);
+        if (mine == c) rank = __popcll(same & lt);
+        if (lane == 0 && s_cnt_slot) s_cnt_slot[c] = __popcll(same);
+        left &= ~same;
+    }
+    return rank;
+}
+__global__ __launch_bounds__(256) void k_layout_count(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+                                                      const unsigned long long *__restrict__ bits, int bit_words, int32_t *__restrict__ blk_cnt) {
+    __shared__ int s_cnt[CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
     const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
     const int tid = threadIdx.x;
     if (tid < CULL_MAX_CHUNKS) s_cnt[tid] = 0;
     __syncthreads();
     const int64_t m0 = int64_t(blockIdx.x) * CULL_LAYOUT_ITEMS;
-    int my_c[CULL_LAYOUT_ITEMS / 256], my_r[CULL_LAYOUT_ITEMS / 256], my_slot[CULL_LAYOUT_ITEMS / 256];
-#pragma unroll
     for (int u = 0; u < CULL_LAYOUT_ITEMS / 256; ++u) {
-        const int64_t m = m0 + u * 256 + tid;
-        my_c[u] = -1;
-        if (m < g.n) {
-            const int i = order[m];
-            if ((X[i >> 6] >> (i & 63)) & 1ull) {
-                int c = i / g.cs;
-                c = c >= g.k ? g.k - 1 : c;
-                my_c[u] = c, my_r[u] = rank_of[i];
-                my_slot[u] = atomicAdd(&s_cnt[c], 1);
-            }
+        int i;
+        const int c = layout_chunk(g, order, X, m0 + u * 256 + tid, i);
+        for (unsigned long long left = __ballot(c >= 0); left;) {   // one LDS atomic per (wavefront, chunk present)
+            const int cc = __shfl(c, __ffsll((long long)left) - 1);
+            const unsigned long long same = __ballot(c == cc);
+            if ((tid & 63) == 0) atomicAdd(&s_cnt[cc], __popcll(same));
+            left &= ~same;
         }
     }
     __syncthreads();
-    if (tid < g.k && s_cnt[tid] > 0) s_base[tid] = cbase[tid] + atomicAdd(&cfill[tid], s_cnt[tid]);
+    if (tid < g.k) blk_cnt[int64_t(blockIdx.x) * CULL_MAX_CHUNKS + tid] = s_cnt[tid];
+}
+// blk_cnt[b][c] -> first position of block b's structures of chunk c: cbase[c] + structures of chunk c in the blocks before b
+__global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__restrict__ st, int n_layout_blocks, const int32_t *__restrict__ cbase,
+                                                     int32_t *__restrict__ blk_cnt) {
+    if (st->pass_on == 0) return;
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    int run = cbase[c];
+    for (int b0 = 0; b0 < n_layout_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < n_layout_blocks ? blk_cnt[int64_t(b) * CULL_MAX_CHUNKS + c] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (b < n_layout_blocks) blk_cnt[int64_t(b) * CULL_MAX_CHUNKS + c] = run + incl - v;
+        run += __shfl(incl, 63);
+    }
+}
+__global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+                                                        const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
+                                                        const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
+                                                        int32_t *__restrict__ crank) {
+    __shared__ int s_cnt[CULL_LAYOUT_SLOTS][CULL_MAX_CHUNKS];
+    if (st->pass_on == 0) return;
+    const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
+    const int tid = threadIdx.x, wv = tid >> 6;
+    for (int e = tid; e < CULL_LAYOUT_SLOTS * CULL_MAX_CHUNKS; e += 256) (&s_cnt[0][0])[e] = 0;
+    __syncthreads();
+    const int64_t m0 = int64_t(blockIdx.x) * CULL_LAYOUT_ITEMS;
+    int my_c[CULL_LAYOUT_ITEMS / 256], my_i[CULL_LAYOUT_ITEMS / 256], my_rank[CULL_LAYOUT_ITEMS / 256];
+#pragma unroll
+    for (int u = 0; u < CULL_LAYOUT_ITEMS / 256; ++u) {
+        my_c[u] = layout_chunk(g, order, X, m0 + u * 256 + tid, my_i[u]);
+        my_rank[u] = layout_wave_rank(my_c[u], s_cnt[u * 4 + wv]);
+    }
+    __syncthreads();
+    // exclusive prefix over the block's 32 slots, per chunk, on top of the block's base
+    if (tid < g.k) {
+        int run = blk_base[int64_t(blockIdx.x) * CULL_MAX_CHUNKS + tid];
+        for (int sl = 0; sl < CULL_LAYOUT_SLOTS; ++sl) {
+            const int v = s_cnt[sl][tid];
+            s_cnt[sl][tid] = run;
+            run += v;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < CULL_LAYOUT_ITEMS / 256; ++u) {
         if (my_c[u] < 0) continue;
-        const int pos = s_base[my_c[u]] + my_slot[u];
-        crank[pos] = my_r[u];
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(Dc + int64_t(my_r[u]) * DW);
+        const int pos = s_cnt[u * 4 + wv][my_c[u]] + my_rank[u];
+        const int r = rank_of[my_i[u]];
+        crank[pos] = r;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Dc + int64_t(r) * DW);
         f32x4 *dst = reinterpret_cast<f32x4 *>(Ds + int64_t(pos) * DW);
 #pragma unroll
         for (int q = 0; q < DW / 4; ++q) dst[q] = src[q];
@@ -193,7 +289,7 @@ struct CullArgs {
 template <int TI>
 __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
                                                   const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                  const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca) {
+                                                  const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const int slot, const int seg) {
     constexpr int CPL = 2, TILE_COLS = 64 * CPL, RS = 20;
     constexpr int QCAP = TI * TILE_COLS + 64;
     static_assert(TI == 16 && TILE_COLS == CULL_COLS && DW == 16, "tile shape");
@@ -203,7 +299,6 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * RS];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * 4 + wid;
     const int tile = a.tile_begin + slot * a.tile_stride;
     const int p0 = tile * TI;
     const int pass_on = st->pass_on, A = st->A;
@@ -218,7 +313,7 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
         const int c_last = __popcll(le) - 1;
         col_end = __builtin_amdgcn_readlane(cb, c_last + 1);
     }
-    const int seg_lo = (p0 & ~(TILE_COLS - 1)) + int(blockIdx.y) * a.seg_cols;
+    const int seg_lo = (p0 & ~(TILE_COLS - 1)) + seg * a.seg_cols;
     const int seg_hi = min(seg_lo + a.seg_cols, col_end);
     if (seg_lo >= seg_hi) return;
     // which column tiles of the segment lie within the limit of this row tile: one lane per column tile, one round trip
@@ -279,7 +374,9 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
         const int64_t i = act[lo], j = act[hi];
         pp = heavy + i * h3, pq = heavy + j * h3;
         Gi = Gall[i], Gj = Gall[j];
-        return hi < cend[lo];  // the column lies inside the row's range (rows of another chunk, or behind a cache hit, do not)
+        // the column lies inside the row's range (rows of another chunk, or behind a cache hit, do not) -- and before the similar column
+        // the row already has: what is left of the ordered walk's early exit (a later column cannot lower the minimum)
+        return hi < cend[lo] && hi < __hip_atomic_load(&best[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
         int lpp = 64;
@@ -427,8 +524,17 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
 __global__ __launch_bounds__(256, TSC_SIEVE_OCC2) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                             const double *__restrict__ Gall, const int32_t *__restrict__ cend,
                                                                             int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca) {
-    sieve_item_sorted<16>(heavy, act, Gall, cend, best, counters, st, a, ca);
+                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, int my_tiles, int n_seg) {
+    // a fixed grid walks the (row tile, column segment) items: half of them lie beyond their chunk's end and leave at once, and a
+    // workgroup per item would be 10^5 launches of nothing.  The four wavefronts of a workgroup take four consecutive row tiles of
+    // one segment (the same column tiles: one trip through the caches), segment after segment
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = (my_tiles + 3) / 4;
+    for (long long item = blockIdx.x; item < (long long)groups * n_seg; item += gridDim.x) {
+        const int seg = int(item / groups), slot = int(item - (long long)seg * groups) * 4 + wid;
+        sieve_item_sorted<16>(heavy, act, Gall, cend, best, counters, st, a, ca, slot, seg);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 }  // namespace tsc

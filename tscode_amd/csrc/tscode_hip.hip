@@ -536,7 +536,7 @@ struct tsc_prune {
     } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
     // culled passes (cull.hpp): allocated when the first one comes up
-    int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr;
+    int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
     int part_rank = 0, part_world = 1, part_min_chunks = 0;
@@ -1108,6 +1108,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, size_t(n) + 256, &p->crank);
         if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cbase);
         if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cfill);
+        if (!rc) rc = palloc(p, (size_t(n) / CULL_LAYOUT_ITEMS + 2) * CULL_MAX_CHUNKS, &p->blk_cnt);
         if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
@@ -1124,7 +1125,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         TSC_HIP(hipGetLastError());
     }
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
-    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range) && !culled;
+    p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
     {
         OpenArgs oa;
         oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
@@ -1158,12 +1159,28 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         hipLaunchKernelGGL(k_compact_coords, dim3(ceil_div(A, 64)), dim3(256), lds, st, p->heavy, p->h, hp3, p->act, (const PruneState *)p->state,
                            p->Xr, p->Xc, p->npad, p->G);
     }
+    bool run_culled = false;
     if (culled) {
+        // culled, or walked in index order?  The rows' ranges decide (k_cull_decide); the host waits for the verdict -- a pass this
+        // large takes a millisecond or more, the round trip some 20 us
+        volatile int *flag = reinterpret_cast<volatile int *>(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET + 64);
+        *flag = 0;
         hipLaunchKernelGGL(k_chunk_bases, dim3(unsigned(k + 1)), dim3(64), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->boff,
                            (const unsigned long long *)p->bits, int(p->bit_words), p->n_blocks, p->cbase, p->cfill);
-        hipLaunchKernelGGL(k_sorted_layout, dim3(unsigned(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS))), dim3(256), 0, st, g, (const PruneState *)p->state,
-                           (const int32_t *)p->morton_order, (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of,
-                           (const float *)p->Dc, (const int32_t *)p->cbase, p->cfill, p->Ds, p->crank);
+        hipLaunchKernelGGL(k_cull_decide, dim3(1), dim3(64), 0, st, p->state, (const PassCounters *)p->counters, (const int32_t *)p->cbase, int(k),
+                           c->cull == 2 ? 1 : 0, const_cast<int *>(flag));
+        TSC_HIP(hipStreamSynchronize(st));
+        run_culled = *flag != 0;
+    }
+    if (run_culled) {
+        p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
+        const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));
+        hipLaunchKernelGGL(k_layout_count, dim3(unsigned(n_lb)), dim3(256), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->morton_order,
+                           (const unsigned long long *)p->bits, int(p->bit_words), p->blk_cnt);
+        hipLaunchKernelGGL(k_layout_scan, dim3(unsigned(k)), dim3(64), 0, st, (const PruneState *)p->state, n_lb, (const int32_t *)p->cbase, p->blk_cnt);
+        hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->morton_order,
+                           (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of, (const float *)p->Dc,
+                           (const int32_t *)p->blk_cnt, p->Ds, p->crank);
         hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
                            p->cbox, p->rbox);
         SieveArgs a;
@@ -1180,8 +1197,10 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         // columns of a row tile: from its own 128-aligned position to the end of its (last row's) chunk -- a chunk and a tile more at most
         const int n_seg = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, a.seg_cols);
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
-        hipExtLaunchKernelGGL(k_rmsd_sieve_sorted, dim3(std::max(1, ceil_div(my_tiles, 4)), n_seg), dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,
-                              (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca);
+        const int64_t items = int64_t(ceil_div(my_tiles, 4)) * n_seg;
+        hipExtLaunchKernelGGL(k_rmsd_sieve_sorted, dim3(unsigned(std::max<int64_t>(1, std::min<int64_t>(items, c->cull_grid)))), dim3(256), 0, st, e0, e1, 0, p->heavy,
+                              (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca,
+                              my_tiles, n_seg);
         TSC_HIP(hipGetLastError());
         p->local_done = true;
         return 0;
@@ -1599,7 +1618,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     }
 #endif
     if (strcmp(name, "cull") == 0) {
-        c->cull = value != 0.0 ? 1 : 0;
+        TSC_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "cull must be 0 (off), 1 (the device decides per pass) or 2 (every candidate pass is culled)");
+        c->cull = int(value);
+        return 0;
+    }
+    if (strcmp(name, "cull_grid") == 0) {
+        TSC_REQUIRE(value >= 1.0, "cull_grid must be positive");
+        c->cull_grid = int64_t(value);
         return 0;
     }
     if (strcmp(name, "cull_min_pairs") == 0) {
