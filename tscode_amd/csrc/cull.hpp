@@ -44,42 +44,87 @@ __device__ inline unsigned morton_cell(const float *__restrict__ d, float inv_dm
     }
     return code;
 }
-__global__ __launch_bounds__(256) void k_morton_count(const float *__restrict__ D, int64_t n, const unsigned *__restrict__ dmax_bits, int *__restrict__ count) {
+// The order has to come out THE SAME on every rank of a sharded run (the ranks deal the row tiles of the sorted layout among
+// themselves: with layouts of their own they would miss pairs), so it is a STABLE sort by cell, ties in index order: two passes of
+// a least-significant-digit radix sort over 8 bits, each an ordered partition into 256 buckets -- per block of 2048 entries the
+// number of entries per bucket; their exclusive prefix over blocks and buckets; a scatter that ranks the entries of a wavefront by
+// ballots (entry order kept).
+constexpr int RADIX_BUCKETS = 256;
+__device__ inline int radix_digit(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t m, int64_t n, float inv, int shift, int &id) {
+    id = 0;
+    if (m >= n) return -1;
+    id = in ? in[m] : int(m);
+    return int((morton_cell(D + int64_t(id) * DW, inv) >> shift) & (RADIX_BUCKETS - 1));
+}
+__global__ __launch_bounds__(256) void k_radix_count(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
+                                                      int shift, int32_t *__restrict__ blk_cnt) {
+    __shared__ int s_cnt[RADIX_BUCKETS];
     const float dmax = __uint_as_float(*dmax_bits);
     const float inv = (dmax > 0.0f && dmax < 3.0e38f) ? 1.0f / dmax : 0.0f;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) atomicAdd(&count[morton_cell(D + i * DW, inv)], 1);
-}
-// exclusive prefix of the cell counts, in place (one block; CULL_BUCKETS = 32 per thread)
-__global__ __launch_bounds__(1024) void k_morton_scan(int *__restrict__ count) {
-    __shared__ int s_part[16], s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int PER = CULL_BUCKETS / 1024;
-    int v[PER], sum = 0;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) v[u] = count[tid * PER + u], sum += v[u];
-    int incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    const int64_t m0 = int64_t(blockIdx.x) * 2048;
+    for (int u = 0; u < 8; ++u) {
+        int id;
+        const int d = radix_digit(D, in, m0 + u * 256 + tid, n, inv, shift, id);
+        if (d >= 0) atomicAdd(&s_cnt[d], 1);
     }
-    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    blk_cnt[int64_t(blockIdx.x) * RADIX_BUCKETS + tid] = s_cnt[tid];
+}
+// blk_cnt[b][d] -> first output slot of block b's entries with digit d (one block; thread = digit)
+__global__ __launch_bounds__(256) void k_radix_scan(int n_blocks, int32_t *__restrict__ blk_cnt) {
+    __shared__ int s_tot[RADIX_BUCKETS];
+    const int d = threadIdx.x;
+    int run = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const int v = blk_cnt[int64_t(b) * RADIX_BUCKETS + d];
+        blk_cnt[int64_t(b) * RADIX_BUCKETS + d] = run;
+        run += v;
+    }
+    s_tot[d] = run;
     __syncthreads();
     int base = 0;
-    for (int q = 0; q < wv; ++q) base += s_part[q];
-    int run = base + incl - sum;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        count[tid * PER + u] = run;
-        run += v[u];
-    }
-    (void)s_base;
+    for (int q = 0; q < d; ++q) base += s_tot[q];
+    for (int b = 0; b < n_blocks; ++b) blk_cnt[int64_t(b) * RADIX_BUCKETS + d] += base;
 }
-// order[slot] = structure, slots of a cell handed out by an atomic (the order inside a cell is whatever the hardware makes it)
-__global__ __launch_bounds__(256) void k_morton_scatter(const float *__restrict__ D, int64_t n, const unsigned *__restrict__ dmax_bits, int *__restrict__ fill,
-                                                         int32_t *__restrict__ order) {
+__global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
+                                                        int shift, const int32_t *__restrict__ blk_base, int32_t *__restrict__ out) {
+    __shared__ int s_cnt[32][RADIX_BUCKETS];
     const float dmax = __uint_as_float(*dmax_bits);
     const float inv = (dmax > 0.0f && dmax < 3.0e38f) ? 1.0f / dmax : 0.0f;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) order[atomicAdd(&fill[morton_cell(D + i * DW, inv)], 1)] = int32_t(i);
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < 32 * RADIX_BUCKETS; e += 256) (&s_cnt[0][0])[e] = 0;
+    __syncthreads();
+    const int64_t m0 = int64_t(blockIdx.x) * 2048;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int my_d[8], my_id[8], my_rank[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        my_d[u] = radix_digit(D, in, m0 + u * 256 + tid, n, inv, shift, my_id[u]);
+        my_rank[u] = 0;
+        for (unsigned long long left = __ballot(my_d[u] >= 0); left;) {   // the lanes of a wavefront that share a digit, in lane order
+            const int dd = __shfl(my_d[u], __ffsll((long long)left) - 1);
+            const unsigned long long same = __ballot(my_d[u] == dd);
+            if (my_d[u] == dd) my_rank[u] = __popcll(same & lt);
+            if (lane == 0) s_cnt[u * 4 + wv][dd] = __popcll(same);
+            left &= ~same;
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the block's 32 (round, wavefront) slots per digit, on top of the block's base
+        int run = blk_base[int64_t(blockIdx.x) * RADIX_BUCKETS + tid];
+        for (int sl = 0; sl < 32; ++sl) {
+            const int v = s_cnt[sl][tid];
+            s_cnt[sl][tid] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (my_d[u] >= 0) out[s_cnt[u * 4 + wv][my_d[u]] + my_rank[u]] = my_id[u];
 }
 
 // ---- once per culled pass ----------------------------------------------------------------------------------------------

@@ -1113,15 +1113,22 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
-        // once per run: the structures in coarse Morton order of their descriptors (a counting sort over 32 768 cells)
+        // once per run: the structures in coarse Morton order of their descriptors -- a stable two-digit radix sort by cell, so that
+        // every rank of a sharded run comes to the same order (cull.hpp)
         Scratch s(c);
-        int *cells;
-        TSC_TRY(s.get(size_t(CULL_BUCKETS), &cells));
-        TSC_HIP(hipMemsetAsync(cells, 0, size_t(CULL_BUCKETS) * sizeof(int), st));
-        hipLaunchKernelGGL(k_morton_count, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, (const float *)p->Dall, n, (const unsigned *)p->dmax_bits, cells);
-        hipLaunchKernelGGL(k_morton_scan, dim3(1), dim3(1024), 0, st, cells);
-        hipLaunchKernelGGL(k_morton_scatter, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, (const float *)p->Dall, n, (const unsigned *)p->dmax_bits, cells,
-                           p->morton_order);
+        int32_t *tmp, *blk;
+        const int n_rb = int(ceil_div<int64_t>(n, 2048));
+        TSC_TRY(s.get(size_t(n), &tmp));
+        TSC_TRY(s.get(size_t(n_rb) * RADIX_BUCKETS, &blk));
+        static_assert(CULL_MORTON_BITS * CULL_MORTON_DIMS <= 16, "two 8-bit digits");
+        for (int pass = 0; pass < 2; ++pass) {
+            const int32_t *in = pass == 0 ? nullptr : tmp;
+            int32_t *out = pass == 0 ? tmp : p->morton_order;
+            hipLaunchKernelGGL(k_radix_count, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass, blk);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(256), 0, st, n_rb, blk);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass,
+                               (const int32_t *)blk, out);
+        }
         TSC_HIP(hipGetLastError());
     }
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
