@@ -603,9 +603,9 @@ static bool screen_is_useless(const double *spread, int h, double thr) {
 
 // Basis of the descriptors: leading principal axes of the two feature families (sieve.hpp) over `n_samples` structures
 // heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
-static size_t moment_doubles(int h) {
+static size_t moment_doubles(int h) {  // (MOM_BLOCKS partial matrices per family: k_feature_moments)
     const size_t a = size_t(n_features(h, 0) + 1), b = size_t(n_features(h, 1) + 1);
-    return a * a + b * b;
+    return size_t(MOM_BLOCKS) * (a * a + b * b);
 }
 
 // d_moments (optional): moment_doubles(h) doubles already zeroed on `st` by the caller; otherwise taken from `s` and cleared here
@@ -615,7 +615,7 @@ static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *hea
     const size_t q_doubles = size_t(KD) * (nf[0] + nf[1]);
     double *d_M[NFAM], *d_zero;
     // the moment matrices of both families in one block (one memset)
-    const size_t m0 = size_t(nf[0] + 1) * (nf[0] + 1), m1 = size_t(nf[1] + 1) * (nf[1] + 1);
+    const size_t m0 = size_t(MOM_BLOCKS) * (nf[0] + 1) * (nf[0] + 1), m1 = size_t(MOM_BLOCKS) * (nf[1] + 1) * (nf[1] + 1);
     if (d_moments) {
         d_zero = d_moments;
     } else {
@@ -627,10 +627,9 @@ static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *hea
         const size_t lds = size_t(32) * (std::max(nf[0], nf[1]) + 1) * sizeof(double);
         if (lds > 64 * 1024)
             TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32), NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0],
-                           d_M[1]);
+        hipLaunchKernelGGL(k_feature_moments, dim3(MOM_BLOCKS, NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0], d_M[1]);
     }
-    hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
+    hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, d_M[0], d_M[1], nf[0], nf[1], n_samples, d_Q,
                        d_Q + q_doubles, zero_word, spread_host);
     TSC_HIP(hipGetLastError());
     return 0;

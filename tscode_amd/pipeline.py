@@ -294,6 +294,7 @@ class HipShardBackend:
         self.eng.set_stream(self.stream.cuda_stream)
         self.fs = FragmentSet(ens.frag_coords)
         n = ens.n_poses
+        self.world = int(world)
         self.lo, self.hi = block_bounds(n, rank, world)
         self.n_local = self.hi - self.lo
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -324,9 +325,16 @@ class HipShardBackend:
 
     def embed_clash_block(self):
         # fused verdicts, then only the passing poses are embedded: straight into `structures` and into the padded send
-        # buffer of the all-gather (heavy_local is a view of it)
-        return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.heavy_idx,
-                                                self.clash_thresh, self.max_clashes, self.clash, self.structures, self.heavy_local)
+        # buffer of the all-gather (heavy_local is a view of it).
+        # With several ranks the descriptor basis must NOT come from this rank's block: the culled passes of the prune deal the tiles
+        # of a layout sorted by descriptor among the ranks, so every rank needs bit-identical descriptors -- the basis is then
+        # estimated by tsc_prune_create from the all-gathered survivors, the same sample on every rank (csrc/cull.hpp)
+        self.eng.set_option("early_basis", 1 if self.world == 1 else 0)
+        try:
+            return self.eng.embed_clash_compact_dev(self.fs, self.d_frags, self.d_ci, self.d_rot, self.d_pos, self.n_local, self.heavy_idx,
+                                                    self.clash_thresh, self.max_clashes, self.clash, self.structures, self.heavy_local)
+        finally:
+            self.eng.set_option("early_basis", 1)
 
     def embed_clash_all(self):
         """front="replicate": the whole pose list on this rank; the survivors' heavy atoms land in heavy_all directly.  The
