@@ -90,6 +90,11 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * register-tiled kernel and for passes searched by several ranks);  "open_lds_blocks": scan blocks (2048 structures each) up to which
  * the per-row kernel stages their prefix in LDS (default: its capacity, 2048; 0 = always read it from memory; tests);  "clash_fp32": 1 (default)
  * decides verdict-only clash masks by a packed-fp32 minimum with fp64 fallback;
+ * "cull": 1 (default) lets the large passes of the sieve (at least "cull_min_pairs" = n (n / k) / 2 pairs, default 2e9, fewer than 64
+ * chunks) lay their active structures out along a Morton curve of the descriptors and skip the tile pairs whose bounding boxes lie
+ * beyond the screen's limit, where the rows' ranges are long enough for that to pay (decided per pass on the device, one
+ * synchronisation); 0 = never, 2 = every such pass (tests).  "deterministic_basis": 1 = the descriptor basis from fixed-order sums, so
+ * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster);
  * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
  * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms),
  * 2 = also around every whole pass (gpu_ms) and the stages of tsc_pipeline_dev. */

@@ -64,22 +64,48 @@ inline int n_features(int h, int fam) { return std::min(fam == 0 ? h : h / 2, DE
 // M[a][b] = sum_s f_a(s) f_b(s), a, b in [0, nf]  (index nf = the constant) -> mean and covariance on the host.
 // blockIdx.y = family: both moment matrices come out of one launch.
 // DETERMINISTIC: the sums are taken in a fixed order -- workgroup b of the MOM_BLOCKS of a family adds the chunks b, b + MOM_BLOCKS,
-// ... into a partial matrix of its own (Mfam + b * m * m, zero on entry: every entry has one owner thread, no atomics) and
-// k_descriptor_basis adds the partials in index order.  The basis, the descriptors and with them the Morton order of a culled pass
+// ... into a partial matrix of its own (Mfam + b * m * m: every entry has one owner thread, no atomics) and the workgroup that
+// finishes last adds the partials in index order.  The basis, the descriptors and with them the Morton order of a culled pass
 // (cull.hpp) then come out bit for bit the same on every rank of a sharded run that feeds them the same sample: the ranks deal
 // the tiles of that order among themselves, and orders that differed in one structure would let pairs go unvisited.
-constexpr int MOM_BLOCKS = 16;
+constexpr int MOM_BLOCKS = 32;
 __global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int nf0, int nf1, int64_t stride_structs,
-                                                          int n_samples, double *__restrict__ M0, double *__restrict__ M1) {
+                                                          int n_samples, double *__restrict__ M0, double *__restrict__ M1, unsigned *__restrict__ tickets) {
+    // tickets == null: the fast form -- one workgroup per chunk of 32 samples, atomicAdd into the (zeroed) first partial matrix of the
+    // family: the order of the additions, and with it the last bits of the basis, differ from run to run.  Any basis gives the same
+    // verdicts; only a SHARDED run needs the same bits on every rank (option "deterministic_basis").
+    // tickets[fam] (zero on entry): the workgroup of a family that finishes LAST adds the partial matrices up, in index order, into the first
     extern __shared__ __attribute__((aligned(16))) double s_n[];  // [chunk][nf + 1]
+    __shared__ int s_last;
     const int fam = blockIdx.y, nf = fam == 0 ? nf0 : nf1;
     if (nf == 0) return;
     const int m = nf + 1;
-    double *__restrict__ M = (fam == 0 ? M0 : M1) + size_t(blockIdx.x) * m * m;
+    double *__restrict__ Mf = fam == 0 ? M0 : M1;
     constexpr int CHUNK = 32;
     const int n_chunks = (n_samples + CHUNK - 1) / CHUNK;
-    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        const int s0 = ch * CHUNK, ns = min(CHUNK, n_samples - s0);
+    if (!tickets) {
+        for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+            const int s0 = ch * CHUNK, ns = min(CHUNK, n_samples - s0);
+            for (int e = threadIdx.x; e < ns * m; e += blockDim.x) {
+                int s = e / m, a = e - s * m;
+                s_n[s * m + a] = (a < nf) ? feature(heavy + int64_t(s0 + s) * stride_structs * h * 3, h, fam, a) : 1.0;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+                int a = e / m, b = e - a * m;
+                if (b < a) continue;
+                double acc = 0.0;
+                for (int s = 0; s < ns; ++s) acc += s_n[s * m + a] * s_n[s * m + b];
+                atomicAdd(&Mf[e], acc);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    double *__restrict__ M = Mf + size_t(blockIdx.x) * m * m;
+    bool first = true;
+    for (int ch = blockIdx.x; ch < n_chunks || first; ch += gridDim.x) {
+        const int s0 = ch * CHUNK, ns = ch < n_chunks ? min(CHUNK, n_samples - s0) : 0;   // (a workgroup without a chunk still writes zeros)
         for (int e = threadIdx.x; e < ns * m; e += blockDim.x) {
             int s = e / m, a = e - s * m;
             s_n[s * m + a] = (a < nf) ? feature(heavy + int64_t(s0 + s) * stride_structs * h * 3, h, fam, a) : 1.0;
@@ -88,11 +114,30 @@ __global__ __launch_bounds__(256) void k_feature_moments(const double *__restric
         for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
             int a = e / m, b = e - a * m;
             if (b < a) continue;
-            double acc = 0.0;
+            double acc = first ? 0.0 : M[e];
             for (int s = 0; s < ns; ++s) acc += s_n[s * m + a] * s_n[s * m + b];
-            M[e] += acc;
+            M[e] = acc;
         }
         __syncthreads();
+        first = false;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[fam], 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+        int a = e / m, b = e - a * m;
+        if (b < a) continue;
+        // (this workgroup has not touched the other workgroups' partials before: the loads miss its CU's cache and come from the L2,
+        // where the writers' stores are since their fences; all of an entry's partials in flight at once, added in index order)
+        double v[MOM_BLOCKS], acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < MOM_BLOCKS; ++u) v[u] = __builtin_nontemporal_load(&Mf[size_t(u) * m * m + e]);   // one round trip
+#pragma unroll
+        for (int u = 0; u < MOM_BLOCKS; ++u) acc += v[u];
+        Mf[e] = acc;   // (entry e of partial 0 is read by this thread alone)
     }
 }
 
@@ -314,7 +359,7 @@ __global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, doubl
 #endif
 constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
-__global__ __launch_bounds__(64) void k_descriptor_basis(double *__restrict__ M0, double *__restrict__ M1, int nf0, int nf1,
+__global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
                                                           int n_samples, double *__restrict__ Q, double *__restrict__ bias,
                                                           unsigned *__restrict__ zero_word, double *__restrict__ spread_host = nullptr) {
     // spread_host (optional): host-visible copy of the two spread values written at the end (pinned memory; the host pre-sets +inf
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(double *__restrict__ M0
     __shared__ double Cs[BASIS_LDS_C][BASIS_LDS_C + 1];
     __shared__ double Gm[KD][KD];  // Gram matrix of the rows being orthonormalised
     const int fam = blockIdx.x, lane = threadIdx.x;
-    double *M = fam == 0 ? M0 : M1;
+    const double *M = fam == 0 ? M0 : M1;
     const int nf = fam == 0 ? nf0 : nf1, m = nf + 1;
     double *Qout = Q + (fam == 0 ? 0 : size_t(KD) * nf0);
     double *bout = bias + fam * KD;
@@ -337,12 +382,6 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(double *__restrict__ M0
         }
         return;
     }
-    for (int e = lane; e < m * m; e += 64) {  // the MOM_BLOCKS partial matrices of k_feature_moments, added in index order into the first
-        double acc = M[e];
-        for (int b = 1; b < MOM_BLOCKS; ++b) acc += M[size_t(b) * m * m + e];
-        M[e] = acc;
-    }
-    __builtin_amdgcn_wave_barrier();
     const double inv = n_samples > 0 ? 1.0 / n_samples : 0.0;
     for (int a = lane; a < nf; a += 64) mu[a] = M[size_t(a) * m + nf] * inv;
     __builtin_amdgcn_wave_barrier();

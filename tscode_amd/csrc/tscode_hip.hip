@@ -605,7 +605,7 @@ static bool screen_is_useless(const double *spread, int h, double thr) {
 // heavy[stride * i], into d_Q (basis_doubles(h)).  Enqueued on `st`; the scratch it takes from `s` must outlive the kernels.
 static size_t moment_doubles(int h) {  // (MOM_BLOCKS partial matrices per family: k_feature_moments)
     const size_t a = size_t(n_features(h, 0) + 1), b = size_t(n_features(h, 1) + 1);
-    return size_t(MOM_BLOCKS) * (a * a + b * b);
+    return size_t(MOM_BLOCKS) * (a * a + b * b) + 1;  // (+ the two arrival counters of k_feature_moments, in the last double)
 }
 
 // d_moments (optional): moment_doubles(h) doubles already zeroed on `st` by the caller; otherwise taken from `s` and cleared here
@@ -619,17 +619,24 @@ static int build_basis(tsc_ctx *c, hipStream_t st, Scratch &s, const double *hea
     if (d_moments) {
         d_zero = d_moments;
     } else {
-        TSC_TRY(s.get(m0 + m1, &d_zero));
-        TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1) * sizeof(double), st));
+        TSC_TRY(s.get(m0 + m1 + 1, &d_zero));
+        // (the arrival counters of the deterministic form -- its partial matrices are written whole --, or the matrices the fast form adds into)
+        if (c->deterministic_basis) TSC_HIP(hipMemsetAsync(d_zero + m0 + m1, 0, sizeof(double), st));
+        else TSC_HIP(hipMemsetAsync(d_zero, 0, (m0 + m1 + 1) * sizeof(double), st));
     }
     d_M[0] = d_zero, d_M[1] = d_zero + m0;
     {
         const size_t lds = size_t(32) * (std::max(nf[0], nf[1]) + 1) * sizeof(double);
         if (lds > 64 * 1024)
             TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_feature_moments), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_feature_moments, dim3(MOM_BLOCKS, NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0], d_M[1]);
+        if (c->deterministic_basis)
+            hipLaunchKernelGGL(k_feature_moments, dim3(MOM_BLOCKS, NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0], d_M[1],
+                               reinterpret_cast<unsigned *>(d_zero + m0 + m1));
+        else
+            hipLaunchKernelGGL(k_feature_moments, dim3(ceil_div(n_samples, 32), NFAM), dim3(256), lds, st, heavy, h, nf[0], nf[1], stride, n_samples, d_M[0],
+                               d_M[1], (unsigned *)nullptr);
     }
-    hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, d_M[0], d_M[1], nf[0], nf[1], n_samples, d_Q,
+    hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, st, (const double *)d_M[0], (const double *)d_M[1], nf[0], nf[1], n_samples, d_Q,
                        d_Q + q_doubles, zero_word, spread_host);
     TSC_HIP(hipGetLastError());
     return 0;
@@ -1626,6 +1633,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "cull") == 0) {
         TSC_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "cull must be 0 (off), 1 (the device decides per pass) or 2 (every candidate pass is culled)");
         c->cull = int(value);
+        return 0;
+    }
+    if (strcmp(name, "deterministic_basis") == 0) {
+        c->deterministic_basis = value != 0.0 ? 1 : 0;
         return 0;
     }
     if (strcmp(name, "cull_grid") == 0) {

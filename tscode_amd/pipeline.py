@@ -287,6 +287,8 @@ class HipShardBackend:
         # with other pipelines or with the drop-in functions (get_engine()) could be switched to another stream between two
         # steps -- kernels and collectives would then no longer be ordered.
         self.eng = Engine(device_index)
+        # every rank must derive bit-identical descriptors (the culled passes deal the tiles of a layout sorted by them): fixed-order sums
+        self.eng.set_option("deterministic_basis", 1 if world > 1 else 0)
         # This library's kernels, torch's copies and the collectives must be ordered on ONE stream.  torch's default stream
         # has handle 0, which tsc_ctx_set_stream reads as "use the library's own stream": a dedicated torch stream is made
         # current for every step instead (torch.distributed orders its collectives against the current stream).
