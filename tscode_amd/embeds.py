@@ -126,14 +126,6 @@ def string_embed_batch(coords1, coords2, centers1, orb_vecs1, centers2, orb_vecs
     return poses
 
 
-def _reactive_pair_indices(pivot_cumnums, v):
-    """_get_cyclical_reactive_indices for two molecules (tscode/embeds.py:862-883): which atoms face each other in polygon
-    orientation v."""
-    swaps = ((0, 0), (0, 1))
-    oriented = [list(reversed(ids)) if swaps[v][i] else list(ids) for i, ids in enumerate(pivot_cumnums)]
-    return [[oriented[0][0], oriented[1][0]], [oriented[0][1], oriented[1][1]]]
-
-
 MAX_GROUP_POSES = 8192      # poses per (conformers, pivots, orientation) group that tsc_cyclical_embed takes (GF_MAX_GROUP, group_filter.hpp)
 
 
@@ -187,7 +179,7 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
         raise ValueError(f"{A} angle pairs per group: tsc_cyclical_embed takes groups of up to {MAX_GROUP_POSES} poses (rotation steps up to 89)")
     directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])                                      # _get_directions for two, :252-253 / :768
     conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])                           # :470-471
-    blocks, groups = [], []
+    blocks, group_ids, group_meta = [], [], []
     for conf_ids in conf_indices:
         pv = [pivots[m][conf_ids[m]] for m in range(2)]
         vec = [np.asarray(p[0], dtype=np.float64).reshape(-1, 3) for p in pv]
@@ -218,26 +210,45 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
             rec[:, :, m, 12:15] = mean[m][pi[:, m]][:, None, :]
             rec[:, :, m, 15:18], rec[:, :, m, 18:21] = r[0], r[1] if len(r) == 2 else r[0]
             rec[:, :, m, 21], rec[:, :, m, 22] = len(r), conf_ids[m]
-        for q in range(n_pi):
-            for v in range(2):
-                ids = _reactive_pair_indices([cum[m][pi[q, m]] for m in range(2)], v)
-                if pairings and not all((list(pair) in ids) or _in_constraints(pair, internal_constraints) for pair in pairings):
-                    continue                                                                         # :642 / :777
-                blocks.append(rec[q, v])
-                groups.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi[q]), v, ids))
+        # which atoms face each other in each of the two orientations (_get_cyclical_reactive_indices for two molecules, :862-883):
+        # orientation 1 walks the second molecule's pivot backwards -- for all pivot pairs at once, [pivot pair, orientation, 2, 2]
+        c0, c1 = cum[0][pi[:, 0]], cum[1][pi[:, 1]]
+        ids = np.empty((n_pi, 2, 2, 2), dtype=np.int64)
+        ids[:, :, :, 0] = c0[:, None, :]
+        ids[:, 0, :, 1], ids[:, 1, :, 1] = c1, c1[:, ::-1]
+        take = np.ones((n_pi, 2), dtype=bool)
+        if pairings:                                                                                 # :642 / :777 (rare: a user's pairing constraints)
+            for q in range(n_pi):
+                for v in range(2):
+                    faces = ids[q, v].tolist()
+                    take[q, v] = all((list(pair) in faces) or _in_constraints(pair, internal_constraints) for pair in pairings)
+        blocks.append(rec[take])                                                                     # (row-major: pivot pair, then orientation -- the loop's order)
+        group_ids.append(ids[take])
+        qs, vs = np.nonzero(take)
+        group_meta.append((np.asarray(conf_ids, dtype=np.int64), pi[qs], vs))
     n_total = sum(c.shape[1] for c in coords)
-    if not blocks:
+    n_groups = sum(len(b) for b in blocks)
+    if not n_groups:
         out = (np.zeros((0, n_total, 3)), np.zeros((0, 2, 2), dtype=np.int64))
         return (*out, EmbedTrace(clash_ok=np.zeros(0, bool), kept=np.zeros(0, bool), group_of=np.zeros(0, np.int64), groups=[])) if return_trace else out
-    rows = np.repeat(np.stack(blocks), A, axis=0).reshape(-1, 23)                                    # a group's A poses share everything but the angles
-    angle_rows = np.tile(angles, (len(blocks), 1)).reshape(-1)                                       # angles[i] for molecule i, :665
-    group_off = np.arange(len(blocks) + 1, dtype=np.int32) * A
-    ok, kept, poses = get_engine().cyclical_embed(FragmentSet(coords), rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12], rows[:, 12:15],
-                                                  rows[:, 15:18], rows[:, 18:21], rows[:, 21].astype(np.int32), angle_rows,
-                                                  rows[:, 22].astype(np.int32), group_off, clash_thresh, max_clashes, rmsd_thr)
-    group_of = np.repeat(np.arange(len(blocks)), A)
-    constrained = np.array([groups[g][3] for g in group_of[kept]], dtype=np.int64).reshape(-1, 2, 2)   # :718
+    blocks = np.concatenate(blocks)                                                                  # [group, molecule, field]
+    group_ids = np.concatenate(group_ids)
+    # one row per (pose, molecule): a group's A poses share everything but the angles.  Every field is expanded straight into the
+    # contiguous array the library takes (expanding the whole 23-field record and slicing it afterwards copied everything twice)
+    expand = lambda lo, hi, dtype=np.float64: np.repeat(np.ascontiguousarray(blocks[:, :, lo:hi], dtype=dtype), A, axis=0).reshape(-1, hi - lo)
+    angle_rows = np.tile(angles, (n_groups, 1)).reshape(-1)                                          # angles[i] for molecule i, :665
+    group_off = np.arange(n_groups + 1, dtype=np.int32) * A
+    ok, kept, poses = get_engine().cyclical_embed(FragmentSet(coords), expand(0, 3), expand(3, 6), expand(6, 9), expand(9, 12), expand(12, 15),
+                                                  expand(15, 18), expand(18, 21), expand(21, 22, np.int32).reshape(-1), angle_rows,
+                                                  expand(22, 23, np.int32).reshape(-1), group_off, clash_thresh, max_clashes, rmsd_thr)
+    group_of = np.repeat(np.arange(n_groups), A)
+    constrained = group_ids[group_of[kept]].reshape(-1, 2, 2)                                        # :718
     if return_trace:
+        groups, g = [], 0
+        for conf, pis, vs in group_meta:                                                             # (conformers, pivots, orientation, facing atoms) per group
+            for q in range(len(vs)):
+                groups.append((tuple(int(c) for c in conf), tuple(int(i) for i in pis[q]), int(vs[q]), group_ids[g].tolist()))
+                g += 1
         return poses, constrained, EmbedTrace(clash_ok=ok, kept=kept, group_of=group_of, groups=groups)
     return poses, constrained
 
