@@ -385,8 +385,9 @@ def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
         assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
 
 
-@pytest.mark.parametrize("world,min_chunks,n_poses,mode", [(2, 4, 12_000, 0), (3, 1, 12_000, 0), (8, 4, 40_000, 0), (3, 4, 9_000, 1), (5, 2, 700, 0)])
-def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_poses, mode):
+@pytest.mark.parametrize("world,min_chunks,n_poses,mode,cull", [(2, 4, 12_000, 0, 0), (3, 1, 12_000, 0, 0), (8, 4, 40_000, 0, 0), (3, 4, 9_000, 1, 0), (5, 2, 700, 0, 0),
+                                                                (2, 4, 12_000, 0, 1), (3, 1, 20_000, 0, 1), (4, 2, 9_000, 1, 1)])
+def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_poses, mode, cull):
     """Rank-partitioned passes (tsc_prune_pass_range / tsc_prune_pass_merge): `world` prune runs over the same heavy-atom array stand
     in for the ranks, each takes the chunks that start inside its block of the structure axis, and the all-reduce(SUM) of the
     exchange buffers is done here with torch.  Every rank must end with the oracle's mask, and the per-pass statistics -- active
@@ -400,6 +401,17 @@ def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_pos
     ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
     one_mask, one_stats = eng.prune_heavy(heavy, 0.5, mode)
     assert np.array_equal(one_mask, ref["mask"])
+    if cull:        # every pass of fewer than 64 chunks that does not fit the chunk-local kernel: sorted layout + bounding boxes inside each rank's chunks
+        eng.set_option("cull", 2)
+        eng.set_option("cull_min_pairs", 0)
+    try:
+        _partitioned_emulation(eng, torch, PruneStepper, heavy, ref, one_stats, world, min_chunks, mode)
+    finally:
+        eng.set_option("cull", 1)
+        eng.set_option("cull_min_pairs", 2.0e9)
+
+
+def _partitioned_emulation(eng, torch, PruneStepper, heavy, ref, one_stats, world, min_chunks, mode):
     dev = torch.device("cuda:0")
     d_heavy = torch.from_numpy(heavy).to(dev)
     n, h = heavy.shape[0], heavy.shape[1]

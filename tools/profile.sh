@@ -5,7 +5,7 @@ set -e
 P=gpurun_out/$1; shift
 mkdir -p "$P"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu $*"
+ARGS="--steps 5 --warmup 1 --no-cpu --no-side-leg $*"   # (the C3 steps only: the side legs run other workloads through the same kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 bench.py $ARGS > "$P/bench_trace.json" 2> "$P/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/pmc_fetch" -- python3 bench.py $ARGS > "$P/bench_fetch.json" 2> "$P/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 bench.py $ARGS > "$P/bench_write.json" 2> "$P/write.err"

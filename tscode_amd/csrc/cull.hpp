@@ -73,24 +73,42 @@ __global__ __launch_bounds__(256) void k_radix_count(const float *__restrict__ D
     __syncthreads();
     blk_cnt[int64_t(blockIdx.x) * RADIX_BUCKETS + tid] = s_cnt[tid];
 }
-// blk_cnt[b][d] -> first output slot of block b's entries with digit d (one block; thread = digit)
-__global__ __launch_bounds__(256) void k_radix_scan(int n_blocks, int32_t *__restrict__ blk_cnt) {
-    __shared__ int s_tot[RADIX_BUCKETS];
-    const int d = threadIdx.x;
+// blk_cnt[b][d] -> entries with digit d in the blocks before b (one wavefront per digit), tot[d] = entries with digit d
+__global__ __launch_bounds__(64) void k_radix_scan(int n_blocks, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ tot) {
+    const int d = blockIdx.x, lane = threadIdx.x & 63;
     int run = 0;
-    for (int b = 0; b < n_blocks; ++b) {
-        const int v = blk_cnt[int64_t(b) * RADIX_BUCKETS + d];
-        blk_cnt[int64_t(b) * RADIX_BUCKETS + d] = run;
-        run += v;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < n_blocks ? blk_cnt[int64_t(b) * RADIX_BUCKETS + d] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (b < n_blocks) blk_cnt[int64_t(b) * RADIX_BUCKETS + d] = run + incl - v;
+        run += __shfl(incl, 63);
     }
-    s_tot[d] = run;
+    if (lane == 0) tot[d] = run;
+}
+// tot[d] -> first output slot of digit d (exclusive prefix over the 256 digits; one block)
+__global__ __launch_bounds__(256) void k_radix_base(int32_t *__restrict__ tot) {
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int v = tot[tid];
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_part[wv] = incl;
     __syncthreads();
     int base = 0;
-    for (int q = 0; q < d; ++q) base += s_tot[q];
-    for (int b = 0; b < n_blocks; ++b) blk_cnt[int64_t(b) * RADIX_BUCKETS + d] += base;
+    for (int q = 0; q < wv; ++q) base += s_part[q];
+    tot[tid] = base + incl - v;
 }
 __global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
-                                                        int shift, const int32_t *__restrict__ blk_base, int32_t *__restrict__ out) {
+                                                        int shift, const int32_t *__restrict__ blk_base, const int32_t *__restrict__ digit_base,
+                                                        int32_t *__restrict__ out) {
     __shared__ int s_cnt[32][RADIX_BUCKETS];
     const float dmax = __uint_as_float(*dmax_bits);
     const float inv = (dmax > 0.0f && dmax < 3.0e38f) ? 1.0f / dmax : 0.0f;
@@ -113,8 +131,8 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__
         }
     }
     __syncthreads();
-    {   // exclusive prefix over the block's 32 (round, wavefront) slots per digit, on top of the block's base
-        int run = blk_base[int64_t(blockIdx.x) * RADIX_BUCKETS + tid];
+    {   // exclusive prefix over the block's 32 (round, wavefront) slots per digit, on top of the digit's base and the block's offset in it
+        int run = digit_base[tid] + blk_base[int64_t(blockIdx.x) * RADIX_BUCKETS + tid];
         for (int sl = 0; sl < 32; ++sl) {
             const int v = s_cnt[sl][tid];
             s_cnt[sl][tid] = run;
@@ -137,8 +155,9 @@ __global__ __launch_bounds__(64) void k_chunk_bases(PassGeom g, const PruneState
     const int n_all = st->n_active;
     const int c = blockIdx.x;  // one wavefront per chunk boundary (grid = k + 1)
     const int64_t pos = c < g.k ? int64_t(c) * g.cs : int64_t(g.n);
-    const int r = rank_below_wave(boff, X, n_blocks, n_all, pos);
-    if ((threadIdx.x & 63) == 0) cbase[c] = r, cfill[c] = 0;
+    // (a pass partitioned over ranks runs on the LOCAL rows 0 .. A - 1 of this rank's chunks: ranks relative to row_lo, clamped to them)
+    const int r = rank_below_wave(boff, X, n_blocks, n_all, pos) - st->row_lo;
+    if ((threadIdx.x & 63) == 0) cbase[c] = r < 0 ? 0 : (r > st->A ? st->A : r), cfill[c] = 0;
 }
 
 // Culled or walked?  The ordered walk looks at the pairs inside the rows' ranges (r, cend[r]) -- W of them, summed by k_open_rows;
@@ -180,11 +199,14 @@ constexpr int CULL_LAYOUT_ITEMS = 2048;
 constexpr int CULL_LAYOUT_SLOTS = CULL_LAYOUT_ITEMS / 64;   // (round, wavefront) slots of a block: 64 consecutive entries each
 
 // chunk of entry m of the Morton order if that structure is active, else -1
-__device__ inline int layout_chunk(const PassGeom &g, const int32_t *__restrict__ order, const unsigned long long *__restrict__ X, int64_t m, int &i) {
+struct LayoutRange {
+    int s_lo, s_hi;   // structures [s_lo, s_hi) take part (a pass partitioned over ranks: this rank's chunks; else all n)
+};
+__device__ inline int layout_chunk(const PassGeom &g, const LayoutRange lr, const int32_t *__restrict__ order, const unsigned long long *__restrict__ X, int64_t m, int &i) {
     i = 0;
     if (m >= g.n) return -1;
     i = order[m];
-    if (!((X[i >> 6] >> (i & 63)) & 1ull)) return -1;
+    if (i < lr.s_lo || i >= lr.s_hi || !((X[i >> 6] >> (i & 63)) & 1ull)) return -1;
     const int c = i / g.cs;
     return c >= g.k ? g.k - 1 : c;
 }
@@ -203,7 +225,7 @@ __device__ inline int layout_wave_rank(int mine, int *s_cnt_slot) {
     }
     return rank;
 }
-__global__ __launch_bounds__(256) void k_layout_count(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256) void k_layout_count(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
                                                       const unsigned long long *__restrict__ bits, int bit_words, int32_t *__restrict__ blk_cnt) {
     __shared__ int s_cnt[CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256) void k_layout_count(PassGeom g, const PruneSta
     const int64_t m0 = int64_t(blockIdx.x) * CULL_LAYOUT_ITEMS;
     for (int u = 0; u < CULL_LAYOUT_ITEMS / 256; ++u) {
         int i;
-        const int c = layout_chunk(g, order, X, m0 + u * 256 + tid, i);
+        const int c = layout_chunk(g, lr, order, X, m0 + u * 256 + tid, i);
         for (unsigned long long left = __ballot(c >= 0); left;) {   // one LDS atomic per (wavefront, chunk present)
             const int cc = __shfl(c, __ffsll((long long)left) - 1);
             const unsigned long long same = __ballot(c == cc);
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__restrict
         run += __shfl(incl, 63);
     }
 }
-__global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
                                                         const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
                                                         const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
                                                         int32_t *__restrict__ crank) {
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, const PruneS
     int my_c[CULL_LAYOUT_ITEMS / 256], my_i[CULL_LAYOUT_ITEMS / 256], my_rank[CULL_LAYOUT_ITEMS / 256];
 #pragma unroll
     for (int u = 0; u < CULL_LAYOUT_ITEMS / 256; ++u) {
-        my_c[u] = layout_chunk(g, order, X, m0 + u * 256 + tid, my_i[u]);
+        my_c[u] = layout_chunk(g, lr, order, X, m0 + u * 256 + tid, my_i[u]);
         my_rank[u] = layout_wave_rank(my_c[u], s_cnt[u * 4 + wv]);
     }
     __syncthreads();

@@ -1106,8 +1106,10 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     }
     // Large passes: the structures laid out along a Morton curve, tile pairs skipped by bounding box (cull.hpp); the verdicts are
     // applied by k_apply_pass behind the pair kernel (tsc_prune_pass_finish), on one rank or several
-    const bool culled = p->algo == ALGO_SIEVE && !range && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS &&
-                        double(n) * double(n / k) * 0.5 >= c->cull_min_pairs;
+    // (the pairs a rank gets to look at: its chunks in a partitioned pass, its row tiles in a pass dealt by tiles -- the layout and
+    // the boxes are made by every rank for itself and have to pay for themselves on that share)
+    const double my_pairs = range ? double(s_hi - s_lo) * double(n / k) * 0.5 : double(n) * double(n / k) * 0.5 / double(world);
+    const bool culled = p->algo == ALGO_SIEVE && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS && my_pairs >= c->cull_min_pairs;
     if (culled && !p->morton_order) {
         int rc = palloc(p, size_t(n), &p->morton_order);
         if (!rc) rc = palloc(p, size_t(n), &p->rank_of);
@@ -1122,18 +1124,20 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         // once per run: the structures in coarse Morton order of their descriptors -- a stable two-digit radix sort by cell, so that
         // every rank of a sharded run comes to the same order (cull.hpp)
         Scratch s(c);
-        int32_t *tmp, *blk;
+        int32_t *tmp, *blk, *tot;
         const int n_rb = int(ceil_div<int64_t>(n, 2048));
         TSC_TRY(s.get(size_t(n), &tmp));
         TSC_TRY(s.get(size_t(n_rb) * RADIX_BUCKETS, &blk));
+        TSC_TRY(s.get(size_t(RADIX_BUCKETS), &tot));
         static_assert(CULL_MORTON_BITS * CULL_MORTON_DIMS <= 16, "two 8-bit digits");
         for (int pass = 0; pass < 2; ++pass) {
             const int32_t *in = pass == 0 ? nullptr : tmp;
             int32_t *out = pass == 0 ? tmp : p->morton_order;
             hipLaunchKernelGGL(k_radix_count, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass, blk);
-            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(256), 0, st, n_rb, blk);
+            hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BUCKETS), dim3(64), 0, st, n_rb, blk, tot);
+            hipLaunchKernelGGL(k_radix_base, dim3(1), dim3(256), 0, st, tot);
             hipLaunchKernelGGL(k_radix_scatter, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass,
-                               (const int32_t *)blk, out);
+                               (const int32_t *)blk, (const int32_t *)tot, out);
         }
         TSC_HIP(hipGetLastError());
     }
@@ -1188,10 +1192,11 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
         const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));
-        hipLaunchKernelGGL(k_layout_count, dim3(unsigned(n_lb)), dim3(256), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->morton_order,
+        const LayoutRange lr{int(s_lo), int(s_hi)};
+        hipLaunchKernelGGL(k_layout_count, dim3(unsigned(n_lb)), dim3(256), 0, st, g, lr, (const PruneState *)p->state, (const int32_t *)p->morton_order,
                            (const unsigned long long *)p->bits, int(p->bit_words), p->blk_cnt);
         hipLaunchKernelGGL(k_layout_scan, dim3(unsigned(k)), dim3(64), 0, st, (const PruneState *)p->state, n_lb, (const int32_t *)p->cbase, p->blk_cnt);
-        hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->morton_order,
+        hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, lr, (const PruneState *)p->state, (const int32_t *)p->morton_order,
                            (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of, (const float *)p->Dc,
                            (const int32_t *)p->blk_cnt, p->Ds, p->crank);
         hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
@@ -1215,6 +1220,15 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                               (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca,
                               my_tiles, n_seg);
         TSC_HIP(hipGetLastError());
+        if (range) {
+            // a partitioned pass is closed by tsc_prune_pass_merge after the exchange: this rank's verdicts go into the exchange buffer
+            // now (k_apply_pass in its noting form), its last block leaves the statistics there
+            int nxt = -1;
+            const StepArgs sa2 = next_step_args(p, &nxt);
+            const int blocks = int(std::min<int64_t>(ceil_div<int64_t>(A, 256), 512));
+            hipLaunchKernelGGL(k_apply_pass, dim3(blocks), dim3(256), 0, st, apply_args(p), step_ctx(p, true), sa2);
+            TSC_HIP(hipGetLastError());
+        }
         p->local_done = true;
         return 0;
     }
