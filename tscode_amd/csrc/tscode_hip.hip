@@ -538,6 +538,7 @@ struct tsc_prune {
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
+    bool morton_sorted = false;          // the run's Morton order exists (made when the first pass is really culled)
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
     int part_rank = 0, part_world = 1, part_min_chunks = 0;
     unsigned long long *exch = nullptr;  // caller-owned exchange buffer: bit_words words of removed rows + 8 of statistics
@@ -1109,7 +1110,10 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     // (the pairs a rank gets to look at: its chunks in a partitioned pass, its row tiles in a pass dealt by tiles -- the layout and
     // the boxes are made by every rank for itself and have to pay for themselves on that share)
     const double my_pairs = range ? double(s_hi - s_lo) * double(n / k) * 0.5 : double(n) * double(n / k) * 0.5 / double(world);
-    const bool culled = p->algo == ALGO_SIEVE && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS && my_pairs >= c->cull_min_pairs;
+    // (row tiles dealt to several ranks: twice the threshold -- every rank lays the whole pass out for an eighth, say, of its tiles;
+    // measured at 1M x 50 and eight ranks the culled k = 2 pass costs a rank 0.82 ms against 0.77 for the walk)
+    const bool culled = p->algo == ALGO_SIEVE && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS &&
+                        my_pairs >= c->cull_min_pairs * ((world > 1 && !range) ? 2.0 : 1.0);
     if (culled && !p->morton_order) {
         int rc = palloc(p, size_t(n), &p->morton_order);
         if (!rc) rc = palloc(p, size_t(n), &p->rank_of);
@@ -1121,25 +1125,6 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
-        // once per run: the structures in coarse Morton order of their descriptors -- a stable two-digit radix sort by cell, so that
-        // every rank of a sharded run comes to the same order (cull.hpp)
-        Scratch s(c);
-        int32_t *tmp, *blk, *tot;
-        const int n_rb = int(ceil_div<int64_t>(n, 2048));
-        TSC_TRY(s.get(size_t(n), &tmp));
-        TSC_TRY(s.get(size_t(n_rb) * RADIX_BUCKETS, &blk));
-        TSC_TRY(s.get(size_t(RADIX_BUCKETS), &tot));
-        static_assert(CULL_MORTON_BITS * CULL_MORTON_DIMS <= 16, "two 8-bit digits");
-        for (int pass = 0; pass < 2; ++pass) {
-            const int32_t *in = pass == 0 ? nullptr : tmp;
-            int32_t *out = pass == 0 ? tmp : p->morton_order;
-            hipLaunchKernelGGL(k_radix_count, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass, blk);
-            hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BUCKETS), dim3(64), 0, st, n_rb, blk, tot);
-            hipLaunchKernelGGL(k_radix_base, dim3(1), dim3(256), 0, st, tot);
-            hipLaunchKernelGGL(k_radix_scatter, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass,
-                               (const int32_t *)blk, (const int32_t *)tot, out);
-        }
-        TSC_HIP(hipGetLastError());
     }
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
     p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
@@ -1188,6 +1173,28 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                            c->cull == 2 ? 1 : 0, const_cast<int *>(flag));
         TSC_HIP(hipStreamSynchronize(st));
         run_culled = *flag != 0;
+    }
+    if (run_culled && !p->morton_sorted) {
+        // once per run: the structures in coarse Morton order of their descriptors -- a stable two-digit radix sort by cell, so that
+        // every rank of a sharded run comes to the same order (cull.hpp)
+        Scratch s(c);
+        int32_t *tmp, *blk, *tot;
+        const int n_rb = int(ceil_div<int64_t>(n, 2048));
+        TSC_TRY(s.get(size_t(n), &tmp));
+        TSC_TRY(s.get(size_t(n_rb) * RADIX_BUCKETS, &blk));
+        TSC_TRY(s.get(size_t(RADIX_BUCKETS), &tot));
+        static_assert(CULL_MORTON_BITS * CULL_MORTON_DIMS <= 16, "two 8-bit digits");
+        for (int pass = 0; pass < 2; ++pass) {
+            const int32_t *in = pass == 0 ? nullptr : tmp;
+            int32_t *out = pass == 0 ? tmp : p->morton_order;
+            hipLaunchKernelGGL(k_radix_count, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass, blk);
+            hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BUCKETS), dim3(64), 0, st, n_rb, blk, tot);
+            hipLaunchKernelGGL(k_radix_base, dim3(1), dim3(256), 0, st, tot);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(unsigned(n_rb)), dim3(256), 0, st, (const float *)p->Dall, in, n, (const unsigned *)p->dmax_bits, 8 * pass,
+                               (const int32_t *)blk, (const int32_t *)tot, out);
+        }
+        TSC_HIP(hipGetLastError());
+        p->morton_sorted = true;
     }
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
