@@ -1,0 +1,143 @@
+"""What the embed drop-ins READ from the objects they are handed (tscode_amd.embeds.string_embed / cyclical_embed).
+
+A recording proxy wraps the embedder and everything reached through it and notes, per kind of object, which attributes were
+read and what came back (type, and for arrays rank and dtype kind).  tests/golden/gen_dropin_reads.py (build container only) runs
+the drop-ins on the REFERENCE'S OWN Hypermolecule objects -- built from its tests/*.xyz, orbitals by its reactive_atoms_classes,
+pivots by Embedder._set_pivots -- with the engine call replaced by a stand-in, and commits the notes as
+tests/golden/G13_dropin_reads.json; tests/test_abi_and_host.py replays the drop-ins on the duck-typed objects the GPU tests use and
+requires the same reads with the same shapes: the duck types stand for the real objects in everything the drop-ins touch.
+"""
+import numpy as np
+
+KINDS = {"embedder": ("objects", "options"), "mol": (), "options": (), "r_atom": (), "pivot": ("start_atom", "end_atom"), "atom": ()}
+
+
+def describe(v):
+    if isinstance(v, np.ndarray) and v.dtype == object:
+        return {"type": "sequence", "of": describe(v.flat[0]) if v.size else None} if v.ndim == 1 else {"type": "sequence", "of": {"type": "sequence", "of": describe(v.flat[0])}}
+    if isinstance(v, np.ndarray):
+        return {"type": "ndarray", "ndim": int(v.ndim), "kind": v.dtype.kind}
+    if isinstance(v, (bool, np.bool_)):
+        return {"type": "bool"}
+    if isinstance(v, (int, np.integer)):
+        return {"type": "int"}
+    if isinstance(v, (float, np.floating)):
+        return {"type": "float"}
+    if isinstance(v, (list, tuple)):
+        return {"type": "sequence", "of": describe(v[0]) if len(v) else None}
+    if isinstance(v, str):
+        return {"type": "str"}
+    if isinstance(v, dict):
+        return {"type": "dict"}
+    if callable(v):
+        return {"type": "callable"}
+    if v is None:
+        return {"type": "none"}
+    return {"type": "object"}
+
+
+class Rec:
+    """Proxy of `obj` that notes attribute reads into log[kind][name]; objects reached through it are wrapped by CHILD."""
+    CHILD = {("embedder", "objects"): "mol", ("embedder", "options"): "options", ("mol", "pivots"): "pivot", ("mol", "get_r_atoms"): "r_atom",
+             ("pivot", "start_atom"): "atom", ("pivot", "end_atom"): "atom"}
+
+    def __init__(self, obj, kind, log):
+        object.__setattr__(self, "_o", obj)
+        object.__setattr__(self, "_k", kind)
+        object.__setattr__(self, "_log", log)
+
+    def _wrap(self, name, v):
+        child = Rec.CHILD.get((self._k, name))
+        if child is None:
+            return v
+        if isinstance(v, (list, tuple)) or (isinstance(v, np.ndarray) and v.dtype == object):
+            return [self._wrap(name, x) for x in v]
+        return Rec(v, child, self._log)
+
+    def __getattr__(self, name):
+        v = getattr(self._o, name)
+        raw = v
+        if callable(v) and not isinstance(v, np.ndarray) and (self._k, name) in (("mol", "get_r_atoms"), ("mol", "get_centers")):
+            def call(*a, **kw):
+                out = raw(*a, **kw)
+                self._log.setdefault(self._k, {})[name + "()"] = describe(out)
+                return self._wrap(name, out)
+            return call
+        self._log.setdefault(self._k, {})[name] = describe(v)
+        return self._wrap(name, v)
+
+    def __setattr__(self, name, value):
+        self._log.setdefault(self._k + ":written", {})[name] = describe(value)
+        setattr(self._o, name, value)
+
+
+class StandInEngine:
+    """In place of the GPU call: answers with arrays of the right shape (every candidate passes, every pose is kept)."""
+
+    def string_embed(self, fs, p1, p2, ref_vec, mol_vec, conf_pair, angles, *a):
+        n = len(p1) * len(np.atleast_1d(angles))
+        return np.ones(n, bool), np.ones(n, bool), np.zeros((n, int(fs.n_total), 3))
+
+    def cyclical_embed(self, fs, start, *a):
+        n = len(start) // 2
+        return np.ones(n, bool), np.ones(n, bool), np.zeros((n, int(fs.n_total), 3))
+
+
+def record(dropin, embedder):
+    """Runs `dropin(embedder)` (tscode_amd.embeds.string_embed / cyclical_embed) with the stand-in engine; returns the notes."""
+    import tscode_amd.embeds as E
+    log = {}
+    saved = E.get_engine
+    E.get_engine = lambda *a, **k: StandInEngine()
+    try:
+        dropin(Rec(embedder, "embedder", log))
+    finally:
+        E.get_engine = saved
+    return log
+
+
+# ---- the duck-typed objects of the GPU drop-in test (test_gpu_parity.test_embed_dropins_with_the_reference_signatures) ----
+def reference_module_standin(zero_error, g11=None, k=0):
+    """A module offering the helper names the drop-ins take from the live tscode.embeds."""
+    import types
+    m = types.ModuleType("tscode.embeds")
+    m.ZeroCandidatesError = zero_error
+    m.pretty_num = str
+    m.get_sum_graph = lambda graphs, extra: ("sum", graphs, extra)
+    m._get_string_constrained_indices = lambda emb, n: np.array([[[int(emb.objects[0].reactive_indices[0]),
+                                                                   int(emb.objects[1].reactive_indices[0] + emb.ids[0])]] for _ in range(n)])
+    m.string_embed = m.cyclical_embed = lambda emb, *a: "the reference's own function"
+    if g11 is not None:
+        m._get_quadruplets = lambda graph: g11[f"quadruplets_{k}"]
+    return m
+
+
+def duck_string_embedder(g11, k, logs):
+    """Embedder + two molecules carrying the recorded inputs of G11 case k."""
+    import types
+    mols = []
+    for m in range(2):
+        centers, vecs = g11[f"centers{m}_{k}"], g11[f"orb_vecs{m}_{k}"]
+        r_atoms = [types.SimpleNamespace(center=centers[c], orb_vecs=vecs[c]) for c in range(len(centers))]
+        mols.append(types.SimpleNamespace(atomcoords=g11[f"coords{m}_{k}"], reactive_indices=np.array([int(g11[f"reactive_index{m}_{k}"])]), graph=None,
+                                          get_r_atoms=lambda c, r=r_atoms: [r[c]], get_centers=lambda c, r=r_atoms: np.array([r[c].center])))
+    return types.SimpleNamespace(objects=mols, ids=g11[f"ids_{k}"], systematic_angles=list(g11[f"angles_{k}"]), candidates=len(g11[f"candidates_{k}"]),
+                                 options=types.SimpleNamespace(clash_thresh=float(g11[f"clash_thresh_{k}"])), log=lambda *a, **kw: logs.append(a))
+
+
+def duck_cyclical_embedder(g12, k, logs):
+    """Embedder + two molecules carrying the recorded inputs of G12 case k."""
+    import types
+    mols = []
+    for m in range(2):
+        coords = g12[f"coords{m}_{k}"]
+        piv = []
+        for c in range(len(coords)):
+            vec, mean, cum = g12[f"pivot_vec{m}_{c}_{k}"], g12[f"pivot_mean{m}_{c}_{k}"], g12[f"pivot_cumnums{m}_{c}_{k}"]
+            piv.append([types.SimpleNamespace(pivot=vec[i], meanpoint=mean[i], start_atom=types.SimpleNamespace(cumnum=int(cum[i, 0])),
+                                              end_atom=types.SimpleNamespace(cumnum=int(cum[i, 1]))) for i in range(len(vec))])
+        mols.append(types.SimpleNamespace(atomcoords=coords, reactive_indices=g12[f"reactive_indices{m}_{k}"], pivots=piv))
+    return types.SimpleNamespace(objects=mols, ids=g12[f"ids_{k}"], systematic_angles=g12[f"angles_{k}"], candidates=len(g12[f"candidates_{k}"]),
+                                 embed="cyclical", pairings_table={}, internal_constraints=[],
+                                 options=types.SimpleNamespace(clash_thresh=float(g12[f"clash_thresh_{k}"]), rigid=bool(g12[f"rigid_{k}"])),
+                                 log=lambda *a, **kw: logs.append(a))

@@ -142,3 +142,46 @@ def test_pairing_filter_reads_internal_constraints_like_the_reference():
         assert _in_constraints(pair, ic) == (pair in ic), pair               # the reference's own expression
     assert _in_constraints([3, 99], ic) and not _in_constraints([7, 3], ic)
     assert not _in_constraints([3, 7], []) and not _in_constraints([3, 7], None)
+
+
+def test_dropins_read_from_duck_types_what_they_read_from_the_reference_objects():
+    """tests/golden/G13_dropin_reads.json: the attributes tscode_amd.embeds.string_embed / cyclical_embed read from the reference's
+    own Embedder-side objects (real Hypermolecule, Pivot and orbital objects; recorded in the build container by
+    tests/golden/gen_dropin_reads.py) and what each held.  The duck-typed objects the GPU parity test hands the drop-ins must be
+    read the same way: the same attributes, holding the same kinds of value (array rank and dtype kind included)."""
+    import json
+    import os
+    import sys
+    import dropin_reads
+    import tscode_amd.embeds as E
+    from conftest import load_golden
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "G13_dropin_reads.json")))
+    g11, g12 = load_golden("G11_string_embed"), load_golden("G12_cyclical_embed")
+
+    class Zero(Exception):
+        pass
+    saved = sys.modules.get("tscode.embeds")
+    sys.modules["tscode.embeds"] = dropin_reads.reference_module_standin(Zero, g11, 0)
+    try:
+        got = {"string_embed": dropin_reads.record(E.string_embed, dropin_reads.duck_string_embedder(g11, 0, [])),
+               "cyclical_embed": dropin_reads.record(E.cyclical_embed, dropin_reads.duck_cyclical_embedder(g12, 0, []))}
+    finally:
+        if saved is None:
+            sys.modules.pop("tscode.embeds", None)
+        else:
+            sys.modules["tscode.embeds"] = saved
+
+    def same(a, b):
+        if a is None or b is None:                      # an empty sequence on either side says nothing about its elements
+            return True
+        if a["type"] != b["type"]:
+            return {a["type"], b["type"]} == {"none", "object"} or {a["type"], b["type"]} <= {"int", "float"}
+        if a["type"] == "ndarray":
+            return a["ndim"] == b["ndim"] and a["kind"] == b["kind"]
+        return same(a.get("of"), b.get("of")) if a["type"] == "sequence" else True
+    for dropin in want:
+        assert set(got[dropin]) == set(want[dropin]), dropin
+        for kind in want[dropin]:
+            assert set(got[dropin][kind]) == set(want[dropin][kind]), (dropin, kind, sorted(got[dropin][kind]), sorted(want[dropin][kind]))
+            for name, held in want[dropin][kind].items():
+                assert same(got[dropin][kind][name], held), (dropin, kind, name, got[dropin][kind][name], held)

@@ -1406,29 +1406,18 @@ def test_embed_dropins_with_the_reference_signatures(eng):
     from tscode_amd import embeds as E
     g11, g12 = load_golden("G11_string_embed"), load_golden("G12_cyclical_embed")
 
+    import dropin_reads
+
     class Zero(Exception):
         pass
     logs = []
-    standin = types.ModuleType("tscode.embeds")
-    standin.ZeroCandidatesError = Zero
-    standin.pretty_num = str
-    standin.get_sum_graph = lambda graphs, extra: ("sum", graphs, extra)
-    standin._get_string_constrained_indices = lambda emb, n: np.array([[[int(emb.objects[0].reactive_indices[0]),
-                                                                         int(emb.objects[1].reactive_indices[0] + emb.ids[0])]] for _ in range(n)])
-    standin.string_embed = standin.cyclical_embed = lambda emb, *a: "the reference's own function"
+    standin = dropin_reads.reference_module_standin(Zero)
     saved = sys.modules.get("tscode.embeds")
     sys.modules["tscode.embeds"] = standin
     try:
         for k in range(int(g11["n_cases"])):
             standin._get_quadruplets = lambda graph, k=k: g11[f"quadruplets_{k}"]
-            mols = []
-            for m in range(2):
-                centers, vecs = g11[f"centers{m}_{k}"], g11[f"orb_vecs{m}_{k}"]
-                r_atoms = [types.SimpleNamespace(center=centers[c], orb_vecs=vecs[c]) for c in range(len(centers))]
-                mols.append(types.SimpleNamespace(atomcoords=g11[f"coords{m}_{k}"], reactive_indices=np.array([int(g11[f"reactive_index{m}_{k}"])]), graph=None,
-                                                  get_r_atoms=lambda c, r=r_atoms: [r[c]], get_centers=lambda c, r=r_atoms: np.array([r[c].center])))
-            emb = types.SimpleNamespace(objects=mols, ids=g11[f"ids_{k}"], systematic_angles=list(g11[f"angles_{k}"]), candidates=len(g11[f"candidates_{k}"]),
-                                        options=types.SimpleNamespace(clash_thresh=float(g11[f"clash_thresh_{k}"])), log=lambda *a, **kw: logs.append(a))
+            emb = dropin_reads.duck_string_embedder(g11, k, logs)
             poses = E.string_embed(emb)
             assert poses.shape == g11[f"poses_{k}"].shape and np.abs(poses - g11[f"poses_{k}"]).max() < VAL_TOL
             assert np.array_equal(emb.constrained_indices, g11[f"constrained_indices_{k}"])
@@ -1436,19 +1425,8 @@ def test_embed_dropins_with_the_reference_signatures(eng):
         with pytest.raises(Zero):
             E.string_embed(emb)
         for k in range(int(g12["n_cases"])):
-            mols = []
-            for m in range(2):
-                coords = g12[f"coords{m}_{k}"]
-                piv = []
-                for c in range(len(coords)):
-                    vec, mean, cum = g12[f"pivot_vec{m}_{c}_{k}"], g12[f"pivot_mean{m}_{c}_{k}"], g12[f"pivot_cumnums{m}_{c}_{k}"]
-                    piv.append([types.SimpleNamespace(pivot=vec[i], meanpoint=mean[i], start_atom=types.SimpleNamespace(cumnum=int(cum[i, 0])),
-                                                      end_atom=types.SimpleNamespace(cumnum=int(cum[i, 1]))) for i in range(len(vec))])
-                mols.append(types.SimpleNamespace(atomcoords=coords, reactive_indices=g12[f"reactive_indices{m}_{k}"], pivots=piv))
-            emb = types.SimpleNamespace(objects=mols, ids=g12[f"ids_{k}"], systematic_angles=g12[f"angles_{k}"], candidates=len(g12[f"candidates_{k}"]),
-                                        embed="cyclical", pairings_table={}, internal_constraints=[],
-                                        options=types.SimpleNamespace(clash_thresh=float(g12[f"clash_thresh_{k}"]), rigid=bool(g12[f"rigid_{k}"])),
-                                        log=lambda *a, **kw: logs.append(a))
+            emb = dropin_reads.duck_cyclical_embedder(g12, k, logs)
+            mols = emb.objects
             poses = E.cyclical_embed(emb)
             assert poses.shape == g12[f"poses_{k}"].shape and np.abs(poses - g12[f"poses_{k}"]).max() < VAL_TOL
             assert np.array_equal(emb.constrained_indices, g12[f"constrained_indices_{k}"])
