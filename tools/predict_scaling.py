@@ -19,6 +19,7 @@ mesh allows) -- both stated in the output.
 usage (GPU box): python tools/predict_scaling.py [C3 C4] [--chunks M] > profiles/r03_predicted_scaling.json
 """
 import json
+import os
 import sys
 import time
 
@@ -86,6 +87,8 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
     # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
     be = HipShardBackend(ens, 0, 0, 1, 1.5, 0, 0.5, 0)
     be.eng.set_option("pass_timing", 0)
+    for name, value in OPTIONS:
+        be.eng.set_option(name, value)
     tm = Timer(be.stream)
     n_pass = int(be.embed_clash_block())
     with torch.cuda.stream(be.stream):
@@ -160,6 +163,14 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
                 passes.append({"k": int(k), "kind": "replicated", "local_ms_per_rank": t_all, "close_ms": 0.0, "bytes": 0})
         t_tail = max(tm(lambda st=st: st.copy_mask(be.keep))[0] for st in sts)
         stats = sts[0].stats()
+        if os.environ.get("PREDICT_COUNTS"):          # work counters of the passes dealt by row tiles, summed over the ranks (they are per rank there)
+            every = [st.stats() for st in sts]
+            tiled = {p["k"] for p in passes if p["kind"] in ("row_tiles", "replicated")}
+            for i, row in enumerate(stats):
+                if row["k"] in tiled:
+                    n = 1 if n_ranks == 1 else n_ranks
+                    print(f"  counts N={n_ranks} k={row['k']}: " + " ".join(f"{f} {sum(e[i][f] for e in every[:n]) / (1 if n_ranks > 1 else 1):.4g}"
+                                                                           for f in ("pairs_screened", "candidates", "pairs_computed")), file=sys.stderr)
         for st in sts:
             st.close()
         runs.append({"setup_ms": setup, "tail_ms": t_tail, "passes": passes, "n_keep": int(stats[-1]["n_active_after"])})
@@ -203,12 +214,25 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
             "allgather_bytes": gather_bytes, "pass_counts_per_rank": counts, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}, embed_all_ms
 
 
+OPTIONS = []
+
+
 def main():
     args = sys.argv[1:]
     chunks = PARTITION_MIN_CHUNKS
     if "--chunks" in args:
         i = args.index("--chunks")
         chunks = int(args[i + 1])
+        del args[i:i + 2]
+    while "--opt" in args:                      # library options for the prune runs: --opt name=value
+        i = args.index("--opt")
+        name, value = args[i + 1].split("=")
+        OPTIONS.append((name, float(value)))
+        del args[i:i + 2]
+    ranks = (1, 2, 4, 8)
+    if "--ranks" in args:                       # e.g. --ranks 1,8 (the one-rank line is needed for the speed-up)
+        i = args.index("--ranks")
+        ranks = tuple(int(v) for v in args[i + 1].split(","))
         del args[i:i + 2]
     cfgs = [a for a in args if a.startswith("C")] or ["C3", "C4"]
     out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
@@ -220,11 +244,11 @@ def main():
     for cfg in cfgs:
         rows = []
         front_all = embed_all = None
-        for n in (1, 2, 4, 8):
+        for n in ranks:
             t0 = time.time()
             row, embed_all = measure(cfg, n, chunks, front_all_ms=front_all, embed_all_ms=embed_all)
             rows.append(row)
-            if n == 1:
+            if n == ranks[0]:
                 front_all = max(rows[0]["front_ms_per_rank"])          # one rank's front half IS the whole pose list
             print(f"{cfg} N={n}: " + " | ".join(f"{name} {f['predicted_ms_per_step']:.3f} (all links {f['predicted_ms_per_step_all_links']:.3f})"
                                                 for name, f in row["fronts"].items()) + f"  prune compute {row['prune_compute_ms']:.3f} [{time.time() - t0:.0f} s]",

@@ -39,15 +39,18 @@ __device__ inline void rot_mat_from_pointer_dev(const double ax[3], double angle
 // torsion into LDS once; the kernels then walk lists, not masks.
 struct TorsionLists {
     uint16_t *moved, *fixed;  // [n_tors][n]
-    int *count;               // [n_tors][2] = (n_moved, n_fixed)
+    int *count;               // [n_tors][4] = (n_moved, n_fixed, whether i2 is among the moved atoms, -)
 };
 
 __host__ __device__ inline size_t torsion_lists_bytes(int n_tors, int n) {
-    return (size_t(n_tors) * n * 2 * sizeof(uint16_t) + size_t(n_tors) * 2 * sizeof(int) + 15) & ~size_t(15);
+    return (size_t(n_tors) * n * 2 * sizeof(uint16_t) + size_t(n_tors) * 4 * sizeof(int) + 15) & ~size_t(15);
 }
 
-// LDS of one wavefront: the structure in fp64 and the fixed side of the current torsion as three packed fp32 arrays
-__host__ __device__ inline size_t csearch_wave_bytes(int n) { return size_t(n) * 3 * sizeof(double) + size_t(3) * ((n + 2) & ~1) * sizeof(float); }
+// LDS of one wavefront: the structure in fp64, the fixed side of the current torsion as three packed fp32 arrays, and the matrix
+// and centre of a walk-back step (12 doubles: wave-uniform values that would otherwise sit in 24 vector registers)
+__host__ __device__ inline size_t csearch_wave_bytes(int n) {
+    return size_t(n) * 3 * sizeof(double) + size_t(3) * ((n + 2) & ~1) * sizeof(float) + 12 * sizeof(double);
+}
 
 __device__ inline TorsionLists torsion_lists_at(void *lds, int n_tors, int n) {
     TorsionLists L;
@@ -72,7 +75,7 @@ __device__ inline void build_torsion_lists(TorsionLists L, const uint8_t *__rest
             if (fx) L.fixed[size_t(t) * n + nf + __popcll(bf & below)] = uint16_t(a);
             nm += __popcll(bm), nf += __popcll(bf);
         }
-        if (lane == 0) L.count[2 * t] = nm, L.count[2 * t + 1] = nf;
+        if (lane == 0) L.count[4 * t] = nm, L.count[4 * t + 1] = nf, L.count[4 * t + 2] = mask[i2] != 0 ? 1 : 0, L.count[4 * t + 3] = 0;
     }
     __syncthreads();
 }
@@ -80,11 +83,7 @@ __device__ inline void build_torsion_lists(TorsionLists L, const uint8_t *__rest
 // utils.py:389-414 on a structure in LDS: every lane forms the (wave-uniform) matrix, lanes apply it to the moved atoms.
 // If i3 itself is masked it maps onto itself exactly (its offset from the centre is zero), so no lane reads a value that
 // another lane is changing.
-__device__ inline void rotate_dihedral_lds(double *c, int i2, int i3, double angle_deg, const uint16_t *moved, int nm, int lane) {
-    const double ax[3] = {c[3 * i2] - c[3 * i3], c[3 * i2 + 1] - c[3 * i3 + 1], c[3 * i2 + 2] - c[3 * i3 + 2]};
-    const double cen[3] = {c[3 * i3], c[3 * i3 + 1], c[3 * i3 + 2]};
-    double R[9];
-    rot_mat_from_pointer_dev(ax, angle_deg, R);
+__device__ inline void apply_rotation_lds(double *c, const double R[9], const double cen[3], const uint16_t *moved, int nm, int lane) {
     __builtin_amdgcn_wave_barrier();
     for (int r = lane; r < nm; r += 64) {
         const int a = moved[r];
@@ -94,6 +93,18 @@ __device__ inline void rotate_dihedral_lds(double *c, int i2, int i3, double ang
         c[3 * a + 2] = R[6] * v0 + R[7] * v1 + R[8] * v2 + cen[2];
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline void dihedral_rotation(const double *c, int i2, int i3, double angle_deg, double R[9], double cen[3]) {
+    const double ax[3] = {c[3 * i2] - c[3 * i3], c[3 * i2 + 1] - c[3 * i3 + 1], c[3 * i2 + 2] - c[3 * i3 + 2]};
+    cen[0] = c[3 * i3], cen[1] = c[3 * i3 + 1], cen[2] = c[3 * i3 + 2];
+    rot_mat_from_pointer_dev(ax, angle_deg, R);
+}
+
+__device__ inline void rotate_dihedral_lds(double *c, int i2, int i3, double angle_deg, const uint16_t *moved, int nm, int lane) {
+    double R[9], cen[3];
+    dihedral_rotation(c, i2, i3, angle_deg, R, cen);
+    apply_rotation_lds(c, R, cen, moved, nm, lane);
 }
 
 // The fixed side of a torsion as packed fp32 (F = X[npad] Y[npad] Z[npad], an odd tail padded far away); returns the largest
@@ -118,7 +129,8 @@ __device__ inline double stage_fixed_f32(const double *c, const uint16_t *fixed,
 // is taken in packed fp32 against the staged fixed side and decided with the rigorous band of k_clash (embed_clash.hpp:
 // fp32_min_band); a minimum inside the band, or max_clashes != 0, takes the fp64 count.
 __device__ inline int torsion_comp_check_lds(const double *c, const uint16_t *moved, int nm, const uint16_t *fixed, int nf, const float *F,
-                                             int npad, double cmax_fixed, double sq_bound, long long max_clashes, int lane) {
+                                             int npad, double cmax_fixed, double sq_bound, long long max_clashes, int lane, int *hint = nullptr) {
+    if (hint) *hint = -1;
     int A = 1;
     while (A < nm && A < 64) A <<= 1;
     const int G = 64 / A, ai = lane & (A - 1), g = lane / A;
@@ -135,24 +147,34 @@ __device__ inline int torsion_comp_check_lds(const double *c, const uint16_t *mo
         if (fp32_min_band(sq_bound, cmax, &lo, &hi)) {
             const float *X = F, *Y = F + npad, *Z = F + 2 * npad;
             float m = __builtin_inff();
-            for (int r = ai; r < nm; r += A) {
+            bool found = false;
+            for (int r = ai; r < nm && !found; r += A) {
                 const int a = moved[r];
                 const float xi = float(c[3 * a]), yi = float(c[3 * a + 1]), zi = float(c[3 * a + 2]);
                 const clash_f32x2 x2 = {xi, xi}, y2 = {yi, yi}, z2 = {zi, zi};
+                // sixteen columns at a time; most rotations a conformational search tries do clash, and a certain clash ends the check
+                for (int jb = b0; jb < b1 && !found; jb += 16) {
+                    const int je = min(jb + 16, b1);
 #pragma unroll 4
-                for (int j = b0; j < b1; j += 2) {
-                    const clash_f32x2 dx = x2 - *reinterpret_cast<const clash_f32x2 *>(X + j);
-                    const clash_f32x2 dy = y2 - *reinterpret_cast<const clash_f32x2 *>(Y + j);
-                    const clash_f32x2 dz = z2 - *reinterpret_cast<const clash_f32x2 *>(Z + j);
-                    clash_f32x2 s2 = dx * dx;
-                    s2 = __builtin_elementwise_fma(dy, dy, s2);
-                    s2 = __builtin_elementwise_fma(dz, dz, s2);
-                    m = fminf(m, fminf(s2.x, s2.y));
+                    for (int j = jb; j < je; j += 2) {
+                        const clash_f32x2 dx = x2 - *reinterpret_cast<const clash_f32x2 *>(X + j);
+                        const clash_f32x2 dy = y2 - *reinterpret_cast<const clash_f32x2 *>(Y + j);
+                        const clash_f32x2 dz = z2 - *reinterpret_cast<const clash_f32x2 *>(Z + j);
+                        clash_f32x2 s2 = dx * dx;
+                        s2 = __builtin_elementwise_fma(dy, dy, s2);
+                        s2 = __builtin_elementwise_fma(dz, dz, s2);
+                        m = fminf(m, fminf(s2.x, s2.y));
+                    }
+                    found = __any(m < lo);
                 }
+            }
+            const unsigned long long certain = __ballot(m < lo);
+            if (certain) {  // some distance certainly < thresh; the lane that saw it is where the next step of a walk-back looks first
+                if (hint) *hint = __ffsll((long long)certain) - 1;
+                return 0;
             }
             for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
             if (m >= hi) return 1;  // every distance certainly >= thresh (NaN: falls through)
-            if (m < lo) return 0;   // some distance certainly < thresh
         }
     }
     int cnt = 0;
@@ -169,6 +191,44 @@ __device__ inline int torsion_comp_check_lds(const double *c, const uint16_t *mo
     return (long long)cnt > max_clashes ? 0 : 1;
 }
 
+// The walk-back of torsion_module.py:490-498 turns the moved side by 5 degrees at a time and asks again; the atoms that clashed
+// a step ago mostly still do.  `hint` = the lane of torsion_comp_check_lds that held the smallest distance: its moved atoms
+// against its slice of the fixed side, spread over the wavefront.  true = one of those distances is certainly below thresh (the
+// same rigorous fp32 band, for a coordinate bound that holds through the whole walk-back) -- the check would fail; false = not
+// decided here, the full check runs.
+__device__ inline bool hint_still_clashes(const double *c, const uint16_t *moved, int nm, int nf, const float *F, int npad, float lo, int hint, int lane) {
+    int A = 1;
+    while (A < nm && A < 64) A <<= 1;
+    const int G = 64 / A, ai = hint & (A - 1), g = hint / A;
+    const int per = (((nf + G - 1) / G) + 1) & ~1;
+    const int b0 = min(nf, g * per), b1 = min(nf, b0 + per);
+    const float *X = F, *Y = F + npad, *Z = F + 2 * npad;
+    float m = __builtin_inff();
+    for (int r = ai; r < nm; r += A) {
+        const int a = moved[r];
+        const float xi = float(c[3 * a]), yi = float(c[3 * a + 1]), zi = float(c[3 * a + 2]);
+        for (int j = b0 + lane; j < b1; j += 64) {
+            const float dx = xi - X[j], dy = yi - Y[j], dz = zi - Z[j];
+            m = fminf(m, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        }
+    }
+    return __any(m < lo);
+}
+
+// Coordinate bound of the moved side that holds for every rotation about the axis through `cen`: |cen|_inf + the atom's distance
+// from cen (a rotation keeps it; a part in 10^6 covers the rounding of many steps)
+__device__ inline double moved_side_bound(const double *c, const double cen[3], const uint16_t *moved, int nm, int lane) {
+    const double c_inf = fmax(fabs(cen[0]), fmax(fabs(cen[1]), fabs(cen[2])));
+    double b = 0.0;
+    for (int r = lane; r < nm; r += 64) {
+        const int a = moved[r];
+        const double v0 = c[3 * a] - cen[0], v1 = c[3 * a + 1] - cen[1], v2 = c[3 * a + 2] - cen[2];
+        b = fmax(b, c_inf + sqrt(v0 * v0 + v1 * v1 + v2 * v2) * 1.000001);
+    }
+    for (int off = 32; off > 0; off >>= 1) b = fmax(b, __shfl_xor(b, off));
+    return b;
+}
+
 // out [n_cand][n][3], rotated_bonds [n_cand]; angles [n_cand][n_tors] int32 degrees; masks [n_tors][n]; torsions [n_tors][4]
 // dynamic LDS: torsion lists, then one csearch_wave_bytes(n) area per wavefront of the block
 __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,
@@ -180,6 +240,7 @@ __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const dou
     build_torsion_lists(L, masks, tors, a.n_tors, n);
     double *c = reinterpret_cast<double *>(s_raw + torsion_lists_bytes(a.n_tors, n) + size_t(wid) * csearch_wave_bytes(n));
     float *F = reinterpret_cast<float *>(c + size_t(n) * 3);
+    double *step_rot = reinterpret_cast<double *>(F + size_t(3) * npad);
     for (int64_t m = int64_t(blockIdx.x) * nw + wid; m < a.n_cand; m += int64_t(gridDim.x) * nw) {
         for (int e = lane; e < n * 3; e += 64) c[e] = base[e];  // new_coords = np.copy(coords), :473
         __builtin_amdgcn_wave_barrier();
@@ -189,20 +250,38 @@ __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const dou
             if (angle == 0) continue;  // :482
             const int i2 = tors[4 * t + 1], i3 = tors[4 * t + 2];
             const uint16_t *moved = L.moved + size_t(t) * n, *fixed = L.fixed + size_t(t) * n;
-            const int nm = L.count[2 * t], nf = L.count[2 * t + 1];
+            const int nm = L.count[4 * t], nf = L.count[4 * t + 1];
             const double cmax_fixed = a.max_clashes == 0 ? stage_fixed_f32(c, fixed, nf, F, npad, lane) : 0.0;
-            rotate_dihedral_lds(c, i2, i3, double(angle), moved, nm, lane);  // :484
-            if (!torsion_comp_check_lds(c, moved, nm, fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane)) {  // :487
-                const int steps = angle >= 0 ? angle / 5 : -((-angle + 4) / 5);  // angle // 5
-                for (int rep = 0; rep < steps; ++rep) {  // :490-498
-                    rotate_dihedral_lds(c, i2, i3, -5.0, moved, nm, lane);
-                    if (torsion_comp_check_lds(c, moved, nm, fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane)) {
-                        ++rotated;
-                        break;
+            // :484-501 as one loop with a single check site: step -1 is the rotation by `angle`, steps 0 .. angle // 5 - 1 the walk-back
+            const int steps = angle >= 0 ? angle / 5 : 0;  // range(angle // 5): a negative angle is never walked back
+            // every step of the walk-back is the same rotation: the axis atoms do not move (i3 is the centre; i2 unless the mask turns
+            // it, in which case the matrix is formed anew each step as the reference does)
+            const bool same_matrix = L.count[4 * t + 2] == 0;
+            int hint = -1;
+            bool hint_ok = false;
+            float lo_h = 0.0f;
+            for (int rep = -1; rep < steps; ++rep) {
+                if (rep <= 0 || !same_matrix) {  // the matrix of this step -> LDS (the one place the trigonometry is done)
+                    double R[9], cen[3];
+                    dihedral_rotation(c, i2, i3, rep < 0 ? double(angle) : -5.0, R, cen);
+                    if (rep == 0) {  // the walk-back begins: the band its hints are decided with
+                        float hi_h;
+                        hint_ok = a.max_clashes == 0 && fp32_min_band(a.sq_bound, fmax(cmax_fixed, moved_side_bound(c, cen, moved, nm, lane)), &lo_h, &hi_h);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) step_rot[i] = R[i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) step_rot[9 + i] = cen[i];
                     }
                 }
-            } else {
-                ++rotated;  // :501
+                apply_rotation_lds(c, step_rot, step_rot + 9, moved, nm, lane);  // :484, :491
+                if (rep >= 0 && hint_ok && hint >= 0 && hint_still_clashes(c, moved, nm, nf, F, npad, lo_h, hint, lane)) continue;  // still clashing
+                if (torsion_comp_check_lds(c, moved, nm, fixed, nf, F, npad, cmax_fixed, a.sq_bound, a.max_clashes, lane, &hint)) {  // :487, :492
+                    ++rotated;  // :494, :501
+                    break;
+                }
             }
         }
         double *o = out + m * n * 3;
