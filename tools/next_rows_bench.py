@@ -132,7 +132,7 @@ eng.tfd_greedy_filter(tfq[:100])
 dt, acc = best_of(lambda: eng.tfd_greedy_filter(tfq), 1)
 ns = 20000
 dc, ref = timed(lambda: oracle.tfd_greedy_filter(tfq[:ns]))
-line("N1", "tsc_tfd_greedy_filter", ["k_tfd_greedy_prior", "k_tfd_greedy_block"], NF, "fingerprints", dt, dc, ns, np.array_equal(eng.tfd_greedy_filter(tfq[:ns]), ref), tfq.nbytes + NF,
+line("N1", "tsc_tfd_greedy_filter", ["k_tfd_greedy_prior", "k_tfd_greedy_pairs", "k_tfd_greedy_replay"], NF, "fingerprints", dt, dc, ns, np.array_equal(eng.tfd_greedy_filter(tfq[:ns]), ref), tfq.nbytes + NF,
      f"is_new_structure over {NF} fingerprints x {TQ} torsions, {int(acc.sum())} kept")
 
 ens3 = make_config("C3", 10)
@@ -149,7 +149,7 @@ dt, (sposes, tr) = best_of(lambda: tscode_amd.string_embed_batch(conf1, conf2, c
 NS = len(tr.kept)
 dc, (oc, ook, okept) = timed(lambda: oracle.string_embed(conf1[:2], conf2[:3], cen1[:2], ov1[:2], cen2[:3], ov2[:3], sangles, 1.5, quadsx))
 _, tr_s = tscode_amd.string_embed_batch(conf1[:2], conf2[:3], cen1[:2], ov1[:2], cen2[:3], ov2[:3], sangles, 1.5, 0, quadsx, return_trace=True)
-line("N1", "tsc_string_embed", ["k_string_embed_params", "k_clash", "k_transform", "k_torsion_fingerprints", "k_tfd_greedy_prior", "k_tfd_greedy_block"], NS, "candidate poses", dt, dc, len(ook),
+line("N1", "tsc_string_embed", ["k_string_embed_params", "k_clash", "k_transform", "k_torsion_fingerprints", "k_tfd_greedy_prior", "k_tfd_greedy_pairs", "k_tfd_greedy_replay"], NS, "candidate poses", dt, dc, len(ook),
      np.array_equal(tr_s.clash_ok, ook) and np.array_equal(tr_s.kept, okept), NS * (2 * 96 + 1) + int(tr.clash_ok.sum()) * (n1 + n2) * 24,
      f"whole string embed: 20 x 25 conformers, 2 x 3 centre pairs, 36 angles = {NS} candidates of {n1 + n2} atoms, {int(tr.clash_ok.sum())} pass the clash check, {int(tr.kept.sum())} kept")
 

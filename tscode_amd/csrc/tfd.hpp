@@ -98,85 +98,187 @@ __device__ inline bool tfd_similar_dev(const float *__restrict__ a, const float 
 // is_new_structure of the string embed (tscode/embeds.py:47-69) over a whole ordered list: structure s is kept iff its
 // fingerprint is not tfd-similar to the fingerprint of any structure KEPT before it.  The reference's "LRU" never evicts
 // (`lru_cache = lru_cache[1:]` rebinds a local name, :66-67), so every kept fingerprint is compared for ever.
-// The filter is sequential by definition, but most of its work is not: the list is walked in super-blocks of TG_SUPER
+// The filter is sequential by definition, but nearly all of its work is not: the list is walked in super-blocks of TG_SUPER
 // candidates, and per super-block
 //   k_tfd_greedy_prior   (whole GPU) marks the candidates that are similar to a structure kept in an EARLIER super-block
 //                        (candidates x slices of the kept list; a lane stops at its first hit);
-//   k_tfd_greedy_block   (one workgroup: the verdicts inside a super-block depend on each other) walks it in blocks of 64:
-//                        all 64 against what this super-block has kept so far (16 wavefronts, a slice of that list each),
-//                        all pairs inside the block into a 64 x 64 bit matrix, then one scalar replay of the greedy order.
-// 100 000 fingerprints with 12 000 kept: 1.07 s in a single-workgroup kernel over the whole list, a few milliseconds this way.
+//   k_tfd_greedy_pairs   (whole GPU) every pair INSIDE the super-block, whatever the greedy order will make of it: row c of a
+//                        TG_SUPER x TG_SUPER bit matrix = the earlier candidates of the super-block c is similar to;
+//   k_tfd_greedy_replay  (one wavefront) the greedy order itself, which is all that is sequential: lane l holds the kept bits of
+//                        candidates 64 l .. 64 l + 63; a candidate is kept iff the prior pass left it alive and its row meets no
+//                        kept bit.  Per block of 64 candidates the rows are in registers (the next block's already in flight),
+//                        the test against the blocks before is 64 independent ballots, and what remains serial is a scalar
+//                        chain over the block's own 64 x 64 corner.
+// 100 000 fingerprints with 12 000 kept: 1.07 s in a single-workgroup kernel over the whole list, 45 ms with the verdicts of a
+// super-block walked by one workgroup (round 2), a few milliseconds this way.
 // kept_list i32[N] (device scratch) ends up holding the kept indices in order; *n_kept their number (zeroed by the caller).
-constexpr int TG_THREADS = 1024;
 constexpr int TG_SUPER = 4096;
+constexpr int TG_WORDS = TG_SUPER / 64;
+constexpr int TG_TILE = 128;        // kept fingerprints staged in LDS at a time (fewer when they are long: tg_tile)
+constexpr int TG_REG_T = 8;         // fingerprints up to this length sit in registers and are screened in fp32 first
+static_assert(TG_WORDS == 64, "k_tfd_greedy_replay: one lane per word of the kept mask");
 
+__host__ __device__ inline int tg_tile(int T) { return T <= 0 ? TG_TILE : (12288 / T < 1 ? 1 : (12288 / T > TG_TILE ? TG_TILE : 12288 / T)); }
+
+// tfd_similar_dev with the candidate's fingerprint in registers and a float32 screen in front: min(d, |360 - d|) is the
+// reference's wrapped difference (d <= 180: itself; d > 180: |d - 360|), summed in float32 it is off by at most
+// T (2^-16 + 2^-23 sum) -- 2^-16 for the rounding of 360 - d, the rest for the additions -- so a sum outside [lo32, hi32] has the
+// verdict of the float64 sum; inside (or NaN) the float64 sum decides.  Longer fingerprints take the float64 sum directly.
+struct TfdScreen {
+    float lo32, hi32;
+};
+__device__ inline TfdScreen tfd_screen(int T, double thresh) {
+    const double abs_err = T * 3.1e-5, rel = T * 2.4e-7;
+    TfdScreen sc;
+    sc.lo32 = float((thresh - abs_err) * (1.0 - rel) - 1e-6 * fabs(thresh));
+    sc.hi32 = float((thresh + abs_err) / (1.0 - rel) + 1e-6 * fabs(thresh));
+    return sc;
+}
+__device__ inline void tfd_load_reg(const float *__restrict__ a, int T, float (&ar)[TG_REG_T]) {
+#pragma unroll
+    for (int t = 0; t < TG_REG_T; ++t) ar[t] = t < T ? a[t] : 0.0f;
+}
+__device__ inline bool tfd_similar_reg(const float *__restrict__ a, const float (&ar)[TG_REG_T], const float *__restrict__ b, int T, double thresh,
+                                       const TfdScreen sc) {
+    if (T <= TG_REG_T) {
+        float s32 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TG_REG_T; ++t)
+            if (t < T) {
+                const float d = fabsf(ar[t] - b[t]);
+                s32 += fminf(d, fabsf(360.0f - d));
+            }
+        if (s32 < sc.lo32) return true;
+        if (s32 > sc.hi32) return false;
+    }
+    return tfd_similar_dev(a, b, T, thresh);
+}
+
+// blockIdx.x: 256 candidates, one per thread; blockIdx.y: a slice of the kept list, staged through LDS in tiles (the indirection
+// kept_list -> fingerprint is paid once per tile, by all threads together, not once per comparison by each)
 __global__ __launch_bounds__(256) void k_tfd_greedy_prior(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
                                                            const int32_t *__restrict__ kept_list, const int32_t *__restrict__ n_kept,
                                                            uint8_t *__restrict__ dead) {
-    // blockIdx.x: 64 candidates; the 4 wavefronts of a block and blockIdx.y cut the kept list into gridDim.y * 4 slices
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane;
-    const int slice = blockIdx.y * 4 + (threadIdx.x >> 6), n_slices = gridDim.y * 4;
-    const int nk = *n_kept;
-    if (c >= n_cand) return;
-    const float *a = tf + (base + c) * T;
-    int it = 0;
-    for (int k = slice; k < nk; k += n_slices, ++it) {
-        if ((it & 15) == 15 && dead[c]) return;                  // another slice has settled this candidate (a hint: a stale read only costs work)
-        if (tfd_similar_dev(a, tf + int64_t(kept_list[k]) * T, T, thresh)) {
-            dead[c] = 1;
-            return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_tfd_raw[];
+    float *s_tile = reinterpret_cast<float *>(s_tfd_raw);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int nk = *n_kept, tile = tg_tile(T);
+    const int per = ((nk + int(gridDim.y) - 1) / int(gridDim.y) + tile - 1) / tile * tile;
+    const int k0 = min(nk, int(blockIdx.y) * per), k1 = min(nk, k0 + per);
+    const float *a = tf + (base + min(c, n_cand - 1)) * T;
+    float ar[TG_REG_T];
+    tfd_load_reg(a, T, ar);
+    const TfdScreen sc = tfd_screen(T, thresh);
+    bool live = c < n_cand;
+    for (int kt = k0; kt < k1; kt += tile) {
+        const int nt = min(tile, k1 - kt);
+        if (live && dead[c]) live = false;  // another slice has settled this candidate
+        if (__syncthreads_count(live ? 1 : 0) == 0) break;
+        for (int e = threadIdx.x; e < nt * T; e += 256) {
+            const int kk = e / T;
+            s_tile[e] = tf[int64_t(kept_list[kt + kk]) * T + (e - kk * T)];
+        }
+        __syncthreads();
+        if (live) {
+            for (int kk = 0; kk < nt; ++kk)
+                if (tfd_similar_reg(a, ar, s_tile + kk * T, T, thresh, sc)) {
+                    dead[c] = 1;
+                    live = false;
+                    break;
+                }
         }
     }
 }
 
-__global__ __launch_bounds__(TG_THREADS) void k_tfd_greedy_block(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
-                                                                  const uint8_t *__restrict__ dead_in, uint8_t *__restrict__ accepted,
-                                                                  int32_t *__restrict__ kept_list, int32_t *__restrict__ n_kept) {
-    __shared__ int s_dead[64];
-    __shared__ int s_nk;
-    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
-    const int nk0 = *n_kept;                                     // kept before this super-block: k_tfd_greedy_prior compared with those
-    if (tid == 0) s_nk = nk0;
-    __syncthreads();
-    for (int b0 = 0; b0 < n_cand; b0 += 64) {
-        const int nb = min(64, n_cand - b0);
-        const int nk = s_nk;
-        if (tid < 64) s_dead[tid] = (tid < nb) ? int(dead_in[b0 + tid]) : 1;
+// sim[c][w] bit j: candidate c of the super-block is similar to its candidate 64 w + j, for 64 w + j < c (zero elsewhere: every
+// word is written); nz[c / 64] bit c % 64: row c has a bit set at all (zeroed by the caller).  blockIdx.x = w (its 64 fingerprints
+// in LDS), blockIdx.y * 256 + threadIdx.x = c.
+__global__ __launch_bounds__(256) void k_tfd_greedy_pairs(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
+                                                           unsigned long long *__restrict__ sim, unsigned long long *__restrict__ nz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_tfd_raw[];
+    float *s_tile = reinterpret_cast<float *>(s_tfd_raw);
+    const int w = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    const int ncol = max(0, min(64, n_cand - 64 * w));
+    const bool staged = 64 * T <= 12288;
+    if (staged) {
+        for (int e = threadIdx.x; e < ncol * T; e += 256) s_tile[e] = tf[(base + 64 * w) * T + e];
         __syncthreads();
-        // (1) candidate `lane` against the structures this super-block has kept so far: slice, slice + 16, ...
-        if (lane < nb && !s_dead[lane]) {
-            const float *a = tf + (base + b0 + lane) * T;
-            bool dead = false;
-            for (int k = nk0 + slice; k < nk && !dead; k += TG_THREADS / 64) dead = tfd_similar_dev(a, tf + int64_t(kept_list[k]) * T, T, thresh);
-            if (dead) s_dead[lane] = 1;
-        }
-        __syncthreads();
-        // (2) + (3): wavefront 0
-        if (slice == 0) {
-            const bool dead = lane < nb ? s_dead[lane] != 0 : true;
-            unsigned long long sim = 0ull;                      // bit j: candidate `lane` is similar to candidate j < lane of this block
-            if (!dead) {
-                const float *a = tf + (base + b0 + lane) * T;
-                for (int j = 0; j < lane; ++j)
-                    if (!s_dead[j] && tfd_similar_dev(a, tf + (base + b0 + j) * T, T, thresh)) sim |= 1ull << j;
-            }
-            unsigned long long acc = 0ull;
-            for (int c = 0; c < nb; ++c) {
-                const unsigned lo = __builtin_amdgcn_readlane(unsigned(sim), c), hi = __builtin_amdgcn_readlane(unsigned(sim >> 32), c);
-                const unsigned long long m = (static_cast<unsigned long long>(hi) << 32) | lo;
-                const int d = __builtin_amdgcn_readlane(int(dead), c);
-                if (!d && (m & acc) == 0ull) acc |= 1ull << c;
-            }
-            if (lane < nb) {
-                const bool ok = (acc >> lane) & 1ull;
-                accepted[base + b0 + lane] = ok ? 1 : 0;
-                if (ok) kept_list[nk + __popcll(acc & ((1ull << lane) - 1ull))] = int32_t(base + b0 + lane);
-            }
-            if (lane == 0) s_nk = nk + __popcll(acc);
-        }
-        __syncthreads();                                        // kept_list and s_nk of this block are visible to the next round
     }
-    if (tid == 0) *n_kept = s_nk;
+    if (c >= TG_SUPER) return;
+    unsigned long long bits = 0ull;
+    if (c < n_cand && 64 * w < c) {
+        const float *a = tf + (base + c) * T;
+        float ar[TG_REG_T];
+        tfd_load_reg(a, T, ar);
+        const TfdScreen sc = tfd_screen(T, thresh);
+        const int jn = min(64, c - 64 * w);
+        for (int j = 0; j < jn; ++j) {
+            const float *b = staged ? s_tile + j * T : tf + (base + 64 * w + j) * T;
+            if (tfd_similar_reg(a, ar, b, T, thresh, sc)) bits |= 1ull << j;
+        }
+    }
+    sim[size_t(c) * TG_WORDS + w] = bits;
+    if (bits) atomicOr(&nz[c >> 6], 1ull << (c & 63));
+}
+
+__device__ inline unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane(unsigned(v), l), hi = __builtin_amdgcn_readlane(unsigned(v >> 32), l);
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long long *__restrict__ sim, const unsigned long long *__restrict__ nz,
+                                                           int64_t base, int n_cand, const uint8_t *__restrict__ dead_in,
+                                                           uint8_t *__restrict__ accepted, int32_t *__restrict__ kept_list, int32_t *__restrict__ n_kept) {
+    const int lane = threadIdx.x;
+    const int n_blocks = (n_cand + 63) / 64;
+    // dead bits of block `lane` (candidates past the end count as dead) and which of its rows have any bit set
+    unsigned long long D = 0ull;
+    for (int i = 0; i < 64; ++i) {
+        const int c = 64 * lane + i;
+        if (c >= n_cand || dead_in[c]) D |= 1ull << i;
+    }
+    const unsigned long long NZ = nz[lane];
+    unsigned long long W = 0ull;  // kept bits of block `lane`
+    unsigned long long row[2][64], corner[2];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) row[0][i] = sim[size_t(i) * TG_WORDS + lane];
+    corner[0] = sim[size_t(lane) * TG_WORDS + 0];
+    int nk = *n_kept;
+    auto block = [&](const int B, const unsigned long long(&cur)[64], unsigned long long(&nxt)[64], const unsigned long long cw,
+                     unsigned long long &cw_next) __attribute__((always_inline)) {
+        if (B + 1 < n_blocks) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) nxt[i] = sim[(size_t(B + 1) * 64 + i) * TG_WORDS + lane];
+            cw_next = sim[(size_t(B + 1) * 64 + lane) * TG_WORDS + (B + 1)];  // row 64 (B + 1) + lane, the word of its own block
+        }
+        const unsigned long long dead = readlane64(D, B);
+        const unsigned long long need = readlane64(NZ, B) & ~dead;  // alive rows that are similar to anything before them
+        // against the blocks before this one: W of lane B is still zero, so the block's own corner does not take part
+        unsigned long long blocked = dead;
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            if ((need >> i) & 1ull)
+                if (__any((cur[i] & W) != 0ull)) blocked |= 1ull << i;
+        // the block's own corner, in order: rows without a bit are kept as they are; a row's bits only name rows before it
+        unsigned long long acc = ~dead & ~need;
+        for (unsigned long long todo = need & ~blocked; todo; todo &= todo - 1ull) {
+            const int i = __ffsll((long long)todo) - 1;
+            if ((readlane64(cw, i) & acc) == 0ull) acc |= 1ull << i;
+        }
+        if (lane == B) W = acc;
+        const int c = 64 * B + lane;
+        if (c < n_cand) {
+            const bool ok = (acc >> lane) & 1ull;
+            accepted[base + c] = ok ? 1 : 0;
+            if (ok) kept_list[nk + __popcll(acc & ((1ull << lane) - 1ull))] = int32_t(base + c);
+        }
+        nk += __popcll(acc);
+    };
+    for (int B = 0; B < n_blocks; B += 2) {
+        block(B, row[0], row[1], corner[0], corner[1]);
+        if (B + 1 < n_blocks) block(B + 1, row[1], row[0], corner[1], corner[0]);
+    }
+    if (lane == 0) *n_kept = nk;
 }
 
 // flags of a compacted list back onto the full index space: full[idx[r]] = part[r] (full is zeroed by the caller)

@@ -2047,19 +2047,27 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(
 // --------------------------------------------------------------------------------------------------
 // the embed loops as drivers: string_embed (tscode/embeds.py:91-120) and cyclical_embed (:636-717, :771-847)
 
-// is_new_structure over fingerprints on the device (tfd.hpp): super-blocks of TG_SUPER candidates, two launches each.
+// is_new_structure over fingerprints on the device (tfd.hpp): super-blocks of TG_SUPER candidates, three launches each.
 // d_acc u8[n], d_list i32[n], d_nk i32[1] (the number kept, on the device)
 static int launch_tfd_greedy(tsc_ctx *c, Scratch &s, const float *d_tf, int64_t n, int T, double thresh, uint8_t *d_acc, int32_t *d_list, int32_t *d_nk) {
-    uint8_t *d_dead;
-    TSC_TRY(s.get(size_t(TG_SUPER), &d_dead));
+    TSC_REQUIRE(T <= 12288, "fingerprints of %d torsions: the greedy filter takes up to 12288", T);
+    // per super-block: dead u8[TG_SUPER] and, right behind it, nz u64[TG_WORDS] -- one memset clears both
+    uint8_t *d_flags;
+    unsigned long long *d_sim;
+    TSC_TRY(s.get(size_t(TG_SUPER) + TG_WORDS * sizeof(unsigned long long), &d_flags));
+    TSC_TRY(s.get(size_t(TG_SUPER) * TG_WORDS, &d_sim));
+    unsigned long long *d_nz = reinterpret_cast<unsigned long long *>(d_flags + TG_SUPER);
+    const size_t lds_prior = size_t(tg_tile(T)) * std::max(T, 1) * sizeof(float), lds_pairs = 64 * T <= 12288 ? size_t(64) * std::max(T, 1) * sizeof(float) : 0;
     TSC_HIP(hipMemsetAsync(d_nk, 0, sizeof(int32_t), c->stream));
     for (int64_t base = 0; base < n; base += TG_SUPER) {
         const int nc = int(std::min<int64_t>(TG_SUPER, n - base));
-        TSC_HIP(hipMemsetAsync(d_dead, 0, size_t(nc), c->stream));
+        TSC_HIP(hipMemsetAsync(d_flags, 0, size_t(TG_SUPER) + TG_WORDS * sizeof(unsigned long long), c->stream));
         if (base > 0)
-            hipLaunchKernelGGL(k_tfd_greedy_prior, dim3(ceil_div(nc, 64), 16), dim3(256), 0, c->stream, d_tf, base, nc, T, thresh, (const int32_t *)d_list,
-                               (const int32_t *)d_nk, d_dead);
-        hipLaunchKernelGGL(k_tfd_greedy_block, dim3(1), dim3(TG_THREADS), 0, c->stream, d_tf, base, nc, T, thresh, (const uint8_t *)d_dead, d_acc, d_list, d_nk);
+            hipLaunchKernelGGL(k_tfd_greedy_prior, dim3(ceil_div(nc, 256), 32), dim3(256), lds_prior, c->stream, d_tf, base, nc, T, thresh, (const int32_t *)d_list,
+                               (const int32_t *)d_nk, d_flags);
+        hipLaunchKernelGGL(k_tfd_greedy_pairs, dim3(TG_WORDS, ceil_div(nc, 256)), dim3(256), lds_pairs, c->stream, d_tf, base, nc, T, thresh, d_sim, d_nz);
+        hipLaunchKernelGGL(k_tfd_greedy_replay, dim3(1), dim3(64), 0, c->stream, (const unsigned long long *)d_sim, (const unsigned long long *)d_nz, base, nc,
+                           (const uint8_t *)d_flags, d_acc, d_list, d_nk);
     }
     TSC_HIP(hipGetLastError());
     return 0;
