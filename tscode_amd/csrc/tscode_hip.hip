@@ -55,7 +55,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->basis_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // the side chain of the pipeline (sample embed, moments, basis) is three tiny kernels running beside the clash kernel, which
+        // fills the device: at the highest priority their workgroups are placed as soon as any of the clash kernel's retire
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->basis_stream, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
