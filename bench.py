@@ -479,7 +479,7 @@ def main():
                         "tile_ms": round(s["tile_ms"], 4),
                         "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
             "detail_note": "stage_ms_per_step and passes[].ms come from 3 extra steps with every library event on (pass_timing 2), "
-                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region",
+                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the chunk-local kernel runs: its events are taken at pass_timing 2 only)",
         }
         if sharded_mode:
             out["rccl_world"] = dist.get_world_size() if use_dist else 1

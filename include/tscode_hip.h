@@ -96,8 +96,8 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * synchronisation); 0 = never, 2 = every such pass (tests).  "deterministic_basis": 1 = the descriptor basis from fixed-order sums, so
  * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster);
  * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
- * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms),
- * 2 = also around every whole pass (gpu_ms) and the stages of tsc_pipeline_dev. */
+ * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms; passes run by the
+ * chunk-local kernel carry theirs at level 2 only), 2 = also around every whole pass (gpu_ms) and the stages of tsc_pipeline_dev. */
 int tsc_ctx_set_option(tsc_ctx *ctx, const char *name, double value);
 /* Device memory helpers for hosts that do not bring their own allocator (tests, C callers). */
 int tsc_malloc(tsc_ctx *ctx, size_t bytes, void **dptr);
@@ -324,7 +324,7 @@ typedef struct {
     int64_t pairs_screened;  /* pairs looked at by the descriptor sieve (0 when the register-tiled kernel ran) */
     int64_t new_keys;        /* cache keys appended (:76, :204) */
     double gpu_ms;           /* HIP-event time of the whole pass on this device (0 unless "pass_timing" is 2) */
-    double tile_ms;          /* HIP-event time of the pass's pair kernel alone (0 unless "pass_timing" >= 1) */
+    double tile_ms;          /* HIP-event time of the pass's pair kernel alone (0 unless "pass_timing" >= 1; chunk-local passes: 2) */
     int32_t algo;            /* kernel that ran the pass: 1 = register-tiled all-pairs, 2 = descriptor sieve, 3 = chunk-local kernel */
     int32_t nonfinite_input; /* 1: the run met a structure with a NaN or infinite coordinate (the same in every entry of a run; descriptor-sieve
                                 runs only).  Such a structure is similar to nothing -- every comparison of :75 with a NaN is false -- and is

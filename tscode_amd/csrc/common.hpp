@@ -108,6 +108,9 @@ struct tsc_ctx {
     bool xd_valid = false;
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
+    double *mom_acc = nullptr;            // moment accumulators of the pipeline's basis chain (k_sample_moments adds, k_descriptor_basis clears)
+    size_t mom_cap = 0;                   // doubles
+    bool mom_clean = false;               // all zero (as far as the host can tell: every chain enqueued so far ended with the clearing kernel)
     std::vector<int32_t> slot_host;       // heavy-atom slot table of the last tsc_pipeline_dev call and its device copy
     int32_t *slot_dev = nullptr;
     std::vector<hipEvent_t> event_pool;   // recycled timing events of prune runs

@@ -361,7 +361,9 @@ constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
 __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
                                                           int n_samples, double *__restrict__ Q, double *__restrict__ bias,
-                                                          unsigned *__restrict__ zero_word, double *__restrict__ spread_host = nullptr) {
+                                                          unsigned *__restrict__ zero_word, double *__restrict__ spread_host = nullptr,
+                                                          int clear_moments = 0) {
+    // clear_moments: the moment matrices are accumulators that k_sample_moments adds into: this kernel, their one reader, leaves them zero
     // spread_host (optional): host-visible copy of the two spread values written at the end (pinned memory; the host pre-sets +inf
     // and looks without waiting: whatever finite values it finds are this kernel's)
     // zero_word (optional): the running max |D| of a descriptor build that follows this kernel, cleared here
@@ -403,43 +405,48 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
         for (int a = 0; a < nf; ++a) g = fma(W[gi][a], W[gj][a], g);
         Gm[gi][gj] = g;
         __builtin_amdgcn_wave_barrier();
-        // every lane factors the 8 x 8 Gram matrix in registers (constant indices only): G = L L^T, then Li = L^-1
-        double L[KD][KD], Li[KD][KD];
-        double tr = 0.0;
+        // every lane factors the 8 x 8 Gram matrix in registers (constant indices only): G = L L^T, then Li = L^-1 -- in float32: this
+        // kernel is one wavefront's instruction stream (about 40 us, on the critical path of the pipeline's front half), most of it the
+        // float64 divisions and square roots of the factorisation; rows orthonormal to 1e-6 serve as well (the second pass of CholeskyQR2
+        // repairs what the first leaves, and the Gershgorin scaling below makes |V x| <= |x| hold for whatever comes out)
+        float L[KD][KD], Li[KD][KD];
+        float tr = 0.0f;
 #pragma unroll
         for (int i = 0; i < KD; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) L[i][j] = Gm[i][j];
+            for (int j = 0; j <= i; ++j) L[i][j] = float(Gm[i][j]);
             tr += L[i][i];
         }
         bool dead[KD];
+        float rinv[KD];  // 1 / L[i][i]
 #pragma unroll
         for (int i = 0; i < KD; ++i) {
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double sacc = L[i][j];
+                float sacc = L[i][j];
 #pragma unroll
-                for (int t = 0; t < j; ++t) sacc = fma(-L[i][t], L[j][t], sacc);
+                for (int t = 0; t < j; ++t) sacc = fmaf(-L[i][t], L[j][t], sacc);
                 if (i == j) {
-                    dead[i] = !(sacc > 1e-13 * tr) || !(tr > 0.0);
-                    L[i][i] = dead[i] ? 1.0 : sqrt(sacc);
+                    dead[i] = !(sacc > 1e-6f * tr) || !(tr > 0.0f);
+                    L[i][i] = dead[i] ? 1.0f : sqrtf(sacc);
+                    rinv[i] = 1.0f / L[i][i];
                 } else {
-                    L[i][j] = dead[j] ? 0.0 : sacc / L[j][j];
+                    L[i][j] = dead[j] ? 0.0f : sacc * rinv[j];
                 }
             }
             if (dead[i]) {
 #pragma unroll
-                for (int j = 0; j < i; ++j) L[i][j] = 0.0;
+                for (int j = 0; j < i; ++j) L[i][j] = 0.0f;
             }
         }
 #pragma unroll
         for (int j = 0; j < KD; ++j) {
 #pragma unroll
             for (int i = j; i < KD; ++i) {
-                double sacc = (i == j) ? 1.0 : 0.0;
+                float sacc = (i == j) ? 1.0f : 0.0f;
 #pragma unroll
-                for (int t = j; t < i; ++t) sacc = fma(-L[i][t], Li[t][j], sacc);
-                Li[i][j] = dead[i] ? 0.0 : sacc / L[i][i];
+                for (int t = j; t < i; ++t) sacc = fmaf(-L[i][t], Li[t][j], sacc);
+                Li[i][j] = dead[i] ? 0.0f : sacc * rinv[i];
             }
         }
         for (int a = lane; a < nf; a += 64) {
@@ -450,14 +457,15 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
             for (int i = 0; i < KD; ++i) {
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j <= i; ++j) acc = fma(Li[i][j], w[j], acc);
+                for (int j = 0; j <= i; ++j) acc = fma(double(Li[i][j]), w[j], acc);
                 W[i][a] = acc;
             }
         }
         __builtin_amdgcn_wave_barrier();
     };
-    cholesky_qr(V);
-    cholesky_qr(V);
+    // (the start rows are not orthonormalised first: C V spans the same nested subspaces whether V or L^-1 V is fed in -- CholeskyQR mixes
+    // row i with rows before it only -- so the rows that come out of the step are the same, and two of the four factorisations of this
+    // one-wavefront kernel, which sits on the critical path of the pipeline's front half, are saved)
     for (int it = 0; it < BASIS_ITERS; ++it) {
         // Z_k = C V_k with C[a][b] = M[a][b]/ns - mu_a mu_b
         for (int a = lane; a < nf; a += 64) {
@@ -533,8 +541,107 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
             __threadfence_system();
         }
     }
+    if (clear_moments) {
+        double *Mw = const_cast<double *>(M);
+        for (int e = lane; e < m * m; e += 64) Mw[e] = 0.0;
+    }
 }
 
+// The first link of the pipeline's basis chain on one device: the sample poses are embedded (heavy atoms, into LDS only) and the second
+// moments of their features added up -- k_transform + k_feature_moments (fast form) in one launch, without the round trip of the sample's
+// coordinates through memory.  grid (groups of SM_CHUNKS chunks of TR_POSES samples, NFAM); M0 / M1 are zero on entry (k_descriptor_basis clears them again).
+// dynamic LDS: sample_moments_lds_bytes
+constexpr int SM_CHUNKS = 1;  // chunks of TR_POSES samples per workgroup of k_sample_moments (4: 52 us instead of 26 -- a chunk is a chain of
+                              // dependent loads, about 13 us beside the clash kernel, and the chains of a workgroup run one after the other)
+__host__ __device__ inline size_t sample_moments_lds_bytes(int n_mols, int h) {
+    return (transform_lds_bytes(n_mols) + 15) / 16 * 16 + size_t(TR_POSES) * (size_t(h) * 3 + size_t(h) + 1) * sizeof(double);
+}
+__global__ __launch_bounds__(256) void k_sample_moments(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
+                                                        const double *__restrict__ rot, const double *__restrict__ pos,
+                                                        const int32_t *__restrict__ sample_idx, int n_samples, const int32_t *__restrict__ heavy_slot,
+                                                        int h, int nf0, int nf1, double *__restrict__ M0, double *__restrict__ M1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_sm_raw[];
+    const int fam = blockIdx.y, nf = fam == 0 ? nf0 : nf1;
+    if (nf == 0) return;
+    const int n = ft.n_total, nm = ft.n_mols, tid = threadIdx.x, m = nf + 1;
+    double *s_tr = reinterpret_cast<double *>(s_sm_raw);
+    int64_t *sP = reinterpret_cast<int64_t *>(s_tr);
+    double *sR = s_tr + TR_POSES, *sT = sR + TR_POSES * nm * 9;
+    int *sC = reinterpret_cast<int *>(sT + TR_POSES * nm * 3);
+    double *s_x = reinterpret_cast<double *>(s_sm_raw + (transform_lds_bytes(nm) + 15) / 16 * 16);   // [TR_POSES][h * 3]
+    double *s_n = s_x + size_t(TR_POSES) * h * 3;                                                    // [TR_POSES][m]
+    double *__restrict__ Mf = fam == 0 ? M0 : M1;
+    const int n_chunks = (n_samples + TR_POSES - 1) / TR_POSES;
+    // a workgroup takes SM_CHUNKS consecutive chunks and adds their products up in registers before it touches the accumulators
+    constexpr int ACC = 8;
+    const bool in_regs = m * m <= 256 * ACC;
+    double acc[ACC];
+#pragma unroll
+    for (int u = 0; u < ACC; ++u) acc[u] = 0.0;
+    for (int ch = blockIdx.x * SM_CHUNKS; ch < min(n_chunks, (int(blockIdx.x) + 1) * SM_CHUNKS); ++ch) {
+        const int s0 = ch * TR_POSES, ns = min(TR_POSES, n_samples - s0);
+        if (tid < ns) sP[tid] = int64_t(sample_idx[s0 + tid]);
+        __syncthreads();
+        for (int q = tid; q < ns * nm * 9; q += 256) {
+            const int row = q / (nm * 9), w = q - row * nm * 9;
+            sR[q] = rot[sP[row] * nm * 9 + w];
+        }
+        for (int q = tid; q < ns * nm * 3; q += 256) {
+            const int row = q / (nm * 3), w = q - row * nm * 3;
+            sT[q] = pos[sP[row] * nm * 3 + w];
+        }
+        for (int q = tid; q < ns * nm; q += 256) {
+            const int row = q / nm, w = q - row * nm;
+            sC[q] = conf_idx[sP[row] * nm + w];
+        }
+        __syncthreads();
+        for (int e = tid; e < ns * n; e += 256) {
+            const int row = e / n, a = e - row * n;
+            const int hs = heavy_slot[a];
+            if (hs < 0) continue;
+            double v[3];
+            embed_atom_staged(frags, ft, sR, sT, sC, row, a, v);
+            double *o = s_x + (size_t(row) * h + hs) * 3;
+            o[0] = v[0], o[1] = v[1], o[2] = v[2];
+        }
+        __syncthreads();
+        for (int e = tid; e < ns * m; e += 256) {
+            const int sm = e / m, a = e - sm * m;
+            s_n[sm * m + a] = (a < nf) ? feature(s_x + size_t(sm) * h * 3, h, fam, a) : 1.0;
+        }
+        __syncthreads();
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < ACC; ++u) {
+                const int e = tid + 256 * u;
+                if (e < m * m) {
+                    const int a = e / m, b = e - a * m;
+                    if (b >= a) {
+                        double t = 0.0;
+                        for (int sm = 0; sm < ns; ++sm) t += s_n[sm * m + a] * s_n[sm * m + b];
+                        acc[u] += t;
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < m * m; e += 256) {
+                const int a = e / m, b = e - a * m;
+                if (b < a) continue;
+                double t = 0.0;
+                for (int sm = 0; sm < ns; ++sm) t += s_n[sm * m + a] * s_n[sm * m + b];
+                atomicAdd(&Mf[e], t);
+            }
+        }
+        __syncthreads();
+    }
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < ACC; ++u) {
+            const int e = tid + 256 * u;
+            if (e < m * m && e % m >= e / m) atomicAdd(&Mf[e], acc[u]);
+        }
+    }
+}
 
 struct SieveArgs {
     int n;   // upper bound of the active count the grid was sized for (structures of the run)

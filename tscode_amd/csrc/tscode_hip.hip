@@ -1081,6 +1081,8 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
     // chunks are a few row tiles long -- at 57k structures the passes k = 1000, 500 and 200 take 37, 39 and 50 us instead of
     // 52-58 -- and loses beyond: k = 100 takes 58 us there against 53 on the two-launch path; "local_max_chunk" moves the limit)
+    // (the longest chunk counts, i.e. the last one with its remainder: at 57 046 structures in 2 000 chunks -- 28 each, 1 074 in the last --
+    // the chunk-local kernel was tried with the long chunk on workgroups of its own: 97 us against 37 for the two launches)
     p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && std::max<int64_t>(longest_chunk, g.cs) <= std::min(LP_MAX_ROWS, c->local_max_chunk) &&
                    c_hi > c_lo;
     p->cur_fused = false;
@@ -1099,7 +1101,9 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         int nxt = -1;
         const StepArgs sa = next_step_args(p, &nxt);
         const int64_t blocks = int64_t(a.n_reg) * a.nb_regular + a.nb_last;
-        hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
+        // (its own events only at pass_timing 2: level 1 is what a timed region carries for the PAIR kernel's durations, and a pair of
+        // events costs a small pass about 6 us)
+        hipEvent_t e0 = c->pass_timing >= 2 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 2 ? p->ev[slot][2] : nullptr;
         hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask, p->bits, int(p->bit_words),
                               view_of_open_pass(p), p->heavy, (const double *)p->Gall, (const float *)p->Dall, later_views(p), p->counters, p->bsum,
                               SCAN_TILE, step_ctx(p, range), sa, &p->tickets->local);
@@ -1496,7 +1500,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             s.nonfinite_input = nonfinite ? 1 : 0;
             float ms = 0;
             if (c->pass_timing >= 2 && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
-            if (c->pass_timing >= 1 && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
+            if (c->pass_timing >= (rec[slot].algo == ALGO_LOCAL ? 2 : 1) && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
         }
         p->collected = true;
     }
@@ -2517,6 +2521,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     } basis_join{c, false};
     int n_samples = 0;
     double *d_sample = nullptr, *d_moments = nullptr;
+    bool fused_sample = false;
     if (c->early_basis && c->prune_algo != ALGO_TILE) {
         TSC_TRY(basis_sample_table(c, n_poses, &n_samples));
         TSC_TRY(s.get(size_t(n_samples) * n_heavy * 3, &d_sample));
@@ -2526,7 +2531,22 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(s.get(size_t(n_poses), &ext.G));
             TSC_TRY(s.get(4, &ext.dmax_bits));
         }
-        TSC_TRY(s.get(moment_doubles(n_heavy), &d_moments));
+        // one device: the sample is embedded and reduced by ONE kernel into accumulators the context keeps zero between runs (sieve.hpp,
+        // k_sample_moments); a sharded run takes the fixed-order sums instead (k_transform + k_feature_moments, "deterministic_basis")
+        fused_sample = !c->deterministic_basis && sample_moments_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024;
+        if (fused_sample) {
+            const size_t a = size_t(n_features(n_heavy, 0) + 1), b = size_t(n_features(n_heavy, 1) + 1), need = a * a + b * b;
+            if (c->mom_cap < need) {
+                if (c->mom_acc) c->release(c->mom_acc);
+                c->mom_acc = nullptr, c->mom_cap = 0;
+                void *q = nullptr;
+                TSC_TRY(c->alloc(need * sizeof(double), &q));
+                c->mom_acc = static_cast<double *>(q), c->mom_cap = need, c->mom_clean = false;
+            }
+            if (!c->mom_clean) TSC_HIP(hipMemsetAsync(c->mom_acc, 0, c->mom_cap * sizeof(double), st));
+        } else {
+            TSC_TRY(s.get(moment_doubles(n_heavy), &d_moments));
+        }
         TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
     }
     // K1+K2 fused verdicts
@@ -2538,14 +2558,27 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         // clash kernel is already running, and the chain has the whole of it (and the scan) to finish in.
         TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
         basis_join.pending = true;
-        hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft, conf_idx,
-                           rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
-                           (const int32_t *)nullptr, d_moments, int(moment_doubles(n_heavy)));
         // (the two families' descriptor spread is written to pinned host memory by the basis kernel itself: no copy, no wait -- the host
-        // pre-sets "no estimate" and looks after it has fetched the count below, long after the chain has finished)
+        // pre-sets "no estimate" and looks after it has fetched the count below)
         double *spread_host = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET);
         spread_host[0] = spread_host[1] = __builtin_inf();
-        TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments, spread_host));
+        if (fused_sample) {
+            const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
+            c->mom_clean = false;
+            hipLaunchKernelGGL(k_sample_moments, dim3(ceil_div(ceil_div(n_samples, TR_POSES), SM_CHUNKS), NFAM), dim3(256), sample_moments_lds_bytes(ft.n_mols, n_heavy), c->basis_stream,
+                               frags, ft, conf_idx, rot, pos, (const int32_t *)c->sample_dev, n_samples, (const int32_t *)d_slot, n_heavy, nf0, nf1, c->mom_acc,
+                               c->mom_acc + size_t(nf0 + 1) * (nf0 + 1));
+            hipLaunchKernelGGL(k_descriptor_basis, dim3(NFAM), dim3(64), 0, c->basis_stream, (const double *)c->mom_acc,
+                               (const double *)(c->mom_acc + size_t(nf0 + 1) * (nf0 + 1)), nf0, nf1, n_samples, d_basis, d_basis + size_t(KD) * (nf0 + nf1),
+                               ext.dmax_bits, spread_host, 1);
+            TSC_HIP(hipGetLastError());
+            c->mom_clean = true;
+        } else {
+            hipLaunchKernelGGL(k_transform, dim3(grid_for(n_samples, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), c->basis_stream, frags, ft,
+                               conf_idx, rot, pos, (const int32_t *)c->sample_dev, int64_t(n_samples), (double *)nullptr, (const int32_t *)d_slot, n_heavy, d_sample,
+                               (const int32_t *)nullptr, d_moments, int(moment_doubles(n_heavy)));
+            TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments, spread_host));
+        }
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
     }
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
