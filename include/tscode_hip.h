@@ -95,6 +95,9 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * beyond the screen's limit, where the rows' ranges are long enough for that to pay (decided per pass on the device, one
  * synchronisation); 0 = never, 2 = every such pass (tests).  "deterministic_basis": 1 = the descriptor basis from fixed-order sums, so
  * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster);
+ * "stage1_f32": the pair kernels' first look at a pair that passed the screen (H = p^T q and the quartic tests) reads a float32 copy
+ * of the coordinates with the rounding bound that goes with it, the float64 coordinates only for what that leaves undecided: 0 = never,
+ * 1 (default) = in runs with 128 MB of heavy-atom coordinates or more (where the gathers come from HBM), 2 = always;
  * "pass_timing": HIP events for tsc_pass_stats.gpu_ms / tile_ms and the pipeline's stage timings: 0 = none (default; an
  * event record in the stream costs about 4 us on MI355X), 1 = the pair kernel's own start/stop events (tile_ms; passes run by the
  * chunk-local kernel carry theirs at level 2 only), 2 = also around every whole pass (gpu_ms) and the stages of tsc_pipeline_dev. */

@@ -179,17 +179,19 @@ def test_prune_golden(eng, algo):
 SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixture `algo` also runs the other setting
 
 
-@pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3)],
+@pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3),
+                        (2, 0, False, 4), (2, 0, False, 5)],
                 ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen", "algo-sieve-separate-apply", "algo-auto-ranks-from-memory",
-                     "algo-sieve-culled"])
+                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1"])
 def algo(request, eng):
     """Runs a test once per route through the prune: automatic choice (descriptor sieve whose pair kernel applies the verdicts
     tile by tile; passes with short chunks in the chunk-local kernel), register-tiled all-pairs (its passes are applied by
     k_apply_pass), descriptor sieve with every pass through the global path, the same with the screen's other instruction
     sequence (option sieve_trim flipped from its default), the same with k_apply_pass as a launch of its own (what a
     multi-rank pass does), the automatic choice with k_open_rows reading the scan-block prefix from memory (the path of
-    ensembles beyond 4 M structures), and the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
-    what the large passes of C4 / C5 run by default)."""
+    ensembles beyond 4 M structures), the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
+    what the large passes of C4 / C5 run by default), and the last two again with stage 1 of the pair kernels reading the float32 copy
+    of the coordinates (what runs of 128 MB of heavy atoms and more do by default)."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
@@ -197,10 +199,13 @@ def algo(request, eng):
     eng.set_option("fused_apply", 1 if request.param[3] else 0)
     if request.param[3] == 2:
         eng.set_option("open_lds_blocks", 0)
-    if request.param[3] == 3:           # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
+    if request.param[3] in (3, 5):      # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
         eng.set_option("cull_min_pairs", 0)
         eng.set_option("cull", 2)
+    if request.param[3] in (4, 5):      # H of stage 1 from the float32 copy, its own rounding bound (sieve.hpp: pair_stage1)
+        eng.set_option("stage1_f32", 2)
     yield request.param[0]
+    eng.set_option("stage1_f32", 1)
     eng.set_option("cull_min_pairs", 2.0e9)
     eng.set_option("cull", 1)
     eng.set_option("prune_algo", 0)

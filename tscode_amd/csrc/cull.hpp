@@ -353,7 +353,7 @@ struct CullArgs {
 // screen's limit of the row tile's box in both families; else the same packed-fp32 screen as k_rmsd_sieve, the same queue,
 // the same two evaluation stages.  A pair that passes the screen is credited to its lower-ranked structure; whether the higher
 // one lies inside that row's range (beyond the row, before its stop column, same chunk) is checked where the pair is decoded.
-template <int TI>
+template <int TI, bool F32>
 __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
                                                   const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                   const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const int slot, const int seg) {
@@ -435,10 +435,12 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
 
     // an entry = (row of the tile, column position inside the segment); the pair = the two structures at those positions, the one
     // with the lower active rank playing the reference's `ref` (rmsd_pruning.py:92: the row), the other its column
+    int64_t si = 0, sj = 0;  // the structures of the pair decoded last
     auto decode = [&](unsigned e, int &lo, int &hi, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
         const int r1 = ca.crank[p0 + int(e >> 12)], r2 = ca.crank[seg_lo + int(e & 0xfffu)];
         lo = min(r1, r2), hi = max(r1, r2);
         const int64_t i = act[lo], j = act[hi];
+        si = i, sj = j;
         pp = heavy + i * h3, pq = heavy + j * h3;
         Gi = Gall[i], Gj = Gall[j];
         // the column lies inside the row's range (rows of another chunk, or behind a cache hit, do not) -- and before the similar column
@@ -499,8 +501,7 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
             const double *pp, *pq;
             double Gi, Gj, H[9];
             if (decode(e, lo, hi, pp, pq, Gi, Gj)) {  // (the lanes of a group hold the same pair: they branch together)
-                pair_H(pp, pq, a.h, sub, lpp, H);
-                const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
+                const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
                 cand = sub == 0 && verdict == PAIR_UNDECIDED;
                 counted = sub == 0;
                 if (sub == 0 && verdict == PAIR_SIMILAR) atomicMin(&best[lo], hi);
@@ -588,6 +589,7 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
     }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256, TSC_SIEVE_OCC2) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                             const double *__restrict__ Gall, const int32_t *__restrict__ cend,
                                                                             int32_t *__restrict__ best, PassCounters *__restrict__ counters,
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256, TSC_SIEVE_OCC2) void k_rmsd_sieve_sorted(const
     const int groups = (my_tiles + 3) / 4;
     for (long long item = blockIdx.x; item < (long long)groups * n_seg; item += gridDim.x) {
         const int seg = int(item / groups), slot = int(item - (long long)seg * groups) * 4 + wid;
-        sieve_item_sorted<16>(heavy, act, Gall, cend, best, counters, st, a, ca, slot, seg);
+        sieve_item_sorted<16, F32>(heavy, act, Gall, cend, best, counters, st, a, ca, slot, seg);
         __builtin_amdgcn_wave_barrier();
     }
 }

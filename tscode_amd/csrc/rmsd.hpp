@@ -998,12 +998,21 @@ __device__ inline Quartic horn_quartic(const double H[9]) {
 // to the explicit-rotation path, it cannot change a verdict.  Structures far from the origin (the path never centres,
 // rmsd_pruning.py:7-41) make Gp, Gq and L grow with the square of the offset while the margin P(L) ~ P'(l1) (L - l1) keeps
 // L - l1 = h (rmsd^2 - thr^2) / 2: the tests decide less and less (at 10^4 A nothing) and everything takes the exact path.
+// H FORMED FROM A FLOAT32 COPY of the coordinates (sieve.hpp, pair_H32: the first look at a pair that passed the screen reads half the
+// bytes): p32 = p (1 + d), |d| <= 2^-24, products of two floats are exact in float64 and summed there, so
+// |dH_ij| <= (2^-23 + 2^-48 + h u) sum_a |p_ai q_aj| and |dH|_F <= gamma32 S with gamma32 = 2.0001 * 2^-24 + h u.  The derivation above goes
+// through with that gamma in the H terms (32 gamma32 rho^4) while the test point keeps its float64 bound (12 h u rho): below
+// 64 gamma32 rho^4 together.  Such a test decides every pair whose margin is not tiny (|P(L)| is some 1e-3 .. 1e-1 of its term sum for
+// the pairs a prune meets, kappa about 8e-6); the others are formed again from the float64 coordinates.
 constexpr double QUARTIC_KAPPA_MIN = 1e-12;
-__device__ inline double quartic_kappa(int h, double half_sum, double L) {
+__device__ inline double quartic_gamma64(int h) { return 1.1102230246251565e-16 * double(h); }
+__device__ inline double quartic_gamma32(int h) { return 2.0001 * 5.9604644775390625e-08 + 1.1102230246251565e-16 * double(h); }
+__device__ inline double quartic_kappa_g(double gamma, double half_sum, double L) {
     const double rho = half_sum / L, r2 = rho * rho;          // callers test L > 0 themselves
-    const double k = 64.0 * 1.1102230246251565e-16 * double(h) * r2 * r2;
+    const double k = 64.0 * gamma * r2 * r2;
     return (k > QUARTIC_KAPPA_MIN) ? k : QUARTIC_KAPPA_MIN;  // (a NaN k -- L == 0 -- keeps the minimum; the L > 0 test fails then)
 }
+__device__ inline double quartic_kappa(int h, double half_sum, double L) { return quartic_kappa_g(quartic_gamma64(h), half_sum, L); }
 
 __device__ inline bool quartic_above_top_root(const Quartic &q, double L, double kappa) {
     const double L2 = L * L;
@@ -1035,13 +1044,16 @@ __device__ inline bool certainly_dissimilar(const double H[9], double L, double 
 
 // half_sum = (Gp + Gq) / 2, half_h_thr2 = h thr^2 / 2, two_thr2 = 2 thr^2 (pass a negative two_thr2 to switch the
 // near-duplicate test off: h < 4, or a maxdev threshold other than 2 thr)
-__device__ inline int pair_verdict(const double H[9], double half_sum, double half_h_thr2, double two_thr2, int h) {
+__device__ inline int pair_verdict_g(const double H[9], double half_sum, double half_h_thr2, double two_thr2, double gamma) {
     const Quartic q = horn_quartic(H);
     const double L = half_sum - half_h_thr2;
-    if (quartic_above_top_root(q, L, quartic_kappa(h, half_sum, L))) return PAIR_DISSIMILAR;
+    if (quartic_above_top_root(q, L, quartic_kappa_g(gamma, half_sum, L))) return PAIR_DISSIMILAR;
     const double x = half_sum - two_thr2;
-    if (two_thr2 > 0.0 && quartic_between_top_roots(q, x, quartic_kappa(h, half_sum, x))) return PAIR_SIMILAR;
+    if (two_thr2 > 0.0 && quartic_between_top_roots(q, x, quartic_kappa_g(gamma, half_sum, x))) return PAIR_SIMILAR;
     return PAIR_UNDECIDED;
+}
+__device__ inline int pair_verdict(const double H[9], double half_sum, double half_h_thr2, double two_thr2, int h) {
+    return pair_verdict_g(H, half_sum, half_h_thr2, two_thr2, quartic_gamma64(h));
 }
 
 // One wavefront = one work item = (row tile of TI consecutive active rows) x (one column segment).

@@ -50,6 +50,9 @@ constexpr int DESC_SAMPLE = 4096;  // structures used to estimate the principal 
 constexpr int DESC_MAX_FEAT = 256; // features per family that enter the descriptor (any subset keeps the bound valid)
 constexpr unsigned NONFINITE_BITS = 0x7fc00000u;  // what the running maximum of |descriptor| reads once a non-finite structure was seen
 
+// floats per structure of the float32 copy of the heavy atoms (pair_stage1 below): x y z of four atoms per three float4, zero-padded
+__host__ __device__ inline int heavy32_pitch(int h) { return 12 * ((h + 3) / 4); }
+
 // feature a of family fam of the structure at x (h atoms, xyz triples)
 __device__ inline double feature(const double *__restrict__ x, int h, int fam, int a) {
     if (fam == 0) return sqrt(x[3 * a] * x[3 * a] + x[3 * a + 1] * x[3 * a + 1] + x[3 * a + 2] * x[3 * a + 2]);
@@ -281,9 +284,11 @@ __global__ __launch_bounds__(256) void k_transform_describe(const double *__rest
                                                              const int32_t *__restrict__ heavy_slot, int n_heavy, double *__restrict__ heavy_out,
                                                              const int32_t *__restrict__ n_out_dev, int nf0, int nf1, const double *__restrict__ Q,
                                                              const double *__restrict__ bias, float *__restrict__ D, double *__restrict__ G,
-                                                             unsigned *__restrict__ dmax_bits) {
+                                                             unsigned *__restrict__ dmax_bits, float *__restrict__ heavy32_out = nullptr) {
+    // heavy32_out (optional): the float32 copy of the heavy atoms that stage 1 of the pair kernels reads (pair_stage1), zero-padded rows
     extern __shared__ __attribute__((aligned(16))) double s_tr[];
     const int n = ft.n_total, nm = ft.n_mols, tid = threadIdx.x, pitch = (n_heavy * 3) | 1;
+    const int pitch32 = heavy32_pitch(n_heavy), pad32 = pitch32 - 3 * n_heavy;
     const int64_t n_out = *n_out_dev;
     int64_t *sP = reinterpret_cast<int64_t *>(s_tr);
     double *sR = s_tr + TR_POSES, *sT = sR + TR_POSES * nm * 9;
@@ -320,8 +325,14 @@ __global__ __launch_bounds__(256) void k_transform_describe(const double *__rest
             if (hs >= 0) {
                 double *hv = heavy_out + (r * n_heavy + hs) * 3, *x = s_x + row * pitch + hs * 3;
                 hv[0] = x[0] = v[0], hv[1] = x[1] = v[1], hv[2] = x[2] = v[2];
+                if (heavy32_out) {
+                    float *hf = heavy32_out + r * pitch32 + hs * 3;
+                    hf[0] = float(v[0]), hf[1] = float(v[1]), hf[2] = float(v[2]);
+                }
             }
         }
+        if (heavy32_out)
+            for (int e = tid; e < np * pad32; e += 256) heavy32_out[(r0 + e / pad32) * pitch32 + 3 * n_heavy + e % pad32] = 0.0f;
         __syncthreads();
         describe_from_lds(s_q, s_x, pitch, n_heavy, nf0, nf1, bias, np, TR_POSES, r0, D, G, dmax_bits);
         __syncthreads();
@@ -656,6 +667,7 @@ struct SieveArgs {
     const int32_t *tile_cmax;   // device: per row tile, the largest stop column of its 16 rows (k_open_rows)
     const unsigned *dmax_bits;  // device: largest |descriptor component| of the run (bit pattern of a float), see screen_limit32
     double desc_limit;          // h thr^2: exact squared descriptor distance above which a pair is certainly dissimilar
+    const float *heavy32;       // float32 copy of the heavy atoms (heavy32_pitch(h) floats per structure), or null: stage 1 in float64 only
     unsigned long long *dbg;    // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront of the launch (tools/stamps.py), else null
 };
 
@@ -692,6 +704,64 @@ __device__ inline void pair_H(const double *__restrict__ p, const double *__rest
     }
 }
 
+// The float32 copy of the heavy atoms that stage 1 reads first: structure i at heavy32 + i * pitch32, pitch32 = 12 * ceil(h / 4) floats
+// (x y z of four atoms per three float4; zero-padded).  The gathers of the pairs that pass the screen are what the pair kernels wait
+// for -- with the float64 loads issued twice a C4 step takes 18.8 instead of 12.2 ms, a C3 step 1.00 instead of 0.86 -- and the quartic
+// tests on H from this copy, with the rounding bound that goes with it (rmsd.hpp: quartic_gamma32), decide all but the pairs with a
+// tiny margin; those are formed again from the float64 coordinates, as is everything the explicit-rotation path needs.
+
+__global__ __launch_bounds__(256) void k_heavy32(const double *__restrict__ heavy, int64_t n, int h, float *__restrict__ out) {
+    const int h3 = h * 3, pitch = heavy32_pitch(h);
+    const int64_t total = n * pitch;
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+        const int64_t i = e / pitch;
+        const int w = int(e - i * pitch);
+        out[e] = w < h3 ? float(heavy[i * h3 + w]) : 0.0f;
+    }
+}
+
+// H = p^T q from the float32 copy: lane `sub` of the pair's `lpp` lanes takes the groups of four atoms sub, sub + lpp, ...; the
+// products of two floats are exact in float64, the sums run there
+__device__ inline void pair_H32(const float *__restrict__ p, const float *__restrict__ q, int hq, int sub, int lpp, double H[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] = 0.0;
+    for (int g = sub; g < hq; g += lpp) {
+        const f32x4 *pv = reinterpret_cast<const f32x4 *>(p + 12 * g), *qv = reinterpret_cast<const f32x4 *>(q + 12 * g);
+        const f32x4 p0 = pv[0], p1 = pv[1], p2 = pv[2], q0 = qv[0], q1 = qv[1], q2 = qv[2];
+        const float pf[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+        const float qf[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double px = pf[3 * a], py = pf[3 * a + 1], pz = pf[3 * a + 2];
+            const double qx = qf[3 * a], qy = qf[3 * a + 1], qz = qf[3 * a + 2];
+            H[0] = fma(px, qx, H[0]), H[1] = fma(px, qy, H[1]), H[2] = fma(px, qz, H[2]);
+            H[3] = fma(py, qx, H[3]), H[4] = fma(py, qy, H[4]), H[5] = fma(py, qz, H[5]);
+            H[6] = fma(pz, qx, H[6]), H[7] = fma(pz, qy, H[7]), H[8] = fma(pz, qz, H[8]);
+        }
+    }
+    for (int off = lpp >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], off);
+    }
+}
+
+// Stage 1 of a pair that passed the screen: PAIR_DISSIMILAR / PAIR_SIMILAR / PAIR_UNDECIDED (rmsd.hpp).  With the float32 copy the tests
+// run on H from that copy alone, with its own rounding bound; what they leave undecided goes to the explicit-rotation stage like any
+// other undecided pair (it forms H from the float64 coordinates).  F32 = false: H from the float64 coordinates, as ever (a template
+// parameter, not a branch: with both loops in one kernel the float64 one lost a tenth of its speed to the register allocation).
+template <bool F32>
+__device__ inline int pair_stage1(const double *__restrict__ heavy, const float *__restrict__ heavy32, int64_t i, int64_t j, int h, double half_sum,
+                                  double half_h_thr2, double two_thr2, int sub, int lpp) {
+    double H[9];
+    if (F32) {
+        const int pitch = heavy32_pitch(h);
+        pair_H32(heavy32 + i * pitch, heavy32 + j * pitch, pitch / 12, sub, lpp, H);
+        return pair_verdict_g(H, half_sum, half_h_thr2, two_thr2, quartic_gamma32(h));
+    }
+    pair_H(heavy + i * h * 3, heavy + j * h * 3, h, sub, lpp, H);
+    return pair_verdict(H, half_sum, half_h_thr2, two_thr2, h);
+}
+
 // One pair end to end: true iff it is similar in the reference's sense (rmsd < thr and maxdev < 2 thr,
 // rmsd_pruning.py:75); exact_taken tells whether the explicit-rotation path ran.
 __device__ inline bool pair_is_similar(const double *__restrict__ p, const double *__restrict__ q, int h, double Gp, double Gq,
@@ -725,7 +795,7 @@ struct FusedApply {
     StepArgs next;
 };
 
-template <int TI, int CPL, bool TRIM>
+template <int TI, int CPL, bool TRIM, bool F32 = false>
 __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                            const double *__restrict__ Gall, const float *__restrict__ D,
                                            const int32_t *__restrict__ cend,
@@ -841,10 +911,12 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     // cost is paid once per 64 candidates instead of once per stage-1 batch with a handful of lanes busy.
     unsigned short *exq = s_exq[wid];
     int qe = 0;
+    int64_t si = 0, sj = 0;  // the structures of the pair decoded last
     auto decode = [&](unsigned e, int &t, int &col, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
         t = int(e >> 12);
         col = seg_lo + int(e & 0xfffu);
         const int64_t i = act[r0 + t], j = act[col];
+        si = i, sj = j;
         pp = heavy + i * h3, pq = heavy + j * h3;
         Gi = Gall[i], Gj = Gall[j];
     };
@@ -861,8 +933,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
             const double *pp, *pq;
             double Gi, Gj, H[9];
             decode(e, t, col, pp, pq, Gi, Gj);
-            pair_H(pp, pq, a.h, sub, lpp, H);
-            const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
+            const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
             cand = sub == 0 && verdict == PAIR_UNDECIDED;
             sim = sub == 0 && verdict == PAIR_SIMILAR;
             if (sim) atomicMin(&best[r0 + t], col);
@@ -1113,7 +1184,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     }
 }
 
-template <int TI, int CPL, bool TRIM = false, bool FUSED = false>
+template <int TI, int CPL, bool TRIM = false, bool FUSED = false, bool F32 = false>
 __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
                                                         const int32_t *__restrict__ cend,
@@ -1131,7 +1202,7 @@ __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TS
     // a pass that is gated off: k_open_rows): one scalar load and out
     const int tcm = a.tile_cmax[tile];
     if (tcm <= seg_lo) return;
-    sieve_item<TI, CPL, TRIM>(heavy, act, Gall, D, cend, best, counters, st, a);
+    sieve_item<TI, CPL, TRIM, F32>(heavy, act, Gall, D, cend, best, counters, st, a);
     if constexpr (FUSED) {
         // this item's atomicMin's on best[] are at the L2 before its arrival is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -544,6 +544,7 @@ struct tsc_prune {
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
+    float *heavy32 = nullptr;            // float32 copy of the heavy atoms for stage 1 of the pair kernels (sieve.hpp: pair_stage1)
     bool morton_sorted = false;          // the run's Morton order exists (made when the first pass is really culled)
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
     int part_rank = 0, part_world = 1, part_min_chunks = 0;
@@ -654,6 +655,7 @@ struct ExternalDescriptors {
     float *D = nullptr;
     double *G = nullptr;
     unsigned *dmax_bits = nullptr;
+    float *heavy32 = nullptr;  // (optional) the float32 copy of the heavy atoms, written by the kernel that embedded them
 };
 
 // Descriptors of every structure for the sieve.  `basis` (optional): a basis already enqueued elsewhere (any orthonormal
@@ -785,6 +787,18 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
         }
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
+        // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
+        // (it pays where the gathers come from HBM: 41 MB of heavy atoms at C3 sit in the 256 MB infinity cache and the conversions cost the
+        // VALU-bound kernel 2 %; at C4's 348 MB a step goes from 12.1 to 10.6 ms.  "stage1_f32": 0 never, 1 from 128 MB on, 2 always)
+        if (!rc && (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n) * h * 24.0 >= 128e6))) {
+            if (ext && ext->heavy32) {  // written by the kernel that embedded the structures
+                p->heavy32 = ext->heavy32;
+            } else {
+                rc = palloc(p, size_t(n) * heavy32_pitch(h), &p->heavy32);
+                if (!rc) hipLaunchKernelGGL(k_heavy32, dim3(unsigned(std::min<int64_t>(ceil_div<int64_t>(n * heavy32_pitch(h), 256), 65536))), dim3(256), 0, c->stream,
+                                            heavy_dev, n, h, p->heavy32);
+            }
+        }
     }
     if (!rc) rc = palloc(p, 1, &p->tickets);
     if (!rc && p->algo == ALGO_TILE) {
@@ -995,6 +1009,7 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.heavy32 = p->heavy32;
         a.tile_cmax = p->tile_cmax;
         a.drain_min = c->drain_min;
         a.dbg = nullptr;
@@ -1024,12 +1039,17 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
                 p->last_slot = -1;  // closed on the device, by the pair kernel's last tile
             }
         }
-#define TSC_LAUNCH_SIEVE(CPL, TRIM, FUSED)                                                                                                        \
-    hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, CPL, TRIM, FUSED>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act,     \
+#define TSC_LAUNCH_SIEVE_F(CPL, TRIM, FUSED, F32)                                                                                                 \
+    hipExtLaunchKernelGGL((k_rmsd_sieve<TILE_ROWS, CPL, TRIM, FUSED, F32>), grid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act, \
                           (const double *)p->Gall, (const float *)p->Dc, (const int32_t *)p->cend, p->best, p->counters,                          \
                           (const PruneState *)p->state, a, fa)
+#define TSC_LAUNCH_SIEVE(CPL, TRIM, FUSED) TSC_LAUNCH_SIEVE_F(CPL, TRIM, FUSED, false)
         const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
-        if (p->cur_fused) {
+        // (stage 1 on the float32 copy exists for the default shape of the kernel only)
+        if (trim && a.heavy32) {
+            if (p->cur_fused) TSC_LAUNCH_SIEVE_F(2, true, true, true);
+            else TSC_LAUNCH_SIEVE_F(2, true, false, true);
+        } else if (p->cur_fused) {
             if (c->sieve_cpl == 1) TSC_LAUNCH_SIEVE(1, false, true);
             else if (trim) TSC_LAUNCH_SIEVE(2, true, true);
             else if (c->sieve_cpl == 2) TSC_LAUNCH_SIEVE(2, false, true);
@@ -1041,6 +1061,7 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
             else TSC_LAUNCH_SIEVE(4, false, false);
         }
 #undef TSC_LAUNCH_SIEVE
+#undef TSC_LAUNCH_SIEVE_F
     }
     TSC_HIP(hipGetLastError());
     return 0;
@@ -1226,6 +1247,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.heavy32 = p->heavy32;
         a.drain_min = c->drain_min;
         CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k)};
         const int n_tiles = ceil_div(A, TILE_ROWS), my_tiles = (n_tiles - rank + world - 1) / world;
@@ -1233,9 +1255,13 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const int n_seg = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, a.seg_cols);
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
         const int64_t items = int64_t(ceil_div(my_tiles, 4)) * n_seg;
-        hipExtLaunchKernelGGL(k_rmsd_sieve_sorted, dim3(unsigned(std::max<int64_t>(1, std::min<int64_t>(items, c->cull_grid)))), dim3(256), 0, st, e0, e1, 0, p->heavy,
-                              (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca,
-                              my_tiles, n_seg);
+        const dim3 sgrid(unsigned(std::max<int64_t>(1, std::min<int64_t>(items, c->cull_grid))));
+        if (a.heavy32)
+            hipExtLaunchKernelGGL(k_rmsd_sieve_sorted<true>, sgrid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                                  (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, my_tiles, n_seg);
+        else
+            hipExtLaunchKernelGGL(k_rmsd_sieve_sorted<false>, sgrid, dim3(256), 0, st, e0, e1, 0, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                                  (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, my_tiles, n_seg);
         TSC_HIP(hipGetLastError());
         if (range) {
             // a partitioned pass is closed by tsc_prune_pass_merge after the exchange: this rank's verdicts go into the exchange buffer
@@ -1673,6 +1699,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "cull_grid") == 0) {
         TSC_REQUIRE(value >= 1.0, "cull_grid must be positive");
         c->cull_grid = int64_t(value);
+        return 0;
+    }
+    if (strcmp(name, "stage1_f32") == 0) {
+        c->stage1_f32 = int(value);
         return 0;
     }
     if (strcmp(name, "cull_min_pairs") == 0) {
@@ -2530,6 +2560,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(s.get(size_t(n_poses) * DW, &ext.D));
             TSC_TRY(s.get(size_t(n_poses), &ext.G));
             TSC_TRY(s.get(4, &ext.dmax_bits));
+            // (the float32 copy for stage 1 of the pair kernels, where the run can be large enough for it: the count is not known yet)
+            if (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n_poses) * n_heavy * 24.0 >= 128e6))
+                TSC_TRY(s.get(size_t(n_poses) * heavy32_pitch(n_heavy), &ext.heavy32));
         }
         // one device: the sample is embedded and reduced by ONE kernel into accumulators the context keeps zero between runs (sieve.hpp,
         // k_sample_moments); a sharded run takes the fixed-order sums instead (k_transform + k_feature_moments, "deterministic_basis")
@@ -2592,7 +2625,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));  // the basis (and the cleared maximum) from the side stream
         hipLaunchKernelGGL(k_transform_describe, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_describe_lds_bytes(ft.n_mols, n_heavy), st,
                            frags, ft, conf_idx, rot, pos, (const int32_t *)act, structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total,
-                           nf0, nf1, (const double *)d_basis, (const double *)(d_basis + size_t(KD) * (nf0 + nf1)), ext.D, ext.G, ext.dmax_bits);
+                           nf0, nf1, (const double *)d_basis, (const double *)(d_basis + size_t(KD) * (nf0 + nf1)), ext.D, ext.G, ext.dmax_bits, ext.heavy32);
     } else {
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos,
                            (const int32_t *)act, int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
