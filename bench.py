@@ -37,6 +37,7 @@ sample, extrapolation stated); it is a reported baseline, not the thing measured
 from __future__ import annotations
 
 import argparse
+import gc
 import glob
 import hashlib
 import json
@@ -53,6 +54,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 
 FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 CHAIN_CANDIDATES = 20000         # --config C5chain: angle sets the conformational search rotates per step
+STEP_TIMES = bool(os.environ.get("BENCH_STEP_TIMES"))
 PMC_PROFILES = ("r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
 
 
@@ -212,12 +214,22 @@ def main():
         res = None
         results = []
         sync()
+        # (as timeit does: a generation-2 collection of this process takes about 40 ms -- it was seen to land inside 10-step loops of 1 to 6 ms
+        # steps and multiply their figure by up to five; collected here, switched off for the loop, back on after it)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(steps):
             res = pipe.step()
             results.append(res)        # statistics are read after the timed region (the result converts them lazily)
+            if STEP_TIMES:
+                marks.append(time.perf_counter())
         sync()
         dt = time.perf_counter() - t0
+        gc.enable()
+        if STEP_TIMES and rank == 0:   # (debugging aid: when each step's call returned, ms since the loop began)
+            print("step returns (ms):", " ".join(f"{(m - t0) * 1e3:.2f}" for m in marks), "| loop", f"{dt * 1e3:.2f}", file=sys.stderr)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -518,6 +530,8 @@ def main():
                     last[i] = pipes[i].step()
             threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
             torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()
             t0 = time.perf_counter()
             for t in threads:
                 t.start()
@@ -525,6 +539,7 @@ def main():
                 t.join()
             torch.cuda.synchronize()
             dtc = time.perf_counter() - t0
+            gc.enable()
             ok = all(verdict(pipes[i], last[i])[1] in (True, None) and last[i]["n_keep"] == n_keep for i in range(D))
             out["steps_in_flight"] = {"in_flight": D, "steps": args.steps * D, "ms_per_step": dtc / (args.steps * D) * 1e3,
                                       "value": ens.n_poses * args.steps * D / dtc, "unit": "conformers/s", "every_step_checked": bool(ok),

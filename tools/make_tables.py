@@ -155,10 +155,10 @@ def main():
         text = open(path).read()
         new = text
         for name, fn in TABLES.items():
-            pat = re.compile(rf"(<!-- tables:{name}:begin -->\n).*?(\n<!-- tables:{name}:end -->)", re.S)
+            pat = re.compile(rf"(<!-- tables:{name}:begin -->\n).*?(<!-- tables:{name}:end -->)", re.S)
             if pat.search(new):
                 body = fn()
-                new = pat.sub(lambda m, body=body: m.group(1) + body + m.group(2), new)
+                new = pat.sub(lambda m, body=body: m.group(1) + body + "\n" + m.group(2), new)
         if new != text:
             changed = True
             if not check:
