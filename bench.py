@@ -55,6 +55,15 @@ FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 CHAIN_CANDIDATES = 20000         # --config C5chain: angle sets the conformational search rotates per step
 STEP_TIMES = bool(os.environ.get("BENCH_STEP_TIMES"))
+if STEP_TIMES:      # debugging aid: every garbage collection with its generation, duration and yield
+    _gc_t = [0.0]
+
+    def _gc_note(phase, info):
+        if phase == "start":
+            _gc_t[0] = time.perf_counter()
+        else:
+            print(f"gc gen {info['generation']}: {(time.perf_counter() - _gc_t[0]) * 1e3:.2f} ms, collected {info['collected']}", file=sys.stderr)
+    gc.callbacks.append(_gc_note)
 PMC_PROFILES = ("r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
 
 
@@ -214,10 +223,13 @@ def main():
         res = None
         results = []
         sync()
-        # (as timeit does: a generation-2 collection of this process takes about 40 ms -- it was seen to land inside 10-step loops of 1 to 6 ms
-        # steps and multiply their figure by up to five; collected here, switched off for the loop, back on after it)
-        gc.collect()
-        gc.disable()
+        # (a generation-2 collection of this process takes about 40 ms -- torch's and numpy's module graphs -- and was seen to land inside
+        # 10-step loops of 1 to 6 ms steps, multiplying their figure by up to five.  Everything alive now goes to the permanent generation:
+        # collections inside the loop then look at the loop's own objects only.  Switching the collector off instead cost the C3 step 30 us)
+        # (the collection itself is made before the warm-up steps, in run_leg: 40 ms of idle GPU right in front of the loop cost its first steps
+        # their clocks)
+        if not os.environ.get("BENCH_KEEP_GC"):
+            gc.freeze()
         t0 = time.perf_counter()
         marks = []
         for _ in range(steps):
@@ -227,7 +239,6 @@ def main():
                 marks.append(time.perf_counter())
         sync()
         dt = time.perf_counter() - t0
-        gc.enable()
         if STEP_TIMES and rank == 0:   # (debugging aid: when each step's call returned, ms since the loop began)
             print("step returns (ms):", " ".join(f"{(m - t0) * 1e3:.2f}" for m in marks), "| loop", f"{dt * 1e3:.2f}", file=sys.stderr)
         if world > 1:
@@ -278,6 +289,9 @@ def main():
         configure(pipe, args.pass_timing)
         if sharded and world > 1 and pipe.front == "auto":
             pipe.tune_front()                                  # both forms of the front half timed on this node, before the warm-up
+        if not os.environ.get("BENCH_KEEP_GC"):
+            gc.collect()                                       # (see timed_loop)
+            gc.freeze()
         for _ in range(args.warmup):
             pipe.step()
         dt, res, acc = timed_loop(pipe, args.steps)           # THE timed region (library events as --pass-timing says)
@@ -531,7 +545,7 @@ def main():
             threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
             torch.cuda.synchronize()
             gc.collect()
-            gc.disable()
+            gc.freeze()
             t0 = time.perf_counter()
             for t in threads:
                 t.start()
@@ -539,7 +553,6 @@ def main():
                 t.join()
             torch.cuda.synchronize()
             dtc = time.perf_counter() - t0
-            gc.enable()
             ok = all(verdict(pipes[i], last[i])[1] in (True, None) and last[i]["n_keep"] == n_keep for i in range(D))
             out["steps_in_flight"] = {"in_flight": D, "steps": args.steps * D, "ms_per_step": dtc / (args.steps * D) * 1e3,
                                       "value": ens.n_poses * args.steps * D / dtc, "unit": "conformers/s", "every_step_checked": bool(ok),

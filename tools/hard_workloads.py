@@ -40,12 +40,11 @@ def pipeline_leg(ens, mode, steps):
         pipe.set_option("prune_algo", algo)
         res = pipe.step()
         torch.cuda.synchronize()
-        gc.collect(); gc.disable()      # (a generation-2 collection costs about 40 ms: bench.py, timed_loop)
+        gc.collect(); gc.freeze()       # (a generation-2 collection costs about 40 ms: bench.py, timed_loop)
         t0 = time.perf_counter()
         for _ in range(steps):
             res = pipe.step()
         torch.cuda.synchronize()
-        gc.enable()
         out[name] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "n_pass_clash": int(res["n_pass"]), "n_survivors": int(res["n_keep"]),
                      **summarize(res["stats"])}
         del pipe
@@ -61,11 +60,10 @@ def prune_leg(heavy, mode, steps):
         eng = Engine(0)
         eng.set_option("prune_algo", algo)
         stats = eng.prune_heavy_dev(d_heavy, len(heavy), heavy.shape[1], 0.5, mode, mask)
-        gc.collect(); gc.disable()
+        gc.collect(); gc.freeze()
         t0 = time.perf_counter()
         for _ in range(steps):
             stats = eng.prune_heavy_dev(d_heavy, len(heavy), heavy.shape[1], 0.5, mode, mask)
-        gc.enable()
         out[name] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "n_survivors": int(mask.sum()), **summarize(stats)}
         del eng
     return out
