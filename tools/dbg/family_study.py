@@ -18,7 +18,7 @@ def pca(f, k=8):
 def pairs(perm):
     return np.linalg.norm(heavy[:, :half] - heavy[:, half + perm], axis=2) / np.sqrt(2.0)
 fams = {"norms": np.linalg.norm(heavy, axis=2), "half": pairs(np.arange(half)), "rev": pairs(np.arange(half)[::-1]),
-        "s5": pairs((np.arange(half) + 5) % half), "s9": pairs((np.arange(half) + 9) % half), "s3": pairs((np.arange(half) + 3) % half), "s7": pairs((np.arange(half) + 7) % half), "s8": pairs((np.arange(half) + 8) % half),
+        "s5": pairs((np.arange(half) + 5) % half), "s9": pairs((np.arange(half) + 9) % half), "s3": pairs((np.arange(half) + 3) % half), "s7": pairs((np.arange(half) + 7) % half), "shalf": pairs((np.arange(half) + half // 2) % half), "sthird": pairs((np.arange(half) + half // 3) % half), "s8": pairs((np.arange(half) + 8) % half),
         "adj": np.linalg.norm(heavy[:, 0:h - 1:2] - heavy[:, 1:h:2], axis=2) / np.sqrt(2.0)}
 D = {k: pca(v) for k, v in fams.items()}
 def sq(a, b):

@@ -103,6 +103,9 @@ struct tsc_ctx {
     float *xd_D = nullptr;
     double *xd_G = nullptr;
     unsigned *xd_dmax = nullptr;
+    float *xd_heavy32 = nullptr;          // ... and the float32 copy of the heavy atoms written beside them (large runs)
+    int64_t xd_h32_cap = 0;               // floats
+    bool xd_h32_valid = false;
     int64_t xd_cap = 0;                   // structures the buffers hold
     int xd_h = 0;
     const double *xd_heavy = nullptr;     // the heavy-atom array they describe

@@ -852,6 +852,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     if (c->xd_valid && c->xd_h == h && c->xd_heavy == heavy_dev && n <= c->xd_cap && c->prune_algo != ALGO_TILE) {
         ExternalDescriptors ext;
         ext.D = c->xd_D, ext.G = c->xd_G, ext.dmax_bits = c->xd_dmax;
+        ext.heavy32 = c->xd_h32_valid ? c->xd_heavy32 : nullptr;
         c->xd_valid = false;
         return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, nullptr, &ext);
     }
@@ -2446,12 +2447,25 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
             c->xd_cap = n_poses;
         }
         const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
+        // the float32 copy for stage 1 of the pair kernels, where the run can be large enough for it (the count is not known yet)
+        float *h32 = nullptr;
+        if (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n_poses) * n_heavy * 24.0 >= 128e6)) {
+            const int64_t need = n_poses * heavy32_pitch(n_heavy);
+            if (c->xd_h32_cap < need) {
+                if (c->xd_heavy32) c->release(c->xd_heavy32);
+                c->xd_heavy32 = nullptr, c->xd_h32_cap = 0;
+                void *q = nullptr;
+                TSC_TRY(c->alloc(size_t(need) * sizeof(float), &q));
+                c->xd_heavy32 = static_cast<float *>(q), c->xd_h32_cap = need;
+            }
+            h32 = c->xd_heavy32;
+        }
         TSC_HIP(hipMemsetAsync(c->xd_dmax, 0, sizeof(unsigned), st));
         TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));  // the basis from the side stream
         hipLaunchKernelGGL(k_transform_describe, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_describe_lds_bytes(ft.n_mols, n_heavy), st,
                            frags, ft, conf_idx, rot, pos, (const int32_t *)act, structures, (const int32_t *)d_slot, n_heavy, heavy, (const int32_t *)total,
-                           nf0, nf1, basis, (const double *)(basis + size_t(KD) * (nf0 + nf1)), c->xd_D, c->xd_G, c->xd_dmax);
-        c->xd_valid = true, c->xd_h = n_heavy, c->xd_heavy = heavy;
+                           nf0, nf1, basis, (const double *)(basis + size_t(KD) * (nf0 + nf1)), c->xd_D, c->xd_G, c->xd_dmax, h32);
+        c->xd_valid = true, c->xd_h = n_heavy, c->xd_heavy = heavy, c->xd_h32_valid = h32 != nullptr;
         c->eb_valid = false;  // (the basis went into the descriptors)
     } else {
         hipLaunchKernelGGL(k_transform, dim3(grid_for(n_poses, TR_POSES, 256 * 64)), dim3(256), transform_lds_bytes(ft.n_mols), st, frags, ft, conf_idx, rot, pos,
