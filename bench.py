@@ -542,22 +542,27 @@ def main():
             def worker(i):
                 for _ in range(args.steps):
                     last[i] = pipes[i].step()
-            threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
             torch.cuda.synchronize()
             gc.collect()
             gc.freeze()
-            t0 = time.perf_counter()
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            torch.cuda.synchronize()
-            dtc = time.perf_counter() - t0
+            runs = []
+            for _ in range(2):      # (twice, the shorter one counts: on these boxes one run in seven has all three threads stand still for
+                                    # 48 ms at the same moment -- not the collector's doing, see tools/dbg/inflight.py; both are kept below)
+                threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
+                t0 = time.perf_counter()
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+                torch.cuda.synchronize()
+                runs.append(time.perf_counter() - t0)
+            dtc = min(runs)
             ok = all(verdict(pipes[i], last[i])[1] in (True, None) and last[i]["n_keep"] == n_keep for i in range(D))
             out["steps_in_flight"] = {"in_flight": D, "steps": args.steps * D, "ms_per_step": dtc / (args.steps * D) * 1e3,
                                       "value": ens.n_poses * args.steps * D / dtc, "unit": "conformers/s", "every_step_checked": bool(ok),
+                                      "ms_per_step_of_both_runs": [r / (args.steps * D) * 1e3 for r in runs],
                                       "what": f"{D} independent steps at a time, each on its own library context, HIP stream and buffers (one host "
-                                              f"thread each, library events off); the line's `value` above is one step at a time"}
+                                              f"thread each, library events off); the shorter of two runs; the line's `value` above is one step at a time"}
             del pipes
         except Exception as exc:
             out["steps_in_flight"] = {"error": f"{type(exc).__name__}: {exc}"}
