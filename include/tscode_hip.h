@@ -95,6 +95,8 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * beyond the screen's limit, where the rows' ranges are long enough for that to pay (decided per pass on the device, one
  * synchronisation); 0 = never, 2 = every such pass (tests).  "deterministic_basis": 1 = the descriptor basis from fixed-order sums, so
  * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster);
+ * "cull_tile_block" (256): a culled pass dealt to several ranks by row tiles (tsc_prune_pass_local(rank, world)) gives a rank runs of this many
+ * consecutive tiles of the sorted layout -- neighbours on the curve share their columns, and a row's early exit knows more of what was found;
  * "stage1_f32": the pair kernels' first look at a pair that passed the screen (H = p^T q and the quartic tests) reads a float32 copy
  * of the coordinates with the rounding bound that goes with it, the float64 coordinates only for what that leaves undecided: 0 = never,
  * 1 (default) = in runs with 128 MB of heavy-atom coordinates or more (where the gathers come from HBM), 2 = always;

@@ -390,6 +390,59 @@ def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
         assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
 
 
+@pytest.mark.parametrize("world,n_poses,tile_block", [(3, 20_000, 256), (8, 30_000, 256), (5, 9_000, 16), (4, 12_000, 1)])
+def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block):
+    """Passes sharded by ROW TILES with every pass culled (sorted layout + bounding boxes, cull.hpp): `world` prune runs over one array stand
+    in for the ranks, rank r takes its runs of `cull_tile_block` consecutive tiles of the sorted layout, best[] is min-merged with torch as the
+    all-reduce(MIN) would.  Each unordered pair of a pass is visited by exactly one rank -- the layouts of the ranks must be bit-identical for
+    that -- so every rank's mask and active counts must be the oracle's."""
+    import torch
+
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", n_poses)
+    heavy = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    ref = oracle.prune_heavy(heavy, 0.5, mode=0, row_parallel=True)
+    dev = torch.device("cuda:0")
+    d_heavy = torch.from_numpy(heavy).to(dev)
+    eng.set_option("cull_min_pairs", 0)
+    eng.set_option("cull", 2)
+    eng.set_option("local_pass", 0)
+    eng.set_option("cull_tile_block", tile_block)
+    eng.set_option("deterministic_basis", 1)
+    try:
+        sts = [eng.prune_stepper(d_heavy, len(heavy), heavy.shape[1], 0.5, 0) for _ in range(world)]
+        bests = [torch.empty(len(heavy), dtype=torch.int32, device=dev) for _ in range(world)]
+        for s, b in zip(sts, bests):
+            s.use_best_buffer(b)
+        while True:
+            ks = {s.next_pass() for s in sts}
+            assert len(ks) == 1
+            if ks.pop() == 0:
+                break
+            for r, s in enumerate(sts):
+                s.pass_local(r, world)
+            eng.synchronize()
+            merged = torch.stack(bests).amin(0)
+            for b in bests:
+                b.copy_(merged)
+            torch.cuda.synchronize()
+            for s in sts:
+                s.pass_finish()
+        keep = torch.empty(len(heavy), dtype=torch.uint8, device=dev)
+        for s in sts:
+            s.copy_mask(keep)
+            eng.synchronize()
+            assert np.array_equal(keep.cpu().numpy().astype(bool), ref["mask"])
+            assert [x["n_active_after"] for x in s.stats()] == [x["n_active_after"] for x in ref["stats"]]
+            s.close()
+    finally:
+        eng.set_option("cull_min_pairs", 2.0e9)
+        eng.set_option("cull", 1)
+        eng.set_option("local_pass", 1)
+        eng.set_option("cull_tile_block", 256)
+        eng.set_option("deterministic_basis", 0)
+
+
 @pytest.mark.parametrize("world,min_chunks,n_poses,mode,cull", [(2, 4, 12_000, 0, 0), (3, 1, 12_000, 0, 0), (8, 4, 40_000, 0, 0), (3, 4, 9_000, 1, 0), (5, 2, 700, 0, 0),
                                                                 (2, 4, 12_000, 0, 1), (3, 1, 20_000, 0, 1), (4, 2, 9_000, 1, 1)])
 def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_poses, mode, cull):

@@ -346,6 +346,7 @@ struct CullArgs {
     const int32_t *cbase;   // [k + 1] first position of every chunk
     const float *cbox, *rbox;
     int k;                  // chunks of the pass
+    int tile_block;         // row tiles are dealt to the ranks in runs of this many consecutive tiles of the sorted layout (1: one by one)
 };
 
 // The pair kernel of a culled pass: one wavefront = (16 consecutive positions of the sorted layout) x (one segment of the
@@ -366,7 +367,10 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
     __shared__ __attribute__((aligned(16))) float s_rowdesc[4][TI * RS];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = a.tile_begin + slot * a.tile_stride;
+    // (runs of consecutive tiles stay on one rank: neighbours on the curve look at the same columns, and what a row has already found --
+    // best[] -- is known where its other candidates are evaluated)
+    const int tile = ca.tile_block <= 1 ? a.tile_begin + slot * a.tile_stride
+                                        : ((slot / ca.tile_block) * a.tile_stride + a.tile_begin) * ca.tile_block + slot % ca.tile_block;
     const int p0 = tile * TI;
     const int pass_on = st->pass_on, A = st->A;
     if (pass_on == 0 || p0 >= A) return;

@@ -1250,8 +1250,11 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         a.dmax_bits = p->dmax_bits, a.desc_limit = double(p->h) * p->thr * p->thr;
         a.heavy32 = p->heavy32;
         a.drain_min = c->drain_min;
-        CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k)};
-        const int n_tiles = ceil_div(A, TILE_ROWS), my_tiles = (n_tiles - rank + world - 1) / world;
+        const int tb = world > 1 ? std::max(1, c->cull_tile_block) : 1;
+        CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k), tb};
+        const int n_tiles = ceil_div(A, TILE_ROWS);
+        // (slots of this rank: one by one, or whole runs of tb tiles -- an upper bound; slots beyond the last tile leave at once)
+        const int my_tiles = tb <= 1 ? (n_tiles - rank + world - 1) / world : (n_tiles / (tb * world) + 1) * tb;
         // columns of a row tile: from its own 128-aligned position to the end of its (last row's) chunk -- a chunk and a tile more at most
         const int n_seg = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, a.seg_cols);
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -1700,6 +1703,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "cull_grid") == 0) {
         TSC_REQUIRE(value >= 1.0, "cull_grid must be positive");
         c->cull_grid = int64_t(value);
+        return 0;
+    }
+    if (strcmp(name, "cull_tile_block") == 0) {
+        TSC_REQUIRE(value >= 1 && value <= 65536, "cull_tile_block must be in [1, 65536]");
+        c->cull_tile_block = int(value);
         return 0;
     }
     if (strcmp(name, "stage1_f32") == 0) {
