@@ -1149,6 +1149,17 @@ def test_csearch_rotations_vs_oracle_large(eng, oracle):
     assert margin > 1e-9
     o2, b2 = eng.csearch_rotate(coords, torsions, masks2, angles[:1500], 1.4, 0)
     assert np.array_equal(b2, rb2) and np.abs(o2 - r2).max() < VAL_TOL
+    # a moved side of more than 64 atoms (several moved atoms per lane; the walk-back's look at the pair that clashed last covers
+    # all of a lane's atoms), and a mask that turns the axis atom i2 with it (the walk-back then forms its matrix anew every step,
+    # as the reference does, instead of keeping one)
+    masks4 = masks.copy()
+    masks4[1] = 0
+    masks4[1, centres[1] + 1:n0 + 40] = 1                 # the rest of fragment 0 and 40 atoms of fragment 1: about 100 atoms turn
+    masks4[5, centres[5]] = 1                             # i2 of torsion 5 turns with its moved side
+    r4, rb4, margin = oracle.csearch_rotate(coords, torsions, masks4, angles[:1500], 1.4, 0, return_margin=True)
+    assert margin > 1e-9 and int(masks4[1].sum()) > 64
+    o4, b4 = eng.csearch_rotate(coords, torsions, masks4, angles[:1500], 1.4, 0)
+    assert np.array_equal(b4, rb4) and np.abs(o4 - r4).max() < VAL_TOL
     # clashes allowed (the fp64 count path)
     r3, rb3 = oracle.csearch_rotate(coords, torsions, masks, angles[:800], 1.4, 3)
     o3, b3 = eng.csearch_rotate(coords, torsions, masks, angles[:800], 1.4, 3)
