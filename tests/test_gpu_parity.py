@@ -1371,10 +1371,16 @@ def test_embed_helpers_golden(eng, oracle):
 def test_tfd_greedy_filter_vs_oracle(eng, oracle):
     """is_new_structure over whole lists (embeds.py:47-69): clustered fingerprints, several blocks of 64, kept list in the hundreds."""
     rng = np.random.default_rng(77)
-    for n, T, n_par, noise in ((1, 3, 1, 0.0), (63, 4, 9, 0.7), (64, 2, 64, 0.0), (65, 5, 20, 1.0), (700, 6, 150, 0.8), (5000, 8, 900, 0.6)):
+    # (4095 / 4096 / 4097 / 9000: the seams of the 4096-candidate super-blocks; T = 9 and 20: fingerprints too long for the register path and its
+    # fp32 screen; 9000 x 3 with few parents: nearly every candidate is dropped by a structure kept in an earlier super-block; angles beyond
+    # +-180 in the last case: differences above 360)
+    for n, T, n_par, noise in ((1, 3, 1, 0.0), (63, 4, 9, 0.7), (64, 2, 64, 0.0), (65, 5, 20, 1.0), (700, 6, 150, 0.8), (5000, 8, 900, 0.6),
+                               (4095, 6, 700, 0.7), (4096, 9, 500, 0.7), (4097, 20, 300, 0.5), (9000, 3, 40, 0.9), (9000, 6, 2500, 0.8)):
         parents = rng.uniform(-180, 180, size=(n_par, T))
         tf = (parents[rng.integers(0, n_par, size=n)] + rng.normal(size=(n, T)) * noise).astype(np.float32)
         tf = ((tf + 180) % 360 - 180).astype(np.float32)                  # wrap-around pairs (+179 vs -179) included
+        if n == 9000 and T == 6:
+            tf[::7] += 360.0                                              # the same angles a turn further: |difference| up to 540
         ref, margin = oracle.tfd_greedy_filter(tf, 10, return_margin=True)
         assert margin > 1e-6
         got = eng.tfd_greedy_filter(tf, 10.0)
