@@ -23,7 +23,13 @@ _h = hashlib.sha256()
 for _p in sorted(glob.glob("tscode_amd/csrc/*")):
     _h.update(os.path.basename(_p).encode())
     _h.update(open(_p, "rb").read())
-out = {"csrc_sha256_16": _h.hexdigest()[:16]}
+# ... and the digest the BINARY of the profiled run carried (bench.py prints it): the summary is labelled with that one, and refused when
+# the sources have moved on since (a profile collected after an edit would otherwise pass for a profile of the edited kernels)
+_line = [l for l in open(f"{src}/bench_trace.json").read().strip().splitlines() if l.startswith("{")][-1]
+_ran = json.loads(_line)["roofline"].get("binary_csrc_sha256_16")
+if _ran != _h.hexdigest()[:16]:
+    sys.exit(f"the profiled run was built from csrc {_ran}, the sources now are {_h.hexdigest()[:16]}: run tools/profile.sh again")
+out = {"csrc_sha256_16": _ran}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = newest(f"{src}/{name}/**/*counter_collection.csv")
     agg = collections.defaultdict(lambda: [0, 0.0])
