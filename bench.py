@@ -70,8 +70,8 @@ PMC_PROFILES = ("r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_f
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", type=int, default=0, help="0 = reference-exact (parity), 1 = cache-free")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
