@@ -1028,8 +1028,8 @@ def test_prune_when_descriptors_cannot_separate(eng, oracle):
 def test_automatic_choice_takes_the_all_pairs_kernel_when_the_screen_separates_nothing(eng, oracle):
     """40 000 structures whose descriptors all coincide (synthetic.make_unscreenable): from the spread of the sample's descriptors
     the automatic choice (prune_algo 0) sees that the screen would let every pair through and runs the register-tiled all-pairs
-    kernel instead -- in a prune of its own (one synchronisation after the basis) and inside the pipeline (the spread arrives with the
-    side chain).  An ordinary ensemble keeps the sieve.  Verdicts and evaluation counts equal the oracle's either way."""
+    kernel instead -- in the cache-free mode, in a prune of its own (one synchronisation after the basis) and inside the pipeline (the
+    spread arrives with the side chain).  The reference-exact mode and an ordinary ensemble keep the sieve.  Verdicts and evaluation counts equal the oracle's either way."""
     import torch
 
     from tscode_amd.pipeline import DevicePipeline
@@ -1040,7 +1040,10 @@ def test_automatic_choice_takes_the_all_pairs_kernel_when_the_screen_separates_n
         mask, stats = eng.prune_heavy(heavy, 0.5, mode)
         assert np.array_equal(mask, ref["mask"]), mode
         assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
-        assert {s["algo"] for s in stats} == {1}, [s["algo"] for s in stats]           # every pass by k_rmsd_tile
+        if mode == 1:
+            assert {s["algo"] for s in stats} == {1}, [s["algo"] for s in stats]       # every pass by k_rmsd_tile
+        else:                                                                           # reference-exact mode: the cache leaves few pairs, the sieve stays
+            assert 1 not in {s["algo"] for s in stats}
     ens = make_config("C2", 40_000)                                                    # an ordinary ensemble: the sieve stays
     ordinary = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
     _, stats = eng.prune_heavy(ordinary, 0.5, 0)

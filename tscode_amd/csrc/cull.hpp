@@ -503,7 +503,7 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
             e = queue[base + g];
             int lo, hi;
             const double *pp, *pq;
-            double Gi, Gj, H[9];
+            double Gi, Gj;
             if (decode(e, lo, hi, pp, pq, Gi, Gj)) {  // (the lanes of a group hold the same pair: they branch together)
                 const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
                 cand = sub == 0 && verdict == PAIR_UNDECIDED;

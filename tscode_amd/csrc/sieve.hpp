@@ -931,7 +931,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
             e = queue[base + g];
             int col;
             const double *pp, *pq;
-            double Gi, Gj, H[9];
+            double Gi, Gj;
             decode(e, t, col, pp, pq, Gi, Gj);
             const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
             cand = sub == 0 && verdict == PAIR_UNDECIDED;

@@ -604,6 +604,8 @@ constexpr int64_t AUTO_TILE_MIN_N = 30000;     // a prune of its own (no pipelin
 // averages stay below that limit most pairs reach H = p^T q whatever the screen does, and the register-tiled all-pairs kernel, which
 // forms H for every pair at 2.5e10 pairs/s, beats the sieve's evaluation stage at 5e9 (profiles/r03_hard_workloads.json: 8 ms
 // against 46 on 100 000 structures whose descriptors coincide, cache-free mode).  Either kernel gives the same verdicts.
+// Asked in the cache-free mode only: in the reference-exact mode the cache's stop columns end nearly every row early on such an ensemble
+// (13 M pair evaluations where the cache-free mode makes 191 M), and with so few pairs the sieve's cheaper passes win (2.6 against 3.6 ms).
 static bool screen_is_useless(const double *spread, int h, double thr) {
     const double limit = double(h) * thr * thr;
     return spread[0] < limit && spread[1] < limit;  // (false for NaN / +inf: no estimate)
@@ -731,7 +733,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     Scratch s_basis(c);
     if (force_algo >= 0) {
         p->algo = force_algo;
-    } else if (c->prune_algo == ALGO_AUTO && h <= MAX_HP && n >= AUTO_TILE_MIN_N && !basis && !(ext && ext->D)) {
+    } else if (c->prune_algo == ALGO_AUTO && mode == 1 && h <= MAX_HP && n >= AUTO_TILE_MIN_N && !basis && !(ext && ext->D)) {
         // automatic choice, no basis from a pipeline around this run: estimate it now and ask whether the screen can separate
         // anything (one synchronisation, some 20 us, on a run of at least 30 000 structures)
         const int n_samples = int(std::min<int64_t>(n, DESC_SAMPLE));
@@ -2662,7 +2664,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     // automatic kernel choice: where the sample's descriptors hardly differ the screen separates nothing and the all-pairs kernel is the
     // faster route (screen_is_useless).  The side chain finished long ago (it runs beside the clash kernel): no wait in practice
     int force_algo = -1;
-    if (d_basis && c->prune_algo == ALGO_AUTO && n_heavy <= MAX_HP) {
+    if (d_basis && c->prune_algo == ALGO_AUTO && mode == 1 && n_heavy <= MAX_HP) {
         const volatile double *sh = reinterpret_cast<const volatile double *>(static_cast<const char *>(c->pinned) + PINNED_SPREAD_OFFSET);
         const double spread[NFAM] = {sh[0], sh[1]};
         if (screen_is_useless(spread, n_heavy, rmsd_thr)) force_algo = ALGO_TILE;
