@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_parity.py::test_sharded_protocol_on_gpu_ranks: one rank of the sharded pipeline on the HIP
 backend.  Launched by torch.distributed.run with the gloo backend, so that several ranks can share the box's one GPU
-(device tensors are staged over the host for the collectives; under nccl = RCCL nothing is staged).
+(device tensors are staged over the host for the collectives; under nccl = RCCL nothing is staged), or -- SHARD_BACKEND=nccl -- with RCCL
+and a world of one: the protocol's collectives on device tensors, as a node runs them.
 Rank 0 prints one JSON line."""
 import hashlib
 import json
@@ -16,9 +17,13 @@ def main():
     import torch
     import torch.distributed as dist
     cfg, n_poses, min_pairs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = os.environ.get("SHARD_BACKEND", "gloo")       # "nccl" (= RCCL): one rank per GPU, so on this box a world of one
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     from tscode_amd.pipeline import DevicePipeline
     from tscode_amd.synthetic import make_config
     if cfg == "C5chain":          # config 5 as a chain, with the inputs of bench.py --config C5chain (tools/record_c5chain.py recorded the oracle's run)
@@ -31,7 +36,8 @@ def main():
                                    shard_min_pairs=min_pairs if min_pairs > 0 else None)
     else:
         ens = make_config(cfg, n_poses if n_poses > 0 else None)
-        pipe = DevicePipeline(ens, device_index=0, rank=rank, world=world, mode=0, shard_min_pairs=min_pairs if min_pairs > 0 else None)
+        pipe = DevicePipeline(ens, device_index=0, rank=rank, world=world, mode=0, shard_min_pairs=min_pairs if min_pairs > 0 else None,
+                              force_sharded=world == 1)    # (a world of one still goes through the multi-rank protocol and its collectives)
     res, digest, unstable = None, None, 0
     for _ in range(int(os.environ.get("SHARD_STEPS", "2"))):   # more steps on the same state: buffers are reused; every step must agree
         res = pipe.step()
@@ -49,9 +55,13 @@ def main():
         torch.cuda.synchronize()
         d2 = hashlib.sha256(np.packbits(pipe.h_keep[:r2["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
         forms_agree = forms_agree and r2["front"] == form and d2 == digest and [s["pairs_evaluated"] for s in r2["stats"]] == evals
-    flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64)
+    flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64, device="cuda:0" if backend == "nccl" else "cpu")
     gathered = [torch.zeros_like(flags) for _ in range(world)]
     dist.all_gather(gathered, flags)
+    if backend == "nccl":      # the reductions the partitioned passes use (a world of one has no such pass): int64 SUM on a device tensor
+        probe = torch.arange(8, dtype=torch.int64, device="cuda:0")
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+        assert probe.tolist() == list(range(8))
     if rank == 0:
         sharded_passes = [s["k"] for s in res["stats"] if s["algo"] in (1, 2)]
         print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "n_conformers": res.get("n_conformers"),
