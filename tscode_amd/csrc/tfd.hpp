@@ -101,7 +101,7 @@ __device__ inline bool tfd_similar_dev(const float *__restrict__ a, const float 
 // The filter is sequential by definition, but nearly all of its work is not: the list is walked in super-blocks of TG_SUPER
 // candidates, and per super-block
 //   k_tfd_greedy_prior   (whole GPU) marks the candidates that are similar to a structure kept in an EARLIER super-block
-//                        (candidates x slices of the kept list; a lane stops at its first hit);
+//                        (candidates x slices of a compact copy of the kept fingerprints; a lane stops at its first hit);
 //   k_tfd_greedy_pairs   (whole GPU) every pair INSIDE the super-block, whatever the greedy order will make of it: row c of a
 //                        TG_SUPER x TG_SUPER bit matrix = the earlier candidates of the super-block c is similar to;
 //   k_tfd_greedy_replay  (one wavefront) the greedy order itself, which is all that is sequential: lane l holds the kept bits of
@@ -114,11 +114,8 @@ __device__ inline bool tfd_similar_dev(const float *__restrict__ a, const float 
 // kept_list i32[N] (device scratch) ends up holding the kept indices in order; *n_kept their number (zeroed by the caller).
 constexpr int TG_SUPER = 4096;
 constexpr int TG_WORDS = TG_SUPER / 64;
-constexpr int TG_TILE = 128;        // kept fingerprints staged in LDS at a time (fewer when they are long: tg_tile)
 constexpr int TG_REG_T = 8;         // fingerprints up to this length sit in registers and are screened in fp32 first
 static_assert(TG_WORDS == 64, "k_tfd_greedy_replay: one lane per word of the kept mask");
-
-__host__ __device__ inline int tg_tile(int T) { return T <= 0 ? TG_TILE : (12288 / T < 1 ? 1 : (12288 / T > TG_TILE ? TG_TILE : 12288 / T)); }
 
 // tfd_similar_dev with the candidate's fingerprint in registers and a float32 screen in front: min(d, |360 - d|) is the
 // reference's wrapped difference (d <= 180: itself; d > 180: |d - 360|), summed in float32 it is off by at most
@@ -154,40 +151,41 @@ __device__ inline bool tfd_similar_reg(const float *__restrict__ a, const float 
     return tfd_similar_dev(a, b, T, thresh);
 }
 
-// blockIdx.x: 256 candidates, one per thread; blockIdx.y: a slice of the kept list, staged through LDS in tiles (the indirection
-// kept_list -> fingerprint is paid once per tile, by all threads together, not once per comparison by each)
+// blockIdx.x: 256 candidates, one per thread; blockIdx.y: a slice of the kept list.  The kept fingerprints are read from `kept_fp`, the
+// compact copy k_tfd_greedy_replay keeps ([n_kept][T], in the order they were kept): the address is the same for every lane, so the
+// loads are scalar loads and the comparison's operands sit in scalar registers -- no LDS, no barrier, no indirection through kept_list
+// in front of every comparison (the first version walked kept_list -> tf per comparison: 207 us per super-block, an LDS-tiled one 153)
 __global__ __launch_bounds__(256) void k_tfd_greedy_prior(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
-                                                           const int32_t *__restrict__ kept_list, const int32_t *__restrict__ n_kept,
+                                                           const float *__restrict__ kept_fp, const int32_t *__restrict__ n_kept,
                                                            uint8_t *__restrict__ dead) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_tfd_raw[];
-    float *s_tile = reinterpret_cast<float *>(s_tfd_raw);
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int nk = *n_kept, tile = tg_tile(T);
-    const int per = ((nk + int(gridDim.y) - 1) / int(gridDim.y) + tile - 1) / tile * tile;
+    const int nk = *n_kept;
+    const int per = (nk + int(gridDim.y) - 1) / int(gridDim.y);
     const int k0 = min(nk, int(blockIdx.y) * per), k1 = min(nk, k0 + per);
     const float *a = tf + (base + min(c, n_cand - 1)) * T;
     float ar[TG_REG_T];
     tfd_load_reg(a, T, ar);
     const TfdScreen sc = tfd_screen(T, thresh);
     bool live = c < n_cand;
-    for (int kt = k0; kt < k1; kt += tile) {
-        const int nt = min(tile, k1 - kt);
-        if (live && dead[c]) live = false;  // another slice has settled this candidate
-        if (__syncthreads_count(live ? 1 : 0) == 0) break;
-        for (int e = threadIdx.x; e < nt * T; e += 256) {
-            const int kk = e / T;
-            s_tile[e] = tf[int64_t(kept_list[kt + kk]) * T + (e - kk * T)];
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {  // four kept fingerprints at a time: their (scalar) loads are in flight together
+        if (((k - k0) & 31) == 0) {
+            if (live && dead[c]) live = false;  // another slice has settled this candidate (a hint: a stale read only costs work)
+            if (!__any(live)) return;
         }
-        __syncthreads();
-        if (live) {
-            for (int kk = 0; kk < nt; ++kk)
-                if (tfd_similar_reg(a, ar, s_tile + kk * T, T, thresh, sc)) {
-                    dead[c] = 1;
-                    live = false;
-                    break;
-                }
+        const float *b = kept_fp + size_t(k) * T;
+        const bool s0 = tfd_similar_reg(a, ar, b, T, thresh, sc), s1 = tfd_similar_reg(a, ar, b + T, T, thresh, sc);
+        const bool s2 = tfd_similar_reg(a, ar, b + 2 * T, T, thresh, sc), s3 = tfd_similar_reg(a, ar, b + 3 * T, T, thresh, sc);
+        if (live && (s0 || s1 || s2 || s3)) {
+            dead[c] = 1;
+            live = false;
         }
     }
+    for (; k < k1; ++k)
+        if (live && tfd_similar_reg(a, ar, kept_fp + size_t(k) * T, T, thresh, sc)) {
+            dead[c] = 1;
+            live = false;
+        }
 }
 
 // sim[c][w] bit j: candidate c of the super-block is similar to its candidate 64 w + j, for 64 w + j < c (zero elsewhere: every
@@ -228,7 +226,8 @@ __device__ inline unsigned long long readlane64(unsigned long long v, int l) {
 
 __global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long long *__restrict__ sim, const unsigned long long *__restrict__ nz,
                                                            int64_t base, int n_cand, const uint8_t *__restrict__ dead_in,
-                                                           uint8_t *__restrict__ accepted, int32_t *__restrict__ kept_list, int32_t *__restrict__ n_kept) {
+                                                           uint8_t *__restrict__ accepted, int32_t *__restrict__ kept_list, int32_t *__restrict__ n_kept,
+                                                           int32_t *__restrict__ n_kept_before) {
     const int lane = threadIdx.x;
     const int n_blocks = (n_cand + 63) / 64;
     // dead bits of block `lane` (candidates past the end count as dead) and which of its rows have any bit set
@@ -244,6 +243,7 @@ __global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long lo
     for (int i = 0; i < 64; ++i) row[0][i] = sim[size_t(i) * TG_WORDS + lane];
     corner[0] = sim[size_t(lane) * TG_WORDS + 0];
     int nk = *n_kept;
+    if (lane == 0) *n_kept_before = nk;  // (k_tfd_greedy_keep copies the fingerprints of what this super-block adds)
     auto block = [&](const int B, const unsigned long long(&cur)[64], unsigned long long(&nxt)[64], const unsigned long long cw,
                      unsigned long long &cw_next) __attribute__((always_inline)) {
         if (B + 1 < n_blocks) {
@@ -279,6 +279,18 @@ __global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long lo
         if (B + 1 < n_blocks) block(B + 1, row[1], row[0], corner[1], corner[0]);
     }
     if (lane == 0) *n_kept = nk;
+}
+
+// the fingerprints of the structures the last super-block kept, appended to the compact copy k_tfd_greedy_prior reads (one workgroup: a few
+// hundred fingerprints; inside the one-wavefront replay kernel the same copy cost 20 us per super-block)
+__global__ __launch_bounds__(256) void k_tfd_greedy_keep(const float *__restrict__ tf, int T, const int32_t *__restrict__ kept_list,
+                                                          const int32_t *__restrict__ n_kept_before, const int32_t *__restrict__ n_kept,
+                                                          float *__restrict__ kept_fp) {
+    const int s0 = *n_kept_before, total = (*n_kept - s0) * T;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int slot = s0 + e / T, t = e - (e / T) * T;
+        kept_fp[size_t(slot) * T + t] = tf[int64_t(kept_list[slot]) * T + t];
+    }
 }
 
 // flags of a compacted list back onto the full index space: full[idx[r]] = part[r] (full is zeroed by the caller)

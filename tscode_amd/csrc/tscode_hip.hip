@@ -2105,20 +2105,27 @@ static int launch_tfd_greedy(tsc_ctx *c, Scratch &s, const float *d_tf, int64_t 
     // per super-block: dead u8[TG_SUPER] and, right behind it, nz u64[TG_WORDS] -- one memset clears both
     uint8_t *d_flags;
     unsigned long long *d_sim;
+    float *d_kfp;  // the kept fingerprints once more, compact and in the order they were kept (k_tfd_greedy_prior)
     TSC_TRY(s.get(size_t(TG_SUPER) + TG_WORDS * sizeof(unsigned long long), &d_flags));
     TSC_TRY(s.get(size_t(TG_SUPER) * TG_WORDS, &d_sim));
+    TSC_TRY(s.get(std::max<size_t>(size_t(n) * T, 1), &d_kfp));
+    int32_t *d_nk_before;
+    TSC_TRY(s.get(1, &d_nk_before));
     unsigned long long *d_nz = reinterpret_cast<unsigned long long *>(d_flags + TG_SUPER);
-    const size_t lds_prior = size_t(tg_tile(T)) * std::max(T, 1) * sizeof(float), lds_pairs = 64 * T <= 12288 ? size_t(64) * std::max(T, 1) * sizeof(float) : 0;
+    const size_t lds_pairs = 64 * T <= 12288 ? size_t(64) * std::max(T, 1) * sizeof(float) : 0;
     TSC_HIP(hipMemsetAsync(d_nk, 0, sizeof(int32_t), c->stream));
     for (int64_t base = 0; base < n; base += TG_SUPER) {
         const int nc = int(std::min<int64_t>(TG_SUPER, n - base));
         TSC_HIP(hipMemsetAsync(d_flags, 0, size_t(TG_SUPER) + TG_WORDS * sizeof(unsigned long long), c->stream));
         if (base > 0)
-            hipLaunchKernelGGL(k_tfd_greedy_prior, dim3(ceil_div(nc, 256), 32), dim3(256), lds_prior, c->stream, d_tf, base, nc, T, thresh, (const int32_t *)d_list,
+            hipLaunchKernelGGL(k_tfd_greedy_prior, dim3(ceil_div(nc, 256), 64), dim3(256), 0, c->stream, d_tf, base, nc, T, thresh, (const float *)d_kfp,
                                (const int32_t *)d_nk, d_flags);
         hipLaunchKernelGGL(k_tfd_greedy_pairs, dim3(TG_WORDS, ceil_div(nc, 256)), dim3(256), lds_pairs, c->stream, d_tf, base, nc, T, thresh, d_sim, d_nz);
         hipLaunchKernelGGL(k_tfd_greedy_replay, dim3(1), dim3(64), 0, c->stream, (const unsigned long long *)d_sim, (const unsigned long long *)d_nz, base, nc,
-                           (const uint8_t *)d_flags, d_acc, d_list, d_nk);
+                           (const uint8_t *)d_flags, d_acc, d_list, d_nk, d_nk_before);
+        if (base + TG_SUPER < n && T > 0)  // (the last super-block's fingerprints are compared with nothing any more)
+            hipLaunchKernelGGL(k_tfd_greedy_keep, dim3(1), dim3(256), 0, c->stream, d_tf, T, (const int32_t *)d_list, (const int32_t *)d_nk_before,
+                               (const int32_t *)d_nk, d_kfp);
     }
     TSC_HIP(hipGetLastError());
     return 0;
