@@ -180,6 +180,48 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
     directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])                                      # _get_directions for two, :252-253 / :768
     conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])                           # :470-471
     blocks, group_ids, group_meta = [], [], []
+    # Every conformer of a molecule has the same number of pivots (the usual case: pivots are a property of the reactive atoms) and no
+    # pairing filter: all conformer pairs at once.  The arrays below are the loop's, with one more leading axis; flattening them under
+    # the mask in row-major order (conformer pair, pivot pair, orientation) is the order the loop appends in.
+    uniform = not pairings and len(conf_indices) > 0 and all(len({len(np.asarray(p[0]).reshape(-1, 3)) for p in pivots[m]}) == 1 for m in range(2))
+    if uniform:
+        vecs = [np.stack([np.asarray(p[0], dtype=np.float64).reshape(-1, 3) for p in pivots[m]]) for m in range(2)]      # [conformer, pivot, 3]
+        means = [np.stack([np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in pivots[m]]) for m in range(2)]
+        cums = [np.stack([np.asarray(p[2]).reshape(-1, 2) for p in pivots[m]]) for m in range(2)]
+        pi = cartesian_product(*[np.arange(v.shape[1]) for v in vecs])
+        if len(pi):
+            ci = np.asarray(conf_indices, dtype=np.int64)
+            nc, npi = len(ci), len(pi)
+            pick = lambda arr, m: arr[m][ci[:, m]][:, pi[:, m]]                                      # [conformer pair, pivot pair, ...]
+            pv = [pick(vecs, m) for m in range(2)]
+            norms = np.stack([np.linalg.norm(pv[m], axis=2) for m in range(2)], axis=2)              # :487
+            delta = np.abs(norms[:, :, 0] - norms[:, :, 1])
+            ok = ~(delta > max_norm_delta) if rigid_shortcut else (delta < max_norm_delta)           # :762 / :492-496, :630-631
+            half = norms / 2.0
+            rec = np.zeros((nc, npi, 2, 2, 23))                                                      # [conformer pair, pivot pair, orientation, molecule, field]
+            for m in range(2):
+                rec[:, :, 0, m, 0], rec[:, :, 0, m, 3] = -half[:, :, m], +half[:, :, m]
+                rec[:, :, 1, m, 0], rec[:, :, 1, m, 3] = (-half[:, :, m], +half[:, :, m]) if m == 0 else (+half[:, :, m], -half[:, :, m])
+                r = coords[m][ci[:, m]][:, reactive[m]]                                              # reactive_coords per conformer pair, :667
+                rec[:, :, :, m, 6:9] = directions[m]
+                rec[:, :, :, m, 9:12] = pv[m][:, :, None, :]
+                rec[:, :, :, m, 12:15] = pick(means, m)[:, :, None, :]
+                rec[:, :, :, m, 15:18] = r[:, 0][:, None, None, :]
+                rec[:, :, :, m, 18:21] = (r[:, 1] if r.shape[1] == 2 else r[:, 0])[:, None, None, :]
+                rec[:, :, :, m, 21], rec[:, :, :, m, 22] = r.shape[1], ci[:, m][:, None, None]
+            c0, c1 = pick(cums, 0), pick(cums, 1)
+            ids = np.empty((nc, npi, 2, 2, 2), dtype=np.int64)
+            ids[:, :, :, :, 0] = c0[:, :, None, :]
+            ids[:, :, 0, :, 1], ids[:, :, 1, :, 1] = c1, c1[:, :, ::-1]
+            take = np.repeat(ok[:, :, None], 2, axis=2)
+            blocks.append(rec[take])
+            group_ids.append(ids[take])
+            if return_trace:
+                for n in range(nc):
+                    qs, vs = np.nonzero(take[n])
+                    if len(qs):
+                        group_meta.append((ci[n], pi[qs], vs))
+        conf_indices = ()
     for conf_ids in conf_indices:
         pv = [pivots[m][conf_ids[m]] for m in range(2)]
         vec = [np.asarray(p[0], dtype=np.float64).reshape(-1, 3) for p in pv]
