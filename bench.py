@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode 0|1] [--config C3|C4|C5] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` from a bare shell starts the N ranks itself, as child processes under torch.distributed.run.)
 
 A "step" is one pass of the hot path over one synthetic ensemble that is already resident in HBM:
 fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_conformers_rmsd
@@ -156,8 +157,29 @@ def cpu_baseline(cfg_name, n_sample, n_full, mode):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (no launcher's RANK / WORLD_SIZE in the environment): start the N ranks as CHILD
+    processes under torch.distributed.run and leave with their status.  Decided before this process imports torch or touches the GPU
+    (a process that has initialised the GPU must not be replaced by, or turn into, the launcher); the children inherit stdout, so
+    rank 0's one JSON line is this command's one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL and tensor sharing across processes need on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     # stdout carries exactly ONE JSON line: everything libraries print there (RCCL prints a version banner at
     # communicator creation) is sent to stderr; the line itself goes to the saved descriptor at the end.
     sys.stdout.flush()
@@ -171,8 +193,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): pass the same N to both (or run `python bench.py --gpus N` "
+                         "from a bare shell: it starts its own ranks)")
     pg = None
     use_dist = world > 1 or args.force_sharded
     if use_dist:
@@ -388,7 +410,7 @@ def main():
         n = ens.n_poses
         flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
         tile_s = tile_ms / 1e3
-        big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: chunk-local kernel)
+        big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: the one-launch kernel of passes with short chunks)
         n_launch = len(big)                                 # pair-kernel launches per step
         launches = n_launch * args.steps
         avg_launch_s = tile_s / launches if launches and tile_s > 0 else None
@@ -482,7 +504,7 @@ def main():
                 "launches_per_step": n_launch,
                 "kernel_ms_per_step": tile_ms / args.steps,
                 "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
-                "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
+                "passes_in_one_launch_kernel": len(res["stats"]) - n_launch,
                 "executed": {"what": "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
                                      "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers",
                              "fp32_TFLOPs": ex32, "fp32_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS, "fp32_frac": (ex32 / FP32_VALU_PEAK_TFLOPS) if ex32 else None,
@@ -503,9 +525,9 @@ def main():
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(pass_ms[i] if pass_ms and i < len(pass_ms) else s["gpu_ms"], 4),
                         "tile_ms": round(s["tile_ms"], 4),
-                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
+                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_rows"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
             "detail_note": "stage_ms_per_step and passes[].ms come from 3 extra steps with every library event on (pass_timing 2), "
-                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the chunk-local kernel runs: its events are taken at pass_timing 2 only)",
+                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the one-launch kernel runs: its events are taken at pass_timing 2 only)",
         }
         if sharded_mode:
             out["rccl_world"] = dist.get_world_size() if use_dist else 1
