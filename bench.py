@@ -410,7 +410,7 @@ def main():
         n = ens.n_poses
         flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
         tile_s = tile_ms / 1e3
-        big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: the one-launch kernel of passes with short chunks)
+        big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: chunk-local kernel)
         n_launch = len(big)                                 # pair-kernel launches per step
         launches = n_launch * args.steps
         avg_launch_s = tile_s / launches if launches and tile_s > 0 else None
@@ -504,7 +504,7 @@ def main():
                 "launches_per_step": n_launch,
                 "kernel_ms_per_step": tile_ms / args.steps,
                 "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
-                "passes_in_one_launch_kernel": len(res["stats"]) - n_launch,
+                "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
                 "executed": {"what": "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
                                      "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers",
                              "fp32_TFLOPs": ex32, "fp32_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS, "fp32_frac": (ex32 / FP32_VALU_PEAK_TFLOPS) if ex32 else None,
@@ -525,9 +525,9 @@ def main():
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(pass_ms[i] if pass_ms and i < len(pass_ms) else s["gpu_ms"], 4),
                         "tile_ms": round(s["tile_ms"], 4),
-                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_rows"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
+                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
             "detail_note": "stage_ms_per_step and passes[].ms come from 3 extra steps with every library event on (pass_timing 2), "
-                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the one-launch kernel runs: its events are taken at pass_timing 2 only)",
+                           "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the chunk-local kernel runs: its events are taken at pass_timing 2 only)",
         }
         if sharded_mode:
             out["rccl_world"] = dist.get_world_size() if use_dist else 1

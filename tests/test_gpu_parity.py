@@ -180,19 +180,18 @@ SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixtu
 
 
 @pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3),
-                        (2, 0, False, 4), (2, 0, False, 5), (0, 1, False, 6)],
+                        (2, 0, False, 4), (2, 0, False, 5)],
                 ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen", "algo-sieve-separate-apply", "algo-auto-ranks-from-memory",
-                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1", "algo-auto-one-launch-long-chunks"])
+                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1"])
 def algo(request, eng):
     """Runs a test once per route through the prune: automatic choice (descriptor sieve whose pair kernel applies the verdicts
-    tile by tile; passes with short chunks in one launch, k_pass_rows), register-tiled all-pairs (its passes are applied by
+    tile by tile; passes with short chunks in the chunk-local kernel), register-tiled all-pairs (its passes are applied by
     k_apply_pass), descriptor sieve with every pass through the global path, the same with the screen's other instruction
     sequence (option sieve_trim flipped from its default), the same with k_apply_pass as a launch of its own (what a
     multi-rank pass does), the automatic choice with k_open_rows reading the scan-block prefix from memory (the path of
     ensembles beyond 4 M structures), the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
     what the large passes of C4 / C5 run by default), and the last two again with stage 1 of the pair kernels reading the float32 copy
-    of the coordinates (what runs of 128 MB of heavy atoms and more do by default); and the automatic choice with every pass whose
-    longest chunk has up to 1536 structures in the one-launch kernel (a wavefront then walks a row tile's columns in up to 24 rounds)."""
+    of the coordinates (what runs of 128 MB of heavy atoms and more do by default)."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
@@ -205,10 +204,7 @@ def algo(request, eng):
         eng.set_option("cull", 2)
     if request.param[3] in (4, 5):      # H of stage 1 from the float32 copy, its own rounding bound (sieve.hpp: pair_stage1)
         eng.set_option("stage1_f32", 2)
-    if request.param[3] == 6:           # the one-launch kernel also for passes with long chunks (row_pass.hpp)
-        eng.set_option("local_max_chunk", 1536)
     yield request.param[0]
-    eng.set_option("local_max_chunk", 384)
     eng.set_option("stage1_f32", 1)
     eng.set_option("cull_min_pairs", 2.0e9)
     eng.set_option("cull", 1)
@@ -237,7 +233,7 @@ def test_prune_c2_vs_oracle(eng, oracle, mode, algo):
         assert s["pairs_evaluated"] == r["pairs_evaluated"]      # the reference's sequential work, reproduced exactly
         assert s["new_keys"] == r["new_keys"]
         assert max(s["pairs_computed"], s["pairs_screened"]) >= s["pairs_evaluated"]   # the GPU looks at a superset
-        assert s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo)      # 3 = one-launch kernel (automatic choice only)
+        assert s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo)      # 3 = chunk-local kernel (automatic choice only)
     print(f"C2 mode {mode}: {len(heavy)} -> {mask.sum()}; margins rmsd {mr:.2e} maxdev {mm:.2e}")
 
 
@@ -463,7 +459,7 @@ def test_partitioned_passes_emulated_ranks(eng, oracle, world, min_chunks, n_pos
     ref = oracle.prune_heavy(heavy, 0.5, mode=mode)
     one_mask, one_stats = eng.prune_heavy(heavy, 0.5, mode)
     assert np.array_equal(one_mask, ref["mask"])
-    if cull:        # every pass of fewer than 64 chunks that does not fit the one-launch kernel: sorted layout + bounding boxes inside each rank's chunks
+    if cull:        # every pass of fewer than 64 chunks that does not fit the chunk-local kernel: sorted layout + bounding boxes inside each rank's chunks
         eng.set_option("cull", 2)
         eng.set_option("cull_min_pairs", 0)
     try:
@@ -678,7 +674,7 @@ def test_concurrent_processes_share_the_gpu():
     """TSCoDe's multiembed runs the path from several processes at once.  Three processes step the C2 pipeline
     1000 times each on this one GPU; every step of every process must give the first step's survivor mask and evaluation
     counts, which equal the recorded oracle result (tools/soak.py).  Contention reorders workgroups: this is the test that
-    found the chunk-local kernel of round 1 reading a mask that workgroups of the same launch were already clearing."""
+    found the chunk-local kernel reading a mask that workgroups of the same launch were already clearing."""
     import os
     import subprocess
     import sys

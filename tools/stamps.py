@@ -51,9 +51,6 @@ names = ["prologue (start -> data arrived)", "screen", "drains (candidates evalu
          "-> arrived at the pass counter", "close the pass"]
 if k < 0:      # k_open_rows of pass -k: 0 started, 1 bit copy made and prefix staged, 2 structure of the row found, 3 stop column and rank, 4 written
     names = ["bit copy, prefix -> LDS", "search + select (the row's structure)", "descriptor, cache view, rank of the stop column", "stores"]
-    if "local_pass=0" not in sys.argv:
-        # k_pass_rows (row_pass.hpp): ... 4 mask words staged + first 64 columns' descriptors arrived, 5 screened, 6 candidates evaluated, 7 applied
-        names = names[:3] + ["mask words staged, first columns arrived", "screen (+ full candidate batches)", "remaining candidates", "apply"]
 for i, nm in enumerate(names, start=1):
     m = (s[:, i] > 0) & (s[:, i - 1] > 0)
     if m.any():

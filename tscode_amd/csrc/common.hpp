@@ -81,8 +81,8 @@ struct tsc_ctx {
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int cull_tile_block = 256;             // culled passes dealt by row tiles: consecutive tiles of the sorted layout per rank and turn
     int stage1_f32 = 1;                   // stage 1 of the pair kernels reads a float32 copy of the coordinates first (sieve.hpp: pair_stage1)
-    int local_max_chunk = 384;            // longest chunk (structures) of a pass that k_pass_rows runs in one launch (row_pass.hpp)
-    int local_pass = 1;                   // passes with short chunks run in one launch
+    int local_max_chunk = 384;            // longest chunk (structures) of a pass that the chunk-local kernel takes
+    int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     void *dbg_buf = nullptr;              // -DTSC_DBG_STAMPS builds: time stamps of the pair kernel's wavefronts
     size_t dbg_bytes = 0;
     int64_t dbg_waves = 0, dbg_stamp_k = -1;

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_init_run(InitArgs a) {
 // Closes the pass in slot `prev` (sums its counters, updates n_active, re-ranks the scan blocks, flips the bit copy) and
 // opens the pass in slot `cur` (gate, A, zeroed counters).  prev / cur = -1: nothing to close / open.  Runs in ONE
 // WAVEFRONT: of the last unit of the closing pass to finish -- a row tile of the pair kernel, a block of k_apply_pass or of
-// k_pass_rows -- or, where no pass precedes, of k_pass_step.
+// k_pass_chunks -- or, where no pass precedes, of k_pass_step.
 struct StepArgs {
     int prev, cur;
     long long k_cur;
@@ -487,7 +487,7 @@ struct StepCtx {
     PassRecord *rec;
     int32_t *bsum, *boff;
     int n_blocks;
-    unsigned *tickets;  // every arrival counter of the run (PassTickets: one per 128-byte line), zeroed on the way out
+    unsigned *tickets;  // every arrival counter of the run (PassTickets and the chunk-local kernel's: one per 128-byte line), zeroed on the way out
     int ticket_lines;
     unsigned long long *exch_tail;  // rank-partitioned pass only (else null): the last unit of this rank's share does not close the
                                     // pass -- it leaves this rank's five statistics here, behind the removed-row bits of the exchange
@@ -651,163 +651,13 @@ struct OpenArgs {
 #else
 #define TSC_OPEN_STAMP(i) do { } while (0)
 #endif
-// What k_open_rows learns about ONE row (OPEN_LPR lanes hold the same values, except dval: lane sl holds floats 4 sl .. 4 sl + 3)
-struct OpenedRow {
-    int64_t i;      // the row's structure (position in the mask)
-    int64_t first;  // first structure of its chunk
-    int64_t found;  // position of its stop column (the end of its chunk when no key of the cache ends it earlier)
-    int r;          // the row (local rank); idle groups of the last tile walk along with row A - 1
-    int my_c;       // rank of the stop column
-    bool mine;      // this lane group has a row of its own
-    f32x4 dval;     // this lane's quarter of the row's descriptor
-};
-
-// The per-row part of k_open_rows for the wavefront's tile (rows r0 .. r0 + 15 < A, OPEN_LPR lanes per row): search + select of the
-// r-th active structure, its chunk, its stop column in the cache view and that column's rank.  s_boff: the scan-block prefix in LDS
-// (in_lds) -- else read from memory.  Shared by k_open_rows and k_pass_rows (row_pass.hpp).
-__device__ __forceinline__ OpenedRow open_tile_rows(const PassGeom &g, const OpenArgs &oa, const int *s_boff, const bool in_lds,
-                                                    const unsigned long long *__restrict__ X, const int A, const int row_lo, const int n_all,
-                                                    const int r0, const float *__restrict__ D) {
-    const int lane = threadIdx.x & 63, sub = lane / OPEN_LPR, sl = lane % OPEN_LPR;
-    OpenedRow o;
-    auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
-    const int r_true = r0 + sub;
-    const bool mine = r_true < A;
-    const int r = mine ? r_true : A - 1;  // (idle groups walk along with the last row: the shuffles below stay convergent)
-    const int rg = r + row_lo;            // its rank among ALL active structures
-    // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg)
-    int lo = 0, hi = oa.n_blocks;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (before(mid) <= rg) lo = mid;
-        else hi = mid;
-    }
-    int64_t i;
-    {
-        const int rem = rg - before(lo);
-        unsigned long long w[OPEN_WPL];
-        int c = 0;
-#pragma unroll
-        for (int u = 0; u < OPEN_WPL; ++u) w[u] = X[size_t(lo) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u], c += __popcll(w[u]);
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < OPEN_LPR; off <<= 1) {
-            const int t = __shfl_up(incl, off, OPEN_LPR);
-            if (sl >= off) incl += t;
-        }
-        int t = rem - (incl - c);  // index of the wanted bit among this lane's; exactly one lane of the row holds it
-        const bool here = t >= 0 && t < c;
-        int pos = 0;
-        {   // the word that holds it (a running count over the lane's words), then ONE select inside that word
-            unsigned long long wsel = w[0];
-            int usel = 0, tsel = t, run = 0;
-#pragma unroll
-            for (int u = 0; u < OPEN_WPL - 1; ++u) {
-                run += __popcll(w[u]);
-                if (t >= run) wsel = w[u + 1], usel = u + 1, tsel = t - run;
-            }
-            if (here) pos = 64 * (OPEN_WPL * sl + usel) + select64(wsel, tsel);
-        }
-        const unsigned hit = unsigned(__ballot(here) >> (OPEN_LPR * sub)) & ((1u << OPEN_LPR) - 1u);
-        pos = __shfl(pos, OPEN_LPR * sub + (__ffs(hit) - 1));
-        i = int64_t(lo) * oa.block_items + pos;
-    }
-    int64_t first, last;
-    chunk_of(g, i, first, last);
-    f32x4 dval = {0.0f, 0.0f, 0.0f, 0.0f};
-    TSC_OPEN_STAMP(2);  // the row's structure found
-    if (D) dval = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * sl);
-    // rank of a position = active structures before it: the prefix of its scan block + the set bits of the block below it
-    // (OPEN_WPL words per lane, summed over the row's lanes)
-    auto block_words = [&](int64_t pos, unsigned long long (&w)[OPEN_WPL]) {
-        const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
-#pragma unroll
-        for (int u = 0; u < OPEN_WPL; ++u) {
-            const int wlo = 64 * (OPEN_WPL * sl + u);
-            w[u] = (bf < oa.n_blocks && wlo < off) ? X[size_t(bf) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u] : 0ull;
-        }
-    };
-    auto rank_of = [&](int64_t pos, const unsigned long long (&w)[OPEN_WPL]) {
-        const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
-        int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < OPEN_WPL; ++u) {
-            const int below = off - 64 * (OPEN_WPL * sl + u);  // bits of this word that lie below the position
-            const unsigned long long m = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1ull : 0ull);
-            cnt += __popcll(w[u] & m);
-        }
-#pragma unroll
-        for (int o2 = OPEN_LPR / 2; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2);
-        return (bf < oa.n_blocks ? before(bf) : n_all) + cnt - row_lo;
-    };
-    // the stop column is the end of the chunk unless the cache view has a hit (rare): its words are requested now, with
-    // the descriptor and the view's summary, not after the walk through the view
-    unsigned long long wr[OPEN_WPL];
-    block_words(last, wr);
-    int64_t found = last;
-    if (oa.use_cache) {
-        // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
-        // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
-        // blocks of it, found through the summary bitmap, instead of every block of its chunk
-        const unsigned long long *dbit = oa.view, *dsum = oa.view + oa.bit_words;
-        const int64_t len = mine ? last - i - 1 : 0;
-        const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
-        int64_t B = p_lo >> 10;
-        const int64_t B_hi = p_hi >> 10;
-        bool scanning = len > 0;
-        while (__ballot(scanning) != 0) {
-            if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
-                bool any = false;
-                while (B <= B_hi) {
-                    const unsigned long long sw = dsum[B >> 6] >> (B & 63);
-                    if (sw) {
-                        B += __ffsll((long long)sw) - 1;
-                        any = B <= B_hi;
-                        break;
-                    }
-                    B = ((B >> 6) + 1) << 6;
-                }
-                scanning = any;
-            }
-            // the 16 words of the block, 16 / OPEN_LPR per lane: first cached column this lane sees (mask position), or none
-            int64_t cand = INT64_MAX;
-            if (scanning) {
-#pragma unroll
-                for (int u = 16 / OPEN_LPR - 1; u >= 0; --u) {
-                    const int64_t p0 = (B * 16 + (16 / OPEN_LPR) * sl + u) * 64;  // first position of this word
-                    if (p0 <= p_hi && p0 + 63 >= p_lo) {
-                        unsigned long long w = dbit[p0 >> 6] & extract64(X, p0 + shift);
-                        if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
-                        if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
-                        if (w) cand = p0 + (__ffsll((long long)w) - 1) + shift;
-                    }
-                }
-            }
-#pragma unroll
-            for (int o2 = OPEN_LPR / 2; o2 > 0; o2 >>= 1) cand = min(cand, (int64_t)__shfl_xor((long long)cand, o2));
-            if (scanning && cand != INT64_MAX) {
-                found = cand;
-                scanning = false;
-            } else {
-                ++B;
-                if (B > B_hi) scanning = false;
-            }
-        }
-    }
-    if (found != last) block_words(found, wr);  // (the lanes of a row agree)
-    o.my_c = rank_of(found, wr);
-    TSC_OPEN_STAMP(3);  // stop column and its rank
-    o.i = i, o.first = first, o.found = found, o.r = r, o.mine = mine, o.dval = dval;
-    return o;
-}
-
 __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
                                                     int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
                                                     const float *__restrict__ D, float *__restrict__ Dc) {
     static_assert(SCAN_BLOCK_WORDS == 32 && 64 / OPEN_LPR == 16 && DESC_WORDS == 4 * OPEN_LPR, "one wavefront = one row tile; a float4 of the descriptor per lane");
     __shared__ int s_boff[OPEN_LDS_BLOCKS + 1];
     const PruneState *st = sc.st;
-    const int lane = threadIdx.x & 63, sl = lane % OPEN_LPR;
+    const int lane = threadIdx.x & 63, sub = lane / OPEN_LPR, sl = lane % OPEN_LPR;
     // (the first 256 entries of the prefix are requested together with the state block: one round trip for both)
     const bool in_lds = oa.n_blocks <= oa.lds_cap;
     const int boff_mine = (in_lds && int(threadIdx.x) <= oa.n_blocks) ? oa.boff[threadIdx.x] : 0;
@@ -841,16 +691,137 @@ __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, Step
     TSC_OPEN_STAMP(1);  // bit copy made, prefix staged
     bool dead = true;
     if (pass_on && r0 < A) {
-        const OpenedRow o = open_tile_rows(g, oa, s_boff, in_lds, X, A, row_lo, n_all, r0, D);
-        const bool mine = o.mine;
-        const int r = o.r;
-        int my_c = o.my_c;
-        if (mine && D) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * sl) = o.dval;
+        auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
+        const int r_true = r0 + sub;
+        const bool mine = r_true < A;
+        const int r = mine ? r_true : A - 1;  // (idle groups walk along with the last row: the shuffles below stay convergent)
+        const int rg = r + row_lo;            // its rank among ALL active structures
+        // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg)
+        int lo = 0, hi = oa.n_blocks;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (before(mid) <= rg) lo = mid;
+            else hi = mid;
+        }
+        int64_t i;
+        {
+            const int rem = rg - before(lo);
+            unsigned long long w[OPEN_WPL];
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) w[u] = X[size_t(lo) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u], c += __popcll(w[u]);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < OPEN_LPR; off <<= 1) {
+                const int t = __shfl_up(incl, off, OPEN_LPR);
+                if (sl >= off) incl += t;
+            }
+            int t = rem - (incl - c);  // index of the wanted bit among this lane's; exactly one lane of the row holds it
+            const bool here = t >= 0 && t < c;
+            int pos = 0;
+            if (here) {
+#pragma unroll
+                for (int u = 0; u < OPEN_WPL; ++u) {
+                    const int cu = __popcll(w[u]);
+                    if (t >= 0 && t < cu) pos = 64 * (OPEN_WPL * sl + u) + select64(w[u], t);
+                    t -= cu;  // (negative from here on, or still to come)
+                }
+            }
+            const unsigned hit = unsigned(__ballot(here) >> (OPEN_LPR * sub)) & ((1u << OPEN_LPR) - 1u);
+            pos = __shfl(pos, OPEN_LPR * sub + (__ffs(hit) - 1));
+            i = int64_t(lo) * oa.block_items + pos;
+        }
+        int64_t first, last;
+        chunk_of(g, i, first, last);
+        f32x4 dval = {0.0f, 0.0f, 0.0f, 0.0f};
+        TSC_OPEN_STAMP(2);  // the row's structure found
+        if (D) dval = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * sl);
+        // rank of a position = active structures before it: the prefix of its scan block + the set bits of the block below it
+        // (OPEN_WPL words per lane, summed over the row's lanes)
+        auto block_words = [&](int64_t pos, unsigned long long (&w)[OPEN_WPL]) {
+            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) {
+                const int wlo = 64 * (OPEN_WPL * sl + u);
+                w[u] = (bf < oa.n_blocks && wlo < off) ? X[size_t(bf) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u] : 0ull;
+            }
+        };
+        auto rank_of = [&](int64_t pos, const unsigned long long (&w)[OPEN_WPL]) {
+            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < OPEN_WPL; ++u) {
+                const int below = off - 64 * (OPEN_WPL * sl + u);  // bits of this word that lie below the position
+                const unsigned long long m = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1ull : 0ull);
+                cnt += __popcll(w[u] & m);
+            }
+#pragma unroll
+            for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            return (bf < oa.n_blocks ? before(bf) : n_all) + cnt - row_lo;
+        };
+        // the stop column is the end of the chunk unless the cache view has a hit (rare): its words are requested now, with
+        // the descriptor and the view's summary, not after the walk through the view
+        unsigned long long wr[OPEN_WPL];
+        block_words(last, wr);
+        int64_t found = last;
+        if (oa.use_cache) {
+            // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
+            // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
+            // blocks of it, found through the summary bitmap, instead of every block of its chunk
+            const unsigned long long *dbit = oa.view, *dsum = oa.view + oa.bit_words;
+            const int64_t len = mine ? last - i - 1 : 0;
+            const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
+            int64_t B = p_lo >> 10;
+            const int64_t B_hi = p_hi >> 10;
+            bool scanning = len > 0;
+            while (__ballot(scanning) != 0) {
+                if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
+                    bool any = false;
+                    while (B <= B_hi) {
+                        const unsigned long long sw = dsum[B >> 6] >> (B & 63);
+                        if (sw) {
+                            B += __ffsll((long long)sw) - 1;
+                            any = B <= B_hi;
+                            break;
+                        }
+                        B = ((B >> 6) + 1) << 6;
+                    }
+                    scanning = any;
+                }
+                // the 16 words of the block, 16 / OPEN_LPR per lane: first cached column this lane sees (mask position), or none
+                int64_t cand = INT64_MAX;
+                if (scanning) {
+#pragma unroll
+                    for (int u = 16 / OPEN_LPR - 1; u >= 0; --u) {
+                        const int64_t p0 = (B * 16 + (16 / OPEN_LPR) * sl + u) * 64;  // first position of this word
+                        if (p0 <= p_hi && p0 + 63 >= p_lo) {
+                            unsigned long long w = dbit[p0 >> 6] & extract64(X, p0 + shift);
+                            if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
+                            if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
+                            if (w) cand = p0 + (__ffsll((long long)w) - 1) + shift;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cand = min(cand, (int64_t)__shfl_xor((long long)cand, o));
+                if (scanning && cand != INT64_MAX) {
+                    found = cand;
+                    scanning = false;
+                } else {
+                    ++B;
+                    if (B > B_hi) scanning = false;
+                }
+            }
+        }
+        if (found != last) block_words(found, wr);  // (the lanes of a row agree)
+        int my_c = rank_of(found, wr);
+        TSC_OPEN_STAMP(3);  // stop column and its rank
+        if (mine && D) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * sl) = dval;
         if (mine && sl == 0) {
-            act[r] = int32_t(o.i);
+            act[r] = int32_t(i);
             cend[r] = my_c;
             best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
-            if (oa.rank_of) oa.rank_of[o.i] = r;
+            if (oa.rank_of) oa.rank_of[i] = r;
         }
         if (oa.rank_of) {  // a pass that may be culled: how many pairs lie inside the rows' ranges (what the ordered walk would look at)
             long long w = (mine && sl == 0) ? (long long)max(0, my_c - r - 1) : 0ll;
@@ -891,19 +862,30 @@ struct ApplyArgs {
     unsigned long long *exch;  // rank-partitioned pass (else null): removed rows are only NOTED here, one bit each; mask, bit copy and
                                // block counts follow in k_pass_merge, from the sum of every rank's notes
 };
-// One row per lane (a whole wavefront calls this): the row at structure i of the chunk that starts at `first` is removed when
-// `removed` -- its similar column is the structure delta behind it.  ev = what the reference's scan evaluated for the lane's row.
-__device__ inline void apply_rows_core(const ApplyArgs &a, int sel, bool removed, int64_t i, int64_t first, int64_t delta, unsigned long long ev,
-                                       unsigned long long &ev_total, unsigned long long &rm_total) {
+__device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool valid, unsigned long long &ev_total, unsigned long long &rm_total) {
     const int lane = threadIdx.x & 63;
+    unsigned long long ev = 0;
+    bool removed = false;
     int my_block = -1;
-    if (removed) {
-        if (a.exch) {
-            atomicOr(&a.exch[i >> 6], 1ull << (i & 63));
+    int64_t first = 0, delta = 0;
+    if (valid) {
+        const int b = __hip_atomic_load(&a.best[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != INT_MAX) {
+            const int64_t i = a.act[r], j = a.act[b];
+            int64_t last;
+            chunk_of(a.g, i, first, last);
+            if (a.exch) {
+                atomicOr(&a.exch[i >> 6], 1ull << (i & 63));
+            } else {
+                a.mask[i] = 0;
+                atomicAnd(&a.bits[size_t(sel ^ 1) * a.bit_words + (i >> 6)], ~(1ull << (i & 63)));
+                my_block = int(i / a.block_items);
+            }
+            delta = j - i;
+            removed = true;
+            ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
         } else {
-            a.mask[i] = 0;
-            atomicAnd(&a.bits[size_t(sel ^ 1) * a.bit_words + (i >> 6)], ~(1ull << (i & 63)));
-            my_block = int(i / a.block_items);
+            ev = (unsigned long long)(a.cend[r] - r - 1);  // every active column before the stop column
         }
     }
     // the per-block counts follow the mask: one atomic per (wavefront, scan block) -- the removed rows of a wavefront fall
@@ -919,27 +901,6 @@ __device__ inline void apply_rows_core(const ApplyArgs &a, int sel, bool removed
     const int n_rm = __popcll(__ballot(removed));
     for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
     ev_total += ev, rm_total += (unsigned long long)n_rm;
-}
-
-__device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool valid, unsigned long long &ev_total, unsigned long long &rm_total) {
-    unsigned long long ev = 0;
-    bool removed = false;
-    int64_t i = 0, first = 0, delta = 0;
-    if (valid) {
-        const int b = __hip_atomic_load(&a.best[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b != INT_MAX) {
-            i = a.act[r];
-            const int64_t j = a.act[b];
-            int64_t last;
-            chunk_of(a.g, i, first, last);
-            delta = j - i;
-            removed = true;
-            ev = (unsigned long long)(b - r);  // columns r+1 .. b were evaluated
-        } else {
-            ev = (unsigned long long)(a.cend[r] - r - 1);  // every active column before the stop column
-        }
-    }
-    apply_rows_core(a, sel, removed, i, first, delta, ev, ev_total, rm_total);
 }
 
 // Gather the active structures into the two layouts the tile kernel reads:

@@ -6,7 +6,7 @@
 #include "rmsd.hpp"
 #include "scan.hpp"
 #include "sieve.hpp"
-#include "row_pass.hpp"
+#include "local_pass.hpp"
 #include "cull.hpp"
 #include "group_filter.hpp"
 #include "csearch.hpp"
@@ -510,7 +510,7 @@ static_assert(MAX_SLOTS == TSC_MAX_PASSES, "one cache view per schedule slot");
 constexpr int TILE_ROWS = 16;
 constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel takes any h
 
-enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2, ALGO_LOCAL = 3 /* reported only: a pass run in one launch by k_pass_rows (row_pass.hpp) */ };
+enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2, ALGO_LOCAL = 3 /* reported only: a pass run by the chunk-local kernel */ };
 
 struct tsc_prune {
     tsc_ctx *ctx = nullptr;
@@ -538,7 +538,8 @@ struct tsc_prune {
     double *Gall = nullptr;
     struct Tickets {
         PassTickets pass;
-    } *tickets = nullptr;  // arrival counters of the kernels that close a pass (row tiles of k_open_rows / k_rmsd_sieve / k_pass_rows)
+        LocalTickets local;
+    } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
@@ -1100,48 +1101,36 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     const int use_cache = (p->mode == 0);
     // the last chunk takes the remainder (:141-142); of this rank's chunks, in a partitioned pass
     const int64_t longest_chunk = c_hi == k ? n - (k - 1) * g.cs : g.cs;
-    // Short chunks: the whole pass in ONE launch (row_pass.hpp: the wavefront that opens a row tile also walks its columns and applies its
-    // rows).  Measured on MI355X at 57 046 structures: a pass is a chain of dependent round trips either way, so the one launch wins where
-    // chunks are a few row tiles long -- k = 1000 / 500 / 200 (chunks of 57 / 114 / 285, the last one 331) take 36 / 39 / 47 us against
-    // 45 - 55 on the two-launch flow -- and loses beyond: k = 100 (570, last 616) 52 against 47, k = 2000 (28, but 1 074 in the last chunk,
-    // whose tiles one wavefront each then walks alone) 72 against 46.  "local_max_chunk" moves the limit; the LONGEST chunk counts.
-    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && (c->fused_apply != 0 || range) &&
-                   std::max<int64_t>(longest_chunk, g.cs) <= std::min(RP_MAX_COLS, c->local_max_chunk) && c_hi > c_lo;
+    // Short chunks: the whole pass in one launch, a workgroup (or a few) per chunk (local_pass.hpp)
+    // (measured on MI355X: a block of the chunk-local kernel is a chain of dependent memory round trips, so it wins where
+    // chunks are a few row tiles long -- at 57k structures the passes k = 1000, 500 and 200 take 37, 39 and 50 us instead of
+    // 52-58 -- and loses beyond: k = 100 takes 58 us there against 53 on the two-launch path; "local_max_chunk" moves the limit)
+    // (the longest chunk counts, i.e. the last one with its remainder: at 57 046 structures in 2 000 chunks -- 28 each, 1 074 in the last --
+    // the chunk-local kernel was tried with the long chunk on workgroups of its own: 97 us against 37 for the two launches)
+    p->cur_local = p->algo == ALGO_SIEVE && world == 1 && c->local_pass != 0 && std::max<int64_t>(longest_chunk, g.cs) <= std::min(LP_MAX_ROWS, c->local_max_chunk) &&
+                   c_hi > c_lo;
     p->cur_fused = false;
     if (p->cur_local) {
-        OpenArgs oa;
-        oa.use_cache = use_cache, oa.fused = 1, oa.lds_cap = std::min(c->open_lds_blocks, RP_LDS_BLOCKS);
-        oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
-        oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
-        oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
-        oa.rank_of = nullptr, oa.dbg = nullptr;
-#ifdef TSC_DBG_STAMPS
-        if (c->dbg_stamp_k == -k) {  // (a negative k selects the kernel that opens pass k)
-            const size_t bytes = size_t(ceil_div(ceil_div(A, 16), 4)) * 32 * sizeof(unsigned long long);
-            if (c->dbg_bytes < bytes) {
-                if (c->dbg_buf) (void)hipFree(c->dbg_buf);
-                TSC_HIP(hipMalloc(&c->dbg_buf, bytes));
-                c->dbg_bytes = bytes;
-            }
-            TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
-            c->dbg_waves = int64_t(ceil_div(ceil_div(A, 16), 4)) * 4;
-            oa.dbg = static_cast<unsigned long long *>(c->dbg_buf);
-        }
-#endif
-        RowPassArgs ra;
-        ra.h = p->h;
-        ra.thr = p->thr, ra.maxdev_thr = 2 * p->thr;  // :95
-        ra.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
-        ra.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
-        ra.desc_limit = double(p->h) * p->thr * p->thr;
-        ra.dmax_bits = p->dmax_bits, ra.heavy = p->heavy, ra.Gall = p->Gall;
-        ra.ap = apply_args(p);
+        LocalPassArgs a;
+        a.h = p->h, a.use_cache = use_cache;
+        a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
+        a.nb_last = c_hi == k ? std::max(1, ceil_div(ceil_div(int(n - (k - 1) * g.cs), LP_TI), LP_TILES_PER_BLOCK)) : 0;
+        a.c_lo = int(c_lo), a.n_reg = int(std::min<int64_t>(c_hi, k - 1) - c_lo);
+        a.exch = range ? p->exch : nullptr;
+        a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
+        a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
+        a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
+        a.desc_limit = double(p->h) * p->thr * p->thr;
+        a.dmax_bits = p->dmax_bits;
         int nxt = -1;
         const StepArgs sa = next_step_args(p, &nxt);
+        const int64_t blocks = int64_t(a.n_reg) * a.nb_regular + a.nb_last;
         // (its own events only at pass_timing 2: level 1 is what a timed region carries for the PAIR kernel's durations, and a pair of
         // events costs a small pass about 6 us)
         hipEvent_t e0 = c->pass_timing >= 2 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 2 ? p->ev[slot][2] : nullptr;
-        hipExtLaunchKernelGGL(k_pass_rows, dim3(ceil_div(ceil_div(A, 16), 4)), dim3(256), 0, st, e0, e1, 0, g, oa, ra, step_ctx(p, range), sa, (const float *)p->Dall);
+        hipExtLaunchKernelGGL(k_pass_chunks, dim3(unsigned(blocks)), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, p->state, p->mask, p->bits, int(p->bit_words),
+                              view_of_open_pass(p), p->heavy, (const double *)p->Gall, (const float *)p->Dall, later_views(p), p->counters, p->bsum,
+                              SCAN_TILE, step_ctx(p, range), sa, &p->tickets->local);
         TSC_HIP(hipGetLastError());
         if (!range) {
             p->opened_slot = nxt;
@@ -1542,16 +1531,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             s.pairs_screened = rec[slot].screened, s.new_keys = rec[slot].removed, s.algo = rec[slot].algo;
             s.nonfinite_input = nonfinite ? 1 : 0;
             float ms = 0;
-            if (c->pass_timing >= 2) {
-                if (hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
-                else (void)hipGetLastError();
-            }
-            // (the one-launch passes carry their own events only at level 2; an event that was never recorded leaves a sticky error behind)
-            const bool one_launch = rec[slot].algo == ALGO_LOCAL;
-            if (c->pass_timing >= (one_launch ? 2 : 1)) {
-                if (hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
-                else (void)hipGetLastError();
-            }
+            if (c->pass_timing >= 2 && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
+            if (c->pass_timing >= (rec[slot].algo == ALGO_LOCAL ? 2 : 1) && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
         }
         p->collected = true;
     }
@@ -1702,7 +1683,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
     if (strcmp(name, "local_max_chunk") == 0) {
-        TSC_REQUIRE(value >= 16 && value <= RP_MAX_COLS, "local_max_chunk must be in [16, %d]", RP_MAX_COLS);
+        TSC_REQUIRE(value >= 16 && value <= LP_MAX_ROWS, "local_max_chunk must be in [16, %d]", LP_MAX_ROWS);
         c->local_max_chunk = int(value);
         return 0;
     }
