@@ -94,7 +94,11 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * chunks) lay their active structures out along a Morton curve of the descriptors and skip the tile pairs whose bounding boxes lie
  * beyond the screen's limit, where the rows' ranges are long enough for that to pay (decided per pass on the device, one
  * synchronisation); 0 = never, 2 = every such pass (tests).  "deterministic_basis": 1 = the descriptor basis from fixed-order sums, so
- * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster);
+ * that every rank of a sharded run derives bit-identical descriptors and hence the same layout (default 0: atomics, 35 us faster).
+ * A run remembers which of the two it was created under: only a run created under 1 culls a pass whose ROW TILES are dealt to several
+ * ranks (tsc_prune_pass_local / tsc_prune_pass_rows with world_size > 1 -- the ranks deal the tiles of ONE sorted layout); a run created
+ * under 0 walks such a pass in index order, and refuses it (TSC_ERR_STATE) when it had itself chosen the all-pairs kernel from its own
+ * basis estimate ("prune_algo" 0), a choice that ranks with different estimates could make differently;
  * "cull_tile_block" (256): a culled pass dealt to several ranks by row tiles (tsc_prune_pass_local(rank, world)) gives a rank runs of this many
  * consecutive tiles of the sorted layout -- neighbours on the curve share their columns, and a row's early exit knows more of what was found;
  * "stage1_f32": the pair kernels' first look at a pair that passed the screen (H = p^T q and the quartic tests) reads a float32 copy
@@ -180,7 +184,9 @@ int tsc_embed_clash_compact_dev(tsc_ctx *ctx, const double *frags, const int64_t
  * tsc_embed_masked_dev: the poses selected by mask u8[n_poses] (device), embedded in order: structures f64[n_sel, n_atoms, 3]
  *   and / or heavy f64[n_sel, n_heavy, 3] (either may be NULL).  With `heavy` and a pending basis the kernel writes the prune's
  *   descriptors as well, and the next tsc_prune_create on this context over the same `heavy` takes them instead of reading the
- *   coordinates back.  n_sel_host (optional): count of selected poses (the call then synchronises for it while the embed runs). */
+ *   coordinates back.  n_sel_host (optional): count of selected poses (the call then synchronises for it while the embed runs).
+ *   That run BORROWS the context's descriptor buffers until tsc_prune_destroy: a later tsc_embed_masked_dev on the same context that
+ *   would have to regrow them while it lives fails with TSC_ERR_STATE instead of pulling them from under it. */
 int tsc_basis_from_poses_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols,
                              const int32_t *conf_idx, const double *rot, const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy);
 int tsc_embed_masked_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols,
@@ -260,6 +266,12 @@ int tsc_csearch_rotate(tsc_ctx *ctx, const double *coords, int n_atoms, const in
 int tsc_csearch_rotate_dev(tsc_ctx *ctx, const double *coords, int n_atoms, const int32_t *torsions, const uint8_t *masks, int n_tors,
                            const int32_t *angles, int64_t n_cand, double thresh, int64_t max_clashes, double *out,
                            int32_t *rotated_bonds);
+/* tsc_rotate_dihedral: rotate_dihedral (tscode/utils.py:389-414) for n_structs structures f64[n_structs, n_atoms, 3] that share the
+ * torsion (i1, i2, i3, i4) and the mask u8[n_atoms] of the atoms that move: structure s turns them by angles[s] degrees -- any real
+ * number, tscode/torsion_module.py:984-1005 searches fractional corrections -- about its own i2 - i3 bond (centre i3).  No clash
+ * check, no walk-back.  out f64[n_structs, n_atoms, 3] must not alias coords.  Host arrays. */
+int tsc_rotate_dihedral(tsc_ctx *ctx, const double *coords, int64_t n_structs, int n_atoms, const int32_t *torsion, const uint8_t *mask,
+                        const double *angles, double *out);
 int tsc_torsion_comp_check(tsc_ctx *ctx, const double *coords, int64_t n_structs, int n_atoms, const int32_t *torsion,
                            const uint8_t *mask, double thresh, int64_t max_clashes, int32_t *ok);
 
@@ -372,7 +384,12 @@ int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs);        /* upper bound
  * every rank) and returns with the first pass that does left open (*k = its k) or *k = 0 at the end of the schedule
  * (rmsd_pruning.py:186-204).  One host call instead of three per small pass. */
 int tsc_prune_run_replicated(tsc_prune *run, int world, int64_t min_pairs, int64_t *k);
-int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous.  With world_size == 1 the verdicts are applied
+int tsc_prune_pass_local(tsc_prune *p, int rank, int world_size); /* asynchronous -- except on a pass that MAY be culled (option "cull":
+                                                                      at least "cull_min_pairs" pairs, fewer than 64 chunks), where the
+                                                                      host waits once for the device's culled-or-walked verdict (the
+                                                                      run's own word of pinned memory: runs of one context driven from
+                                                                      different host threads do not share it); tsc_prune_pass_range
+                                                                      likewise.  With world_size == 1 the verdicts are applied
                                                                       in here as well -- by the pair kernel itself, tile by tile
                                                                       (option "fused_apply"; best[] stays readable), or, for a pass
                                                                       whose chunks are short, by the chunk-local kernel (option

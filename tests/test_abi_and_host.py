@@ -32,6 +32,32 @@ def test_library_exports_every_header_symbol():
     assert lib.tsc_version() == 100
 
 
+def test_no_cpp_exception_can_cross_the_c_abi():
+    """SURVEY.md 8b: "no C++ exception crosses the boundary".  The library's context holds std::map / std::vector and calls `new`:
+    every `extern "C"` entry point that returns a status must run its body inside the try / catch of TSC_API_GUARD_BEGIN / _END
+    (csrc/common.hpp: std::bad_alloc -> TSC_ERR_NOMEM, anything else -> TSC_ERR_INVALID).  Checked on the source text: a thrown
+    exception cannot be provoked from here without a GPU."""
+    csrc = os.path.join(ROOT, "tscode_amd", "csrc")
+    guarded, bare = [], []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'^extern "C"[^\n]*?\bint (tsc_[a-z0-9_]+)\(', text, flags=re.M):
+            body_start = text.index("{", m.end())
+            first = text[body_start + 1:body_start + 200].lstrip()
+            if first.startswith("TSC_API_GUARD_BEGIN"):
+                guarded.append(m.group(1))
+            elif first.startswith("return TSC_VERSION"):      # a constant: nothing in it can throw
+                continue
+            else:
+                bare.append(m.group(1))
+    assert not bare, f"entry points without the exception barrier: {bare}"
+    assert len(guarded) >= 60
+    common = open(os.path.join(csrc, "common.hpp")).read()
+    assert "catch (const std::bad_alloc &)" in common and "catch (...)" in common
+
+
 def test_product_does_not_import_oracle():
     import tscode_amd  # noqa: F401
     pkg = os.path.join(ROOT, "tscode_amd")
@@ -89,6 +115,23 @@ def test_fragment_set_layout():
     assert fs.n_atoms.tolist() == [5, 7, 4] and fs.n_conf.tolist() == [2, 1, 3]
     assert fs.frag_off.tolist() == [0, 30, 51] and fs.flat.size == 30 + 21 + 36
     assert np.all(fs.flat[30:51] == 1)
+
+
+def test_install_table_equals_the_reference_binding_sites():
+    """G14 (tests/golden/gen_install_sites.py, build container only): every module of the REAL reference imported, and for every
+    hot-path name the modules whose namespace binds it to the defining module's object.  install.py's hand-written table must be
+    exactly that -- a module missing from it keeps calling the reference's function after install()."""
+    import json
+    from tscode_amd.install import _PATCHES
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "G14_install_sites.json")))
+    assert not g["modules_not_importable_here"], g["modules_not_importable_here"]
+    assert len(g["modules_imported"]) >= 25
+    for attr, (fn, names) in _PATCHES.items():
+        site = g["sites"][attr]
+        assert site["defined_in"] is not None, f"{attr}: not defined anywhere in the reference"
+        assert sorted(names) == site["bound_in"], f"{attr}: install.py patches {sorted(names)}, the reference binds it in {site['bound_in']}"
+        assert callable(fn)
+    assert set(g["sites"]) == set(_PATCHES)
 
 
 def test_install_patches_every_binding_site():

@@ -390,12 +390,14 @@ def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
         assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
 
 
-@pytest.mark.parametrize("world,n_poses,tile_block", [(3, 20_000, 256), (8, 30_000, 256), (5, 9_000, 16), (4, 12_000, 1)])
-def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block):
+@pytest.mark.parametrize("world,n_poses,tile_block,det", [(3, 20_000, 256, 1), (8, 30_000, 256, 1), (5, 9_000, 16, 1), (4, 12_000, 1, 1), (3, 20_000, 256, 0)])
+def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block, det):
     """Passes sharded by ROW TILES with every pass culled (sorted layout + bounding boxes, cull.hpp): `world` prune runs over one array stand
     in for the ranks, rank r takes its runs of `cull_tile_block` consecutive tiles of the sorted layout, best[] is min-merged with torch as the
     all-reduce(MIN) would.  Each unordered pair of a pass is visited by exactly one rank -- the layouts of the ranks must be bit-identical for
-    that -- so every rank's mask and active counts must be the oracle's."""
+    that -- so every rank's mask and active counts must be the oracle's.  det = 0: runs created WITHOUT "deterministic_basis" (each with an
+    atomic-sum basis of its own: their layouts differ) -- the library must then not cull a pass dealt by row tiles: it walks
+    the pass in index order on every rank, and the results are the oracle's all the same."""
     import torch
 
     from tscode_amd.synthetic import make_config
@@ -408,7 +410,7 @@ def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, t
     eng.set_option("cull", 2)
     eng.set_option("local_pass", 0)
     eng.set_option("cull_tile_block", tile_block)
-    eng.set_option("deterministic_basis", 1)
+    eng.set_option("deterministic_basis", det)
     try:
         sts = [eng.prune_stepper(d_heavy, len(heavy), heavy.shape[1], 0.5, 0) for _ in range(world)]
         bests = [torch.empty(len(heavy), dtype=torch.int32, device=dev) for _ in range(world)]
@@ -1308,6 +1310,36 @@ def test_moi_and_scores_golden(eng, oracle):
     none_targets = [[None if np.isnan(t) else float(t) for t in row] for row in g["fitness_none"]]
     assert np.array_equal(tscode_amd.fitness_mask(g["sc_structures"], g["sc_indices"], none_targets, thr), g["fitness_ok_none"])
     assert tscode_amd.fitness_check(g["sc_structures"][0], g["sc_indices"][0], list(g["sc_distances"][0]), thr) == bool(g["fitness_ok"][0])
+
+
+def test_rotate_dihedral_fractional_angles(eng, oracle):
+    """G15: the reference's rotate_dihedral (tscode/utils.py:389-414) with the fractional angles tscode/torsion_module.py:984-1005 passes
+    -- the drop-in (one structure, in place, returns its argument), the batched form (the whole angle list in ONE call) and the
+    rotate - look - rotate back trail of the correction search; and against the oracle on a larger random batch."""
+    import tscode_amd
+    g = load_golden("G15_rotate_dihedral_fractional")
+    coords, dih, mask = g["coords"], g["dihedral"], g["mask"].astype(bool)
+    for a, rm, rf in zip(g["angles"], g["out_mask"], g["out_first"]):
+        c = coords.copy()
+        assert tscode_amd.rotate_dihedral(c, dih, float(a), mask=mask) is c and np.abs(c - rm).max() < VAL_TOL
+        assert np.abs(tscode_amd.rotate_dihedral(coords.copy(), dih, float(a)) - rf).max() < VAL_TOL
+    batch = tscode_amd.rotate_dihedral_batch(np.repeat(coords[None], len(g["angles"]), axis=0), dih, g["angles"], mask)
+    assert np.abs(batch - g["out_mask"]).max() < VAL_TOL
+    seq, q = coords.copy(), 0
+    for a in g["angles"][:4]:
+        for sign in (1.0, -1.0):
+            seq = tscode_amd.rotate_dihedral(seq, dih, sign * float(a), mask=mask)
+            assert np.abs(seq - g["trail"][q]).max() < VAL_TOL
+            q += 1
+    rng = np.random.default_rng(15)
+    big = rng.normal(size=(3000, 37, 3)) * 4
+    m = rng.random(37) < 0.4
+    ang = rng.uniform(-360, 360, size=3000)
+    got = eng.rotate_dihedral_batch(big, [4, 9, 20, 30], m, ang)
+    for s in rng.integers(0, 3000, size=40):
+        assert np.abs(got[s] - oracle.rotate_dihedral(big[s], [4, 9, 20, 30], float(ang[s]), m.astype(np.uint8))).max() < VAL_TOL
+    assert np.array_equal(got[:, ~m], big[:, ~m])                       # the other atoms are copied, bit for bit
+    assert eng.rotate_dihedral_batch(np.zeros((0, 5, 3)), [0, 1, 2, 3], np.ones(5, bool), []).shape == (0, 5, 3)
 
 
 def test_adjacent_rows_edge_cases(eng, oracle):

@@ -353,3 +353,20 @@ def test_g12_cyclical_embed(oracle):
         assert np.array_equal(ok, g[f"clash_ok_{k}"])
         assert np.array_equal(kept, g[f"kept_{k}"]), (k, kept.sum(), g[f"kept_{k}"].sum())
         assert np.array_equal(gids[group_of[kept]], g[f"constrained_indices_{k}"])
+
+
+def test_g15_rotate_dihedral_fractional_angles(oracle):
+    """The reference's rotate_dihedral (tscode/utils.py:389-414) with fractional angles, as tscode/torsion_module.py:984-1005 calls it:
+    single rotations (mask given / first atom only) and the rotate - look - rotate back trail of the correction search."""
+    g = load_golden("G15_rotate_dihedral_fractional")
+    first = np.zeros(len(g["coords"]), np.uint8)
+    first[g["dihedral"][0]] = 1
+    for a, rm, rf in zip(g["angles"], g["out_mask"], g["out_first"]):
+        assert np.abs(oracle.rotate_dihedral(g["coords"], g["dihedral"], float(a), g["mask"]) - rm).max() < 1e-12
+        assert np.abs(oracle.rotate_dihedral(g["coords"], g["dihedral"], float(a), first) - rf).max() < 1e-12
+    seq, q = g["coords"].copy(), 0
+    for a in g["angles"][:4]:
+        for sign in (1.0, -1.0):
+            seq = oracle.rotate_dihedral(seq, g["dihedral"], sign * float(a), g["mask"])
+            assert np.abs(seq - g["trail"][q]).max() < 1e-12
+            q += 1

@@ -6,7 +6,6 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (MI355X_MICROARCH.md, HB
 import collections
 import csv
 import glob
-import hashlib
 import json
 import os
 import shutil
@@ -18,17 +17,16 @@ newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
 stats = newest(f"{src}/trace/**/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{prefix}_kernel_stats.csv")
 shutil.copy(f"{src}/bench_trace.json", f"profiles/{prefix}_bench_under_rocprof.json")
-# digest of the HIP sources the profile was taken from (bench.py prints `traffic` only while it still matches)
-_h = hashlib.sha256()
-for _p in sorted(glob.glob("tscode_amd/csrc/*")):
-    _h.update(os.path.basename(_p).encode())
-    _h.update(open(_p, "rb").read())
+# digest of what the library is built from -- sources, headers, flags: tscode_amd/build.py -- (bench.py prints `traffic` only while it still matches)
+sys.path.insert(0, os.getcwd())
+from tscode_amd.build import csrc_digest
+_now = csrc_digest()
 # ... and the digest the BINARY of the profiled run carried (bench.py prints it): the summary is labelled with that one, and refused when
 # the sources have moved on since (a profile collected after an edit would otherwise pass for a profile of the edited kernels)
 _line = [l for l in open(f"{src}/bench_trace.json").read().strip().splitlines() if l.startswith("{")][-1]
 _ran = json.loads(_line)["roofline"].get("binary_csrc_sha256_16")
-if _ran != _h.hexdigest()[:16]:
-    sys.exit(f"the profiled run was built from csrc {_ran}, the sources now are {_h.hexdigest()[:16]}: run tools/profile.sh again")
+if _ran != _now:
+    sys.exit(f"the profiled run was built from csrc {_ran}, the sources now are {_now}: run tools/profile.sh again")
 out = {"csrc_sha256_16": _ran}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = newest(f"{src}/{name}/**/*counter_collection.csv")

@@ -20,7 +20,7 @@ from .numba_functions import (_get_tf_mat, compenetration_check, compenetration_
                               prune_conformers_tfd, tfd_similarity)
 from .optimization_methods import (_score_embed_poses, fitness_check, fitness_mask, get_inertia_moments,  # noqa: F401
                                    get_moi_similarity_matches, prune_by_moment_of_inertia)
-from .torsion_module import csearch_candidates, csearch_rotate, rotate_dihedral, torsion_comp_check  # noqa: F401
+from .torsion_module import csearch_candidates, csearch_rotate, rotate_dihedral, rotate_dihedral_batch, torsion_comp_check  # noqa: F401
 from .rmsd_pruning import _rmsd_similarity, last_prune_stats, prune_conformers_rmsd, rmsd_and_max_numba  # noqa: F401
 
 __version__ = "0.1.0"

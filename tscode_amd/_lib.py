@@ -84,6 +84,7 @@ _SIGNATURES = {
     "tsc_csearch_rotate": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_double, C.c_int64, _vp, _vp]),
     "tsc_csearch_rotate_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_double, C.c_int64, _vp, _vp]),
     "tsc_torsion_comp_check": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_double, C.c_int64, _vp]),
+    "tsc_rotate_dihedral": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
     "tsc_greedy_group_filter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp]),
     "tsc_greedy_group_filter_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, _vp]),
     "tsc_tfd_greedy_filter": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_double, _vp, c_i64p]),

@@ -38,23 +38,30 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
 def csrc_digest():
-    """SHA-256 (16 hex digits) over the HIP sources, file names included: baked into the library (tsc_build_digest) so that a
-    measurement can say which kernels the BINARY it ran was built from, not only which sources lie next to it."""
-    import glob
+    """SHA-256 (16 hex digits) over what the binary is made of -- the translation units, the headers they include (the public
+    include/tscode_hip.h among them) and the compiler flags, names included: baked into the library (tsc_build_digest) so that a
+    measurement can say which kernels the BINARY it ran was built from, not only which sources lie next to it.  Exactly these files:
+    an editor's backup or a stray directory under csrc/ changes nothing."""
     import hashlib
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(CSRC, "*"))):
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
+    for name in SOURCES + HEADERS:
+        path = os.path.join(CSRC, name)
+        if not os.path.isfile(path):
+            continue
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", f'-DTSC_CSRC_DIGEST="{csrc_digest()}"', "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + [f'-DTSC_CSRC_DIGEST="{csrc_digest()}"', "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

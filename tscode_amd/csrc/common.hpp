@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <new>
 #include <vector>
@@ -45,6 +46,21 @@ inline int fail(int code, const char *fmt, ...) {
     do {                                                              \
         if (!(cond)) return ::tsc::fail(TSC_ERR_INVALID, __VA_ARGS__); \
     } while (0)
+
+// No C++ exception crosses the C ABI: every `extern "C"` entry point that returns a status runs its body between these two.
+// The containers of tsc_ctx (std::map / std::vector) and `new` are what can throw in this library: std::bad_alloc -> TSC_ERR_NOMEM.
+#define TSC_API_GUARD_BEGIN try {
+#define TSC_API_GUARD_END                                                                                  \
+    }                                                                                                      \
+    catch (const std::bad_alloc &) {                                                                       \
+        return ::tsc::fail(TSC_ERR_NOMEM, "%s: out of host memory", __func__);                             \
+    }                                                                                                      \
+    catch (const std::exception &e_) {                                                                     \
+        return ::tsc::fail(TSC_ERR_INVALID, "%s: unexpected C++ exception: %s", __func__, e_.what());     \
+    }                                                                                                      \
+    catch (...) {                                                                                          \
+        return ::tsc::fail(TSC_ERR_INVALID, "%s: unexpected C++ exception", __func__);                    \
+    }
 
 constexpr int WAVE = 64;
 
@@ -111,6 +127,8 @@ struct tsc_ctx {
     int xd_h = 0;
     const double *xd_heavy = nullptr;     // the heavy-atom array they describe
     bool xd_valid = false;
+    int xd_borrowers = 0;                 // live prune runs that read the xd_* buffers (tsc_prune_create borrowed them): no release / regrow meanwhile
+    int next_flag_slot = 0;               // pinned flag words handed to prune runs, round robin (tscode_hip.hip: PINNED_FLAG_OFFSET)
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
     double *mom_acc = nullptr;            // moment accumulators of the pipeline's basis chain (k_sample_moments adds, k_descriptor_basis clears)

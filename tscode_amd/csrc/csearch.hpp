@@ -229,6 +229,29 @@ __device__ inline double moved_side_bound(const double *c, const double cen[3], 
     return b;
 }
 
+// rotate_dihedral (tscode/utils.py:389-414) for a batch of structures that share torsion and mask: structure s turns its masked atoms by
+// angles[s] DEGREES (any real number: tscode/torsion_module.py:984-1005 searches fractional corrections) about its own i2 - i3 bond,
+// centre i3; no clash check, no walk-back.  One thread per (structure, atom); out must not alias coords (the axis atoms are read by
+// every thread of a structure).
+__global__ __launch_bounds__(256) void k_rotate_dihedral(const double *__restrict__ coords, int64_t n_structs, int n, int i2, int i3,
+                                                          const uint8_t *__restrict__ mask, const double *__restrict__ angles, double *__restrict__ out) {
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n_structs * n; e += int64_t(gridDim.x) * 256) {
+        const int64_t s = e / n;
+        const int a = int(e - s * n);
+        const double *c = coords + s * n * 3;
+        double v[3] = {c[3 * a], c[3 * a + 1], c[3 * a + 2]};
+        if (mask[a]) {
+            double R[9], cen[3];
+            dihedral_rotation(c, i2, i3, angles[s], R, cen);
+            const double d0 = v[0] - cen[0], d1 = v[1] - cen[1], d2 = v[2] - cen[2];  // (mat @ (coords[mask] - center).T).T + center, :412
+            v[0] = (R[0] * d0 + R[1] * d1 + R[2] * d2) + cen[0];
+            v[1] = (R[3] * d0 + R[4] * d1 + R[5] * d2) + cen[1];
+            v[2] = (R[6] * d0 + R[7] * d1 + R[8] * d2) + cen[2];
+        }
+        out[e * 3] = v[0], out[e * 3 + 1] = v[1], out[e * 3 + 2] = v[2];
+    }
+}
+
 // out [n_cand][n][3], rotated_bonds [n_cand]; angles [n_cand][n_tors] int32 degrees; masks [n_tors][n]; torsions [n_tors][4]
 // dynamic LDS: torsion lists, then one csearch_wave_bytes(n) area per wavefront of the block
 __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,

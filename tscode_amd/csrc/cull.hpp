@@ -593,8 +593,11 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
     }
 }
 
+#ifndef TSC_SORTED_OCC
+#define TSC_SORTED_OCC TSC_SIEVE_OCC2
+#endif
 template <bool F32>
-__global__ __launch_bounds__(256, TSC_SIEVE_OCC2) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+__global__ __launch_bounds__(256, TSC_SORTED_OCC) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                             const double *__restrict__ Gall, const int32_t *__restrict__ cend,
                                                                             int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                                             const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, int my_tiles, int n_seg) {

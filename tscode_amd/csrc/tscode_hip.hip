@@ -29,6 +29,7 @@ extern "C" __attribute__((visibility("default"))) const char *tsc_last_error(voi
 extern "C" __attribute__((visibility("default"))) const char *tsc_build_digest(void) { return TSC_CSRC_DIGEST; }
 
 extern "C" __attribute__((visibility("default"))) int tsc_device_count(void) {
+    TSC_API_GUARD_BEGIN
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
@@ -36,9 +37,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_device_count(void) {
         return fail(TSC_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
     }
     return n;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device, tsc_ctx **out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(out != nullptr, "tsc_ctx_create: out is null");
     *out = nullptr;
     int n = tsc_device_count();
@@ -77,9 +80,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_create(int device,
     }
     *out = c;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c) {
+    TSC_API_GUARD_BEGIN
     if (!c) return 0;
     DeviceGuard guard(c->device);
     // everything enqueued on any of the context's streams ends before what it uses is freed (also the teardown of a context
@@ -101,10 +106,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
+    TSC_API_GUARD_END
 }
 
 static hipStream_t g_dummy;
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_stream(tsc_ctx *c, void *hip_stream) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c != nullptr, "null context");
     DeviceGuard guard(c->device);
     TSC_HIP(hipStreamSynchronize(c->stream));
@@ -118,29 +125,37 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_stream(tsc_ctx
     }
     (void)g_dummy;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_synchronize(tsc_ctx *c) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c != nullptr, "null context");
     DeviceGuard guard(c->device);
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_malloc(tsc_ctx *c, size_t bytes, void **dptr) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && dptr, "null argument");
     DeviceGuard guard(c->device);
     TSC_HIP(hipMalloc(dptr, bytes ? bytes : 8));
     return 0;
+    TSC_API_GUARD_END
 }
 extern "C" __attribute__((visibility("default"))) int tsc_free(tsc_ctx *c, void *dptr) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c != nullptr, "null context");
     DeviceGuard guard(c->device);
     TSC_HIP(hipStreamSynchronize(c->stream));
     if (dptr) TSC_HIP(hipFree(dptr));
     return 0;
+    TSC_API_GUARD_END
 }
 extern "C" __attribute__((visibility("default"))) int tsc_memcpy_h2d(tsc_ctx *c, void *dst, const void *src, size_t bytes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
     DeviceGuard guard(c->device);
     if (bytes) {
@@ -148,8 +163,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_memcpy_h2d(tsc_ctx *c,
         TSC_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;
+    TSC_API_GUARD_END
 }
 extern "C" __attribute__((visibility("default"))) int tsc_memcpy_d2h(tsc_ctx *c, void *dst, const void *src, size_t bytes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
     DeviceGuard guard(c->device);
     if (bytes) {
@@ -157,20 +174,25 @@ extern "C" __attribute__((visibility("default"))) int tsc_memcpy_d2h(tsc_ctx *c,
         TSC_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;
+    TSC_API_GUARD_END
 }
 extern "C" __attribute__((visibility("default"))) int tsc_timer_begin(tsc_ctx *c) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c != nullptr, "null context");
     DeviceGuard guard(c->device);
     TSC_HIP(hipEventRecord(c->ev0, c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 extern "C" __attribute__((visibility("default"))) int tsc_timer_end(tsc_ctx *c, float *ms) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && ms, "null argument");
     DeviceGuard guard(c->device);
     TSC_HIP(hipEventRecord(c->ev1, c->stream));
     TSC_HIP(hipEventSynchronize(c->ev1));
     TSC_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -212,6 +234,7 @@ static int upload(tsc_ctx *c, Scratch &s, const T *host, size_t count, T **dev) 
 extern "C" __attribute__((visibility("default"))) int tsc_transform_batch_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                        const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                        const double *pos, int64_t n_poses, double *out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && out, "tsc_transform_batch_dev: null argument");
     TSC_REQUIRE(n_poses >= 0, "negative n_poses");
     FragTable ft;
@@ -222,6 +245,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_transform_batch_dev(ts
                        pos, (const int32_t *)nullptr, n_poses, out, (const int32_t *)nullptr, 0, (double *)nullptr, (const int32_t *)nullptr);
     TSC_HIP(hipGetLastError());
     return 0;
+    TSC_API_GUARD_END
 }
 
 static int64_t frags_total_doubles(const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols) {
@@ -233,6 +257,7 @@ static int64_t frags_total_doubles(const int64_t *frag_off, const int32_t *n_ato
 extern "C" __attribute__((visibility("default"))) int tsc_transform_batch(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                    const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                    const double *pos, int64_t n_poses, double *out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && out, "tsc_transform_batch: null argument");
     FragTable ft;
     TSC_TRY(make_frag_table(frag_off, n_atoms, n_conf, n_mols, &ft));
@@ -253,6 +278,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_transform_batch(tsc_ct
     TSC_HIP(hipMemcpyAsync(out, d_out, size_t(n_poses) * ft.n_total * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -320,6 +346,7 @@ static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, co
 
 extern "C" __attribute__((visibility("default"))) int tsc_clash_mask_dev(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
                                   double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && mask, "tsc_clash_mask_dev: null argument");
     ClashArgs a;
     TSC_TRY(make_clash_args(n_poses, n_atoms, ids, n_ids, thresh, max_clashes, &a));
@@ -327,10 +354,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_clash_mask_dev(tsc_ctx
     FragTable ft;
     memset(&ft, 0, sizeof(ft));
     return launch_clash<false>(c, a, coords, nullptr, ft, nullptr, nullptr, nullptr, mask, counts);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_clash_mask(tsc_ctx *c, const double *coords, int64_t n_poses, int n_atoms, const int32_t *ids, int n_ids,
                               double thresh, int64_t max_clashes, uint8_t *mask, int32_t *counts) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && mask, "tsc_clash_mask: null argument");
     ClashArgs a;
     TSC_TRY(make_clash_args(n_poses, n_atoms, ids, n_ids, thresh, max_clashes, &a));
@@ -348,12 +377,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_clash_mask(tsc_ctx *c,
     if (counts) TSC_HIP(hipMemcpyAsync(counts, d_counts, size_t(n_poses) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_mask_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                         const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                         const double *pos, int64_t n_poses, double thresh, int64_t max_clashes, uint8_t *mask,
                                         int32_t *counts) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && mask, "tsc_embed_clash_mask_dev: null argument");
     TSC_REQUIRE(n_mols == 2 || n_mols == 3, "the fused embed+clash path needs 2 or 3 fragments, got %d", n_mols);
     FragTable ft;
@@ -362,9 +393,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_mask_dev(t
     TSC_TRY(make_clash_args(n_poses, ft.n_total, n_atoms, n_mols, thresh, max_clashes, &a));
     DeviceGuard guard(c->device);
     return launch_clash<true>(c, a, nullptr, frags, ft, conf_idx, rot, pos, mask, counts);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_all_dists(tsc_ctx *c, const double *A, int na, const double *B, int nb, double *out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && A && B && out && na >= 0 && nb >= 0, "tsc_all_dists: bad argument");
     if (na == 0 || nb == 0) return 0;
     DeviceGuard guard(c->device);
@@ -378,6 +411,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_all_dists(tsc_ctx *c, 
     TSC_HIP(hipMemcpyAsync(out, dO, size_t(na) * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -406,6 +440,7 @@ static int read_i32(tsc_ctx *c, const int32_t *dev, int32_t *host_out) {
 
 extern "C" __attribute__((visibility("default"))) int tsc_compact_rows_dev(tsc_ctx *c, const void *src, const uint8_t *mask, int64_t n_rows, int64_t row_bytes, void *dst,
                                     int64_t *n_kept_host) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && src && mask && dst, "tsc_compact_rows_dev: null argument");
     TSC_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_bytes > 0 && row_bytes % 8 == 0 && row_bytes / 8 < INT32_MAX, "bad sizes");
     if (n_rows == 0) {
@@ -424,10 +459,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_compact_rows_dev(tsc_c
     TSC_TRY(launch_gather_rows(c->stream, src, act, kept, int(row_bytes / 8), nullptr, int(row_bytes / 8), dst));
     if (n_kept_host) *n_kept_host = kept;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_gather_heavy_dev(tsc_ctx *c, const double *coords, const uint8_t *mask, int64_t n_poses, int n_atoms,
                                     const int32_t *heavy_idx, int n_heavy, double *heavy_out, int64_t *n_kept_host) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && heavy_idx && heavy_out, "tsc_gather_heavy_dev: null argument");
     TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX && n_atoms > 0 && n_heavy > 0 && n_heavy <= n_atoms, "bad sizes");
     if (n_poses == 0) {
@@ -458,6 +495,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_gather_heavy_dev(tsc_c
     if (!mask) TSC_HIP(hipStreamSynchronize(c->stream));
     if (n_kept_host) *n_kept_host = kept;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -465,6 +503,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_gather_heavy_dev(tsc_c
 
 extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs_dev(tsc_ctx *c, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                                   double *rmsd, double *maxdev) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && heavy && pairs && rmsd && maxdev, "tsc_rmsd_pairs_dev: null argument");
     TSC_REQUIRE(n_structs >= 0 && h > 0 && n_pairs >= 0, "bad sizes");
     if (n_pairs == 0) return 0;
@@ -472,10 +511,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs_dev(tsc_ctx
     hipLaunchKernelGGL(k_rmsd_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, c->stream, heavy, h, pairs, n_pairs, rmsd, maxdev);
     TSC_HIP(hipGetLastError());
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                               double *rmsd, double *maxdev) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && heavy && pairs && rmsd && maxdev, "tsc_rmsd_pairs: null argument");
     TSC_REQUIRE(n_structs >= 0 && h > 0 && n_pairs >= 0, "bad sizes");
     for (int64_t k = 0; k < 2 * n_pairs; ++k)
@@ -494,6 +535,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c,
     TSC_HIP(hipMemcpyAsync(maxdev, d_m, size_t(n_pairs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -570,6 +612,12 @@ struct tsc_prune {
     tsc_pass_stats stats[TSC_MAX_PASSES];
     int n_passes = 0;
     bool collected = false;
+    bool borrows_xd = false;   // the descriptors (and the float32 copy) are the context's xd_* buffers, written by tsc_embed_masked_dev: the context
+                               // must not release them while this run lives (tsc_ctx::xd_borrowers)
+    bool det_desc = false;     // the descriptors were built with fixed-order sums ("deterministic_basis"): every rank of a sharded run that fed
+                               // its run the same sample holds the same bits -- what row tiles of a SORTED layout dealt among ranks rely on
+    bool auto_tile = false;    // ALGO_TILE was this run's own choice (screen_is_useless on its own basis estimate), not the caller's
+    int flag_slot = 0;         // this run's word in the context's pinned buffer (the culled-or-walked verdict of a candidate pass)
 };
 
 template <typename T>
@@ -582,14 +630,17 @@ static int palloc(tsc_prune *p, size_t count, T **out) {
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prune *p) {
+    TSC_API_GUARD_BEGIN
     if (!p) return 0;
     DeviceGuard guard(p->ctx->device);
+    if (p->borrows_xd && p->ctx->xd_borrowers > 0) --p->ctx->xd_borrowers;
     for (void *q : p->blocks) p->ctx->release(q);
     for (auto &slot : p->ev)
         for (hipEvent_t e : slot)
             if (e) p->ctx->event_pool.push_back(e);
     delete p;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // Doubles of a descriptor basis: KD rows per feature family, then the DW projections of the mean feature vector (+ 1 spare)
@@ -597,6 +648,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
 static size_t basis_doubles(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW + NFAM + 1; }
 static size_t basis_spread_offset(int h) { return size_t(KD) * (n_features(h, 0) + n_features(h, 1)) + DW; }
 constexpr size_t PINNED_SPREAD_OFFSET = 8192;  // where a basis' two spread values land in the context's pinned buffer
+constexpr size_t PINNED_FLAG_OFFSET = PINNED_SPREAD_OFFSET + 128;  // ... and the culled-or-walked verdicts of the context's runs, one 64-byte line each
+constexpr int PINNED_FLAG_SLOTS = 64;
 constexpr int64_t AUTO_TILE_MIN_N = 30000;     // a prune of its own (no pipeline around it) spends a synchronisation on the question from here on
 
 // "Would the screen let (almost) every pair through?"  Two structures of the sample lie 2 sum_k lambda_k apart, on average, in a
@@ -730,6 +783,8 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     p->thr = rmsd_thr;
     p->mode = mode;
     p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
+    p->det_desc = c->deterministic_basis != 0;
+    p->flag_slot = c->next_flag_slot++ % PINNED_FLAG_SLOTS;
     Scratch s_basis(c);
     if (force_algo >= 0) {
         p->algo = force_algo;
@@ -745,7 +800,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             hipError_t e = hipMemcpyAsync(host, q + basis_spread_offset(h), NFAM * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) rc0 = fail(TSC_ERR_HIP, "descriptor spread read-back failed: %s", hipGetErrorString(e));
-            else if (screen_is_useless(host, h, rmsd_thr)) p->algo = ALGO_TILE;
+            else if (screen_is_useless(host, h, rmsd_thr)) p->algo = ALGO_TILE, p->auto_tile = true;
             else basis = q;  // (the sieve's descriptors are built from it further down)
         }
         if (rc0) {
@@ -849,6 +904,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
 static const double *pending_basis(const tsc_ctx *c, int h);  // (with the pipeline's helpers, below)
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *c, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c != nullptr, "tsc_prune_create: null argument");
     // descriptors that tsc_embed_masked_dev wrote with this very array are used once, by the run created next ...
     if (c->xd_valid && c->xd_h == h && c->xd_heavy == heavy_dev && n <= c->xd_cap && c->prune_algo != ALGO_TILE) {
@@ -856,7 +912,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         ext.D = c->xd_D, ext.G = c->xd_G, ext.dmax_bits = c->xd_dmax;
         ext.heavy32 = c->xd_h32_valid ? c->xd_heavy32 : nullptr;
         c->xd_valid = false;
-        return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, nullptr, &ext);
+        TSC_TRY(prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, nullptr, &ext));
+        (*out)->borrows_xd = true;   // (tsc_embed_masked_dev will not release or regrow the buffers under this run)
+        ++c->xd_borrowers;
+        return 0;
     }
     c->xd_valid = false;
     // ... and so is a basis that tsc_embed_clash_compact_dev / tsc_basis_from_poses_dev estimated on the side stream
@@ -867,9 +926,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
     }
     c->eb_valid = false;
     return prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, basis);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && k_out, "null argument");
     if (p->cur_k != 0) return fail(TSC_ERR_STATE, "tsc_prune_next_pass: previous pass not finished");
     *k_out = 0;
@@ -887,15 +948,18 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_next_pass(tsc_pr
         }
     }
     return 0;
+    TSC_API_GUARD_END
 }
 
 // Rough size of the open pass in pairs (n structures, every row against half of an average chunk); it depends only
 // on n and k, so every rank of a sharded run computes the same number.
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_estimate(tsc_prune *p, int64_t *pairs) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && pairs, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_pass_estimate: no pass open");
     *pairs = p->n * (p->n / p->cur_k) / 2;
     return 0;
+    TSC_API_GUARD_END
 }
 
 template <int HP>
@@ -1146,7 +1210,15 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     const double my_pairs = range ? double(s_hi - s_lo) * double(n / k) * 0.5 : double(n) * double(n / k) * 0.5 / double(world);
     // (row tiles dealt to several ranks: twice the threshold -- every rank lays the whole pass out for an eighth, say, of its tiles;
     // measured at 1M x 50 and eight ranks the culled k = 2 pass costs a rank 0.82 ms against 0.77 for the walk)
-    const bool culled = p->algo == ALGO_SIEVE && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS &&
+    // Row tiles of a pass dealt to several ranks (tsc_prune_pass_local / _rows with world > 1): the ranks deal the tiles of ONE sorted layout,
+    // so every rank must hold bit-identical descriptors -- only runs created under "deterministic_basis" may be culled that way; the others
+    // walk the pass in index order, every rank alike.  (Inside a pass partitioned by chunks a rank culls its own chunks with a layout of
+    // its own: no such condition.)
+    const bool shared_layout_ok = world == 1 || range || p->det_desc;
+    if (world > 1 && p->auto_tile && !p->det_desc)
+        return fail(TSC_ERR_STATE, "tsc_prune_pass_local: this run chose the all-pairs kernel from its own basis estimate; ranks of a sharded run could "
+                                   "choose differently -- create the runs under deterministic_basis = 1, or force prune_algo 1 or 2 on every rank");
+    const bool culled = p->algo == ALGO_SIEVE && c->cull != 0 && c->sieve_cpl == 2 && k < CULL_MAX_CHUNKS && shared_layout_ok &&
                         my_pairs >= c->cull_min_pairs * ((world > 1 && !range) ? 2.0 : 1.0);
     if (culled && !p->morton_order) {
         int rc = palloc(p, size_t(n), &p->morton_order);
@@ -1199,7 +1271,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     if (culled) {
         // culled, or walked in index order?  The rows' ranges decide (k_cull_decide); the host waits for the verdict -- a pass this
         // large takes a millisecond or more, the round trip some 20 us
-        volatile int *flag = reinterpret_cast<volatile int *>(static_cast<char *>(c->pinned) + PINNED_SPREAD_OFFSET + 64);
+        volatile int *flag = reinterpret_cast<volatile int *>(static_cast<char *>(c->pinned) + PINNED_FLAG_OFFSET + 64 * size_t(p->flag_slot));
         *flag = 0;
         hipLaunchKernelGGL(k_chunk_bases, dim3(unsigned(k + 1)), dim3(64), 0, st, g, (const PruneState *)p->state, (const int32_t *)p->boff,
                            (const unsigned long long *)p->bits, int(p->bit_words), p->n_blocks, p->cbase, p->cfill);
@@ -1287,6 +1359,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_prune *p, int rank, int world) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
     if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_local: no pass open (call tsc_prune_next_pass)");
@@ -1294,6 +1367,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_local(tsc_p
         return fail(TSC_ERR_STATE, "tsc_prune_pass_local: rank-partitioned passes have run; sum the cache views over the ranks first "
                                    "(tsc_prune_views_ptr, tsc_prune_views_merged)");
     return pass_launch(p, rank, world, false);
+    TSC_API_GUARD_END
 }
 
 // ---- rank-partitioned passes (rmsd.hpp, k_pass_merge) ----
@@ -1308,13 +1382,16 @@ static int64_t views_words_of(int64_t n, int mode) {
     return int64_t(n_views) * (bit_words + bit_words / 1024 + 4);
 }
 extern "C" __attribute__((visibility("default"))) int tsc_prune_exchange_words(int64_t n, int mode, int64_t *words) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(words && n > 0, "bad argument");
     *words = n / 64 + 40 + 8 + views_words_of(n, mode);
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_set_partition(tsc_prune *p, int rank, int world, int min_chunks_per_rank, void *exch_dev,
                                                                               int64_t exch_words) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && exch_dev, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world && min_chunks_per_rank >= 1, "bad rank %d / world %d / min_chunks_per_rank %d", rank, world,
                 min_chunks_per_rank);
@@ -1327,25 +1404,31 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_set_partition(ts
     TSC_HIP(hipMemsetAsync(p->exch, 0, size_t(need) * sizeof(unsigned long long), p->ctx->stream));
     if (p->mode == 0) p->views = p->exch + p->bit_words + 8;  // the cache views live in the caller's buffer from here on (still empty)
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_partitioned(tsc_prune *p, int *flag) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && flag, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_pass_partitioned: no pass open");
     *flag = pass_is_partitioned(p, p->cur_k) ? 1 : 0;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_range(tsc_prune *p) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k == 0 || p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_range: no pass open (call tsc_prune_next_pass)");
     if (!pass_is_partitioned(p, p->cur_k)) return fail(TSC_ERR_STATE, "tsc_prune_pass_range: the open pass (k = %lld) is not rank-partitioned", (long long)p->cur_k);
     TSC_TRY(pass_launch(p, 0, 1, true));
     p->views_split = true;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_merge(tsc_prune *p) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k == 0 || !p->local_done || !p->cur_range) return fail(TSC_ERR_STATE, "tsc_prune_pass_merge: tsc_prune_pass_range has not run");
     tsc_ctx *c = p->ctx;
@@ -1371,12 +1454,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_merge(tsc_p
     p->cur_range = false;
     p->collected = false;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // The cache views of the passes that have not run yet (the open one included), as one block of 64-bit words: after partitioned
 // passes they hold the keys of this rank's removed rows only.  *words = 0: nothing to exchange (cache-free mode, or no partitioned
 // pass has run).  Otherwise: sum the block over the ranks (the ranks' bits are disjoint), then tsc_prune_views_merged.
 extern "C" __attribute__((visibility("default"))) int tsc_prune_views_ptr(tsc_prune *p, void **views_dev, int64_t *offset_words, int64_t *words) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && views_dev && offset_words && words, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_views_ptr: no pass open");
     *views_dev = nullptr, *offset_words = 0, *words = 0;
@@ -1386,9 +1471,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_views_ptr(tsc_pr
     *offset_words = int64_t(p->views - p->exch) + int64_t(v) * int64_t(p->bit_words + p->dsum_words);
     *words = int64_t(p->n_views - v) * int64_t(p->bit_words + p->dsum_words);
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_views_merged(tsc_prune *p) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_views_merged: no pass open");
     if (p->views_split && p->mode == 0) {
@@ -1401,33 +1488,41 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_views_merged(tsc
     }
     p->views_split = false;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_rows(tsc_prune *p, int rank, int world) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
     if (p->cur_k == 0 || !p->local_done || p->cur_local || p->cur_fused)
         return fail(TSC_ERR_STATE, "tsc_prune_pass_rows: needs an open pass whose tsc_prune_pass_local ran with world_size > 1");
     DeviceGuard guard(p->ctx->device);
     return launch_pair_search(p, rank, world, p->n);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && best_dev && n_entries, "null argument");
     if (p->cur_k == 0) return fail(TSC_ERR_STATE, "tsc_prune_best_ptr: no pass open");
     *best_dev = p->best;
     *n_entries = p->n;  // entries beyond the (device-side) active count are not touched by the pass
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && best_dev, "null argument");
     if (p->cur_k != 0 || p->next_ks != 0) return fail(TSC_ERR_STATE, "tsc_prune_use_best_buffer: call it right after tsc_prune_create");
     p->best = static_cast<int32_t *>(best_dev);
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_prune *p) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k == 0 || !p->local_done) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: tsc_prune_pass_local has not run");
     if (p->cur_range) return fail(TSC_ERR_STATE, "tsc_prune_pass_finish: a rank-partitioned pass is closed by tsc_prune_pass_merge");
@@ -1447,6 +1542,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
     p->cur_slot = -1;
     p->collected = false;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // Runs every pass that needs no exchange between ranks (all of them for world == 1; for world > 1 those whose estimate is
@@ -1454,6 +1550,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_finish(tsc_
 // open (*k_out = its k; the caller runs tsc_prune_pass_local(rank, world), merges best[], tsc_prune_pass_finish) or with
 // *k_out = 0 when the schedule is exhausted.  One host call instead of three per small pass.
 extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(tsc_prune *p, int world, int64_t min_pairs, int64_t *k_out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && k_out && world >= 1, "null argument");
     for (;;) {
         int64_t k = 0;
@@ -1466,36 +1563,44 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(t
         TSC_TRY(tsc_prune_pass_local(p, 0, 1));
         TSC_TRY(tsc_prune_pass_finish(p));
     }
+    TSC_API_GUARD_END
 }
 
 #ifdef TSC_DBG_STAMPS
 // measurement builds only: the time stamps of the last stamped pair-kernel launch, 8 per wavefront (tools/stamps.py)
 extern "C" __attribute__((visibility("default"))) int tsc_debug_stamps(tsc_ctx *c, unsigned long long *dst, int64_t max_waves, int64_t *n_waves) {
+    TSC_API_GUARD_BEGIN
     DeviceGuard guard(c->device);
     TSC_HIP(hipStreamSynchronize(c->stream));
     const int64_t n = std::min(max_waves, c->dbg_waves);
     if (n > 0) TSC_HIP(hipMemcpy(dst, c->dbg_buf, size_t(n) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *n_waves = n;
     return 0;
+    TSC_API_GUARD_END
 }
 #endif
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && mask_dev, "null argument");
     *mask_dev = p->mask;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_copy_mask_dev(tsc_prune *p, uint8_t *dst) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p && dst, "null argument");
     DeviceGuard guard(p->ctx->device);
     TSC_HIP(hipMemcpyAsync(dst, p->mask, size_t(p->n), hipMemcpyDeviceToDevice, p->ctx->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // Close the last pass on the device, read the records back (the one synchronisation of a run) and build the
 // per-pass statistics of the passes whose gate was open.
 extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(p != nullptr, "null argument");
     if (p->cur_k != 0) return fail(TSC_ERR_STATE, "tsc_prune_stats: a pass is still open");
     tsc_ctx *c = p->ctx;
@@ -1539,6 +1644,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     if (stats) memcpy(stats, p->stats, sizeof(tsc_pass_stats) * size_t(p->n_passes));
     if (n_passes) *n_passes = p->n_passes;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
@@ -1584,16 +1690,19 @@ static int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double r
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd_dev(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
                                   tsc_pass_stats *stats, int *n_passes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd_dev: null argument");
     if (n == 0) {
         if (n_passes) *n_passes = 0;
         return 0;
     }
     return prune_run(c, heavy, n, h, rmsd_thr, mode, mask, nullptr, stats, n_passes);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask,
                               tsc_pass_stats *stats, int *n_passes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && heavy && mask, "tsc_prune_rmsd: null argument");
     TSC_REQUIRE(n >= 0 && h > 0, "bad sizes");
     if (n == 0) {
@@ -1610,6 +1719,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c,
     TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // prune_conformers_rmsd as the reference calls it (rmsd_pruning.py:164-206): ALL atoms of every structure in host memory plus
@@ -1618,6 +1728,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_rmsd(tsc_ctx *c,
 extern "C" __attribute__((visibility("default"))) int tsc_prune_structures(tsc_ctx *c, const double *structures, int64_t n, int n_atoms, const int32_t *heavy_idx,
                                                                            int n_heavy, double rmsd_thr, int mode, uint8_t *mask, tsc_pass_stats *stats,
                                                                            int *n_passes) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && structures && heavy_idx && mask, "tsc_prune_structures: null argument");
     TSC_REQUIRE(n >= 0 && n_atoms > 0 && n_heavy > 0 && n_heavy <= n_atoms, "bad sizes");
     if (n == 0) {
@@ -1636,11 +1747,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_structures(tsc_c
     TSC_HIP(hipMemcpyAsync(mask, d_mask, size_t(n), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // Tunables: "prune_algo" 0 / 2 = descriptor sieve (any size), 1 = register-tiled all-pairs kernel (h <= 32);
 // "seg_cols" = columns per work item.
 extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx *c, const char *name, double value) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && name, "null argument");
     if (strcmp(name, "prune_algo") == 0) {
         TSC_REQUIRE(value == 0 || value == 1 || value == 2, "prune_algo must be 0, 1 or 2");
@@ -1747,6 +1860,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
     return fail(TSC_ERR_INVALID, "unknown option '%s'", name);
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1754,6 +1868,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
 
 extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter_dev(tsc_ctx *c, const double *poses, const int32_t *group_off_dev, int n_groups,
                                                                              int64_t n_poses, int n_atoms, double rmsd_thr, uint8_t *accepted) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && poses && group_off_dev && accepted, "tsc_greedy_group_filter_dev: null argument");
     TSC_REQUIRE(n_groups >= 0 && n_poses >= 0 && n_atoms > 0 && rmsd_thr > 0, "bad sizes");
     if (n_groups == 0 || n_poses == 0) return 0;
@@ -1765,10 +1880,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter_de
                        accepted, G);
     TSC_HIP(hipGetLastError());
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(tsc_ctx *c, const double *poses, const int32_t *group_off, int n_groups, int n_atoms,
                                                                          double rmsd_thr, uint8_t *accepted) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && poses && group_off && accepted, "tsc_greedy_group_filter: null argument");
     TSC_REQUIRE(n_groups >= 0 && n_atoms > 0 && rmsd_thr > 0, "bad sizes");
     if (n_groups == 0) return 0;
@@ -1790,6 +1907,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_greedy_group_filter(ts
     TSC_HIP(hipMemcpyAsync(accepted, d_acc, size_t(n_poses), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1822,6 +1940,7 @@ static int check_torsions(const int32_t *torsions, int n_tors, int n_atoms) {
 extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate_dev(tsc_ctx *c, const double *coords, int n_atoms, const int32_t *torsions,
                                                                              const uint8_t *masks, int n_tors, const int32_t *angles, int64_t n_cand,
                                                                              double thresh, int64_t max_clashes, double *out, int32_t *rotated_bonds) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && out && rotated_bonds && torsions && masks && angles, "tsc_csearch_rotate_dev: null argument");
     CsearchArgs a;
     TSC_TRY(csearch_args(n_atoms, n_tors, n_cand, thresh, max_clashes, &a));
@@ -1835,11 +1954,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate_dev(tsc
                        rotated_bonds);
     TSC_HIP(hipGetLastError());
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate(tsc_ctx *c, const double *coords, int n_atoms, const int32_t *torsions,
                                                                          const uint8_t *masks, int n_tors, const int32_t *angles, int64_t n_cand,
                                                                          double thresh, int64_t max_clashes, double *out, int32_t *rotated_bonds) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && out && rotated_bonds && (n_tors == 0 || (torsions && masks && angles)), "tsc_csearch_rotate: null argument");
     TSC_REQUIRE(n_atoms > 0 && n_tors >= 0 && n_cand >= 0, "bad sizes");
     TSC_TRY(check_torsions(torsions, n_tors, n_atoms));
@@ -1860,11 +1981,38 @@ extern "C" __attribute__((visibility("default"))) int tsc_csearch_rotate(tsc_ctx
     TSC_HIP(hipMemcpyAsync(rotated_bonds, d_rb, size_t(n_cand) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
+}
+
+extern "C" __attribute__((visibility("default"))) int tsc_rotate_dihedral(tsc_ctx *c, const double *coords, int64_t n_structs, int n_atoms, const int32_t *torsion,
+                                                                          const uint8_t *mask, const double *angles, double *out) {
+    TSC_API_GUARD_BEGIN
+    TSC_REQUIRE(c && coords && torsion && mask && angles && out, "tsc_rotate_dihedral: null argument");
+    TSC_REQUIRE(n_structs >= 0 && n_atoms > 0, "bad sizes");
+    TSC_REQUIRE(out != coords, "tsc_rotate_dihedral: out must not alias coords");
+    for (int q = 1; q <= 2; ++q) TSC_REQUIRE(torsion[q] >= 0 && torsion[q] < n_atoms, "torsion index %d out of range", torsion[q]);
+    if (n_structs == 0) return 0;
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    double *d_c, *d_o, *d_a;
+    uint8_t *d_m;
+    TSC_TRY(upload(c, s, coords, size_t(n_structs) * n_atoms * 3, &d_c));
+    TSC_TRY(upload(c, s, angles, size_t(n_structs), &d_a));
+    TSC_TRY(upload(c, s, mask, size_t(n_atoms), &d_m));
+    TSC_TRY(s.get(size_t(n_structs) * n_atoms * 3, &d_o));
+    hipLaunchKernelGGL(k_rotate_dihedral, dim3(grid_for(n_structs * n_atoms, 256)), dim3(256), 0, c->stream, (const double *)d_c, n_structs, n_atoms, int(torsion[1]),
+                       int(torsion[2]), (const uint8_t *)d_m, (const double *)d_a, d_o);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(out, d_o, size_t(n_structs) * n_atoms * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc_ctx *c, const double *coords, int64_t n_structs, int n_atoms,
                                                                              const int32_t *torsion, const uint8_t *mask, double thresh,
                                                                              int64_t max_clashes, int32_t *ok) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && torsion && mask && ok, "tsc_torsion_comp_check: null argument");
     CsearchArgs a;
     TSC_TRY(csearch_args(n_atoms, 1, n_structs, thresh, max_clashes, &a));
@@ -1889,6 +2037,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc
     TSC_HIP(hipMemcpyAsync(ok, d_ok, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1896,6 +2045,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_comp_check(tsc
 
 extern "C" __attribute__((visibility("default"))) int tsc_torsion_fingerprints(tsc_ctx *c, const double *coords, int64_t n_structs, int n_atoms,
                                                                                const int32_t *quads, int n_quads, float *out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && coords && quads && out, "tsc_torsion_fingerprints: null argument");
     TSC_REQUIRE(n_structs >= 0 && n_atoms > 0 && n_quads >= 0, "bad sizes");
     for (int q = 0; q < 4 * n_quads; ++q) TSC_REQUIRE(quads[q] >= 0 && quads[q] < n_atoms, "quadruplet atom index %d out of range", quads[q]);
@@ -1914,10 +2064,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_torsion_fingerprints(t
     TSC_HIP(hipMemcpyAsync(out, d_out, size_t(n_structs) * n_quads * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, int64_t d,
                                                                             int64_t k, int64_t num_active, double thresh, int32_t *first) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && tf && first, "tsc_tfd_first_similar: null argument");
     if (n_structs == 0) return 0;
     TSC_REQUIRE(n_structs >= 0 && n_quads >= 0 && d > 0 && k > 0 && num_active >= 0 && num_active <= n_structs && d * k <= n_structs,
@@ -1936,12 +2088,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_tfd_first_similar(tsc_
     TSC_HIP(hipMemcpyAsync(first, d_first, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // the graph step of the similarity prunings on the host (host_order.hpp): no device involved
 extern "C" __attribute__((visibility("default"))) int tsc_host_graph_step(const int64_t *rel_i, const int64_t *rel_j, const int64_t *chunk_ptr,
                                                                           const int64_t *chunk_off, const int64_t *chunk_len, int64_t n_chunks,
                                                                           int64_t n_total, uint8_t *keep) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(rel_i && rel_j && chunk_ptr && chunk_off && chunk_len && keep && n_chunks >= 0 && n_total >= 0, "tsc_host_graph_step: bad argument");
     int64_t longest = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -1956,6 +2110,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_host_graph_step(const 
     for (int64_t c = 0; c < n_chunks; ++c)
         tsc_host::graph_step_chunk(rel_i + chunk_ptr[c], rel_j + chunk_ptr[c], chunk_ptr[c + 1] - chunk_ptr[c], chunk_off[c], keep, index_of);
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1963,6 +2118,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_host_graph_step(const 
 
 extern "C" __attribute__((visibility("default"))) int tsc_inertia_moments(tsc_ctx *c, const double *structures, int64_t n_structs, int n_atoms,
                                                                           const double *masses, double *out) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && structures && masses && out && n_structs >= 0 && n_atoms > 0, "tsc_inertia_moments: bad argument");
     if (n_structs == 0) return 0;
     DeviceGuard guard(c->device);
@@ -1977,10 +2133,12 @@ extern "C" __attribute__((visibility("default"))) int tsc_inertia_moments(tsc_ct
     TSC_HIP(hipMemcpyAsync(out, d_o, size_t(n_structs) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_moi_first_similar(tsc_ctx *c, const double *moments, int64_t n_structs, double max_deviation,
                                                                             int32_t *first) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && moments && first && n_structs >= 0 && n_structs < INT32_MAX, "tsc_moi_first_similar: bad argument");
     if (n_structs == 0) return 0;
     DeviceGuard guard(c->device);
@@ -1994,11 +2152,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_moi_first_similar(tsc_
     TSC_HIP(hipMemcpyAsync(first, d_f, size_t(n_structs) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_embed_scores(tsc_ctx *c, const double *structures, int64_t n_structs, int n_atoms,
                                                                        const int32_t *indices, const double *distances, int n_c, float *scores,
                                                                        double *fitness_error) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && structures && indices && distances && scores && fitness_error && n_structs >= 0 && n_atoms > 0 && n_c >= 0, "tsc_embed_scores: bad argument");
     for (int64_t q = 0; q < n_structs * n_c * 2; ++q) TSC_REQUIRE(indices[q] >= 0 && indices[q] < n_atoms, "constrained index %d out of range", indices[q]);
     if (n_structs == 0) return 0;
@@ -2019,6 +2179,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_scores(tsc_ctx *
     TSC_HIP(hipMemcpyAsync(fitness_error, d_e, size_t(n_structs) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -2028,6 +2189,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params_de
                                                                                   const double *mol_vec, const int32_t *conf_pair, int64_t n_sites,
                                                                                   const double *angles, int n_angles, double *rot, double *pos,
                                                                                   int32_t *conf_idx) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && rot && pos && conf_idx, "tsc_string_embed_params_dev: null argument");
     TSC_REQUIRE(n_sites >= 0 && n_angles >= 0, "bad sizes");
     if (n_sites == 0 || n_angles == 0) return 0;
@@ -2036,12 +2198,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params_de
                        conf_pair, n_sites, angles, n_angles, rot, pos, conf_idx);
     TSC_HIP(hipGetLastError());
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params(tsc_ctx *c, const double *p1, const double *p2, const double *ref_vec,
                                                                               const double *mol_vec, const int32_t *conf_pair, int64_t n_sites,
                                                                               const double *angles, int n_angles, double *rot, double *pos,
                                                                               int32_t *conf_idx) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && rot && pos && conf_idx, "tsc_string_embed_params: null argument");
     TSC_REQUIRE(n_sites >= 0 && n_angles >= 0, "bad sizes");
     if (n_sites == 0 || n_angles == 0) return 0;
@@ -2065,12 +2229,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed_params(ts
     TSC_HIP(hipMemcpyAsync(conf_idx, d_ci, N * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(tsc_ctx *c, const double *start, const double *end,
                                                                                 const double *direction, const double *pivot, const double *meanpoint,
                                                                                 const double *r0, const double *r1, const int32_t *n_reactive,
                                                                                 const double *angle, int64_t n, double *rot, double *pos) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && start && end && direction && pivot && meanpoint && r0 && r1 && n_reactive && angle && rot && pos, "tsc_cyclical_embed_params: null argument");
     TSC_REQUIRE(n >= 0, "bad size");
     for (int64_t q = 0; q < n; ++q) TSC_REQUIRE(n_reactive[q] == 1 || n_reactive[q] == 2, "row %lld: n_reactive must be 1 or 2", (long long)q);
@@ -2093,6 +2259,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed_params(
     TSC_HIP(hipMemcpyAsync(pos, d_pos, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TSC_HIP(hipStreamSynchronize(c->stream));
     return 0;
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -2133,6 +2300,7 @@ static int launch_tfd_greedy(tsc_ctx *c, Scratch &s, const float *d_tf, int64_t 
 
 extern "C" __attribute__((visibility("default"))) int tsc_tfd_greedy_filter(tsc_ctx *c, const float *tf, int64_t n_structs, int n_quads, double thresh,
                                                                             uint8_t *accepted, int64_t *n_kept) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && tf && accepted, "tsc_tfd_greedy_filter: null argument");
     TSC_REQUIRE(n_structs >= 0 && n_structs < INT32_MAX && n_quads >= 0, "bad sizes");
     if (n_kept) *n_kept = 0;
@@ -2152,6 +2320,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_tfd_greedy_filter(tsc_
     TSC_TRY(read_i32(c, d_nk, &nk));
     if (n_kept) *n_kept = nk;
     return 0;
+    TSC_API_GUARD_END
 }
 
 // What both drivers share once the pose parameters are on the device: clash verdicts of all candidates, the passing poses
@@ -2218,6 +2387,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed(tsc_ctx *
                                                                        int n_angles, double clash_thresh, int64_t max_clashes, const int32_t *quads, int n_quads,
                                                                        double tfd_thresh, uint8_t *clash_ok, uint8_t *kept, double *poses,
                                                                        int64_t poses_capacity, int64_t *n_pass, int64_t *n_kept) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && frag_off && n_atoms && n_conf && p1 && p2 && ref_vec && mol_vec && conf_pair && angles && clash_ok && kept && n_pass && n_kept,
                 "tsc_string_embed: null argument");
     TSC_REQUIRE(n_sites >= 0 && n_angles >= 0 && n_quads >= 0 && (n_quads == 0 || quads), "bad sizes");
@@ -2263,6 +2433,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_string_embed(tsc_ctx *
     };
     return embed_filter_run(c, s, d_frags, ft, frag_off, n_atoms, n_conf, d_ci, d_rot, d_pos, N, clash_thresh, max_clashes, clash_ok, kept, poses, poses_capacity,
                             n_pass, n_kept, filter);
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
@@ -2272,6 +2443,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed(tsc_ctx
                                                                          int64_t n_poses, const int32_t *group_off, int n_groups, double clash_thresh,
                                                                          int64_t max_clashes, double rmsd_thr, uint8_t *clash_ok, uint8_t *kept, double *poses,
                                                                          int64_t poses_capacity, int64_t *n_pass, int64_t *n_kept) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && frag_off && n_atoms && n_conf && start && end && direction && pivot && meanpoint && r0 && r1 && n_reactive && angle && conf_idx &&
                     group_off && clash_ok && kept && n_pass && n_kept,
                 "tsc_cyclical_embed: null argument");
@@ -2316,6 +2488,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_cyclical_embed(tsc_ctx
     };
     return embed_filter_run(c, s, d_frags, ft, frag_off, n_atoms, n_conf, d_ci, d_rot, d_pos, n_poses, clash_thresh, max_clashes, clash_ok, kept, poses,
                             poses_capacity, n_pass, n_kept, filter);
+    TSC_API_GUARD_END
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -2407,6 +2580,7 @@ static const double *pending_basis(const tsc_ctx *c, int h) {
 extern "C" __attribute__((visibility("default"))) int tsc_basis_from_poses_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
                                                                                const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                                                                const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx, "tsc_basis_from_poses_dev: null argument");
     TSC_REQUIRE(n_poses > 0 && n_poses < INT32_MAX, "bad n_poses");
     FragTable ft;
@@ -2419,6 +2593,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_basis_from_poses_dev(t
     BasisFork bf;
     TSC_TRY(basis_fork_begin(c, n_poses, n_heavy, &bf));
     return basis_fork_launch(c, bf, s, frags, ft, conf_idx, rot, pos, d_slot, n_heavy);
+    TSC_API_GUARD_END
 }
 
 // The poses selected by a mask that is ALREADY on the device (clash verdicts gathered from every rank, say), embedded in order:
@@ -2430,6 +2605,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
                                                                            const int32_t *n_conf, int n_mols, const int32_t *conf_idx, const double *rot,
                                                                            const double *pos, int64_t n_poses, const uint8_t *mask, const int32_t *heavy_idx,
                                                                            int n_heavy, double *structures, double *heavy, int64_t *n_sel_host) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && mask && (structures || heavy), "tsc_embed_masked_dev: null argument");
     TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX, "bad n_poses");
     if (n_sel_host) *n_sel_host = 0;
@@ -2451,6 +2627,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
     c->xd_valid = false;
     if (basis && c->fuse_descriptors && transform_describe_lds_bytes(ft.n_mols, n_heavy) <= 64 * 1024) {
         if (!(c->xd_D && c->xd_cap >= n_poses)) {
+            if (c->xd_borrowers > 0)
+                return fail(TSC_ERR_STATE, "tsc_embed_masked_dev: %d live prune run(s) still read the descriptor buffers of an earlier call, which %lld poses "
+                                           "would outgrow: destroy them first (tsc_prune_destroy)", c->xd_borrowers, (long long)n_poses);
             for (void *q : {static_cast<void *>(c->xd_D), static_cast<void *>(c->xd_G), static_cast<void *>(c->xd_dmax)})
                 if (q) c->release(q);
             c->xd_D = nullptr, c->xd_G = nullptr, c->xd_dmax = nullptr, c->xd_cap = 0;
@@ -2469,6 +2648,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
         if (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n_poses) * n_heavy * 24.0 >= 128e6)) {
             const int64_t need = n_poses * heavy32_pitch(n_heavy);
             if (c->xd_h32_cap < need) {
+                if (c->xd_borrowers > 0)
+                    return fail(TSC_ERR_STATE, "tsc_embed_masked_dev: %d live prune run(s) still read the float32 copy of an earlier call: destroy them first",
+                                c->xd_borrowers);
                 if (c->xd_heavy32) c->release(c->xd_heavy32);
                 c->xd_heavy32 = nullptr, c->xd_h32_cap = 0;
                 void *q = nullptr;
@@ -2495,6 +2677,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
         *n_sel_host = n_sel;
     }
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms,
@@ -2502,6 +2685,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_de
                                                                                   const double *pos, int64_t n_poses, const int32_t *heavy_idx, int n_heavy,
                                                                                   double clash_thresh, int64_t max_clashes, uint8_t *clash_mask,
                                                                                   double *structures, double *heavy, int64_t *n_pass_host) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && clash_mask && heavy && n_pass_host, "tsc_embed_clash_compact_dev: null argument");
     TSC_REQUIRE(n_poses >= 0 && n_poses < INT32_MAX, "bad n_poses");
     *n_pass_host = 0;
@@ -2533,6 +2717,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_clash_compact_de
     TSC_TRY(read_i32_finish(c, &n_pass));
     *n_pass_host = n_pass;
     return 0;
+    TSC_API_GUARD_END
 }
 
 extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *c, const double *frags, const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf,
@@ -2540,6 +2725,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
                                 const int32_t *heavy_idx, int n_heavy, double clash_thresh, int64_t max_clashes, double rmsd_thr, int mode,
                                 uint8_t *clash_mask, double *structures, uint8_t *keep_mask, uint8_t *keep_mask_host, int64_t *n_pass_host,
                                 int64_t *n_keep_host, tsc_pass_stats *stats, int *n_passes, float *timings_ms) {
+    TSC_API_GUARD_BEGIN
     TSC_REQUIRE(c && frags && conf_idx && rot && pos && heavy_idx && clash_mask && structures && keep_mask, "tsc_pipeline_dev: null argument");
     TSC_REQUIRE(n_poses > 0 && n_poses < INT32_MAX, "bad n_poses");
     FragTable ft;
@@ -2707,4 +2893,5 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         TSC_HIP(hipEventElapsedTime(&timings_ms[3], ev[0], ev[3]));
     }
     return 0;
+    TSC_API_GUARD_END
 }

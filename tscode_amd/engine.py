@@ -397,6 +397,20 @@ class Engine:
         check(self.lib.tsc_csearch_rotate_dev(self._h, ptr(coords), C.c_int(n_atoms), ptr(torsions), ptr(masks), C.c_int(n_tors), ptr(angles),
                                               C.c_int64(n_cand), C.c_double(thresh), C.c_int64(int(max_clashes)), ptr(out), ptr(rotated_bonds)))
 
+    def rotate_dihedral_batch(self, coords, torsion, mask, angles):
+        """rotate_dihedral (tscode/utils.py:389-414) on structures f64[M, n, 3] sharing torsion and mask: structure s by angles[s]
+        degrees (floats).  Returns the rotated copies."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.ndim != 3 or coords.shape[2] != 3:
+            raise ValueError("coords must be (n_structs, n_atoms, 3)")
+        torsion = np.ascontiguousarray(torsion, dtype=np.int32).reshape(4)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(coords.shape[1])
+        angles = np.ascontiguousarray(np.broadcast_to(np.asarray(angles, dtype=np.float64), (len(coords),)))
+        out = np.empty_like(coords)
+        check(self.lib.tsc_rotate_dihedral(self._h, ptr(coords), C.c_int64(len(coords)), C.c_int(coords.shape[1]), ptr(torsion), ptr(mask),
+                                           ptr(angles), ptr(out)))
+        return out
+
     def torsion_comp_check(self, coords, torsion, mask, thresh=1.5, max_clashes=0):
         """ok i32[M] for structures f64[M, n, 3] sharing one torsion and mask (tscode/numba_functions.py:26-47)."""
         coords = np.ascontiguousarray(coords, dtype=np.float64)

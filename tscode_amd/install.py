@@ -25,8 +25,9 @@ _PATCHES = {
     "get_embed": (embeds.get_embed, ("tscode.embeds",)),
     "all_dists": (algebra.all_dists, ("tscode.algebra", "tscode.numba_functions", "tscode.graph_manipulations")),
     "transform_coords": (algebra.transform_coords, ("tscode.algebra",)),
-    # (rotate_dihedral is NOT patched: tscode/torsion_module.py:984-1005 calls it with fractional angles, the batched
-    # kernel takes the integer tables of the conformational search; use tscode_amd.csearch_rotate for those loops)
+    # (any real angle: tscode/torsion_module.py:984-1005 calls it with fractional corrections; the candidate loops of the
+    # conformational search belong on tscode_amd.csearch_rotate, which takes their integer tables whole)
+    "rotate_dihedral": (torsion_module.rotate_dihedral, ("tscode.utils", "tscode.torsion_module")),
     "torsion_comp_check": (torsion_module.torsion_comp_check, ("tscode.numba_functions", "tscode.torsion_module")),
     "get_moi_similarity_matches": (optimization_methods.get_moi_similarity_matches, ("tscode.algebra", "tscode.optimization_methods")),
     "_score_embed_poses": (optimization_methods._score_embed_poses, ("tscode.numba_functions",)),

@@ -12,7 +12,7 @@ import numpy as np
 
 from .engine import get_engine
 
-__all__ = ["rotate_dihedral", "torsion_comp_check", "csearch_rotate", "csearch_candidates"]
+__all__ = ["rotate_dihedral", "rotate_dihedral_batch", "torsion_comp_check", "csearch_rotate", "csearch_candidates"]
 
 
 def csearch_rotate(coords, torsions, masks, angles, thresh=1.5, max_clashes=0):
@@ -43,6 +43,12 @@ def csearch_candidates(coords, torsions, masks, angles, n_out=100, max_tries=100
     return np.concatenate(out) if out else np.zeros((0,) + coords.shape)
 
 
+def rotate_dihedral_batch(coords, dihedral, angles, mask):
+    """Structures f64[M, n, 3] sharing torsion and mask, structure s turned by ``angles[s]`` degrees (floats): what a search over
+    correction angles (tscode/torsion_module.py:984-1005: rotate, look, rotate back, per angle) becomes as ONE call -- rotate M copies."""
+    return get_engine().rotate_dihedral_batch(coords, [int(i) for i in dihedral], mask, angles)
+
+
 def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None):
     """tscode/utils.py:389-414.  Like the reference it changes ``coords`` in place and returns it."""
     coords_arr = np.asarray(coords)
@@ -54,12 +60,10 @@ def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None
         m[dihedral[0]] = True
         mask = m
     mask = np.asarray(mask, dtype=bool)
-    if float(angle) != int(angle):
-        raise ValueError("the batched kernel takes whole degrees (the reference's angle tables are integers)")
-    if int(angle) == 0:
-        return coords                                    # (the candidate loop never rotates by zero, :482)
-    # one candidate, one torsion; a clash budget nothing can exceed switches the walk-back off
-    out, _ = get_engine().csearch_rotate(coords_arr, [tuple(int(i) for i in dihedral)], [mask], [[int(angle)]], 1.5, 2 ** 62)
+    if float(angle) == 0.0:
+        return coords                                    # (the identity; the candidate loop never rotates by zero, :482)
+    # one structure, one rotation by any real angle (tscode/torsion_module.py:984-1005 passes fractional corrections): no clash check
+    out = get_engine().rotate_dihedral_batch(coords_arr[None], [int(i) for i in dihedral], mask, [float(angle)])
     coords_arr[...] = out[0]
     return coords
 
