@@ -11,7 +11,10 @@ fused embed+clash verdicts -> ordered compaction of the passing poses -> prune_c
 
 N = 1: the one-call pipeline (tsc_pipeline_dev).
 
-N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): the line's `value` is ONE ensemble sharded over the
+N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): for the 100k-conformer workloads (C2, C3: the metric's) the line's
+`value` is `replicas` -- every GPU its own ensemble, `"scaling": "weak"`, no data-path collective: such an ensemble is a one-GPU job and does
+not strong-scale (`multi.why`) -- with the sharded leg beside it (`sharded_single_ensemble`); for C4 / C5 / the C5 chain (and with
+`--multi sharded`) the line's `value` is ONE ensemble sharded over the
 ranks, `"scaling": "strong"` -- every prune pass with at least 4 chunks per rank PARTITIONED BY CHUNKS (a rank runs the whole pass
 on the chunks that start inside its block of the structure axis; one bit per structure + statistics summed per pass,
 `partitioned_passes`), the later passes with their row tiles dealt round-robin and an all-reduce(MIN) over best[]
@@ -78,8 +81,10 @@ def parse():
     ap.add_argument("--n-poses", type=int, default=None, help="override the config's N (debugging)")
     ap.add_argument("--algo", type=int, default=0, help="pair kernel: 0/2 = descriptor sieve (default), 1 = register-tiled all-pairs")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (seg_cols, drain_min), repeatable")
-    ap.add_argument("--multi", choices=["sharded", "replicas"], default="sharded",
-                    help="N > 1: what the line's value is.  'sharded' (default) = ONE ensemble sharded over the ranks under RCCL "
+    ap.add_argument("--multi", choices=["auto", "sharded", "replicas"], default="auto",
+                    help="N > 1: what the line's value is.  'auto' (default) = 'replicas' for the 100k-conformer workloads (C2, C3: a one-GPU job of "
+                         "under a millisecond, of which only half divides by N -- a node runs N of them), 'sharded' for C4 / C5 / the C5 chain; "
+                         "'sharded' = ONE ensemble sharded over the ranks under RCCL "
                          "(strong scaling; all-gather + per-pass all-reduce), 'replicas' = one whole ensemble per GPU, no data-path "
                          "collective (weak scaling).  The other one is timed too and reported beside it.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one GPU to rehearse "
@@ -351,49 +356,57 @@ def main():
                     "survivors' heavy atoms embedded on every rank -- whichever `front_tuning` measured fastest on this node")
     REPLICAS_WHAT = "one whole ensemble per GPU (the same ensemble on every rank), no data-path collective"
 
-    main_sharded = (world > 1 and args.multi == "sharded") or args.force_sharded
+    # what the line's value is at N > 1 (docstring): a 100k-conformer ensemble is a one-GPU job -- its 0.8 ms step is a chain of about
+    # 30 dependent launches of which half divides by N, and every pass costs a collective (predicted 0.83 - 0.91 x
+    # at 2 - 8 ranks) -- so a node runs N of them (`replicas`, weak scaling) and the sharded leg is reported beside it; the 1M-conformer
+    # and 200-atom workloads are sharded (strong scaling), replicas beside them
+    multi = args.multi if args.multi != "auto" else ("replicas" if args.config in ("C2", "C3") else "sharded")
+    multi_reason = ("asked for (--multi)" if args.multi != "auto" else
+                    ("automatic: a 100k-conformer ensemble is a one-GPU job (its step does not strong-scale, DESIGN.md 6); a node runs one per GPU"
+                     if multi == "replicas" else "automatic: a workload this size is sharded over the ranks"))
+    main_sharded = (world > 1 and multi == "sharded") or args.force_sharded
     side = None
     error = None
     exit_code = 0
-    if world > 1 and main_sharded:
+    if world > 1:
         # the replicas leg first (it cannot hang on a collective), then the sharded leg under a watchdog: if RCCL should hang
-        # on some node, a line is still printed -- with the replicas figure as its value, the failure named, exit code 3
-        replicas = None if args.no_side_leg else run_leg(False)
-        box = {}
-
-        def bail():
-            if rank == 0:
-                line = {"metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
-                        "value": None, "unit": "conformers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                        "config": {"workload": f"{args.config}: {ens.n_poses} conformers x {ens.n_atoms} atoms"},
-                        "error": "the sharded single-ensemble leg did not finish within 180 s (collective hung?); value = replicas leg"}
-                if replicas is not None:
-                    s = leg_summary(replicas, REPLICAS_WHAT)
-                    line.update(value=s["value"], ms_per_step=s["ms_per_step"], replicas=s)
-                os.write(real_stdout, (json.dumps(line) + "\n").encode())
-            os._exit(3)
-        watchdog = threading.Timer(180.0, bail)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            leg = run_leg(True)
-        except Exception as exc:
-            error = f"sharded single-ensemble leg failed: {type(exc).__name__}: {exc}; value = replicas leg"
-            exit_code = 3
-            leg = replicas
-            if leg is None:
-                raise
-        watchdog.cancel()
-        if leg is not replicas and replicas is not None:
-            side = ("replicas", leg_summary(replicas, REPLICAS_WHAT))
-    elif world > 1:
-        leg = run_leg(False)
-        if not args.no_side_leg and args.backend == "nccl":
+        # on some node, a line is still printed -- with the replicas figure as its value, the failure named (exit code 3 when the
+        # sharded leg was to be the line's value)
+        replicas = run_leg(False) if (not main_sharded or not args.no_side_leg) else None
+        sharded_leg = None
+        if main_sharded or not args.no_side_leg:
+            def bail():
+                if rank == 0:
+                    line = {"metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
+                            "value": None, "unit": "conformers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                            "config": {"workload": f"{args.config}: {ens.n_poses} conformers x {ens.n_atoms} atoms"},
+                            "error": "the sharded single-ensemble leg did not finish within 180 s (collective hung?); value = replicas leg"}
+                    if replicas is not None:
+                        s = leg_summary(replicas, REPLICAS_WHAT)
+                        line.update(value=s["value"], ms_per_step=s["ms_per_step"], replicas=s)
+                    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+                os._exit(3 if main_sharded else 0)
+            watchdog = threading.Timer(180.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
             try:
-                side = ("sharded_single_ensemble", leg_summary(run_leg(True), SHARDED_WHAT))
+                sharded_leg = run_leg(True)
             except Exception as exc:
-                side = ("sharded_single_ensemble", {"error": f"{type(exc).__name__}: {exc}"})
+                error = f"sharded single-ensemble leg failed: {type(exc).__name__}: {exc}" + ("; value = replicas leg" if main_sharded else "")
+                if main_sharded:
+                    exit_code = 3
+                    if replicas is None:
+                        raise
+            watchdog.cancel()
+        if main_sharded and sharded_leg is not None:
+            leg = sharded_leg
+            if replicas is not None:
+                side = ("replicas", leg_summary(replicas, REPLICAS_WHAT))
+        else:
+            leg = replicas
+            if sharded_leg is not None:
+                side = ("sharded_single_ensemble", leg_summary(sharded_leg, SHARDED_WHAT))
     else:
         leg = run_leg(main_sharded)
 
@@ -542,6 +555,9 @@ def main():
             # is partitioned by chunks or sharded by row tiles, one for the cache views between the two kinds
             out["collectives_per_step"] = ({"shard": 2, "hybrid": 1}.get(res.get("front"), 0) + len(res.get("exchanges", []))
                                            + len(res.get("partitioned", [])) + (1 if res.get("partitioned") and args.mode == 0 else 0))
+        if world > 1:
+            out["multi"] = {"value_is": "sharded_single_ensemble" if sharded_mode else "replicas", "why": multi_reason,
+                            "beside_it": side[0] if side is not None else None}
         if side is not None:
             out[side[0]] = side[1]
         if error is not None:

@@ -432,6 +432,33 @@ int tsc_prune_best_ptr(tsc_prune *p, void **best_dev, int64_t *n_entries); /* i3
  * torch.distributed can all-reduce); call right after tsc_prune_create. */
 int tsc_prune_use_best_buffer(tsc_prune *p, void *best_dev_i32_n);
 int tsc_prune_pass_finish(tsc_prune *p);                          /* asynchronous */
+
+/* ---- the pass loop of a sharded run behind ONE call (the multi-rank variant of the prune) ----
+ * tsc_prune_run_sharded walks the whole schedule of `run` as the step-by-step calls above would -- passes below `min_pairs` pairs whole
+ * on every rank; passes with at least `min_chunks_per_rank` chunks per rank partitioned by chunks (0: never; needs the exchange buffer
+ * exch_dev of tsc_prune_exchange_words words, which then also holds the cache views); the cache views summed once before the first pass
+ * of the other kind; the remaining passes dealt by row tiles -- and calls back only for the collectives:
+ *     exchange(user, kind, buf_dev, count)   reduce `count` elements at the DEVICE address buf_dev over all ranks, in place:
+ *                                            TSC_XCHG_SUM_I64 = all-reduce SUM of int64 (removed-row bits and statistics of a partitioned
+ *                                            pass; the cache views), TSC_XCHG_MIN_I32 = all-reduce MIN of int32 (best[] of a pass dealt
+ *                                            by row tiles).  Everything the library enqueued before the call is on the context's stream:
+ *                                            enqueue the collective on that stream (RCCL: ncclAllReduce(buf, buf, count, ncclInt64 /
+ *                                            ncclInt32, ncclSum / ncclMin, comm, stream)) or synchronise around it.  Return 0; anything
+ *                                            else aborts the run with TSC_ERR_STATE.
+ * One process per GPU owns the communicator; the library opens none.  Every rank makes the same sequence of calls (it depends on n, k
+ * and the world size only).  log (optional, log_cap entries): the exchanges made, in order -- k < 0 marks the one exchange of the cache
+ * views in front of pass |k|.  With world == 1 the function is tsc_prune_run_replicated to the end (exchange may be NULL).
+ * Afterwards: tsc_prune_copy_mask_dev / tsc_prune_stats / tsc_prune_destroy as usual.
+ * tscode/rmsd_pruning.py:139-157 (chunks independent), :92,101-113 (rows independent). */
+enum { TSC_XCHG_SUM_I64 = 1, TSC_XCHG_MIN_I32 = 2 };
+typedef int (*tsc_exchange_fn)(void *user, int kind, void *buf_dev, int64_t count);
+typedef struct tsc_exchange_record {
+    int64_t k;      /* the pass (negative: the cache views in front of pass -k) */
+    int32_t kind;   /* TSC_XCHG_* */
+    int64_t count;  /* elements reduced */
+} tsc_exchange_record;
+int tsc_prune_run_sharded(tsc_prune *run, int rank, int world_size, int min_chunks_per_rank, int64_t min_pairs, void *exch_dev, int64_t exch_words,
+                          tsc_exchange_fn exchange, void *user, tsc_exchange_record *log, int log_cap, int *n_log);
 int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev);
 int tsc_prune_copy_mask_dev(tsc_prune *p, uint8_t *dst_dev); /* dst[0..n) <- mask, asynchronous on the stream */
 int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes); /* synchronises */

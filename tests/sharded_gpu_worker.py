@@ -55,6 +55,17 @@ def main():
         torch.cuda.synchronize()
         d2 = hashlib.sha256(np.packbits(pipe.h_keep[:r2["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
         forms_agree = forms_agree and r2["front"] == form and d2 == digest and [s["pairs_evaluated"] for s in r2["stats"]] == evals
+    # the pass loop behind the C ABI (tsc_prune_run_sharded: what every step above ran) against the same loop driven from the host, call by call
+    be = getattr(pipe, "backend", None) or getattr(getattr(pipe, "pipe", None), "backend", None)
+    loops_agree = None
+    if be is not None:
+        be.python_pass_loop = True
+        r3 = pipe.step()
+        torch.cuda.synchronize()
+        d3 = hashlib.sha256(np.packbits(pipe.h_keep[:r3["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
+        loops_agree = bool(d3 == digest and [s["pairs_evaluated"] for s in r3["stats"]] == evals and r3["exchanges"] == res["exchanges"]
+                           and r3["partitioned"] == res["partitioned"])
+        be.python_pass_loop = False
     flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64, device="cuda:0" if backend == "nccl" else "cpu")
     gathered = [torch.zeros_like(flags) for _ in range(world)]
     dist.all_gather(gathered, flags)
@@ -67,6 +78,7 @@ def main():
         print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "n_conformers": res.get("n_conformers"),
                           "keep_sha256_16": digest, "steps_that_differ": unstable,
                           "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"], "forms_agree": forms_agree,
+                          "loops_agree": loops_agree, "exchanges": res["exchanges"], "partitioned": res["partitioned"],
                           "front_tuning": pipe.front_tuning,
                           "pairs_evaluated": [s["pairs_evaluated"] for s in res["stats"]], "global_path_passes": sharded_passes}), flush=True)
     dist.barrier()

@@ -1625,6 +1625,11 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     # embedded everywhere) were timed, one was chosen by every
     # rank alike, and each of them, forced, gives the same survivors and evaluation counts
     assert got["forms_agree"]
+    # every step above ran its pass loop INSIDE the library (tsc_prune_run_sharded, the host called back for the collectives only);
+    # the same loop driven from the host call by call gives the same survivors, evaluation counts and sequence of exchanges
+    assert got["loops_agree"] is True
+    if world > 1 and cfg in ("C3", "C4"):
+        assert len(got["partitioned"]) >= 3 and len(got["exchanges"]) >= 2, (got["partitioned"], got["exchanges"])
     if world > 1:           # (a world of one does not time the forms: it has nothing to choose)
         assert got["front_tuning"]["chosen"] in ("shard", "replicate", "hybrid") and len(got["front_tuning"]["ms_per_step"]) == 3
     if cfg == "C5chain" and n_poses > 0:

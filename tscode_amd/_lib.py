@@ -40,6 +40,14 @@ class PassStats(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class ExchangeRecord(C.Structure):
+    """tsc_exchange_record: one collective of tsc_prune_run_sharded (k < 0: the cache views in front of pass -k)."""
+    _fields_ = [("k", C.c_int64), ("kind", C.c_int32), ("count", C.c_int64)]
+
+
+XCHG_SUM_I64, XCHG_MIN_I32 = 1, 2
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)     # tsc_exchange_fn(user, kind, buf_dev, count)
+
 # name -> (restype, argtypes); mirrors include/tscode_hip.h one to one
 _vp = C.c_void_p
 _SIGNATURES = {
@@ -114,6 +122,8 @@ _SIGNATURES = {
     "tsc_prune_use_best_buffer": (C.c_int, [_vp, _vp]),
     "tsc_prune_pass_finish": (C.c_int, [_vp]),
     "tsc_prune_mask_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "tsc_prune_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, C.c_int64, EXCHANGE_FN, _vp, C.POINTER(ExchangeRecord), C.c_int,
+                                        C.POINTER(C.c_int)]),
     "tsc_prune_copy_mask_dev": (C.c_int, [_vp, _vp]),
     "tsc_prune_stats": (C.c_int, [_vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_destroy": (C.c_int, [_vp]),

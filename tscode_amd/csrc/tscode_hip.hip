@@ -1566,6 +1566,66 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_run_replicated(t
     TSC_API_GUARD_END
 }
 
+// The whole pass loop of a SHARDED run behind one call (the multi-rank variant of the prune; 8e: the protocol).  The library
+// walks the schedule exactly as tscode_amd/pipeline.py::sharded_step does -- passes below `min_pairs` whole on every rank, passes with at
+// least `min_chunks_per_rank` chunks per rank partitioned by chunks (removed-row bits summed), the cache views summed once before the
+// first pass of the other kind, the remaining large passes dealt by row tiles (best[] min-merged) -- and hands the host nothing but the
+// collectives: `exchange(user, kind, buf, count)` must reduce the `count` elements at device address `buf` over the ranks IN PLACE, in
+// stream order with the context's stream (enqueue it there, or synchronise on both sides), and return 0.  One process per GPU owns the
+// communicator (RCCL through torch.distributed, or ncclAllReduce on the context's stream from a C host); the library opens none.
+extern "C" __attribute__((visibility("default"))) int tsc_prune_run_sharded(tsc_prune *p, int rank, int world, int min_chunks_per_rank, int64_t min_pairs,
+                                                                            void *exch_dev, int64_t exch_words, tsc_exchange_fn exchange, void *user,
+                                                                            tsc_exchange_record *log, int log_cap, int *n_log) {
+    TSC_API_GUARD_BEGIN
+    TSC_REQUIRE(p != nullptr, "null argument");
+    TSC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    TSC_REQUIRE(world == 1 || exchange != nullptr, "tsc_prune_run_sharded: %d ranks and no exchange function", world);
+    TSC_REQUIRE(min_chunks_per_rank >= 0 && log_cap >= 0 && (log || log_cap == 0), "bad argument");
+    int logged = 0;
+    if (n_log) *n_log = 0;
+    auto xchg = [&](int kind, void *buf, int64_t count, int64_t k) -> int {
+        if (log && logged < log_cap) log[logged] = tsc_exchange_record{k, kind, count};
+        ++logged;
+        if (n_log) *n_log = std::min(logged, log_cap);
+        if (world == 1 && !exchange) return 0;
+        const int rc = exchange(user, kind, buf, count);
+        if (rc != 0) return fail(TSC_ERR_STATE, "tsc_prune_run_sharded: the exchange function returned %d (pass k = %lld, kind %d, %lld elements)", rc,
+                                 (long long)k, kind, (long long)count);
+        return 0;
+    };
+    const bool can_partition = world > 1 && min_chunks_per_rank > 0 && exch_dev != nullptr && p->algo == ALGO_SIEVE;
+    if (can_partition) TSC_TRY(tsc_prune_set_partition(p, rank, world, min_chunks_per_rank, exch_dev, exch_words));
+    for (;;) {
+        int64_t k = 0;
+        TSC_TRY(tsc_prune_run_replicated(p, world, min_pairs, &k));  // (every pass that needs no exchange; returns with the first that does, open)
+        if (k == 0) break;
+        if (pass_is_partitioned(p, k)) {
+            // the whole pass on this rank's chunks; what the ranks tell each other is which rows they removed (+ the statistics)
+            TSC_TRY(tsc_prune_pass_range(p));
+            TSC_TRY(xchg(TSC_XCHG_SUM_I64, p->exch, int64_t(p->bit_words) + 8, k));
+            TSC_TRY(tsc_prune_pass_merge(p));
+            continue;
+        }
+        if (p->views_split && p->mode == 0) {
+            // first pass after the partitioned ones: every rank needs every rank's cache keys from here on
+            void *views = nullptr;
+            int64_t off = 0, words = 0;
+            TSC_TRY(tsc_prune_views_ptr(p, &views, &off, &words));
+            if (words > 0) TSC_TRY(xchg(TSC_XCHG_SUM_I64, views, words, -k));
+            TSC_TRY(tsc_prune_views_merged(p));
+        }
+        if (world > 1 && p->n * (p->n / k) / 2 >= min_pairs) {
+            TSC_TRY(tsc_prune_pass_local(p, rank, world));  // this rank's row tiles only ...
+            TSC_TRY(xchg(TSC_XCHG_MIN_I32, p->best, p->n, k));  // ... merged
+        } else {
+            TSC_TRY(tsc_prune_pass_local(p, 0, 1));  // (a small pass that only came back for the views' exchange)
+        }
+        TSC_TRY(tsc_prune_pass_finish(p));
+    }
+    return 0;
+    TSC_API_GUARD_END
+}
+
 #ifdef TSC_DBG_STAMPS
 // measurement builds only: the time stamps of the last stamped pair-kernel launch, 8 per wavefront (tools/stamps.py)
 extern "C" __attribute__((visibility("default"))) int tsc_debug_stamps(tsc_ctx *c, unsigned long long *dst, int64_t max_waves, int64_t *n_waves) {

@@ -576,6 +576,35 @@ class PruneStepper:
     def pass_finish(self):
         check(self.e.lib.tsc_prune_pass_finish(self._p))
 
+    def run_sharded(self, rank, world, min_chunks_per_rank, min_pairs, exch_dev, exchange):
+        """The whole pass loop of a sharded run in ONE library call (tsc_prune_run_sharded): the library walks the schedule and calls
+        ``exchange(kind, ptr, count)`` for every collective -- kind XCHG_SUM_I64 / XCHG_MIN_I32 (tscode_amd._lib), ``ptr`` the device
+        address of ``count`` elements to reduce over the ranks in place, in stream order with the context's stream.  Returns the list
+        of exchanges made as (k, kind, count); k < 0 = the cache views in front of pass -k.  An exception raised by ``exchange``
+        aborts the run and is re-raised here."""
+        from ._lib import EXCHANGE_FN, ExchangeRecord
+        failure = []
+
+        def _cb(_user, kind, buf, count):
+            try:
+                exchange(int(kind), int(buf), int(count))
+                return 0
+            except BaseException as exc:  # noqa: BLE001  (must not propagate through the C frames)
+                failure.append(exc)
+                return 1
+        cb = EXCHANGE_FN(_cb)
+        log = (ExchangeRecord * (2 * TSC_MAX_PASSES + 2))()
+        n_log = C.c_int()
+        rc = self.e.lib.tsc_prune_run_sharded(self._p, C.c_int(rank), C.c_int(world), C.c_int(min_chunks_per_rank), C.c_int64(int(min_pairs)),
+                                              ptr(exch_dev), C.c_int64(exch_dev.numel() if exch_dev is not None else 0), cb, None, log,
+                                              C.c_int(len(log)), C.byref(n_log))
+        if failure:
+            raise failure[0]
+        check(rc)
+        if exch_dev is not None:
+            self._keep_exch = exch_dev
+        return [(log[i].k, log[i].kind, log[i].count) for i in range(n_log.value)]
+
     def mask_ptr(self) -> int:
         p = C.c_void_p()
         check(self.e.lib.tsc_prune_mask_dev(self._p, C.byref(p)))

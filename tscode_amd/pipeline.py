@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._lib import XCHG_MIN_I32, XCHG_SUM_I64
 from .engine import Engine, FragmentSet
 
 __all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "ShardedCsearchChain", "sharded_step", "block_bounds", "partition_bounds", "SHARD_MIN_PAIRS",
@@ -168,10 +169,28 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
         st = backend.make_stepper(n_pass)
         limit = SHARD_MIN_PAIRS if min_pairs is None else min_pairs
         can_partition = world > 1 and partition_chunks > 0 and hasattr(st, "set_partition")
-        if can_partition:
+        in_library = hasattr(st, "run_sharded") and not getattr(backend, "python_pass_loop", False)
+        if can_partition and not in_library:
             st.set_partition(rank, world, partition_chunks)
         try:
-            while True:
+            if in_library:
+                # the product backend: the pass loop lives behind the C ABI (tsc_prune_run_sharded); the host is called back for the
+                # collectives only -- one Python frame per collective instead of three library calls + this loop per pass
+                def exchange(kind, addr, count):
+                    if kind == XCHG_SUM_I64:
+                        off = (addr - backend.exch.data_ptr()) // 8
+                        _all_reduce(dist, backend.exch[off:off + count], dist.ReduceOp.SUM, group)
+                    else:
+                        assert addr == backend.best.data_ptr()
+                        _all_reduce(dist, backend.best[:count], dist.ReduceOp.MIN, group)
+                for k, kind, count in st.run_sharded(rank, world, partition_chunks if can_partition else 0, limit, exchange):
+                    if kind == XCHG_MIN_I32:
+                        exchanges.append((int(k), int(count)))
+                    elif k > 0:
+                        partitioned.append((int(k), int(count)))
+                    else:
+                        views_words += int(count)
+            while not in_library:                       # the same loop on the host: test backends, and the product's with python_pass_loop set
                 if hasattr(st, "run_replicated"):       # the small passes in one library call; back here for an exchange
                     k = st.run_replicated(world, limit)
                     if k == 0:
@@ -230,6 +249,9 @@ class _HipStepper:
 
     def run_replicated(self, world, min_pairs):
         return self.s.run_replicated(world, min_pairs)
+
+    def run_sharded(self, rank, world, min_chunks, min_pairs, exchange):
+        return self.s.run_sharded(rank, world, min_chunks, min_pairs, self.exch, exchange)
 
     def pass_local(self, rank, world):
         self.s.pass_local(rank, world)
