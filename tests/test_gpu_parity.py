@@ -1097,6 +1097,78 @@ def test_clash_fp32_band_falls_back_to_fp64(eng, oracle):
     assert 0 < ref.sum() < len(ref)
 
 
+def test_fused_clash_one_pose_per_lane(eng, oracle):
+    """k_clash_lanes (the fused embed + clash verdicts of two-fragment ensembles: one pose per lane, the smaller fragment in registers)
+    against the oracle's embed + compenetration_check and against k_clash (option clash_lanes 0): fragment sizes on both sides of the
+    register tiers (8 / 16 / 24 / 26 / 32 atoms; 33: the kernel does not take it), either fragment the smaller one, several conformers
+    per fragment, pose counts that are no multiple of 64, poses whose closest distance sits 1e-12 .. 1e-3 from the threshold (the
+    fp32 band's fp64 recount) and ensembles far from the origin (no usable band at all)."""
+    import torch
+
+    from tscode_amd.engine import FragmentSet
+    rng = np.random.default_rng(4)
+    dev = torch.device("cuda:0")
+
+    def run(frag_coords, ci, rot, pos, lanes):
+        fs = FragmentSet(frag_coords)
+        eng.set_option("clash_lanes", lanes)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_mask = torch.zeros(len(ci), dtype=torch.uint8, device=dev)
+        eng.embed_clash_mask_dev(fs, t(fs.flat), t(ci.astype(np.int32)), t(rot), t(pos), len(ci), 1.5, 0, d_mask)
+        eng.synchronize()
+        return d_mask.cpu().numpy().astype(bool)
+
+    def rotations(n):
+        q = rng.normal(size=(n, 4))
+        from tscode_amd.synthetic import quat_to_mat
+        return quat_to_mat(q)
+
+    try:
+        for n_a, n_b, n_conf, n_poses, offset in ((1, 1, 1, 1, 0.0), (2, 9, 1, 63, 0.0), (8, 7, 3, 65, 0.0), (9, 16, 2, 1000, 0.0), (17, 40, 1, 700, 0.0),
+                                                  (24, 25, 1, 3000, 0.0), (25, 25, 4, 20000, 0.0), (26, 31, 1, 500, 0.0), (32, 33, 2, 1500, 0.0),
+                                                  (33, 33, 1, 300, 0.0), (25, 25, 1, 2000, 1.0e5), (25, 25, 1, 500, 1.0e16)):
+            fa = rng.normal(size=(n_conf, n_a, 3)) * 1.6
+            fb = rng.normal(size=(n_conf, n_b, 3)) * 1.6
+            ci = rng.integers(0, n_conf, size=(n_poses, 2))
+            rot = np.stack([rotations(n_poses), rotations(n_poses)], axis=1)
+            pos = np.stack([np.zeros((n_poses, 3)), rng.normal(size=(n_poses, 3)) * 3.5], axis=1) + offset
+            ref_poses = oracle.transform_batch([fa, fb], ci.astype(np.int32), rot, pos)
+            ref = oracle.compenetration_mask(ref_poses, np.array([n_a, n_b], np.int32), 1.5, 0).astype(bool)
+            for lanes in (1, 0):
+                got = run([fa, fb], ci, rot, pos, lanes)
+                assert np.array_equal(got, ref), (n_a, n_b, n_conf, n_poses, offset, lanes, got.sum(), ref.sum())
+            if offset == 0.0 and n_poses >= 500:
+                assert 0 < ref.sum() < n_poses
+        # inside the band: fragment b placed so that its atom 0 sits 1.5 + eps from atom 3 of a; everything else far away
+        n_a, n_b = 25, 25
+        fa = rng.normal(size=(1, n_a, 3)) * 2.0
+        fb = rng.normal(size=(1, n_b, 3)) * 0.4 + np.array([9.0, 0.0, 0.0])      # a tight clump 9 A from its own atom 0
+        fb[0, 0] = 0.0
+        rot_l, pos_l = [], []
+        for eps in (0.0, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3):
+            for rep in range(9):
+                d = rng.normal(size=3)
+                d /= np.linalg.norm(d)
+                # rotate b so that its clump points AWAY from a (along d), then put its atom 0 at a[3] + d (1.5 + eps)
+                from tscode_amd.algebra import rotation_matrix_from_vectors
+                Rb = rotation_matrix_from_vectors(np.array([1.0, 0.0, 0.0]), d)
+                shift = rng.normal(size=3) * 15.0
+                rot_l.append(np.stack([np.eye(3), Rb]))
+                pos_l.append(np.stack([shift, fa[0, 3] + d * (1.5 + eps) + shift]))
+        rot, pos = np.array(rot_l), np.array(pos_l)
+        ci = np.zeros((len(rot), 2), np.int64)
+        ref_poses = oracle.transform_batch([fa, fb], ci.astype(np.int32), rot, pos)
+        assert oracle.clash_margin(ref_poses, np.array([n_a, n_b], np.int32), 1.5) < 1e-9            # (this set is MEANT to sit on the threshold)
+        ref = oracle.compenetration_mask(ref_poses, np.array([n_a, n_b], np.int32), 1.5, 0).astype(bool)
+        for lanes in (1, 0):
+            got = run([fa, fb], ci, rot, pos, lanes)
+            # eps = 0 and +-1e-12 are decided by the last bits of the embedding (FMA contraction differs between compilers): compare from 1e-9 on
+            assert np.array_equal(got[27:], ref[27:]), lanes
+        assert 0 < ref[27:].sum() < len(ref) - 27
+    finally:
+        eng.set_option("clash_lanes", 1)
+
+
 # ----------------------------------------------------------------------------- N3: csearch rotations
 def test_csearch_rotations_golden(eng, oracle):
     """tscode/torsion_module.py:463-500 candidates against the reference-derived fixture G7 and the oracle."""

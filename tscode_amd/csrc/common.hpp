@@ -105,6 +105,7 @@ struct tsc_ctx {
     int fused_apply = 1;                  // single-rank sieve passes: the pair kernel applies the verdicts tile by tile and closes the pass (sieve.hpp)
     int open_lds_blocks = 1 << 30;        // k_open_rows stages the scan-block prefix in LDS up to this many blocks (tests lower it to take the other path)
     int clash_fp32 = 1;                   // clash verdicts (max_clashes = 0, no counts): packed-fp32 minimum with fp64 fallback
+    int clash_lanes = 1;                  // ... of two fragments, the smaller of at most 32 atoms, fused with the embed: one pose per lane (k_clash_lanes)
     int deterministic_basis = 0;          // the descriptor basis from fixed-order sums (sieve.hpp, k_feature_moments): a sharded run sets it -- its ranks
                                           // must derive bit-identical descriptors (the culled passes deal the tiles of a layout sorted by them)
     int cull = 1;                         // large passes of the sieve lay their structures out along a Morton curve and skip tile pairs by bounding box (cull.hpp)

@@ -300,6 +300,113 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
     }
 }
 
+// K1 + K2 fused, ONE POSE PER LANE (two fragments, verdict only, no clash allowed: the pipeline's case at 100k - 1M poses of 50 atoms).
+// k_clash gives a pose to a group of lanes: every wavefront is then a chain of dependent round trips -- the pose's parameters, its
+// fragments' coordinates, the pose through LDS, the group's shuffles -- for two poses of work, and 60 us pass over 19 MB of input
+// (0.3 TB/s) with the VALU a tenth busy.  Here a lane owns a pose from its 200 bytes of parameters to its verdict byte: the atoms of the
+// SMALLER fragment ("A", at most 2 NA2 of them) are embedded once and stay in registers as packed fp32 pairs, the atoms of the other are
+// embedded one after the other and each is compared with all of A (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 / min: 3.5 instructions per
+// distance, nothing but registers), so a wavefront issues some 2 500 independent-enough instructions for 64 poses and the kernel is
+// bound by VALU issue, not by latency.  Same arithmetic and the same rigorous band as k_clash's MINMODE (fp64 embedding, fp32 copy,
+// s32 = dx^2 + dy^2 + dz^2 by mul + 2 fma; fp32_min_band with the POSE's own largest coordinate): a pose whose minimum falls inside the
+// band is recounted in fp64 by the whole wavefront, all its n_A n_B distances at once (d^2 < sq_bound: exactly the reference's
+// sqrt-then-compare verdict, numba_functions.py:77-86).
+template <int NA2>
+__global__ __launch_bounds__(256) void k_clash_lanes(int64_t n_poses, const double *__restrict__ frags, FragTable ft, int mA, int mB,
+                                                      const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
+                                                      const double *__restrict__ pos, double sq_bound, uint8_t *__restrict__ mask) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nA = ft.n_atoms[mA], nB = ft.n_atoms[mB], nm = ft.n_mols;
+    for (int64_t s0 = (int64_t(blockIdx.x) * 4 + wid) * 64; s0 < n_poses; s0 += int64_t(gridDim.x) * 256) {
+        const bool valid = s0 + lane < n_poses;
+        const int64_t s = valid ? s0 + lane : n_poses - 1;  // (idle lanes of the last wavefront walk along with the last pose)
+        double RA[9], tA[3], RB[9], tB[3];
+        {
+            const double *r = rot + (s * nm + mA) * 9, *t = pos + (s * nm + mA) * 3;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) RA[q] = r[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tA[q] = t[q];
+            r = rot + (s * nm + mB) * 9, t = pos + (s * nm + mB) * 3;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) RB[q] = r[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tB[q] = t[q];
+        }
+        const double *XA = frags + ft.frag_off[mA] + int64_t(conf_idx[s * nm + mA]) * nA * 3;
+        const double *XB = frags + ft.frag_off[mB] + int64_t(conf_idx[s * nm + mB]) * nB * 3;
+        clash_f32x2 ax[NA2], ay[NA2], az[NA2];
+        double cmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA2; ++k) {
+            float v[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int a = 2 * k + u;
+                if (a < nA) {
+                    const double x0 = XA[3 * a], x1 = XA[3 * a + 1], x2 = XA[3 * a + 2];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double w = RA[3 * i] * x0 + RA[3 * i + 1] * x1 + RA[3 * i + 2] * x2 + tA[i];  // embed_atom
+                        cmax = fmax(cmax, fabs(w));
+                        v[u][i] = float(w);
+                    }
+                } else {
+                    v[u][0] = v[u][1] = v[u][2] = 1.0e18f;  // (padding: an atom far from everything; its squared distances stay finite in fp32)
+                }
+            }
+            ax[k] = clash_f32x2{v[0][0], v[1][0]}, ay[k] = clash_f32x2{v[0][1], v[1][1]}, az[k] = clash_f32x2{v[0][2], v[1][2]};
+        }
+        float m = __builtin_inff();
+        for (int b = 0; b < nB; ++b) {
+            const double x0 = XB[3 * b], x1 = XB[3 * b + 1], x2 = XB[3 * b + 2];
+            float bf[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double w = RB[3 * i] * x0 + RB[3 * i + 1] * x1 + RB[3 * i + 2] * x2 + tB[i];
+                cmax = fmax(cmax, fabs(w));
+                bf[i] = float(w);
+            }
+            const clash_f32x2 bx = {bf[0], bf[0]}, by = {bf[1], bf[1]}, bz = {bf[2], bf[2]};
+            // two running minima: consecutive pairs of A do not wait for each other
+            float m0 = m, m1 = __builtin_inff();
+#pragma unroll
+            for (int k = 0; k < NA2; ++k) {
+                const clash_f32x2 dx = bx - ax[k], dy = by - ay[k], dz = bz - az[k];
+                clash_f32x2 s2 = dx * dx;
+                s2 = __builtin_elementwise_fma(dy, dy, s2);
+                s2 = __builtin_elementwise_fma(dz, dz, s2);
+                if (k & 1) m1 = fminf(m1, fminf(s2.x, s2.y));
+                else m0 = fminf(m0, fminf(s2.x, s2.y));
+            }
+            m = fminf(m0, m1);
+        }
+        float lo, hi;
+        const bool banded = fp32_min_band(sq_bound, cmax, &lo, &hi);
+        int verdict = 1;
+        bool decided = !valid;
+        if (banded && m >= hi) decided = true, verdict = 1;      // every distance certainly >= thresh (a NaN minimum: undecided)
+        else if (banded && m < lo) decided = true, verdict = 0;  // some distance certainly < thresh
+        // ---- poses inside the band (a few in 10^4), or without a usable band: every distance in fp64, by the whole wavefront
+        for (unsigned long long und = __builtin_amdgcn_ballot_w64(!decided); und; und &= und - 1) {
+            const int l = __ffsll((long long)und) - 1;
+            const int64_t sp = s0 + l;
+            bool hit = false;
+            for (int e = lane; e < nA * nB; e += 64) {
+                const int a = e / nB, b = e - a * nB;
+                double p[3], q[3];
+                embed_atom(frags, ft, conf_idx, rot, pos, sp, ft.atom_off[mA] + a, p);
+                embed_atom(frags, ft, conf_idx, rot, pos, sp, ft.atom_off[mB] + b, q);
+                const double dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+                hit = hit || (dx * dx + dy * dy + dz * dz < sq_bound);
+            }
+            const bool any = __builtin_amdgcn_ballot_w64(hit) != 0;
+            if (lane == l) verdict = any ? 0 : 1;  // count(D < thresh) <= 0
+        }
+        if (valid) mask[s0 + lane] = uint8_t(verdict);
+    }
+}
+
 // all_dists (algebra.py:98-157): out[i, j] = sqrt(sum_k (A[i,k] - B[j,k])^2)
 __global__ __launch_bounds__(256) void k_all_dists(const double *__restrict__ A, int na, const double *__restrict__ B, int nb,
                                                     double *__restrict__ out) {

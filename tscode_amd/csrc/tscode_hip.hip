@@ -340,6 +340,22 @@ static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, co
     if (a.self_mode) return launch_clash_impl<FUSED, true, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
     // verdict only and no clash allowed: the packed-fp32 minimum with its fp64 fallback (embed_clash.hpp)
     const bool minmode = !counts && a.max_clashes == 0 && c->clash_fp32 != 0 && 4 * clash_lds_per_wave(a.n, a.lp, true) <= 160 * 1024;
+    if (minmode && FUSED && c->clash_lanes != 0 && a.n_mols == 2 && ft.n_mols == 2 && a.atom_off[1] == ft.atom_off[1] && a.n == ft.n_total &&
+        std::min(ft.n_atoms[0], ft.n_atoms[1]) >= 1 && std::min(ft.n_atoms[0], ft.n_atoms[1]) <= 32) {
+        // one pose per lane, the smaller fragment in registers (embed_clash.hpp, k_clash_lanes)
+        const int mA = ft.n_atoms[0] <= ft.n_atoms[1] ? 0 : 1, mB = 1 - mA, na2 = (ft.n_atoms[mA] + 1) / 2;
+        const dim3 grid(unsigned(grid_for(ceil_div<int64_t>(a.n_poses, 64), 4, 256 * 32)));
+#define TSC_LAUNCH_CLASH_LANES(N)                                                                                                          \
+    hipLaunchKernelGGL(k_clash_lanes<N>, grid, dim3(256), 0, c->stream, a.n_poses, frags, ft, mA, mB, conf_idx, rot, pos, a.sq_bound, mask)
+        if (na2 <= 4) TSC_LAUNCH_CLASH_LANES(4);
+        else if (na2 <= 8) TSC_LAUNCH_CLASH_LANES(8);
+        else if (na2 <= 12) TSC_LAUNCH_CLASH_LANES(12);
+        else if (na2 <= 13) TSC_LAUNCH_CLASH_LANES(13);
+        else TSC_LAUNCH_CLASH_LANES(16);
+#undef TSC_LAUNCH_CLASH_LANES
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
     if (minmode) return launch_clash_impl<FUSED, false, true>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
     return launch_clash_impl<FUSED, false, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
 }
@@ -1907,6 +1923,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
     if (strcmp(name, "local_pass") == 0) {
         TSC_REQUIRE(value == 0 || value == 1, "local_pass must be 0 or 1");
         c->local_pass = int(value);
+        return 0;
+    }
+    if (strcmp(name, "clash_lanes") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "clash_lanes must be 0 or 1");
+        c->clash_lanes = int(value);
         return 0;
     }
     if (strcmp(name, "clash_fp32") == 0) {
