@@ -58,6 +58,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (datasheet; = FP32 vector 
 FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector FP32 with packed v_pk_fma_f32
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 CHAIN_CANDIDATES = 20000         # --config C5chain: angle sets the conformational search rotates per step
+EVENT_EVERY = 4                  # the timed region carries the pair kernel's HIP events in every 4th step (timed_loop)
 STEP_TIMES = bool(os.environ.get("BENCH_STEP_TIMES"))
 if STEP_TIMES:      # debugging aid: every garbage collection with its generation, duration and yield
     _gc_t = [0.0]
@@ -243,9 +244,9 @@ def main():
             name, val = opt.split("=")
             pipe.set_option(name, float(val))
 
-    def timed_loop(pipe, steps):
+    def timed_loop(pipe, steps, timing_level=0):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks. Returns (seconds, last result, sums)."""
-        acc = {"tile_ms": 0.0, "evals": 0, "computed": 0, "screened": 0,
+        acc = {"tile_ms": 0.0, "evals": 0, "computed": 0, "screened": 0, "evented_steps": 0,
                "stage_ms": {"embed_clash": 0.0, "compact": 0.0, "prune": 0.0, "total": 0.0}}
         res = None
         results = []
@@ -259,7 +260,16 @@ def main():
             gc.freeze()
         t0 = time.perf_counter()
         marks = []
-        for _ in range(steps):
+        for i in range(steps):
+            # the pair kernel's start / stop events ride on its dispatches in every EVENT_EVERY-th step of the timed region only: a pair
+            # of events costs a launch about 6 us, eight launches per step were 6 - 9 % of a C3 step -- measuring the kernel was slowing
+            # down what `value` reports.  The average launch duration comes from the steps that carry them (3 - 5 of the default 20).
+            if timing_level == 1 and EVENT_EVERY > 1:
+                on = (steps - 1 - i) % EVENT_EVERY == 0       # (the last step among them: its per-pass figures are printed)
+                pipe.set_option("pass_timing", 1 if on else 0)
+                acc["evented_steps"] += 1 if on else 0
+            elif timing_level == 1:
+                acc["evented_steps"] += 1
             res = pipe.step()
             results.append(res)        # statistics are read after the timed region (the result converts them lazily)
             if STEP_TIMES:
@@ -321,7 +331,8 @@ def main():
             gc.freeze()
         for _ in range(args.warmup):
             pipe.step()
-        dt, res, acc = timed_loop(pipe, args.steps)           # THE timed region (library events as --pass-timing says)
+        dt, res, acc = timed_loop(pipe, args.steps, args.pass_timing)   # THE timed region (library events as --pass-timing says, sampled)
+        pipe.set_option("pass_timing", args.pass_timing)
         leg = {"dt": dt, "res": res, "acc": acc, "pipe": pipe, "sharded": sharded, "events_off": None, "pass_ms": None, "stage_ms": acc["stage_ms"]}
         units = ens.n_poses * (1 if sharded else world)
         leg["units_per_step"] = units
@@ -423,9 +434,10 @@ def main():
         n = ens.n_poses
         flops_per_eval = 46 * h + 500                       # F = 46h + 500 per pair evaluation
         tile_s = tile_ms / 1e3
+        ev_steps = acc.get("evented_steps") or args.steps    # steps of the timed region whose pair-kernel dispatches carried events
         big = [s for s in res["stats"] if s["algo"] in (1, 2)]   # passes run by the pair kernel (the others: chunk-local kernel)
         n_launch = len(big)                                 # pair-kernel launches per step
-        launches = n_launch * args.steps
+        launches = n_launch * (acc.get("evented_steps") or args.steps)   # (the dispatches that carried events: every EVENT_EVERY-th step)
         avg_launch_s = tile_s / launches if launches and tile_s > 0 else None
         # algorithmic bytes of the prune: sum over passes (A_p * h * 24 + 2 N)  (SURVEY.md 8d), per launch: the mean
         b_k3 = sum(s["n_active_before"] * h * 24 + 2 * n_pass for s in res["stats"])
@@ -468,15 +480,26 @@ def main():
         # forming H for most pairs, so that ratio exceeds 1 and is NOT a roofline fraction.
         evals_big = sum(s["pairs_evaluated"] for s in big)
         screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
-        ref_equiv = evals_big * flops_per_eval / (tile_s / args.steps) / 1e12 if tile_s > 0 else None
+        ref_equiv = evals_big * flops_per_eval / (tile_s / ev_steps) / 1e12 if tile_s > 0 else None
         if screened_big:
             f32_flops = screened_big * 34        # dot-product form: 2 families x (8 fma + add + fma) per pair
             f64_flops = computed_big * (18 * h + 110)
         else:
             f32_flops = 0.0
             f64_flops = computed_big * (18 * ((h + 3) // 4 * 4) + 110)
-        per_s = (lambda x: x / (tile_s / args.steps) / 1e12) if tile_s > 0 else (lambda x: None)
+        per_s = (lambda x: x / (tile_s / ev_steps) / 1e12) if tile_s > 0 else (lambda x: None)
         ex32, ex64 = per_s(f32_flops), per_s(f64_flops)
+        # the part of the path SURVEY.md 8(d) calls HBM-streaming: fused embed + clash verdicts, ordered compaction, the passing poses embedded
+        # with their descriptors.  Algorithmic bytes B_K12 over the two stages' own HIP events (the 3 steps with every library event on,
+        # outside the timed region: each stage carries some 4 us of event cost, so the figure is a lower bound)
+        front_ms = (stage_ms.get("embed_clash", 0.0) + stage_ms.get("compact", 0.0)) / args.steps if stage_ms else 0.0
+        front_roofline = None
+        if front_ms > 0 and not sharded_mode:
+            gbs = b_k12 / (front_ms / 1e3) / 1e9
+            front_roofline = {"kernels": "k_clash_lanes (k_clash where it does not apply) + k_scan_block_sums + k_scan_write + k_transform_describe",
+                              "bound": "hbm", "algorithmic_bytes": b_k12, "ms": front_ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": gbs / HBM_PEAK_GBS,
+                              "what": "B_K12 = N n_mols 96 + N_pass n 24 + N (SURVEY.md 8d) over the embed_clash + compact stages' HIP events"}
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
             "value": units_per_step * args.steps / dt,
@@ -515,8 +538,9 @@ def main():
                 "algorithmic_bytes_per_launch": b_launch,
                 "avg_launch_us": avg_launch_s * 1e6 if avg_launch_s else None,
                 "launches_per_step": n_launch,
-                "kernel_ms_per_step": tile_ms / args.steps,
-                "timing": "HIP start/stop events attached to every dispatch of the kernel (hipExtLaunchKernel) inside the timed region",
+                "kernel_ms_per_step": tile_ms / ev_steps,
+                "timing": f"HIP start/stop events attached to the kernel's dispatches (hipExtLaunchKernel) inside the timed region, in every {EVENT_EVERY}th step "
+                          f"of it ({acc.get('evented_steps')} of {args.steps} steps): a pair of events costs a launch about 6 us",
                 "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
                 "executed": {"what": "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
                                      "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers",
@@ -535,6 +559,7 @@ def main():
                              "frac": (b_k12 + b_k3) * (units_per_step // n) / (ms_per_step / 1e3) / 1e9 / (HBM_PEAK_GBS * world)},
             "events_off": leg["events_off"],
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "roofline_front": front_roofline,
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(pass_ms[i] if pass_ms and i < len(pass_ms) else s["gpu_ms"], 4),
                         "tile_ms": round(s["tile_ms"], 4),

@@ -5,6 +5,7 @@ set -e
 R=$1
 O=gpurun_out/final_$R
 python tools/collect_profiles.py $O/prof $R > /dev/null
+python tools/collect_profiles.py $O/prof_c4 $R _C4 > /dev/null
 cp $O/sq/sq_counters.json profiles/${R}_sq_counters_c4.json
 cp $O/bench.json profiles/${R}_final_bench.json
 for c in C4 C5 C5chain; do cp $O/bench_$c.json profiles/${R}_final_bench_$c.json; done

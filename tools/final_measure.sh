@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the round's closing measurements, everything into gpurun_out/final_RR/ (copy to profiles/ afterwards:
-# tools/final_collect.sh RR).   usage: tools/final_measure.sh r03 [part ...]     parts: tests prof sq bench configs scaling hard rows
+# tools/final_collect.sh RR).   usage: tools/final_measure.sh r03 [part ...]     parts: tests prof profc4 sq bench configs scaling hard rows
 set -e
 R=$1; shift
-PARTS=${*:-"tests prof sq bench configs scaling hard rows"}
+PARTS=${*:-"tests prof profc4 sq bench configs scaling hard rows"}
 O=gpurun_out/final_$R
 mkdir -p $O
 for part in $PARTS; do
@@ -11,6 +11,7 @@ for part in $PARTS; do
   case $part in
     tests)   python -m pytest tests -x -q -m gpu > $O/gpu_tests.txt 2>&1; tail -2 $O/gpu_tests.txt ;;
     prof)    bash tools/profile.sh final_$R/prof > $O/prof.txt 2>&1 ;;
+    profc4)  bash tools/profile.sh final_$R/prof_c4 --config C4 > $O/prof_c4.txt 2>&1 ;;
     sq)      bash tools/pmc_sq.sh final_$R/sq --config C4 > $O/sq.txt 2>&1 ;;
     bench)   python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json ;;
     configs) for c in C4 C5 C5chain; do python bench.py --config $c --no-cpu --no-side-leg > $O/bench_$c.json 2> $O/bench_$c.err; cut -c1-200 $O/bench_$c.json; done

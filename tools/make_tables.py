@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-R = "r03"
+R = "r04"
 
 
 def last_json_line(name):
@@ -35,9 +35,9 @@ def f(x, nd=3):
 def headline():
     b = last_json_line(f"{R}_final_bench.json")
     if not b:
-        return "(profiles/r03_final_bench.json missing)"
+        return f"(profiles/{R}_final_bench.json missing)"
     rows = ["| | ms / step | conformers/s |", "|---|---|---|"]
-    rows.append(f"| C3 (100 000 x 50), timed region as the bench contract asks (HIP events on every pair-kernel dispatch): `value` | {b['ms_per_step']:.3f} | **{b['value'] / 1e6:.1f} M** |")
+    rows.append(f"| C3 (100 000 x 50), timed region as the bench contract asks (HIP events on the pair-kernel dispatches of every 4th step): `value` | {b['ms_per_step']:.3f} | **{b['value'] / 1e6:.1f} M** |")
     if b.get("events_off"):
         rows.append(f"| the same K steps with the library's events off (`events_off`) | {b['events_off']['ms_per_step']:.3f} | {b['events_off']['value'] / 1e6:.1f} M |")
     if b.get("steps_in_flight") and "ms_per_step" in b["steps_in_flight"]:
@@ -60,7 +60,7 @@ def headline():
 def roofline():
     b = last_json_line(f"{R}_final_bench.json")
     if not b or not b.get("roofline"):
-        return "(no roofline in profiles/r03_final_bench.json)"
+        return f"(no roofline in profiles/{R}_final_bench.json)"
     r = b["roofline"]
     ex = r.get("executed", {})
     rows = ["| `roofline` of the dominant kernel (`k_rmsd_sieve`, per launch) | |", "|---|---|",
@@ -71,6 +71,14 @@ def roofline():
             + (f" = {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f} x the algorithmic bytes" if r.get("traffic") else f" ({r.get('traffic_source')})") + " |",
             f"| what the instructions execute | {ex.get('fp32_TFLOPs', 0):.1f} TFLOP/s packed fp32 = {ex.get('fp32_frac', 0):.3f} of {ex.get('fp32_peak_TFLOPs')} + {ex.get('fp64_TFLOPs', 0):.2f} TFLOP/s fp64 |",
             f"| pairs screened / H formed per step | {ex.get('pairs_screened_per_step', 0):.3g} / {ex.get('pairs_with_H_formed_per_step', 0):.3g} |"]
+    fr = b.get("roofline_front")
+    if fr:
+        rows.append(f"| front half (`roofline_front`: fused embed + clash, compaction, the passing poses embedded + described): B_K12 = {fr['algorithmic_bytes'] / 1e6:.1f} MB "
+                    f"over {fr['ms'] * 1e3:.0f} us of stage events | {fr['achieved']:.0f} / {fr['peak']:.0f} GB/s = {fr['frac']:.3f} |")
+    c4 = b.get("c4") or {}
+    if c4.get("traffic_over_algorithmic"):
+        rows.append(f"| C4 (1M x 50), pair kernels (`k_rmsd_sieve` + `k_rmsd_sieve_sorted`): HBM traffic / algorithmic bytes per step | "
+                    f"{c4['pair_kernels_traffic_bytes_per_step'] / 1e9:.2f} GB / {c4['pair_kernels_algorithmic_bytes_per_step'] / 1e9:.2f} GB = {c4['traffic_over_algorithmic']:.2f} x |")
     ph = b.get("pipeline_hbm")
     if ph:
         rows.append(f"| whole step: algorithmic bytes over the step | {ph['algorithmic_bytes'] / 1e6:.0f} MB -> {ph['achieved_GBs']:.0f} GB/s = {ph['frac']:.3f} of peak |")
@@ -80,7 +88,7 @@ def roofline():
 def kernels():
     path = os.path.join(P, f"{R}_kernel_stats.csv")
     if not os.path.exists(path):
-        return "(profiles/r03_kernel_stats.csv missing)"
+        return f"(profiles/{R}_kernel_stats.csv missing)"
     rows_in = list(csv.DictReader(open(path)))
     steps = max([int(r["Calls"]) for r in rows_in if "k_init_run" in r["Name"]] or [1])
     rows = [f"| kernel (C3, {steps} steps under `rocprofv3 --kernel-trace --stats`) | launches / step | average us | us / step |", "|---|---|---|---|"]
@@ -95,10 +103,28 @@ def kernels():
     return "\n".join(rows) + f"\n\n(from `profiles/{R}_kernel_stats.csv`)"
 
 
+def kernels_c4():
+    path = os.path.join(P, f"{R}_kernel_stats_C4.csv")
+    if not os.path.exists(path):
+        return f"(profiles/{R}_kernel_stats_C4.csv missing)"
+    rows_in = list(csv.DictReader(open(path)))
+    steps = max([int(r["Calls"]) for r in rows_in if "k_init_run" in r["Name"]] or [1])
+    rows = [f"| kernel (C4, {steps} steps under `rocprofv3 --kernel-trace --stats`) | launches / step | average us | us / step |", "|---|---|---|---|"]
+    tot = 0.0
+    for r in sorted(rows_in, key=lambda r: -int(r["TotalDurationNs"])):
+        per = int(r["TotalDurationNs"]) / steps / 1e3
+        tot += per
+        if per >= 40.0:
+            name = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("tsc::", "")
+            rows.append(f"| `{name}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {per:.1f} |")
+    rows.append(f"| sum over all kernels | | | {tot:.0f} |")
+    return "\n".join(rows) + f"\n\n(from `profiles/{R}_kernel_stats_C4.csv`)"
+
+
 def hard():
     d = load(f"{R}_hard_workloads.json")
     if not d:
-        return "(profiles/r03_hard_workloads.json missing)"
+        return f"(profiles/{R}_hard_workloads.json missing)"
     rows = ["| workload (100 000 structures) | automatic choice: ms (kernels) | sieve | all-pairs kernel | conformers/s (automatic) | screen lets through | H formed | CPU port on a sample |",
             "|---|---|---|---|---|---|---|---|"]
     for name, l in d["legs"].items():
@@ -114,7 +140,7 @@ def hard():
 def scaling():
     d = load(f"{R}_predicted_scaling.json")
     if not d:
-        return "(profiles/r03_predicted_scaling.json missing)"
+        return f"(profiles/{R}_predicted_scaling.json missing)"
     rows = ["| config | ranks | front: shard / replicate / hybrid (compute + modelled exchange, ring) | prune: setup + partitioned (local / close) + row tiles (local / close) + small | per-pass collectives ring - all links | step (best front) ring - all links | speed-up vs one rank |",
             "|---|---|---|---|---|---|---|"]
     for cfg, rws in d["configs"].items():
@@ -133,18 +159,18 @@ def scaling():
 
 
 def culling():
-    d = load(f"{R}_culling_study.json")
+    d = load("r03_culling_study.json")       # (offline CPU study of round 3: not re-run)
     if not d:
-        return "(profiles/r03_culling_study.json missing)"
+        return f"(profiles/{R}_culling_study.json missing)"
     rows = ["| config | pass k | active structures per chunk | tile pairs (16 x 128) of a chunk | visited by the ordered walk (if no cache stop) | within the limit, each unordered pair once | ratio | pairs the screen lets through |",
             "|---|---|---|---|---|---|---|---|"]
     for cfg, rws in d["configs"].items():
         for r in rws:
             rows.append(f"| {cfg} | {r['k']} | {r['structures']} | {r['tile_pairs_all']:.0f} | {r['tile_pairs_present_walk']:.0f} | {r['tile_pairs_within_limit']:.0f} | {r['culled_over_walk']:.2f} | {r['screen_pass_rate_of_pairs']:.5f} |")
-    return "\n".join(rows) + f"\n\n(from `profiles/{R}_culling_study.json`, `tools/culling_study.py`, offline on the CPU)"
+    return "\n".join(rows) + f"\n\n(from `profiles/r03_culling_study.json`, `tools/culling_study.py`, offline on the CPU)"
 
 
-TABLES = {"headline": headline, "roofline": roofline, "kernels": kernels, "hard": hard, "scaling": scaling, "culling": culling}
+TABLES = {"headline": headline, "roofline": roofline, "kernels": kernels, "kernels_c4": kernels_c4, "hard": hard, "scaling": scaling, "culling": culling}
 
 
 def main():

@@ -18,6 +18,7 @@ mesh allows) -- both stated in the output.
 
 usage (GPU box): python tools/predict_scaling.py [C3 C4] [--chunks M] > profiles/r03_predicted_scaling.json
 """
+import hashlib
 import json
 import os
 import sys
@@ -65,6 +66,9 @@ def allreduce_ms(nbytes, n, all_links=False):
     return 2.0 * (nbytes / n) * steps / (LINK_GBS * LINK_EFF * 1e9) * 1e3 + COLL_FIXED_US / 1e3
 
 
+REFERENCE_MASKS = {}      # (config, structures entering the prune) -> digest of the survivor mask of the first run measured (N = 1 comes first)
+
+
 def measure_front(ens, n_ranks, reps):
     """(slowest rank of `shard`, pass counts per rank, slowest rank's clash verdicts alone)"""
     front, counts, clash_only = [], [], []
@@ -87,6 +91,11 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
     # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
     be = HipShardBackend(ens, 0, 0, 1, 1.5, 0, 0.5, 0)
     be.eng.set_option("pass_timing", 0)
+    # every emulated rank must derive bit-identical descriptors, as the ranks of a real run do (HipShardBackend sets deterministic_basis
+    # at world > 1): fixed-order sums, and no pose-sample basis left pending by the embed that only the FIRST stepper would consume
+    # (layouts that differ between the emulated ranks leave pairs unvisited in a culled pass dealt by row tiles)
+    be.eng.set_option("deterministic_basis", 1)
+    be.eng.set_option("early_basis", 0)
     for name, value in OPTIONS:
         be.eng.set_option(name, value)
     tm = Timer(be.stream)
@@ -163,6 +172,16 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
                 passes.append({"k": int(k), "kind": "replicated", "local_ms_per_rank": t_all, "close_ms": 0.0, "bytes": 0})
         t_tail = max(tm(lambda st=st: st.copy_mask(be.keep))[0] for st in sts)
         stats = sts[0].stats()
+        # every emulated rank ends with the same survivors and active counts -- and with the one-rank run's (REFERENCE_MASKS)
+        digests = []
+        for st in sts:
+            st.copy_mask(be.keep)
+            torch.cuda.synchronize()
+            digests.append(hashlib.sha256(np.packbits(be.keep[:n_pass].cpu().numpy().astype(bool)).tobytes()).hexdigest()[:16])
+            assert [x["n_active_after"] for x in st.stats()] == [x["n_active_after"] for x in stats], "the emulated ranks disagree on the active counts"
+        assert len(set(digests)) == 1, f"the emulated ranks end with different survivor masks: {digests}"
+        ref = REFERENCE_MASKS.setdefault((cfg, n_pass), digests[0])
+        assert ref == digests[0], f"{cfg} with {n_ranks} emulated ranks: survivors differ from the first run's ({digests[0]} != {ref})"
         if os.environ.get("PREDICT_COUNTS"):          # work counters of the passes dealt by row tiles, summed over the ranks (they are per rank there)
             every = [st.stats() for st in sts]
             tiled = {p["k"] for p in passes if p["kind"] in ("row_tiles", "replicated")}
