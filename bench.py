@@ -69,7 +69,8 @@ if STEP_TIMES:      # debugging aid: every garbage collection with its generatio
         else:
             print(f"gc gen {info['generation']}: {(time.perf_counter() - _gc_t[0]) * 1e3:.2f} ms, collected {info['collected']}", file=sys.stderr)
     gc.callbacks.append(_gc_note)
-PMC_PROFILES = ("r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
+PMC_PROFILES = ("r04_pmc_hbm_counters.json", "r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
+PMC_PROFILES_C4 = ("r04_pmc_hbm_counters_C4.json",)
 
 
 def parse():
@@ -523,6 +524,9 @@ def main():
                        "parallelism": (f"one ensemble sharded over {world} rank(s): front half per `front`, passes partitioned by chunks or sharded by row tiles, one all-reduce per pass" if sharded_mode else
                                        f"{world} x (one whole ensemble per GPU), no data-path collective"),
                        "conformers_per_step_all_ranks": units_per_step,
+                       "poses": ("synthetic rigid-body transforms of three fragments (tscode_amd/synthetic.py): the reference's trimolecular cyclical_embed is "
+                                 "undefined -- vec_angle on 2-vectors, embeds.py:297-299 / algebra.py:87 -- so config 5 cannot be fed by it (INTEGRATION.md D)"
+                                 if args.config in ("C5", "C5chain") else "synthetic rigid-body transforms (tscode_amd/synthetic.py, SURVEY.md 8d)"),
                        "library_events_in_timed_region": args.pass_timing},
             "roofline": {
                 "kernel": kernel + " (all-pairs Kabsch RMSD of one pass; one launch per pass)",
@@ -610,7 +614,7 @@ def main():
             gc.freeze()
             runs = []
             for _ in range(2):      # (twice, the shorter one counts: on these boxes one run in seven has all three threads stand still for
-                                    # 48 ms at the same moment -- not the collector's doing, see tools/dbg/inflight.py; both are kept below)
+                                    # 48 ms at the same moment -- not the collector's doing; both are kept below)
                 threads = [threading.Thread(target=worker, args=(i,)) for i in range(D)]
                 t0 = time.perf_counter()
                 for t in threads:
@@ -649,6 +653,31 @@ def main():
             c4 = leg_summary(leg4, SHARDED_WHAT if world > 1 else "the one-call pipeline on one GPU")
             c4["workload"] = f"C4: {ens4.n_poses} conformers x {ens4.n_atoms} atoms ({ens4.n_heavy} heavy), seed {ens4.seed}"
             c4["n_pass_clash"] = int(leg4["res"]["n_pass"])
+            # HBM traffic of the pair kernels at C4 against their algorithmic bytes, from the committed PMC passes of `bench.py --config C4`
+            # (tools/profile.sh; only while that profile was taken from the kernels that run now)
+            st4 = leg4["res"]["stats"]
+            h4, np4 = ens4.n_heavy, int(leg4["res"]["n_pass"])
+            alg4 = sum(s_["n_active_before"] * h4 * 24 + 2 * np4 for s_ in st4 if s_["algo"] in (1, 2))
+            for name in PMC_PROFILES_C4:
+                pmc_path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc_path) or world > 1:
+                    continue
+                pmc = json.load(open(pmc_path))
+                if pmc.get("csrc_sha256_16") != csrc_digest() or binary_digest() != csrc_digest():
+                    c4["traffic_source"] = f"profiles/{name} is STALE (csrc {pmc.get('csrc_sha256_16')}): traffic withheld"
+                    break
+                tot = 0.0
+                for kname in ("k_rmsd_sieve_sorted", "k_rmsd_sieve<"):
+                    f_ = [v for k_, v in pmc.get("FETCH_SIZE", {}).items() if kname in k_]
+                    w_ = [v for k_, v in pmc.get("WRITE_SIZE", {}).items() if kname in k_]
+                    tot += sum(2.0 * v["total_KB"] for v in f_) + sum(v["total_KB"] for v in w_)
+                steps_prof = pmc.get("steps_profiled")
+                if tot and steps_prof:
+                    c4["pair_kernels_traffic_bytes_per_step"] = tot * 1024.0 / steps_prof
+                    c4["pair_kernels_algorithmic_bytes_per_step"] = alg4
+                    c4["traffic_over_algorithmic"] = tot * 1024.0 / steps_prof / alg4 if alg4 else None
+                    c4["traffic_source"] = f"profiles/{name}: (2 x FETCH_SIZE + WRITE_SIZE) of k_rmsd_sieve + k_rmsd_sieve_sorted per step, rocprofv3 --pmc"
+                break
             if world > 1:
                 c4["front"] = leg4["res"].get("front")
                 c4["front_tuning"] = getattr(leg4["pipe"], "front_tuning", None)

@@ -95,7 +95,9 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
     # at world > 1): fixed-order sums, and no pose-sample basis left pending by the embed that only the FIRST stepper would consume
     # (layouts that differ between the emulated ranks leave pairs unvisited in a culled pass dealt by row tiles)
     be.eng.set_option("deterministic_basis", 1)
-    be.eng.set_option("early_basis", 0)
+    be.world = 2      # (embed_clash_block forks a pose-sample basis for the NEXT prune run when its backend is alone in the world: the first stepper would
+                      # take it, the others build their own from the survivors, and a culled pass dealt by row tiles then misses pairs -- which is what the
+                      # mask comparison below caught at C4 x 2 on its first run; the pose block was cut for a world of one and stays whole)
     for name, value in OPTIONS:
         be.eng.set_option(name, value)
     tm = Timer(be.stream)
@@ -180,8 +182,10 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
             digests.append(hashlib.sha256(np.packbits(be.keep[:n_pass].cpu().numpy().astype(bool)).tobytes()).hexdigest()[:16])
             assert [x["n_active_after"] for x in st.stats()] == [x["n_active_after"] for x in stats], "the emulated ranks disagree on the active counts"
         assert len(set(digests)) == 1, f"the emulated ranks end with different survivor masks: {digests}"
-        ref = REFERENCE_MASKS.setdefault((cfg, n_pass), digests[0])
-        assert ref == digests[0], f"{cfg} with {n_ranks} emulated ranks: survivors differ from the first run's ({digests[0]} != {ref})"
+        actives = [(x["k"], x["n_active_after"], x["pairs_evaluated"]) for x in stats]
+        ref, ref_actives = REFERENCE_MASKS.setdefault((cfg, n_pass), (digests[0], actives))
+        assert ref == digests[0], (f"{cfg} with {n_ranks} emulated ranks: survivors differ from the first run's ({digests[0]} != {ref}); first pass that differs "
+                                   f"(k, active after, evaluations): {next(((a, b) for a, b in zip(actives, ref_actives) if a != b), None)}; kinds {[(p['k'], p['kind']) for p in passes]}")
         if os.environ.get("PREDICT_COUNTS"):          # work counters of the passes dealt by row tiles, summed over the ranks (they are per rank there)
             every = [st.stats() for st in sts]
             tiled = {p["k"] for p in passes if p["kind"] in ("row_tiles", "replicated")}

@@ -155,7 +155,7 @@ def load():
             except ImportError:
                 pass
             lib = C.CDLL(LIB_PATH)
-            lax = bool(os.environ.get("TSCODE_AMD_LAX"))   # A/B runs against an older build (tools/dbg/ablib.py): symbols it lacks are skipped
+            lax = bool(os.environ.get("TSCODE_AMD_LAX"))   # A/B runs against an older build (TSCODE_AMD_LIB): symbols it lacks are skipped
             for name, (res, args) in _SIGNATURES.items():
                 if lax and not hasattr(lib, name):
                     continue

@@ -95,6 +95,7 @@ struct tsc_ctx {
     int64_t pca_min_n = 6000;             // below this many structures the descriptors use the identity basis (no principal-axis estimate)
     int fuse_descriptors = 1;             // ... and the descriptors by the kernel that embeds the passing poses (needs early_basis)
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
+    int clash_first = 0;                  // ... whose chain is enqueued in front of the clash launch (0) or behind it (1: rounds 1 - 3)
     int cull_tile_block = 256;             // culled passes dealt by row tiles: consecutive tiles of the sorted layout per rank and turn
     int stage1_f32 = 1;                   // stage 1 of the pair kernels reads a float32 copy of the coordinates first (sieve.hpp: pair_stage1)
     int local_max_chunk = 384;            // longest chunk (structures) of a pass that the chunk-local kernel takes

@@ -124,12 +124,22 @@ __global__ __launch_bounds__(256) void k_feature_moments(const double *__restric
         __syncthreads();
         first = false;
     }
-    __threadfence();
+    // Hand-off of the partial matrices to the workgroup that finishes last, in the form MI355X_MICROARCH.md lists as valid (inter-workgroup
+    // visibility): every storing wavefront drains its stores, the workgroup meets, ONE lane releases at agent scope (write-back of the XCD's
+    // L2) and -- behind an explicit wait the compiler cannot drop: its pass removes the one after buffer_wbl2 when it believes the scoreboard
+    // empty, and the ticket could then overtake the write-back -- takes the ticket; the last workgroup acquires before it loads.  (Rounds
+    // 2 - 3 had __threadfence() on both sides and no explicit wait; no wrong basis was ever traced to it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[fam], 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (atomicAdd(&tickets[fam], 1u) == gridDim.x - 1) ? 1 : 0;
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
         int a = e / m, b = e - a * m;
         if (b < a) continue;

@@ -1925,6 +1925,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->local_pass = int(value);
         return 0;
     }
+    if (strcmp(name, "clash_first") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "clash_first must be 0 or 1");
+        c->clash_first = int(value);
+        return 0;
+    }
     if (strcmp(name, "clash_lanes") == 0) {
         TSC_REQUIRE(value == 0 || value == 1, "clash_lanes must be 0 or 1");
         c->clash_lanes = int(value);
@@ -2880,13 +2885,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
         }
         TSC_HIP(hipEventRecord(c->ev_fork, st));  // the inputs (and the tables above) are ordered on the main stream
     }
-    // K1+K2 fused verdicts
-    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
-                                     clash_mask, nullptr));
-    if (timed) TSC_HIP(hipEventRecord(ev[1], st));
-    if (d_basis) {
-        // The side stream's chain (sample embed, moments, basis: about 50 us) is enqueued right behind the clash launch: the
-        // clash kernel is already running, and the chain has the whole of it (and the scan) to finish in.
+    auto enqueue_basis_chain = [&]() -> int {
+        // The side stream's chain (sample embed + moments, basis: 37 us + its event's way back across queues) is enqueued IN FRONT of the
+        // clash launch since round 4: with the clash kernel at 24 us (k_clash_lanes; 60 before) the chain is what the embed of the passing
+        // poses waits for, and every microsecond of host time in front of it is on the critical path ("clash_first" 1: the old order).
         TSC_HIP(hipStreamWaitEvent(c->basis_stream, c->ev_fork, 0));
         basis_join.pending = true;
         // (the two families' descriptor spread is written to pinned host memory by the basis kernel itself: no copy, no wait -- the host
@@ -2911,7 +2913,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(build_basis(c, c->basis_stream, s, d_sample, n_heavy, n_samples, 1, d_basis, ext.dmax_bits, d_moments, spread_host));
         }
         TSC_HIP(hipEventRecord(c->ev_join, c->basis_stream));
-    }
+        return 0;
+    };
+    if (d_basis && !c->clash_first) TSC_TRY(enqueue_basis_chain());
+    // K1+K2 fused verdicts
+    TSC_TRY(tsc_embed_clash_mask_dev(c, frags, frag_off, n_atoms, n_conf, n_mols, conf_idx, rot, pos, n_poses, clash_thresh, max_clashes,
+                                     clash_mask, nullptr));
+    if (timed) TSC_HIP(hipEventRecord(ev[1], st));
+    if (d_basis && c->clash_first) TSC_TRY(enqueue_basis_chain());
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
     TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
     // the passing poses are embedded (all atoms + heavy atoms) by a launch sized for every pose that reads the count on the
