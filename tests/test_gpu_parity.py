@@ -1669,6 +1669,145 @@ def test_c5_chain_csearch_feeds_the_pipeline(eng, oracle):
     assert (res2["n_conformers"], res2["n_pass"], res2["n_keep"]) == (res["n_conformers"], res["n_pass"], res["n_keep"])
 
 
+def test_run_sharded_c_entry_two_ranks_in_threads(oracle):
+    """tsc_prune_run_sharded driven as a C host would drive it: two ranks in ONE process, each with its own library context, stream
+    and prune run, each inside ONE call of the library that walks the whole pass schedule and calls back for the collectives; the
+    callbacks of the two threads meet at a barrier and reduce the two device buffers (SUM of int64 / MIN of int32) as RCCL would.
+    Every rank ends with the oracle's mask and evaluation counts; the exchange log names partitioned passes, the views and row-tile
+    passes; a callback that fails aborts the run with its own exception; with a world of one the call needs no callback at all."""
+    import threading
+
+    import torch
+
+    from tscode_amd._lib import XCHG_MIN_I32, XCHG_SUM_I64, TscodeHipError
+    from tscode_amd.engine import Engine, PruneStepper
+    from tscode_amd.synthetic import make_config
+    ens = make_config("C2", 30_000)
+    heavy = np.ascontiguousarray(ens.poses()[:, ens.atomnos != 1])
+    ref = oracle.prune_heavy(heavy, 0.5, mode=0, row_parallel=True)
+    n, h = heavy.shape[0], heavy.shape[1]
+    dev = torch.device("cuda:0")
+    world = 2
+    engs = [Engine(0) for _ in range(world)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+    for e, s in zip(engs, streams):
+        e.set_stream(s.cuda_stream)
+        e.set_option("deterministic_basis", 1)       # the ranks deal the tiles of one sorted layout where a pass is culled
+    d_heavy = torch.from_numpy(heavy).to(dev)
+    words = PruneStepper.exchange_words(engs[0].lib, n, 0)
+    exch = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(world)]
+    bests = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(world)]
+    barrier = threading.Barrier(world)
+    slots, logs, errors = [None] * world, [None] * world, [None] * world
+
+    def exchange_for(r):
+        def exchange(kind, addr, count):
+            buf = exch[r] if kind == XCHG_SUM_I64 else bests[r]
+            off = (addr - buf.data_ptr()) // buf.element_size()
+            slots[r] = buf[off:off + count]
+            streams[r].synchronize()
+            barrier.wait()
+            if r == 0:                                    # "the collective": every rank's buffer <- the reduction over the ranks
+                st = torch.stack(slots)
+                red = st.sum(0) if kind == XCHG_SUM_I64 else st.amin(0)
+                for s_ in slots:
+                    s_.copy_(red)
+                torch.cuda.synchronize()
+            barrier.wait()
+        return exchange
+
+    def rank_main(r, fail_at=None):
+        try:
+            with torch.cuda.stream(streams[r]):
+                st = engs[r].prune_stepper(d_heavy, n, h, 0.5, 0)
+                st.use_best_buffer(bests[r])
+                calls = [0]
+                inner = exchange_for(r)
+
+                def exchange(kind, addr, count):
+                    calls[0] += 1
+                    if fail_at is not None and calls[0] == fail_at:
+                        raise RuntimeError("the host's collective failed")
+                    inner(kind, addr, count)
+                logs[r] = st.run_sharded(r, world, 4, 2_000_000, exch[r], exchange)
+                keep = torch.empty(n, dtype=torch.uint8, device=dev)
+                st.copy_mask(keep)
+                streams[r].synchronize()
+                slots[r] = None
+                errors[r] = (keep.cpu().numpy().astype(bool), st.stats())
+                st.close()
+        except BaseException as exc:  # noqa: BLE001
+            errors[r] = exc
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for r in range(world):
+        assert not isinstance(errors[r], BaseException), errors[r]
+        mask, stats = errors[r]
+        assert np.array_equal(mask, ref["mask"]), (r, mask.sum(), ref["mask"].sum())
+        assert [x["pairs_evaluated"] for x in stats] == [x["pairs_evaluated"] for x in ref["stats"]]
+        assert [x["n_active_after"] for x in stats] == [x["n_active_after"] for x in ref["stats"]]
+    assert logs[0] == logs[1] and len(logs[0]) >= 4
+    kinds = {(k > 0, kind) for k, kind, _ in logs[0]}
+    assert (True, XCHG_SUM_I64) in kinds and (False, XCHG_SUM_I64) in kinds and (True, XCHG_MIN_I32) in kinds, logs[0]
+    # a callback that raises: the run is aborted (TSC_ERR_STATE inside) and the exception is the caller's
+    barrier.reset()
+    threads = [threading.Thread(target=rank_main, args=(r, 2 if r == 0 else None)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert isinstance(errors[0], RuntimeError) and "collective failed" in str(errors[0])
+    assert isinstance(errors[1], BaseException)           # (its partner never arrived: the barrier broke)
+    # a world of one: tsc_prune_run_replicated to the end, no callback, nothing logged
+    with torch.cuda.stream(streams[0]):
+        st = engs[0].prune_stepper(d_heavy, n, h, 0.5, 0)
+        assert st.run_sharded(0, 1, 4, 2_000_000, None, None) == []
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        st.copy_mask(keep)
+        streams[0].synchronize()
+        assert np.array_equal(keep.cpu().numpy().astype(bool), ref["mask"])
+        st.close()
+        # ... and several ranks without an exchange function are refused
+        st = engs[0].prune_stepper(d_heavy, n, h, 0.5, 0)
+        with pytest.raises(TscodeHipError):
+            st.run_sharded(0, 2, 4, 2_000_000, exch[0], None)
+        st.close()
+
+
+def test_embed_masked_does_not_pull_buffers_from_under_a_live_run(eng):
+    """the prune run created right after tsc_embed_masked_dev BORROWS the context's descriptor buffers; a later embed on the
+    same context that would have to regrow them fails loudly (TSC_ERR_STATE) while the run lives, and works once it is destroyed."""
+    from tscode_amd._lib import TscodeHipError
+    from tscode_amd.pipeline import HipShardBackend
+    from tscode_amd.synthetic import make_config
+    small, big = make_config("C2", 20_000), make_config("C2", 60_000)
+    a = HipShardBackend(small, 0, 0, 1, 1.5, 0, 0.5, 0)
+    b = HipShardBackend(big, 0, 0, 1, 1.5, 0, 0.5, 0)
+    b.eng = a.eng                                          # both front halves on ONE library context
+    b.stream = a.stream
+    with a.stream_context():
+        a.clash_block_into_all()
+        n_a = int(a.embed_masked_all())
+        st = a.make_stepper(n_a)                           # takes the descriptors the embed wrote: borrows the context's buffers
+        b.clash_block_into_all()
+        with pytest.raises(TscodeHipError) as err:
+            b.embed_masked_all()                           # three times the poses: the buffers would have to grow
+        assert "still read" in str(err.value)
+        while st.next_pass():
+            st.pass_local(0, 1)
+            st.pass_finish()
+        n_keep = st.stats()[-1]["n_active_after"]
+        st.close()
+        b.clash_block_into_all()
+        assert int(b.embed_masked_all()) > n_a             # the run is gone: now it may
+    assert 0 < n_keep <= n_a
+
+
 @pytest.mark.parametrize("world,cfg,n_poses,min_pairs", [(2, "C3", 0, 0), (3, "C2", 0, 100_000), (4, "C3", 0, 0), (3, "C4", 0, 0), (2, "C5", 0, 0),
                                                          (3, "C5chain", 30_000, 0), (2, "C5chain", 0, 0), (1, "C2", 0, 100_000), (1, "C3", 0, 0)])
 def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):

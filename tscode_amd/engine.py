@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 
@@ -104,9 +105,14 @@ class Engine:
         check(self.lib.tsc_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._runs = weakref.WeakSet()      # live PruneSteppers: they hold blocks and events of this context
 
     def close(self):
         if getattr(self, "_h", None):
+            # (a run and its engine can become garbage together -- e.g. both held by the traceback of an exception -- and the
+            # collector finalises them in no particular order: the runs go first, whichever finaliser is called first)
+            for run in list(getattr(self, "_runs", ())):
+                run.close()
             self.lib.tsc_ctx_destroy(self._h)
             self._h = None
 
@@ -506,6 +512,7 @@ class PruneStepper:
                                           C.byref(h_)))
         self._p = h_
         self._keep = heavy_dev
+        engine._runs.add(self)
 
     def next_pass(self) -> int:
         k = C.c_int64()
@@ -592,7 +599,7 @@ class PruneStepper:
             except BaseException as exc:  # noqa: BLE001  (must not propagate through the C frames)
                 failure.append(exc)
                 return 1
-        cb = EXCHANGE_FN(_cb)
+        cb = EXCHANGE_FN(_cb) if exchange is not None else C.cast(None, EXCHANGE_FN)     # (no callback: a world of one needs none)
         log = (ExchangeRecord * (2 * TSC_MAX_PASSES + 2))()
         n_log = C.c_int()
         rc = self.e.lib.tsc_prune_run_sharded(self._p, C.c_int(rank), C.c_int(world), C.c_int(min_chunks_per_rank), C.c_int64(int(min_pairs)),
@@ -621,7 +628,8 @@ class PruneStepper:
 
     def close(self):
         if getattr(self, "_p", None):
-            self.e.lib.tsc_prune_destroy(self._p)
+            if getattr(self.e, "_h", None):      # (a closed engine has closed its runs already)
+                self.e.lib.tsc_prune_destroy(self._p)
             self._p = None
 
     def __del__(self):
