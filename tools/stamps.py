@@ -2,7 +2,7 @@
 
 Build a second library with -DTSC_DBG_STAMPS next to the product one (it must live under tscode_amd/ to travel to the GPU box):
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -DTSC_DBG_STAMPS \
-          -o tscode_amd/libtscode_hip_stamps.so tscode_amd/csrc/tscode_hip.hip
+          -o tscode_amd/libtscode_hip_stamps.so tscode_amd/csrc/*.hip
 and run   TSCODE_AMD_LIB=$PWD/tscode_amd/libtscode_hip_stamps.so python tools/stamps.py C3 100 [opt=value ...]
 (a negative k stamps k_open_rows of that pass instead of the pair kernel)
 The kernel stamps the 100 MHz wall clock (after draining its outstanding memory operations: the stamps perturb it a little) at:

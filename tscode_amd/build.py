@@ -11,9 +11,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")           # object files and their dependency lists (git-ignored; travels to the GPU box, unused there)
 OUT = os.path.join(HERE, "libtscode_hip.so")
-SOURCES = ["tscode_hip.hip"]
+# One translation unit per kernel family: an edit rebuilds the units that include what changed (hipcc -MD), side by side.
+SOURCES = ["ctx.hip", "embed.hip", "prune.hip", "pairs_tile.hip", "pairs_sieve.hip", "pairs_sieve_plain.hip", "pairs_sorted.hip", "adjacent.hip", "pipeline.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "tscode_hip.h")]
+DIGEST_UNIT = "ctx.hip"                     # the unit that bakes the digest in (tsc_build_digest): rebuilt whenever anything changes
 
 
 def _hipcc():
@@ -29,16 +32,27 @@ def needs_build():
     # the digest of the sources the binary was built from is kept beside it (and inside it: tsc_build_digest); file times alone
     # say nothing after a checkout or a copy to another machine
     try:
-        if open(OUT + ".digest").read().strip() != csrc_digest():
-            return True
+        return open(OUT + ".digest").read().strip() != csrc_digest()
     except OSError:
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+          "-Wno-cuda-compat"]   # (-Wcuda-compat: "inline" on a kernel -- which is what lets a header's kernels be included by several units)
+LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
+FLAGS = CFLAGS + LDFLAGS
+
+
+def _sha(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256()
+    for path in paths:
+        if not os.path.isfile(path):
+            continue
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(extra.encode())
+    return h.hexdigest()[:16]
 
 
 def csrc_digest():
@@ -46,28 +60,56 @@ def csrc_digest():
     include/tscode_hip.h among them) and the compiler flags, names included: baked into the library (tsc_build_digest) so that a
     measurement can say which kernels the BINARY it ran was built from, not only which sources lie next to it.  Exactly these files:
     an editor's backup or a stray directory under csrc/ changes nothing."""
-    import hashlib
-    h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
-        path = os.path.join(CSRC, name)
-        if not os.path.isfile(path):
-            continue
-        h.update(os.path.basename(path).encode())
-        h.update(open(path, "rb").read())
-    h.update(" ".join(FLAGS).encode())
-    return h.hexdigest()[:16]
+    return _sha([os.path.join(CSRC, name) for name in SOURCES + HEADERS], " ".join(FLAGS))
+
+
+def _unit_deps(src):
+    """The files a unit was last compiled from (hipcc -MD): its source and the project headers it includes, transitively."""
+    dep = os.path.join(OBJ, src + ".d")
+    try:
+        words = open(dep).read().replace("\\\n", " ").split()
+    except OSError:
+        return None
+    root = os.path.dirname(HERE)
+    return sorted({os.path.normpath(w) for w in words[1:] if os.path.normpath(w).startswith(root)})
+
+
+def _unit_stale(src, digest):
+    obj, stamp = os.path.join(OBJ, src + ".o"), os.path.join(OBJ, src + ".sha")
+    deps = _unit_deps(src)
+    if deps is None or not os.path.exists(obj):
+        return True
+    want = _sha(deps, " ".join(CFLAGS) + (digest if src == DIGEST_UNIT else ""))
+    try:
+        return open(stamp).read().strip() != want
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc()] + FLAGS + [f'-DTSC_CSRC_DIGEST="{csrc_digest()}"', "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    digest = csrc_digest()
+    stale = [s for s in SOURCES if force or _unit_stale(s, digest)]
+    procs = []
+    for src in stale:
+        cmd = [_hipcc()] + CFLAGS + ["-c", "-MD", "-MF", os.path.join(OBJ, src + ".d"), "-o", os.path.join(OBJ, src + ".o"), os.path.join(CSRC, src)]
+        if src == DIGEST_UNIT:
+            cmd.insert(1, f'-DTSC_CSRC_DIGEST="{digest}"')
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))     # (nine units: side by side)
+    failed = [src for src, pr in procs if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    for src in stale:
+        with open(os.path.join(OBJ, src + ".sha"), "w") as f:
+            f.write(_sha(_unit_deps(src), " ".join(CFLAGS) + (digest if src == DIGEST_UNIT else "")) + "\n")
+    subprocess.run([_hipcc()] + LDFLAGS + ["-o", OUT] + [os.path.join(OBJ, s + ".o") for s in SOURCES], check=True)
     with open(OUT + ".digest", "w") as f:
-        f.write(csrc_digest() + "\n")
+        f.write(digest + "\n")
     return OUT
 
 

@@ -130,7 +130,7 @@ struct tsc_ctx {
     const double *xd_heavy = nullptr;     // the heavy-atom array they describe
     bool xd_valid = false;
     int xd_borrowers = 0;                 // live prune runs that read the xd_* buffers (tsc_prune_create borrowed them): no release / regrow meanwhile
-    int next_flag_slot = 0;               // pinned flag words handed to prune runs, round robin (tscode_hip.hip: PINNED_FLAG_OFFSET)
+    int next_flag_slot = 0;               // pinned flag words handed to prune runs, round robin (host.hpp: PINNED_FLAG_OFFSET)
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
     double *mom_acc = nullptr;            // moment accumulators of the pipeline's basis chain (k_sample_moments adds, k_descriptor_basis clears)

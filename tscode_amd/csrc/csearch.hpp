@@ -233,7 +233,7 @@ __device__ inline double moved_side_bound(const double *c, const double cen[3], 
 // angles[s] DEGREES (any real number: tscode/torsion_module.py:984-1005 searches fractional corrections) about its own i2 - i3 bond,
 // centre i3; no clash check, no walk-back.  One thread per (structure, atom); out must not alias coords (the axis atoms are read by
 // every thread of a structure).
-__global__ __launch_bounds__(256) void k_rotate_dihedral(const double *__restrict__ coords, int64_t n_structs, int n, int i2, int i3,
+inline __global__ __launch_bounds__(256) void k_rotate_dihedral(const double *__restrict__ coords, int64_t n_structs, int n, int i2, int i3,
                                                           const uint8_t *__restrict__ mask, const double *__restrict__ angles, double *__restrict__ out) {
     for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n_structs * n; e += int64_t(gridDim.x) * 256) {
         const int64_t s = e / n;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_rotate_dihedral(const double *__restric
 
 // out [n_cand][n][3], rotated_bonds [n_cand]; angles [n_cand][n_tors] int32 degrees; masks [n_tors][n]; torsions [n_tors][4]
 // dynamic LDS: torsion lists, then one csearch_wave_bytes(n) area per wavefront of the block
-__global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,
+inline __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const double *__restrict__ base, const int32_t *__restrict__ tors,
                                                          const uint8_t *__restrict__ masks, const int32_t *__restrict__ angles,
                                                          double *__restrict__ out, int32_t *__restrict__ rotated_bonds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_csearch_rotate(CsearchArgs a, const dou
 }
 
 // torsion_comp_check for a batch of structures sharing torsion and mask: ok[s] = 1 / 0
-__global__ __launch_bounds__(256) void k_torsion_comp_check(CsearchArgs a, const double *__restrict__ coords, const int32_t *__restrict__ tors,
+inline __global__ __launch_bounds__(256) void k_torsion_comp_check(CsearchArgs a, const double *__restrict__ coords, const int32_t *__restrict__ tors,
                                                              const uint8_t *__restrict__ mask, int32_t *__restrict__ ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, n = a.n, npad = (n + 2) & ~1;
@@ -373,7 +373,7 @@ __device__ inline void rotation_matrix_from_vectors_dev(const double v1[3], cons
     for (int i = 0; i < 9; ++i) out[i] = (i % 4 == 0) ? 1.0 : 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_string_embed_params(const double *__restrict__ p1, const double *__restrict__ p2,
+inline __global__ __launch_bounds__(256) void k_string_embed_params(const double *__restrict__ p1, const double *__restrict__ p2,
                                                               const double *__restrict__ ref_vec, const double *__restrict__ mol_vec,
                                                               const int32_t *__restrict__ conf_pair, int64_t n_sites,
                                                               const double *__restrict__ angles, int n_angles, double *__restrict__ rot,
@@ -442,7 +442,7 @@ __device__ inline void align_vec_pair_dev(const double ref0[3], const double ref
     R[6] = 2 * (x * z - w * y), R[7] = 2 * (y * z + w * x), R[8] = w * w - x * x - y * y + z * z;
 }
 
-__global__ __launch_bounds__(256) void k_cyclical_embed_params(const double *__restrict__ start, const double *__restrict__ end,
+inline __global__ __launch_bounds__(256) void k_cyclical_embed_params(const double *__restrict__ start, const double *__restrict__ end,
                                                                 const double *__restrict__ direction, const double *__restrict__ pivot,
                                                                 const double *__restrict__ meanpoint, const double *__restrict__ r0,
                                                                 const double *__restrict__ r1, const int32_t *__restrict__ n_reactive,

@@ -56,7 +56,7 @@ __device__ inline int radix_digit(const float *__restrict__ D, const int32_t *__
     id = in ? in[m] : int(m);
     return int((morton_cell(D + int64_t(id) * DW, inv) >> shift) & (RADIX_BUCKETS - 1));
 }
-__global__ __launch_bounds__(256) void k_radix_count(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
+inline __global__ __launch_bounds__(256) void k_radix_count(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
                                                       int shift, int32_t *__restrict__ blk_cnt) {
     __shared__ int s_cnt[RADIX_BUCKETS];
     const float dmax = __uint_as_float(*dmax_bits);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_radix_count(const float *__restrict__ D
     blk_cnt[int64_t(blockIdx.x) * RADIX_BUCKETS + tid] = s_cnt[tid];
 }
 // blk_cnt[b][d] -> entries with digit d in the blocks before b (one wavefront per digit), tot[d] = entries with digit d
-__global__ __launch_bounds__(64) void k_radix_scan(int n_blocks, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ tot) {
+inline __global__ __launch_bounds__(64) void k_radix_scan(int n_blocks, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ tot) {
     const int d = blockIdx.x, lane = threadIdx.x & 63;
     int run = 0;
     for (int b0 = 0; b0 < n_blocks; b0 += 64) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void k_radix_scan(int n_blocks, int32_t *__rest
     if (lane == 0) tot[d] = run;
 }
 // tot[d] -> first output slot of digit d (exclusive prefix over the 256 digits; one block)
-__global__ __launch_bounds__(256) void k_radix_base(int32_t *__restrict__ tot) {
+inline __global__ __launch_bounds__(256) void k_radix_base(int32_t *__restrict__ tot) {
     __shared__ int s_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int v = tot[tid];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_radix_base(int32_t *__restrict__ tot) {
     for (int q = 0; q < wv; ++q) base += s_part[q];
     tot[tid] = base + incl - v;
 }
-__global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
+inline __global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__ D, const int32_t *__restrict__ in, int64_t n, const unsigned *__restrict__ dmax_bits,
                                                         int shift, const int32_t *__restrict__ blk_base, const int32_t *__restrict__ digit_base,
                                                         int32_t *__restrict__ out) {
     __shared__ int s_cnt[32][RADIX_BUCKETS];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const float *__restrict__
 // ---- once per culled pass ----------------------------------------------------------------------------------------------
 // cbase[c] = active structures before chunk c of the open pass (c = 0 .. k; cbase[k] = A): chunk c takes the positions
 // [cbase[c], cbase[c + 1]) of the sorted layout -- the rank range of the chunk, in another order.  Also clears the fill counters.
-__global__ __launch_bounds__(64) void k_chunk_bases(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ boff,
+inline __global__ __launch_bounds__(64) void k_chunk_bases(PassGeom g, const PruneState *__restrict__ st, const int32_t *__restrict__ boff,
                                                      const unsigned long long *__restrict__ bits, int bit_words, int n_blocks, int32_t *__restrict__ cbase,
                                                      int32_t *__restrict__ cfill) {
     const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void k_chunk_bases(PassGeom g, const PruneState
 // k = 1 passes) the walk has little to do and keeps the pass.  One wavefront; the verdict goes to pinned host memory, the host
 // waits for it (a pass that large takes a millisecond or more; enqueueing both kernels and letting the loser's 10^5 workgroups
 // start and leave cost 0.1-0.2 ms a pass) and launches one flow or the other.
-__global__ __launch_bounds__(64) void k_cull_decide(PruneState *__restrict__ st, const PassCounters *__restrict__ cnt, const int32_t *__restrict__ cbase, int k,
+inline __global__ __launch_bounds__(64) void k_cull_decide(PruneState *__restrict__ st, const PassCounters *__restrict__ cnt, const int32_t *__restrict__ cbase, int k,
                                                      int force, int *__restrict__ flag_host) {
     const int lane = threadIdx.x & 63;
     unsigned long long w = __hip_atomic_load(&cnt->w[lane][CNT_WALK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -225,7 +225,7 @@ __device__ inline int layout_wave_rank(int mine, int *s_cnt_slot) {
     }
     return rank;
 }
-__global__ __launch_bounds__(256) void k_layout_count(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+inline __global__ __launch_bounds__(256) void k_layout_count(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
                                                       const unsigned long long *__restrict__ bits, int bit_words, int32_t *__restrict__ blk_cnt) {
     __shared__ int s_cnt[CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_layout_count(PassGeom g, LayoutRange lr
     if (tid < g.k) blk_cnt[int64_t(blockIdx.x) * CULL_MAX_CHUNKS + tid] = s_cnt[tid];
 }
 // blk_cnt[b][c] -> first position of block b's structures of chunk c: cbase[c] + structures of chunk c in the blocks before b
-__global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__restrict__ st, int n_layout_blocks, const int32_t *__restrict__ cbase,
+inline __global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__restrict__ st, int n_layout_blocks, const int32_t *__restrict__ cbase,
                                                      int32_t *__restrict__ blk_cnt) {
     if (st->pass_on == 0) return;
     const int c = blockIdx.x, lane = threadIdx.x & 63;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__restrict
         run += __shfl(incl, 63);
     }
 }
-__global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
+inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
                                                         const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
                                                         const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
                                                         int32_t *__restrict__ crank) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, LayoutRange 
 
 // Bounding boxes of the sorted layout: per 128 positions one column box and eight row boxes (16 positions each), lo[16] then
 // hi[16].  Positions beyond the active count do not exist: an empty box (lo = +inf, hi = -inf) is infinitely far from everything.
-__global__ __launch_bounds__(128) void k_tile_boxes(const PruneState *__restrict__ st, const float *__restrict__ Ds, float *__restrict__ cbox,
+inline __global__ __launch_bounds__(128) void k_tile_boxes(const PruneState *__restrict__ st, const float *__restrict__ Ds, float *__restrict__ cbox,
                                                      float *__restrict__ rbox) {
     __shared__ float s_d[CULL_COLS][DW + 1];
     const int A = st->pass_on ? st->A : 0;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void sieve_item_sorted(const double *__restrict__ hea
 #define TSC_SORTED_OCC TSC_SIEVE_OCC2
 #endif
 template <bool F32>
-__global__ __launch_bounds__(256, TSC_SORTED_OCC) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+inline __global__ __launch_bounds__(256, TSC_SORTED_OCC) void k_rmsd_sieve_sorted(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                             const double *__restrict__ Gall, const int32_t *__restrict__ cend,
                                                                             int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                                             const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, int my_tiles, int n_seg) {

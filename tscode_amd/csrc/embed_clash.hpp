@@ -64,7 +64,7 @@ __device__ inline void embed_atom_staged(const double *__restrict__ frags, const
 constexpr int TR_POSES = 32;
 __host__ __device__ inline size_t transform_lds_bytes(int n_mols) { return size_t(TR_POSES) * n_mols * (12 * sizeof(double) + sizeof(int)) + TR_POSES * sizeof(int64_t); }
 
-__global__ __launch_bounds__(256) void k_transform(const double *__restrict__ frags, FragTable ft,
+inline __global__ __launch_bounds__(256) void k_transform(const double *__restrict__ frags, FragTable ft,
                                                     const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
                                                     const double *__restrict__ pos, const int32_t *__restrict__ idx,
                                                     int64_t n_out, double *__restrict__ out,
@@ -175,7 +175,7 @@ __device__ inline bool fp32_min_band(double x0, double cmax, float *lo_out, floa
 }
 
 template <bool FUSED, bool SELF, bool MINMODE>
-__global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
+inline __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__restrict__ coords,
                                                 const double *__restrict__ frags, FragTable ft,
                                                 const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
                                                 const double *__restrict__ pos, uint8_t *__restrict__ mask,
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_clash(ClashArgs a, const double *__rest
 // band is recounted in fp64 by the whole wavefront, all its n_A n_B distances at once (d^2 < sq_bound: exactly the reference's
 // sqrt-then-compare verdict, numba_functions.py:77-86).
 template <int NA2>
-__global__ __launch_bounds__(256) void k_clash_lanes(int64_t n_poses, const double *__restrict__ frags, FragTable ft, int mA, int mB,
+inline __global__ __launch_bounds__(256) void k_clash_lanes(int64_t n_poses, const double *__restrict__ frags, FragTable ft, int mA, int mB,
                                                       const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
                                                       const double *__restrict__ pos, double sq_bound, uint8_t *__restrict__ mask) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_clash_lanes(int64_t n_poses, const doub
 }
 
 // all_dists (algebra.py:98-157): out[i, j] = sqrt(sum_k (A[i,k] - B[j,k])^2)
-__global__ __launch_bounds__(256) void k_all_dists(const double *__restrict__ A, int na, const double *__restrict__ B, int nb,
+inline __global__ __launch_bounds__(256) void k_all_dists(const double *__restrict__ A, int na, const double *__restrict__ B, int nb,
                                                     double *__restrict__ out) {
     int64_t total = int64_t(na) * nb;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {

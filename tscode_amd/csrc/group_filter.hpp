@@ -21,7 +21,7 @@ constexpr int GF_MAX_GROUP = 8192;  // poses per group: the reference's groups h
 // dependent ones (96 000 poses in 4 000 groups of 24: 0.99 -> 0.47 ms; what is left is every thread walking its own two
 // structures in global memory).  Larger groups: wavefront 0
 // walks the poses in order and tests each against up to 64 accepted poses at a time.
-__global__ __launch_bounds__(256) void k_greedy_group_filter(const double *__restrict__ poses, const int32_t *__restrict__ group_off,
+inline __global__ __launch_bounds__(256) void k_greedy_group_filter(const double *__restrict__ poses, const int32_t *__restrict__ group_off,
                                                               int n_groups, int n_atoms, double thr, uint8_t *__restrict__ accepted,
                                                               double *__restrict__ Gscratch) {
     __shared__ int s_kept[GF_MAX_GROUP];

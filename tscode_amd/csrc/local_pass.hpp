@@ -61,7 +61,7 @@ __device__ inline unsigned long long lds_extract64(const unsigned long long *bit
     return lo | hi;
 }
 
-__global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
+inline __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,
                                                              unsigned long long *__restrict__ bits, int bit_words,
                                                              const unsigned long long *__restrict__ dbit, const double *__restrict__ heavy,
                                                              const double *__restrict__ Gall, const float *__restrict__ D,

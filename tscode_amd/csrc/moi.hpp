@@ -10,7 +10,7 @@
 
 namespace tsc {
 
-__global__ __launch_bounds__(256) void k_inertia_moments(const double *__restrict__ structures, int64_t N, int n, const double *__restrict__ masses,
+inline __global__ __launch_bounds__(256) void k_inertia_moments(const double *__restrict__ structures, int64_t N, int n, const double *__restrict__ masses,
                                                           double *__restrict__ out) {
     for (int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < N; s += int64_t(gridDim.x) * blockDim.x) {
         const double *c = structures + s * n * 3;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_inertia_moments(const double *__restric
 }
 
 // algebra.py:188-205: first[i] = first j > i with all(|im_i - im_j| / im_i < max_deviation), -1 if none
-__global__ __launch_bounds__(256) void k_moi_first_similar(const double *__restrict__ mo, int64_t N, double max_deviation, int32_t *__restrict__ first) {
+inline __global__ __launch_bounds__(256) void k_moi_first_similar(const double *__restrict__ mo, int64_t N, double max_deviation, int32_t *__restrict__ first) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); i < N; i += int64_t(gridDim.x) * 4) {
         const double a0 = mo[3 * i], a1 = mo[3 * i + 1], a2 = mo[3 * i + 2];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_moi_first_similar(const double *__restr
 
 // numba_functions.py:273-288 _score_embed_poses (float32 accumulator, as the reference's array) and the signed error of
 // fitness_check (optimization_methods.py:544-557; a NaN target stands for None and is skipped)
-__global__ __launch_bounds__(256) void k_embed_scores(const double *__restrict__ structures, int64_t N, int n, const int32_t *__restrict__ indices,
+inline __global__ __launch_bounds__(256) void k_embed_scores(const double *__restrict__ structures, int64_t N, int n, const int32_t *__restrict__ indices,
                                                        const double *__restrict__ distances, int n_c, float *__restrict__ scores,
                                                        double *__restrict__ fitness_error) {
     for (int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < N; s += int64_t(gridDim.x) * blockDim.x) {

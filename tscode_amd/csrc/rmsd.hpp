@@ -275,7 +275,7 @@ __device__ inline void rmsd_and_max_pair(const double *__restrict__ p, const dou
     exact_rmsd_maxdev(p, q, h, S, Gp, Gq, rmsd, maxdev);
 }
 
-__global__ __launch_bounds__(256) void k_rmsd_pairs(const double *__restrict__ heavy, int h, const int32_t *__restrict__ pairs,
+inline __global__ __launch_bounds__(256) void k_rmsd_pairs(const double *__restrict__ heavy, int h, const int32_t *__restrict__ pairs,
                                                      int64_t n_pairs, double *__restrict__ rmsd, double *__restrict__ maxdev) {
     for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < n_pairs; k += int64_t(gridDim.x) * blockDim.x) {
         double r, m;
@@ -425,7 +425,7 @@ struct InitArgs {
     long long first_k;
     int first_algo;
 };
-__global__ __launch_bounds__(256) void k_init_run(InitArgs a) {
+inline __global__ __launch_bounds__(256) void k_init_run(InitArgs a) {
     // first_slot >= 0: the first pass of the schedule is opened here as well (gate of rmsd_pruning.py:192 on the full count,
     // its record), which is all a k_pass_step launch would do at this point
     const int64_t n = a.n;
@@ -568,10 +568,10 @@ __device__ inline void pass_step_wave(const StepCtx &sc, const StepArgs &sa) {
     for (int e = lane; e < sc.ticket_lines; e += 64) sc.tickets[32 * e] = 0;
 }
 
-__global__ __launch_bounds__(64) void k_pass_step(StepCtx sc, StepArgs sa) { pass_step_wave(sc, sa); }
+inline __global__ __launch_bounds__(64) void k_pass_step(StepCtx sc, StepArgs sa) { pass_step_wave(sc, sa); }
 
 // ---------------------------------------------------------------------------------------------------
-// per-pass helper kernels (the pass sequence is in tscode_hip.hip, tsc_prune_pass_local / tsc_prune_pass_finish)
+// per-pass helper kernels (the pass sequence is in prune.hip, tsc_prune_pass_local / tsc_prune_pass_finish)
 
 struct PassGeom {
     int n;   // structures (< 2^31)
@@ -651,7 +651,7 @@ struct OpenArgs {
 #else
 #define TSC_OPEN_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
+inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
                                                     int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
                                                     const float *__restrict__ D, float *__restrict__ Dc) {
     static_assert(SCAN_BLOCK_WORDS == 32 && 64 / OPEN_LPR == 16 && DESC_WORDS == 4 * OPEN_LPR, "one wavefront = one row tile; a float4 of the descriptor per lane");
@@ -908,7 +908,7 @@ __device__ inline void apply_wave_rows(const ApplyArgs &a, int sel, int r, bool 
 //   Xc[d][ld]    coordinate-major                    (column structures: lane = column, coalesced)
 //   G[r] = sum |x|^2
 // One block moves 64 structures through an LDS tile so that both global sides are coalesced.
-__global__ __launch_bounds__(256) void k_compact_coords(const double *__restrict__ heavy, int h, int hp3,
+inline __global__ __launch_bounds__(256) void k_compact_coords(const double *__restrict__ heavy, int h, int hp3,
                                                          const int32_t *__restrict__ act_idx, const PruneState *__restrict__ st,
                                                          double *__restrict__ Xr, double *__restrict__ Xc, int64_t ld,
                                                          double *__restrict__ G) {
@@ -1063,7 +1063,7 @@ __device__ inline int pair_verdict(const double H[9], double half_sum, double ha
 // A row stops being visited once it has a similar column to its left (the reference returns at the
 // first similar column, rmsd_pruning.py:75-77).
 template <int HP, int TI>
-__global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__ Xr, const double *__restrict__ Xc,
+inline __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__ Xr, const double *__restrict__ Xc,
                                                        const double *__restrict__ G, const int32_t *__restrict__ cend,
                                                        int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                        const PruneState *__restrict__ st, TileArgs a) {
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(256, 2) void k_rmsd_tile(const double *__restrict__
 // Apply a finished pass as a launch of its own (the register-tiled kernel's passes, and passes whose rows were searched by
 // several ranks: best[] is complete only after the exchange).  The sieve kernel of a single-rank run does this itself, tile
 // by tile (sieve.hpp).
-__global__ __launch_bounds__(256) void k_apply_pass(ApplyArgs a, StepCtx sc, StepArgs next) {
+inline __global__ __launch_bounds__(256) void k_apply_pass(ApplyArgs a, StepCtx sc, StepArgs next) {
     __shared__ int s_last;
     PruneState *st = sc.st;
     const bool pass_on = st->pass_on != 0;
@@ -1224,7 +1224,7 @@ __device__ inline int rank_below_wave(const int32_t *__restrict__ boff, const un
 
 // The rows of this rank in the OPEN pass: the active structures of [s_lo, s_hi) (whole chunks of that pass).  Needed as a
 // launch of its own only where no k_pass_merge precedes the pass (the first pass of a run).
-__global__ __launch_bounds__(64) void k_range_open(PruneState *__restrict__ st, const int32_t *__restrict__ boff, const unsigned long long *__restrict__ bits,
+inline __global__ __launch_bounds__(64) void k_range_open(PruneState *__restrict__ st, const int32_t *__restrict__ boff, const unsigned long long *__restrict__ bits,
                                                     int bit_words, int n_blocks, int s_lo, int s_hi) {
     const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
     const int n_all = st->n_active;
@@ -1240,7 +1240,7 @@ struct MergeArgs {
     int next_s_lo, next_s_hi;   // the next pass is rank-partitioned: this rank's structures [s_lo, s_hi) in it; -1: it is not
 };
 constexpr int MERGE_LDS_BLOCKS = 8192;  // scan blocks counted in LDS (16.7 M structures); beyond: every thread counts whole blocks from memory
-__global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, StepArgs sa) {
+inline __global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, StepArgs sa) {
     __shared__ int s_cnt[MERGE_LDS_BLOCKS];
     __shared__ int s_part[16], s_run;
     PruneState *st = sc.st;
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(1024) void k_pass_merge(MergeArgs a, StepCtx sc, St
 
 // Summary words of `count` cache views (one bit per 1024 view bits, CacheViews) rebuilt from their bits: after the host has
 // summed the views of the remaining passes over the ranks, the summed summary words mean nothing.
-__global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__restrict__ views, long long stride, int bit_words, int dsum_words, int count) {
+inline __global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__restrict__ views, long long stride, int bit_words, int dsum_words, int count) {
     // one thread per summary BIT (16 view words); the 64 bits of a summary word sit in one wavefront and meet by ballot
     const int per_view = dsum_words * 64;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < int64_t(count) * per_view; e += int64_t(gridDim.x) * blockDim.x) {
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_views_summaries(unsigned long long *__r
 
 // End of a run: the pass records and (optionally) the survivor mask go to host-visible memory from ONE small launch instead
 // of two copy commands.  `rec_host` and `mask_host` are pinned host allocations mapped into the device's address space.
-__global__ __launch_bounds__(256) void k_export_run(const unsigned long long *__restrict__ rec, int rec_words, unsigned long long *__restrict__ rec_host,
+inline __global__ __launch_bounds__(256) void k_export_run(const unsigned long long *__restrict__ rec, int rec_words, unsigned long long *__restrict__ rec_host,
                                                      const unsigned long long *__restrict__ mask, int64_t mask_words, const uint8_t *__restrict__ mask_bytes,
                                                      int64_t n, unsigned long long *__restrict__ mask_host, const unsigned *__restrict__ dmax_bits) {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_export_run(const unsigned long long *__
     }
 }
 
-__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {
+inline __global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v) {
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = v;
 }
 

@@ -30,7 +30,7 @@ __device__ inline int count_nonzero_bytes(uint64_t v) {
 
 // pass 1: per-block count of non-zero mask bytes
 // gate (optional): the kernels of a speculatively enqueued pass return at once when *gate == 0.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t *__restrict__ mask, int64_t n,
+inline __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint8_t *__restrict__ mask, int64_t n,
                                                                    int32_t *__restrict__ bsum, const int *__restrict__ gate) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
     if (gate && *gate == 0) return;
@@ -87,7 +87,7 @@ __device__ inline void scan_write_block(const uint8_t *__restrict__ mask, int64_
     }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
+inline __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
                                                               const int32_t *__restrict__ bsum, int32_t *__restrict__ pos,
                                                               int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
                                                               int32_t *__restrict__ total_out, const int *__restrict__ gate) {
@@ -117,7 +117,7 @@ inline size_t scan_bsum_count(int64_t n) { return size_t(ceil_div<int64_t>(n + 1
 // dst[r] = src[idx[r]] for rows of row_words 8-byte words; idx == nullptr means identity.
 // sel (optional) picks words inside the row: dst[r][w] = src[idx[r]][sel[w]] for w < out_words
 // (used for the heavy-atom gather, where a "word" is one coordinate triple = 3 doubles handled as 3 words).
-__global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ src, const int32_t *__restrict__ idx,
+inline __global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ src, const int32_t *__restrict__ idx,
                                                       int64_t n_out, int row_words, const int32_t *__restrict__ sel,
                                                       int out_words, uint64_t *__restrict__ dst) {
     int64_t total = n_out * out_words;

@@ -72,7 +72,7 @@ inline int n_features(int h, int fam) { return std::min(fam == 0 ? h : h / 2, DE
 // (cull.hpp) then come out bit for bit the same on every rank of a sharded run that feeds them the same sample: the ranks deal
 // the tiles of that order among themselves, and orders that differed in one structure would let pairs go unvisited.
 constexpr int MOM_BLOCKS = 32;
-__global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int nf0, int nf1, int64_t stride_structs,
+inline __global__ __launch_bounds__(256) void k_feature_moments(const double *__restrict__ heavy, int h, int nf0, int nf1, int64_t stride_structs,
                                                           int n_samples, double *__restrict__ M0, double *__restrict__ M1, unsigned *__restrict__ tickets) {
     // tickets == null: the fast form -- one workgroup per chunk of 32 samples, atomicAdd into the (zeroed) first partial matrix of the
     // family: the order of the additions, and with it the last bits of the basis, differ from run to run.  Any basis gives the same
@@ -256,7 +256,7 @@ __device__ inline void describe_from_lds(const double *s_q, const double *s_x, i
 // integer view; zero on entry) -- the pair kernel turns it into the fp32 limit of the screen (screen_limit32).
 // A block stages S structures in LDS with coalesced loads (a thread-per-structure walk reads 64 lines per instruction and
 // thrashes the L1); T = 256 / S consecutive lanes share a structure (atoms sub, sub + T, ...) and reduce with shuffles.
-__global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
+inline __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ heavy, int64_t n, int h, int nf0, int nf1,
                                                       const double *__restrict__ Q, const double *__restrict__ bias, float *__restrict__ D,
                                                       double *__restrict__ G, unsigned *__restrict__ dmax_bits, int S) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];  // [KD][nf0], [KD][nf1], then S rows of pitch doubles
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const double *__restrict__ 
 // embedded): k_transform's workgroup of TR_POSES poses keeps the heavy atoms it has just computed in LDS and takes their
 // descriptor rows from there, so the 24 h bytes per structure are not read back by a k_descriptors launch.
 // dynamic LDS: transform_lds_bytes(n_mols), then [KD][nf0 + nf1] basis doubles, then TR_POSES rows of (3 h | 1) doubles.
-__global__ __launch_bounds__(256) void k_transform_describe(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
+inline __global__ __launch_bounds__(256) void k_transform_describe(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
                                                              const double *__restrict__ rot, const double *__restrict__ pos,
                                                              const int32_t *__restrict__ idx, double *__restrict__ out,
                                                              const int32_t *__restrict__ heavy_slot, int n_heavy, double *__restrict__ heavy_out,
@@ -356,7 +356,7 @@ inline size_t transform_describe_lds_bytes(int n_mols, int h) {
 // The trivial basis for small ensembles: component k of a family = its feature k (rows of the identity: |Q x| <= |x|), no
 // centring.  Any basis gives the same verdicts; with a few thousand structures the screen has little to do, and estimating
 // principal axes (a memset, a moments launch and the one-wavefront basis kernel: about 45 us of latency) costs more than it saves.
-__global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, double *__restrict__ bias) {
+inline __global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, double *__restrict__ bias) {
     const int total = KD * (nf0 + nf1);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int fam = e < KD * nf0 ? 0 : 1, r = fam == 0 ? e : e - KD * nf0, nf = fam == 0 ? nf0 : nf1;
@@ -380,7 +380,7 @@ __global__ void k_identity_basis(int nf0, int nf1, double *__restrict__ Q, doubl
 #endif
 constexpr int BASIS_ITERS = TSC_BASIS_ITERS;
 constexpr int BASIS_LDS_C = 64;  // covariance staged in LDS up to this many features
-__global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
+inline __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restrict__ M0, const double *__restrict__ M1, int nf0, int nf1,
                                                           int n_samples, double *__restrict__ Q, double *__restrict__ bias,
                                                           unsigned *__restrict__ zero_word, double *__restrict__ spread_host = nullptr,
                                                           int clear_moments = 0) {
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64) void k_descriptor_basis(const double *__restric
     }
     // How far apart two structures of the sample lie in this family's descriptor, on average: E |V (f(p) - f(q))|^2 = 2 sum_k V_k^T C V_k.
     // The host compares it with the screen's limit h thr^2: where both families stay below it the screen can separate (almost)
-    // nothing -- every pair would reach H anyway -- and an all-pairs kernel without a screen is the faster route (tscode_hip.hip,
+    // nothing -- every pair would reach H anyway -- and an all-pairs kernel without a screen is the faster route (host.hpp,
     // screen_is_useless).  Only worked out where that kernel exists (up to 32 heavy atoms); +inf otherwise.
     double spread = __builtin_inf();
     if (nf <= 32) {  // (c_in_lds) lane = (row k of V, an eighth of the features a): 64 lanes share the nf^2 KD products
@@ -577,7 +577,7 @@ constexpr int SM_CHUNKS = 1;  // chunks of TR_POSES samples per workgroup of k_s
 __host__ __device__ inline size_t sample_moments_lds_bytes(int n_mols, int h) {
     return (transform_lds_bytes(n_mols) + 15) / 16 * 16 + size_t(TR_POSES) * (size_t(h) * 3 + size_t(h) + 1) * sizeof(double);
 }
-__global__ __launch_bounds__(256) void k_sample_moments(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
+inline __global__ __launch_bounds__(256) void k_sample_moments(const double *__restrict__ frags, FragTable ft, const int32_t *__restrict__ conf_idx,
                                                         const double *__restrict__ rot, const double *__restrict__ pos,
                                                         const int32_t *__restrict__ sample_idx, int n_samples, const int32_t *__restrict__ heavy_slot,
                                                         int h, int nf0, int nf1, double *__restrict__ M0, double *__restrict__ M1) {
@@ -720,7 +720,7 @@ __device__ inline void pair_H(const double *__restrict__ p, const double *__rest
 // tests on H from this copy, with the rounding bound that goes with it (rmsd.hpp: quartic_gamma32), decide all but the pairs with a
 // tiny margin; those are formed again from the float64 coordinates, as is everything the explicit-rotation path needs.
 
-__global__ __launch_bounds__(256) void k_heavy32(const double *__restrict__ heavy, int64_t n, int h, float *__restrict__ out) {
+inline __global__ __launch_bounds__(256) void k_heavy32(const double *__restrict__ heavy, int64_t n, int h, float *__restrict__ out) {
     const int h3 = h * 3, pitch = heavy32_pitch(h);
     const int64_t total = n * pitch;
     for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
 }
 
 template <int TI, int CPL, bool TRIM = false, bool FUSED = false, bool F32 = false>
-__global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+inline __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OCC2 : TSC_SIEVE_OCC1)) void k_rmsd_sieve(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                         const double *__restrict__ Gall, const float *__restrict__ D,
                                                         const int32_t *__restrict__ cend,
                                                         int32_t *__restrict__ best, PassCounters *__restrict__ counters,

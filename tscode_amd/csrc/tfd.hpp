@@ -34,7 +34,7 @@ __device__ inline double dihedral_deg_dev(const double *__restrict__ p0, const d
 }
 
 // _get_tf_mat (:233-240): out f32[N][T]
-__global__ __launch_bounds__(256) void k_torsion_fingerprints(const double *__restrict__ coords, int64_t N, int n, const int32_t *__restrict__ quads,
+inline __global__ __launch_bounds__(256) void k_torsion_fingerprints(const double *__restrict__ coords, int64_t N, int n, const int32_t *__restrict__ quads,
                                                                int T, float *__restrict__ out) {
     const int64_t total = N * T;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_torsion_fingerprints(const double *__re
 
 // One pass of the pair search (:171-199).  first[i] = absolute index of the first similar j > i inside i's chunk, -1 if
 // none or if i lies in no chunk (the last chunk ends at num_active, :175-178).
-__global__ __launch_bounds__(256) void k_tfd_first_similar(const float *__restrict__ tf, int64_t N, int T, int64_t d, int64_t k, int64_t num_active,
+inline __global__ __launch_bounds__(256) void k_tfd_first_similar(const float *__restrict__ tf, int64_t N, int T, int64_t d, int64_t k, int64_t num_active,
                                                             double thresh, int32_t *__restrict__ first) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); i < N; i += int64_t(gridDim.x) * 4) {
@@ -155,7 +155,7 @@ __device__ inline bool tfd_similar_reg(const float *__restrict__ a, const float 
 // compact copy k_tfd_greedy_replay keeps ([n_kept][T], in the order they were kept): the address is the same for every lane, so the
 // loads are scalar loads and the comparison's operands sit in scalar registers -- no LDS, no barrier, no indirection through kept_list
 // in front of every comparison (the first version walked kept_list -> tf per comparison: 207 us per super-block, an LDS-tiled one 153)
-__global__ __launch_bounds__(256) void k_tfd_greedy_prior(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
+inline __global__ __launch_bounds__(256) void k_tfd_greedy_prior(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
                                                            const float *__restrict__ kept_fp, const int32_t *__restrict__ n_kept,
                                                            uint8_t *__restrict__ dead) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_tfd_greedy_prior(const float *__restric
 // sim[c][w] bit j: candidate c of the super-block is similar to its candidate 64 w + j, for 64 w + j < c (zero elsewhere: every
 // word is written); nz[c / 64] bit c % 64: row c has a bit set at all (zeroed by the caller).  blockIdx.x = w (its 64 fingerprints
 // in LDS), blockIdx.y * 256 + threadIdx.x = c.
-__global__ __launch_bounds__(256) void k_tfd_greedy_pairs(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
+inline __global__ __launch_bounds__(256) void k_tfd_greedy_pairs(const float *__restrict__ tf, int64_t base, int n_cand, int T, double thresh,
                                                            unsigned long long *__restrict__ sim, unsigned long long *__restrict__ nz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_tfd_raw[];
     float *s_tile = reinterpret_cast<float *>(s_tfd_raw);
@@ -224,7 +224,7 @@ __device__ inline unsigned long long readlane64(unsigned long long v, int l) {
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long long *__restrict__ sim, const unsigned long long *__restrict__ nz,
+inline __global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long long *__restrict__ sim, const unsigned long long *__restrict__ nz,
                                                            int64_t base, int n_cand, const uint8_t *__restrict__ dead_in,
                                                            uint8_t *__restrict__ accepted, int32_t *__restrict__ kept_list, int32_t *__restrict__ n_kept,
                                                            int32_t *__restrict__ n_kept_before) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void k_tfd_greedy_replay(const unsigned long lo
 
 // the fingerprints of the structures the last super-block kept, appended to the compact copy k_tfd_greedy_prior reads (one workgroup: a few
 // hundred fingerprints; inside the one-wavefront replay kernel the same copy cost 20 us per super-block)
-__global__ __launch_bounds__(256) void k_tfd_greedy_keep(const float *__restrict__ tf, int T, const int32_t *__restrict__ kept_list,
+inline __global__ __launch_bounds__(256) void k_tfd_greedy_keep(const float *__restrict__ tf, int T, const int32_t *__restrict__ kept_list,
                                                           const int32_t *__restrict__ n_kept_before, const int32_t *__restrict__ n_kept,
                                                           float *__restrict__ kept_fp) {
     const int s0 = *n_kept_before, total = (*n_kept - s0) * T;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_tfd_greedy_keep(const float *__restrict
 }
 
 // flags of a compacted list back onto the full index space: full[idx[r]] = part[r] (full is zeroed by the caller)
-__global__ __launch_bounds__(256) void k_scatter_flags(const uint8_t *__restrict__ part, const int32_t *__restrict__ idx, const int32_t *__restrict__ n_dev,
+inline __global__ __launch_bounds__(256) void k_scatter_flags(const uint8_t *__restrict__ part, const int32_t *__restrict__ idx, const int32_t *__restrict__ n_dev,
                                                         uint8_t *__restrict__ full) {
     const int n = *n_dev;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) full[idx[r]] = part[r];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_scatter_flags(const uint8_t *__restrict
 
 // offsets of candidate groups in the list of the candidates that passed a filter: out[g] = pos[group_off[g]] (pos = exclusive
 // scan of the filter's mask), out[n_groups] = total
-__global__ __launch_bounds__(256) void k_group_offsets_after_filter(const int32_t *__restrict__ group_off, int n_groups, const int32_t *__restrict__ pos,
+inline __global__ __launch_bounds__(256) void k_group_offsets_after_filter(const int32_t *__restrict__ group_off, int n_groups, const int32_t *__restrict__ pos,
                                                                      int64_t n, const int32_t *__restrict__ total, int32_t *__restrict__ out) {
     for (int g = blockIdx.x * 256 + threadIdx.x; g <= n_groups; g += gridDim.x * 256) out[g] = (g == n_groups || group_off[g] >= n) ? *total : pos[group_off[g]];
 }

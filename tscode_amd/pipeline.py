@@ -49,7 +49,7 @@ PARTITION_MIN_CHUNKS = 4
 
 def partition_bounds(n: int, k: int, rank: int, world: int):
     """Chunks [c_lo, c_hi) of a pass of k chunks that start inside rank's block of the structure axis and the structures
-    [s_lo, s_hi) they cover (mirror of the library's partition_bounds, tscode_hip.hip)."""
+    [s_lo, s_hi) they cover (mirror of the library's partition_bounds, csrc/prune_host.hpp)."""
     cs = n // k
 
     def first_chunk(r):
