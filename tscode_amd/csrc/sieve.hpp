@@ -810,7 +810,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
                                            const double *__restrict__ Gall, const float *__restrict__ D,
                                            const int32_t *__restrict__ cend,
                                            int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                           const PruneState *__restrict__ st, const SieveArgs a) {
+                                           const PruneState *__restrict__ st, const SieveArgs a, int &A_out, int &bitsel_out) {
     static_assert(TI <= 16, "queue entries keep the row in 4 bits");
     static_assert(DW == 2 * KD, "two families of KD components");
     constexpr int QCAP = TI * 64 * CPL + 64;  // one column tile can add TI * 64 * CPL pairs on top of a remainder below 64
@@ -836,6 +836,7 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     // act[x] (needed for the coordinates of the pairs that reach H) is a valid structure index for every x < n:
     // k_init_run fills it with the identity, every pass rewrites a prefix.
     const int pass_on = st->pass_on, n_active = st->A;
+    A_out = n_active, bitsel_out = st->bitsel;  // (for the fused tail: the state block cannot change before this item has arrived there)
     int my_cend = 0, my_best = 0;
     if (lane < TI && r0 + lane < a.n) {
         my_cend = cend[r0 + lane];
@@ -1212,20 +1213,24 @@ inline __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OC
     // a pass that is gated off: k_open_rows): one scalar load and out
     const int tcm = a.tile_cmax[tile];
     if (tcm <= seg_lo) return;
-    sieve_item<TI, CPL, TRIM, F32>(heavy, act, Gall, D, cend, best, counters, st, a);
+    int A = 0, bitsel = 0;
+    sieve_item<TI, CPL, TRIM, F32>(heavy, act, Gall, D, cend, best, counters, st, a, A, bitsel);
     if constexpr (FUSED) {
         // this item's atomicMin's on best[] are at the L2 before its arrival is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const int lim = min(a.n, tcm);
         const int n_live = min(int(gridDim.y), (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
-        int last = 0;
-        if (lane == 0) last = (atomicAdd(&fa.tile_done[tile], 1) == n_live - 1) ? 1 : 0;
-        TSC_STAMP(4);  // arrived at the tile's counter
-        if (!__builtin_amdgcn_readfirstlane(last)) return;
-        if (lane == 0) fa.tile_done[tile] = 0;
+        // (the tail of a light pass is a chain of dependent round trips -- arrival, state, best[], act[], the atomics' way out, the pass's
+        // counter -- and its length is the pass: the only item of its tile needs no arrival, and the state block was read in the prologue)
+        if (n_live > 1) {
+            int last = 0;
+            if (lane == 0) last = (atomicAdd(&fa.tile_done[tile], 1) == n_live - 1) ? 1 : 0;
+            TSC_STAMP(4);  // arrived at the tile's counter
+            if (!__builtin_amdgcn_readfirstlane(last)) return;
+            if (lane == 0) fa.tile_done[tile] = 0;
+        }
         unsigned long long ev_total = 0, rm_total = 0;
-        const int A = st->A;
-        apply_wave_rows(fa.ap, st->bitsel, r0 + lane, lane < TI && r0 + lane < A, ev_total, rm_total);
+        apply_wave_rows(fa.ap, bitsel, r0 + lane, lane < TI && r0 + lane < A, ev_total, rm_total);
         int fin = 0;
         if (lane == 0) {
             count_add(counters, unsigned(slot), CNT_EVALUATED, ev_total);
