@@ -15,7 +15,7 @@ N > 1 (one process per GPU, torch.distributed backend nccl = RCCL): for the 100k
 `value` is `replicas` -- every GPU its own ensemble, `"scaling": "weak"`, no data-path collective: such an ensemble is a one-GPU job and does
 not strong-scale (`multi.why`) -- with the sharded leg beside it (`sharded_single_ensemble`); for C4 / C5 / the C5 chain (and with
 `--multi sharded`) the line's `value` is ONE ensemble sharded over the
-ranks, `"scaling": "strong"` -- every prune pass with at least 4 chunks per rank PARTITIONED BY CHUNKS (a rank runs the whole pass
+ranks, `"scaling": "strong"` -- every prune pass with at least 2 chunks per rank PARTITIONED BY CHUNKS (a rank runs the whole pass
 on the chunks that start inside its block of the structure axis; one bit per structure + statistics summed per pass,
 `partitioned_passes`), the later passes with their row tiles dealt round-robin and an all-reduce(MIN) over best[]
 (`sharded_passes`), and in front of it one of three forms of the embed / clash half: pose blocks + one RCCL all-gather of the
@@ -361,7 +361,7 @@ def main():
                "events_off": leg["events_off"], "what": what}
         return out
 
-    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: passes with >= 4 chunks per rank partitioned by chunks (all-reduce SUM of one bit "
+    SHARDED_WHAT = ("ONE ensemble sharded over the ranks: passes with >= 2 chunks per rank partitioned by chunks (all-reduce SUM of one bit "
                     "per structure + statistics), the later ones by row tiles (all-reduce MIN over best[]); the front half as `front` says -- "
                     "'shard': pose blocks + one RCCL all-gather of the surviving heavy-atom shards, 'replicate': every rank embeds and "
                     "clash-filters all poses itself, 'hybrid': clash verdicts per block (one byte per pose summed over the ranks), all "

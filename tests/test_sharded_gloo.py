@@ -242,11 +242,11 @@ def _worker(rank, world, port, n_poses, mode, out_dir, front="shard", partition_
         dist.destroy_process_group()
 
 
-# partition_chunks: 4 = the default (passes with >= 4 chunks per rank are partitioned by chunks, the rest sharded by row tiles or
-# replicated), 1 = every pass down to k = world partitioned (chunks as long as a rank's block: every block boundary is a seam
+# partition_chunks: 2 = the default since round 4, 4 = rounds 2 - 3 (passes with at least that many chunks per rank are partitioned by chunks, the
+# rest sharded by row tiles or replicated), 1 = every pass down to k = world partitioned (chunks as long as a rank's block: every block boundary is a seam
 # that a chunk straddles), 0 = no partitioned pass (the protocol of round 2)
 @pytest.mark.parametrize("world,n_poses,mode,front,partition_chunks", [
-    (2, 3000, 0, "shard", 4), (3, 2001, 0, "shard", 4), (2, 1500, 1, "shard", 4), (2, 2500, 0, "replicate", 4), (3, 1201, 1, "replicate", 4),
+    (2, 3000, 0, "shard", 2), (3, 2001, 0, "shard", 4), (2, 1500, 1, "shard", 2), (2, 2500, 0, "replicate", 4), (3, 1201, 1, "replicate", 2),
     (2, 2999, 0, "replicate", 1), (3, 2503, 0, "shard", 1), (3, 1801, 0, "replicate", 0), (2, 2200, 0, "hybrid", 4), (3, 1901, 1, "hybrid", 2)])
 def test_sharded_step_gloo(oracle, tmp_path, world, n_poses, mode, front, partition_chunks):
     import torch.multiprocessing as mp

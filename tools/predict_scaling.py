@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from tscode_amd.engine import PruneStepper
-from tscode_amd.pipeline import PARTITION_MIN_CHUNKS, SHARD_MIN_PAIRS, HipShardBackend
+from tscode_amd.pipeline import PARTITION_MIN_CHUNKS, SHARD_MIN_PAIRS, SHARDED_CULL_MIN_PAIRS, HipShardBackend
 from tscode_amd.synthetic import make_config
 
 LINK_GBS, LINK_EFF, COLL_FIXED_US = 153.0, 0.7, 20.0
@@ -98,6 +98,8 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
     be.world = 2      # (embed_clash_block forks a pose-sample basis for the NEXT prune run when its backend is alone in the world: the first stepper would
                       # take it, the others build their own from the survivors, and a culled pass dealt by row tiles then misses pairs -- which is what the
                       # mask comparison below caught at C4 x 2 on its first run; the pose block was cut for a world of one and stays whole)
+    if n_ranks > 1:   # (what HipShardBackend sets on a rank of a real sharded run)
+        be.eng.set_option("cull_min_pairs", SHARDED_CULL_MIN_PAIRS)
     for name, value in OPTIONS:
         be.eng.set_option(name, value)
     tm = Timer(be.stream)
@@ -262,7 +264,8 @@ def main():
            "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
                      "ring (predicted_ms_per_step)": "per-link bound: all-gather = (N-1) steps of one shard over one link; all-reduce = reduce-scatter + all-gather of that pattern",
                      "all_links (predicted_ms_per_step_all_links)": "the fully connected xGMI mesh used at once: every shard straight to its N-1 peers, one link each",
-                     "shard_min_pairs": SHARD_MIN_PAIRS, "partition_min_chunks": chunks},
+                     "shard_min_pairs": SHARD_MIN_PAIRS, "partition_min_chunks": chunks,
+                     "cull_min_pairs_of_a_rank_share": SHARDED_CULL_MIN_PAIRS},
            "measured_on": torch.cuda.get_device_name(0), "configs": {}}
     for cfg in cfgs:
         rows = []

@@ -32,7 +32,7 @@ from ._lib import XCHG_MIN_I32, XCHG_SUM_I64
 from .engine import Engine, FragmentSet
 
 __all__ = ["DevicePipeline", "HipShardBackend", "CsearchChain", "ShardedCsearchChain", "sharded_step", "block_bounds", "partition_bounds", "SHARD_MIN_PAIRS",
-           "PARTITION_MIN_CHUNKS"]
+           "PARTITION_MIN_CHUNKS", "SHARDED_CULL_MIN_PAIRS"]
 
 # A pass smaller than this many pairs (estimate n * (n / k) / 2, identical on every rank) is not worth a collective:
 # every rank runs it whole and reaches the same verdicts on its own.  On MI355X such a pass takes tens of
@@ -42,9 +42,17 @@ SHARD_MIN_PAIRS = 50_000_000
 
 # A pass with at least this many chunks per rank is PARTITIONED: every rank runs the whole pass on the chunks that start inside its
 # block of the structure axis (chunks are independent, tscode/rmsd_pruning.py:139-157) and the ranks exchange one bit per structure.
-# With fewer chunks per rank the ranks' shares would differ by more than 1 / PARTITION_MIN_CHUNKS (a rank gets a whole chunk more or
-# less than another): those passes deal their ROW TILES round-robin instead and exchange best[].
-PARTITION_MIN_CHUNKS = 4
+# With fewer chunks per rank a rank's share differs from another's by up to a whole chunk in PARTITION_MIN_CHUNKS: those passes deal
+# their ROW TILES round-robin instead and exchange best[].  2 since round 4 (4 before): a pass dealt by row tiles opens and applies ALL
+# rows on every rank, a partitioned one only its own -- in the one-GPU model of an 8-rank C4 step the k = 20 pass (2.5 chunks per rank,
+# 3 on the fullest) costs a rank 0.40 ms partitioned against 0.50 dealt by tiles, and the passes behind it get cheaper with it
+# (tools/predict_scaling.py --chunks; profiles/r04_predicted_scaling.json).  With 1 the k = 10 pass on eight ranks leaves two of them idle: no gain.
+PARTITION_MIN_CHUNKS = 2
+
+# A sharded run culls a pass (cull.hpp: sorted layout + bounding boxes) from this many pairs of a rank's SHARE on, where one GPU on its own
+# waits for 2e9 ("cull_min_pairs"): the walk's cost falls with the share, a layout's does not, but the shares of C4's five largest passes on
+# eight ranks (0.3 - 1.5e9 pairs) still lie where the layout pays -- 0.5 ms of a 4.4 ms step in the same model.
+SHARDED_CULL_MIN_PAIRS = 5.0e8
 
 
 def partition_bounds(n: int, k: int, rank: int, world: int):
@@ -311,6 +319,8 @@ class HipShardBackend:
         self.eng = Engine(device_index)
         # every rank must derive bit-identical descriptors (the culled passes deal the tiles of a layout sorted by them): fixed-order sums
         self.eng.set_option("deterministic_basis", 1 if world > 1 else 0)
+        if world > 1:
+            self.eng.set_option("cull_min_pairs", SHARDED_CULL_MIN_PAIRS)
         # This library's kernels, torch's copies and the collectives must be ordered on ONE stream.  torch's default stream
         # has handle 0, which tsc_ctx_set_stream reads as "use the library's own stream": a dedicated torch stream is made
         # current for every step instead (torch.distributed orders its collectives against the current stream).
