@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Writes the measurement tables of README.md and DESIGN.md FROM the files under profiles/ (hand-kept tables
+"""Writes the measurement tables of README.md, DESIGN.md and MEASURED.md FROM the files under profiles/ (hand-kept tables
 drift).  Everything between `<!-- tables:NAME:begin -->` and `<!-- tables:NAME:end -->` in the two documents is replaced; the
 numbers' sources are named in each table's caption.
 
@@ -176,7 +176,7 @@ TABLES = {"headline": headline, "roofline": roofline, "kernels": kernels, "kerne
 def main():
     check = "--check" in sys.argv
     changed = False
-    for doc in ("README.md", "DESIGN.md"):
+    for doc in ("README.md", "DESIGN.md", "MEASURED.md"):
         path = os.path.join(ROOT, doc)
         text = open(path).read()
         new = text
