@@ -58,6 +58,30 @@ def test_no_cpp_exception_can_cross_the_c_abi():
     assert "catch (const std::bad_alloc &)" in common and "catch (...)" in common
 
 
+def test_build_covers_every_translation_unit_and_the_binary_is_current():
+    """tscode_amd/build.py compiles the units it lists: a .hip file under csrc/ that is not in SOURCES would never reach the library (its entry
+    points would be missing symbols at load, its kernels silently absent), a header that is not hashed could change under a binary that still
+    calls itself current.  And the library beside the sources carries the digest of exactly these sources (what bench.py and
+    tools/collect_profiles.py tie a profile to)."""
+    from tscode_amd import build as b
+    from tscode_amd import _lib
+    on_disk = sorted(f for f in os.listdir(b.CSRC) if f.endswith(".hip"))
+    assert sorted(b.SOURCES) == on_disk
+    assert b.DIGEST_UNIT in b.SOURCES
+    hashed = {os.path.basename(h) for h in b.HEADERS}
+    assert {f for f in os.listdir(b.CSRC) if f.endswith(".hpp")} <= hashed and "tscode_hip.h" in hashed
+    b.build()
+    assert _lib.load().tsc_build_digest().decode() == b.csrc_digest()
+    # every unit's dependency list (hipcc -MD) names the unit itself and only files the digest covers
+    if os.path.isdir(b.OBJ):
+        for src in b.SOURCES:
+            deps = b._unit_deps(src)
+            if deps is None:
+                continue                                   # (a checkout whose objects were never built here)
+            names = {os.path.basename(d) for d in deps}
+            assert src in names and names <= hashed | set(b.SOURCES), (src, names)
+
+
 def test_product_does_not_import_oracle():
     import tscode_amd  # noqa: F401
     pkg = os.path.join(ROOT, "tscode_amd")
