@@ -567,7 +567,7 @@ def main():
             "passes": [{"k": s["k"], "active": s["n_active_before"], "evals": s["pairs_evaluated"], "screened": s["pairs_screened"], "H_formed": s["pairs_computed"],
                         "exact": s["candidates"], "ms": round(pass_ms[i] if pass_ms and i < len(pass_ms) else s["gpu_ms"], 4),
                         "tile_ms": round(s["tile_ms"], 4),
-                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks", 4: "k_pass_group"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
+                        "kernel": {1: "k_rmsd_tile", 2: "k_rmsd_sieve", 3: "k_pass_chunks"}.get(s["algo"], "?")} for i, s in enumerate(res["stats"])],
             "detail_note": "stage_ms_per_step and passes[].ms come from 3 extra steps with every library event on (pass_timing 2), "
                            "outside the timed regions; passes[].tile_ms (the pair kernel's own events) from the timed region (0 for passes the chunk-local kernel runs: its events are taken at pass_timing 2 only)",
         }

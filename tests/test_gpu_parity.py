@@ -180,9 +180,9 @@ SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixtu
 
 
 @pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3),
-                        (2, 0, False, 4), (2, 0, False, 5), (0, 1, False, 6)],
+                        (2, 0, False, 4), (2, 0, False, 5)],
                 ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen", "algo-sieve-separate-apply", "algo-auto-ranks-from-memory",
-                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1", "algo-auto-pass-by-pass"])
+                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1"])
 def algo(request, eng):
     """Runs a test once per route through the prune: automatic choice (descriptor sieve whose pair kernel applies the verdicts
     tile by tile; passes with short chunks in the chunk-local kernel), register-tiled all-pairs (its passes are applied by
@@ -191,8 +191,7 @@ def algo(request, eng):
     multi-rank pass does), the automatic choice with k_open_rows reading the scan-block prefix from memory (the path of
     ensembles beyond 4 M structures), the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
     what the large passes of C4 / C5 run by default), and the last two again with stage 1 of the pair kernels reading the float32 copy
-    of the coordinates (what runs of 128 MB of heavy atoms and more do by default), and the automatic choice with the first passes of a run
-    one by one (the chunk-local kernel) instead of together in one launch (k_pass_group: what "algo-auto" runs them in)."""
+    of the coordinates (what runs of 128 MB of heavy atoms and more do by default)."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
@@ -200,8 +199,6 @@ def algo(request, eng):
     eng.set_option("fused_apply", 1 if request.param[3] else 0)
     if request.param[3] == 2:
         eng.set_option("open_lds_blocks", 0)
-    if request.param[3] == 6:
-        eng.set_option("pass_group", 0)
     if request.param[3] in (3, 5):      # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
         eng.set_option("cull_min_pairs", 0)
         eng.set_option("cull", 2)
@@ -216,7 +213,6 @@ def algo(request, eng):
     eng.set_option("sieve_trim", SIEVE_TRIM_DEFAULT)
     eng.set_option("fused_apply", 1)
     eng.set_option("open_lds_blocks", 2 ** 30)
-    eng.set_option("pass_group", 1)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -237,7 +233,7 @@ def test_prune_c2_vs_oracle(eng, oracle, mode, algo):
         assert s["pairs_evaluated"] == r["pairs_evaluated"]      # the reference's sequential work, reproduced exactly
         assert s["new_keys"] == r["new_keys"]
         assert max(s["pairs_computed"], s["pairs_screened"]) >= s["pairs_evaluated"]   # the GPU looks at a superset
-        assert s["algo"] in (1, 2, 3, 4) and (algo == 0 or s["algo"] == algo)   # 3 = chunk-local kernel, 4 = the first passes in one launch (automatic choice only)
+        assert s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo)      # 3 = chunk-local kernel (automatic choice only)
     print(f"C2 mode {mode}: {len(heavy)} -> {mask.sum()}; margins rmsd {mr:.2e} maxdev {mm:.2e}")
 
 

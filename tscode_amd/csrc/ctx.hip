@@ -239,16 +239,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->early_basis = int(value);
         return 0;
     }
-    if (strcmp(name, "pass_group") == 0) {
-        TSC_REQUIRE(value == 0.0 || value == 1.0, "pass_group must be 0 or 1");
-        c->pass_group = int(value);
-        return 0;
-    }
-    if (strcmp(name, "group_max_chunk") == 0) {
-        TSC_REQUIRE(value >= 1 && value <= LPG_ROWS, "group_max_chunk must be in [1, %d]", LPG_ROWS);
-        c->group_max_chunk = int(value);
-        return 0;
-    }
     if (strcmp(name, "local_max_chunk") == 0) {
         TSC_REQUIRE(value >= 16 && value <= LP_MAX_ROWS, "local_max_chunk must be in [16, %d]", LP_MAX_ROWS);
         c->local_max_chunk = int(value);

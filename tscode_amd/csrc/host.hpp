@@ -16,8 +16,7 @@ using namespace tsc;
 constexpr int TILE_ROWS = 16;
 constexpr int MAX_HP = 32;  // register-tiled kernel only; the sieve kernel takes any h
 
-enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2, ALGO_LOCAL = 3 /* reported only: a pass run by the chunk-local kernel */,
-       ALGO_GROUP = 4 /* reported only: one of the first passes of a run, run together in one launch (group_pass.hpp) */ };
+enum { ALGO_AUTO = 0, ALGO_TILE = 1, ALGO_SIEVE = 2, ALGO_LOCAL = 3 /* reported only: a pass run by the chunk-local kernel */ };
 
 static inline int make_frag_table(const int64_t *frag_off, const int32_t *n_atoms, const int32_t *n_conf, int n_mols, FragTable *ft) {
     TSC_REQUIRE(frag_off && n_atoms && n_conf, "null fragment table");

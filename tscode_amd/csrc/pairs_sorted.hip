@@ -1,5 +1,5 @@
-// pairs_sorted.hip -- the pair kernel of the culled passes, k_rmsd_sieve_sorted<F32> (cull.hpp), the one-launch pass of short chunks,
-// k_pass_chunks (local_pass.hpp), and the first passes of a run in one launch, k_pass_group (group_pass.hpp).  gfx950 only.
+// pairs_sorted.hip -- the pair kernel of the culled passes, k_rmsd_sieve_sorted<F32> (cull.hpp), and the one-launch pass of short chunks,
+// k_pass_chunks (local_pass.hpp).  gfx950 only.
 #include "prune_host.hpp"
 
 int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
@@ -16,19 +16,6 @@ int launch_pass_chunks(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_
                        const CacheViews &cv, PassCounters *counters, int32_t *bsum, int block_items, const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets) {
     hipExtLaunchKernelGGL(k_pass_chunks, dim3(blocks), dim3(LP_THREADS), 0, st, e0, e1, 0, g, a, state, mask, bits, bit_words, view, heavy, Gall, Dall, cv, counters,
                           bsum, block_items, sc, sa, tickets);
-    TSC_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_pass_group(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_t e1, const GroupArgs &a, PruneState *state, uint8_t *mask, unsigned long long *bits,
-                      int bit_words, const double *heavy, const double *Gall, const float *Dall, const CacheViews &cv, int32_t *bsum, int block_items,
-                      const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets, int cap) {
-    // cap: structures of the largest region of this launch (<= LPG_ROWS): the descriptors staged in LDS, 64 B each, beside the static arrays
-    const size_t lds = size_t(cap) * DW * sizeof(float);
-    // (per device, and 3 us of host time: set on every launch rather than remembered per process)
-    TSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_group), hipFuncAttributeMaxDynamicSharedMemorySize, int(size_t(LPG_ROWS) * DW * sizeof(float))));
-    hipExtLaunchKernelGGL(k_pass_group, dim3(blocks), dim3(LPG_THREADS), lds, st, e0, e1, 0, a, state, mask, bits, bit_words, heavy, Gall, Dall, cv, bsum, block_items, sc, sa,
-                          tickets, cap);
     TSC_HIP(hipGetLastError());
     return 0;
 }

@@ -439,7 +439,6 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                            p->n_blocks, int(s_lo), int(s_hi));
     p->last_slot = slot;
     p->slot_used[slot] = true;
-    p->any_pass = true;
     const int use_cache = (p->mode == 0);
     // the last chunk takes the remainder (:141-142); of this rank's chunks, in a partitioned pass
     const int64_t longest_chunk = c_hi == k ? n - (k - 1) * g.cs : g.cs;
@@ -954,11 +953,8 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
             s.pairs_screened = rec[slot].screened, s.new_keys = rec[slot].removed, s.algo = rec[slot].algo;
             s.nonfinite_input = nonfinite ? 1 : 0;
             float ms = 0;
-            // (the passes k_pass_group ran together have ONE set of events, on the first of them)
-            if (c->pass_timing >= 2 && p->ev[slot][0] && p->ev[slot][3] && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
-            if (c->pass_timing >= ((rec[slot].algo == ALGO_LOCAL || rec[slot].algo == ALGO_GROUP) ? 2 : 1) && p->ev[slot][1] && p->ev[slot][2] &&
-                hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess)
-                s.tile_ms = ms;
+            if (c->pass_timing >= 2 && hipEventElapsedTime(&ms, p->ev[slot][0], p->ev[slot][3]) == hipSuccess) s.gpu_ms = ms;
+            if (c->pass_timing >= (rec[slot].algo == ALGO_LOCAL ? 2 : 1) && hipEventElapsedTime(&ms, p->ev[slot][1], p->ev[slot][2]) == hipSuccess) s.tile_ms = ms;
         }
         p->collected = true;
     }
@@ -968,129 +964,44 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_stats(tsc_prune 
     TSC_API_GUARD_END
 }
 
-// The first passes of a run, while their chunks are short, in ONE launch (group_pass.hpp): *taken = how many (0: none, the caller goes pass by pass).
-// Only for a whole run on one device (prune_run): the gates of the second and later passes of the group are taken as open and checked by the
-// caller from the records.
-static int launch_first_passes(tsc_prune *p, int *taken) {
-    *taken = 0;
-    tsc_ctx *c = p->ctx;
-    const int64_t n = p->n;
-    if (!(c->pass_group && c->local_pass && p->algo == ALGO_SIEVE && !p->group_off && !p->any_pass && p->cur_k == 0 && p->part_world == 1 && n < (int64_t(1) << 30)))
-        return 0;
-    GroupArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n = int(n);
-    int G = 0, ks_end = p->next_ks, cap = 0;
-    for (int s = p->next_ks; s < TSC_MAX_PASSES && G < LPG_MAX; ++s) {
-        const int64_t k = int64_t(KS[s]);
-        if (!(k == 1 || 20 * k < n)) continue;  // never enqueued (tsc_prune_next_pass)
-        const int64_t cs = n / k;
-        if (cs > c->group_max_chunk) break;
-        a.k[G] = int(k), a.cs[G] = int(cs), a.slot[G] = s, a.G = G + 1;
-        int widest = 0;  // every workgroup's region (own chunk + halos) must fit its LDS arrays
-        for (int ch = 0; ch < int(k) && widest <= LPG_ROWS; ++ch) {
-            int lo, hi;
-            group_region(a, ch, 0, lo, hi);
-            widest = std::max(widest, hi - lo);
-        }
-        if (widest > LPG_ROWS) break;
-        ++G, ks_end = s + 1, cap = widest;
-    }
-    a.G = G;
-    if (G < 2) return 0;
-    DeviceGuard guard(c->device);
-    hipStream_t st = c->stream;
-    const int first_slot = a.slot[0], last_slot = a.slot[G - 1];
-    for (int i = 0; i < 4; ++i)
-        if (!p->ev[first_slot][i]) TSC_TRY(get_event(c, &p->ev[first_slot][i]));
-    if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[first_slot][0], st));
-    if (p->opened_slot != first_slot) {  // (k_init_run opens the first pass of a run: not taken in practice)
-        StepArgs so{p->last_slot, first_slot, (long long)a.k[0], p->algo, -1};
-        hipLaunchKernelGGL(k_pass_step, dim3(1), dim3(64), 0, st, step_ctx(p), so);
-    }
-    p->next_ks = ks_end;
-    p->cur_slot = last_slot, p->cur_k = a.k[G - 1];  // (what later_views and next_step_args look at)
-    p->cur_local = false, p->cur_fused = false, p->cur_range = false;
-    a.h = p->h, a.use_cache = p->mode == 0 ? 1 : 0, a.algo_tag = ALGO_GROUP;
-    a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
-    a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
-    a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;
-    a.desc_limit = double(p->h) * p->thr * p->thr;
-    a.dmax_bits = p->dmax_bits;
-    a.gstat = p->tickets->gstat;
-    int nxt = -1;
-    const StepArgs sa = next_step_args(p, &nxt);
-    hipEvent_t e0 = c->pass_timing >= 2 ? p->ev[first_slot][1] : nullptr, e1 = c->pass_timing >= 2 ? p->ev[first_slot][2] : nullptr;
-    TSC_TRY(launch_pass_group(st, unsigned(a.k[G - 1]), e0, e1, a, p->state, p->mask, p->bits, int(p->bit_words), p->heavy, (const double *)p->Gall,
-                              (const float *)p->Dall, later_views(p), p->bsum, SCAN_TILE, step_ctx(p), sa, &p->tickets->local, (cap + 63) & ~63));
-    if (c->pass_timing >= 2) TSC_HIP(hipEventRecord(p->ev[first_slot][3], st));
-    for (int q = 0; q < G; ++q) p->slot_used[a.slot[q]] = true;
-    p->opened_slot = nxt;
-    p->last_slot = -1;  // closed on the device, by the group's last workgroup
-    p->cur_k = 0, p->cur_slot = -1;
-    p->collected = false;
-    p->any_pass = true;
-    p->group_n = G;
-    *taken = G;
-    return 0;
-}
-
 // One whole run on device data; mask_host (optional) also receives the verdicts, copied before the run's single
 // synchronisation (the statistics read-back).
 int prune_run(tsc_ctx *c, const double *heavy, int64_t n, int h, double rmsd_thr, int mode, uint8_t *mask, uint8_t *mask_host,
                      tsc_pass_stats *stats, int *n_passes, const double *basis, const ExternalDescriptors *ext, int force_algo) {
+    tsc_prune *p = nullptr;
     const bool in_place = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;  // run on the caller's buffer: no copy at the end
+    TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis, ext, force_algo));
     int rc = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        tsc_prune *p = nullptr;
-        TSC_TRY(prune_create_impl(c, heavy, n, h, rmsd_thr, mode, in_place ? mask : nullptr, &p, basis, ext, force_algo));
-        p->group_off = attempt > 0;
-        int taken = 0;
-        rc = launch_first_passes(p, &taken);
-        while (!rc) {
-            int64_t k = 0;
-            if ((rc = tsc_prune_next_pass(p, &k)) != 0 || k == 0) break;
-            if ((rc = tsc_prune_pass_local(p, 0, 1)) != 0) break;
-            if ((rc = tsc_prune_pass_finish(p)) != 0) break;
-        }
-        if (!rc) {
-            DeviceGuard guard(c->device);
-            hipError_t e = in_place ? hipSuccess : hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
-            // the verdicts go to the host with the statistics (one launch, k_export_run) when the buffer is pinned host memory the
-            // device can write; any other pointer takes a copy command
-            p->export_mask_host = nullptr;
-            if (e == hipSuccess && mask_host) {
-                hipPointerAttribute_t at;
-                const bool mapped = (reinterpret_cast<uintptr_t>(mask_host) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p->mask) & 7u) == 0 &&
-                                    hipPointerGetAttributes(&at, mask_host) == hipSuccess && at.type == hipMemoryTypeHost;
-                // the address the DEVICE sees: for hipHostRegister'ed or non-mapped pinned memory it need not be the host address,
-                // and may not exist at all
-                uint8_t *dev_view = mapped ? static_cast<uint8_t *>(at.devicePointer) : nullptr;
-                if (dev_view && (reinterpret_cast<uintptr_t>(dev_view) & 7u) == 0) {
-                    p->export_mask_host = dev_view;
-                } else {
-                    (void)hipGetLastError();
-                    e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
-                }
-            }
-            if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
-        }
-        if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
-        // the gates inside the group (rmsd_pruning.py:192) were taken as open: the records say whether they were.  A closed one means the
-        // reference would have skipped that pass -- the run is repeated pass by pass (never seen: the first passes of a run would have to
-        // remove more than half of the ensemble)
-        bool gate_closed = false;
-        if (!rc && taken > 0) {
-            int seen = 0;
-            for (int i = 0; i < p->n_passes; ++i) {
-                const tsc_pass_stats &s = p->stats[i];
-                if (s.algo != ALGO_GROUP) continue;
-                if (seen++ > 0 && !(s.k == 1 || 20 * s.k < s.n_active_before)) gate_closed = true;
-            }
-        }
-        tsc_prune_destroy(p);
-        if (rc || !gate_closed) break;
+    for (;;) {
+        int64_t k = 0;
+        if ((rc = tsc_prune_next_pass(p, &k)) != 0 || k == 0) break;
+        if ((rc = tsc_prune_pass_local(p, 0, 1)) != 0) break;
+        if ((rc = tsc_prune_pass_finish(p)) != 0) break;
     }
+    if (!rc) {
+        DeviceGuard guard(c->device);
+        hipError_t e = in_place ? hipSuccess : hipMemcpyAsync(mask, p->mask, size_t(n), hipMemcpyDeviceToDevice, c->stream);
+        // the verdicts go to the host with the statistics (one launch, k_export_run) when the buffer is pinned host memory the
+        // device can write; any other pointer takes a copy command
+        p->export_mask_host = nullptr;
+        if (e == hipSuccess && mask_host) {
+            hipPointerAttribute_t at;
+            const bool mapped = (reinterpret_cast<uintptr_t>(mask_host) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p->mask) & 7u) == 0 &&
+                                hipPointerGetAttributes(&at, mask_host) == hipSuccess && at.type == hipMemoryTypeHost;
+            // the address the DEVICE sees: for hipHostRegister'ed or non-mapped pinned memory it need not be the host address,
+            // and may not exist at all
+            uint8_t *dev_view = mapped ? static_cast<uint8_t *>(at.devicePointer) : nullptr;
+            if (dev_view && (reinterpret_cast<uintptr_t>(dev_view) & 7u) == 0) {
+                p->export_mask_host = dev_view;
+            } else {
+                (void)hipGetLastError();
+                e = hipMemcpyAsync(mask_host, p->mask, size_t(n), hipMemcpyDeviceToHost, c->stream);
+            }
+        }
+        if (e != hipSuccess) rc = fail(TSC_ERR_HIP, "mask copy failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = tsc_prune_stats(p, stats, n_passes);
+    tsc_prune_destroy(p);
     return rc;
 }
 

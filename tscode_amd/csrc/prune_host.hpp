@@ -6,7 +6,6 @@
 #include "rmsd.hpp"
 #include "scan.hpp"
 #include "local_pass.hpp"
-#include "group_pass.hpp"
 #include "cull.hpp"
 
 // --------------------------------------------------------------------------------------------------
@@ -48,8 +47,7 @@ struct tsc_prune {
     struct Tickets {
         PassTickets pass;
         LocalTickets local;
-        unsigned long long gstat[LPG_MAX * 8 + 8];  // per-pass statistics of the passes k_pass_group runs together (group_pass.hpp); zero between uses
-    } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernels
+    } *tickets = nullptr;  // arrival counters of the fused pair kernel and of the chunk-local pass kernel
     bool cur_local = false;           // the open pass ran (whole) in tsc_prune_pass_local
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
@@ -86,9 +84,6 @@ struct tsc_prune {
                                // its run the same sample holds the same bits -- what row tiles of a SORTED layout dealt among ranks rely on
     bool auto_tile = false;    // ALGO_TILE was this run's own choice (screen_is_useless on its own basis estimate), not the caller's
     int flag_slot = 0;         // this run's word in the context's pinned buffer (the culled-or-walked verdict of a candidate pass)
-    bool group_off = false;    // prune_run repeats a run pass by pass when a gate inside the group turns out to have been closed (group_pass.hpp)
-    int group_n = 0;           // passes the group of this run took (0: none)
-    bool any_pass = false;     // a pass of this run has been enqueued (the group is only ever the first passes)
 };
 
 template <typename T>
@@ -173,10 +168,6 @@ int launch_rmsd_sieve_plain(int cpl, bool trim, bool f32, hipStream_t st, dim3 g
 int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                              const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
                              int my_tiles, int n_seg);
-// k_pass_group (pairs_sorted.hip): the first passes of a run in one launch, one workgroup per chunk of the last of them
-int launch_pass_group(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_t e1, const GroupArgs &a, PruneState *state, uint8_t *mask, unsigned long long *bits,
-                      int bit_words, const double *heavy, const double *Gall, const float *Dall, const CacheViews &cv, int32_t *bsum, int block_items,
-                      const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets, int cap);
 int launch_pass_chunks(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_t e1, const PassGeom &g, const LocalPassArgs &a, PruneState *state, uint8_t *mask,
                        unsigned long long *bits, int bit_words, const unsigned long long *view, const double *heavy, const double *Gall, const float *Dall,
                        const CacheViews &cv, PassCounters *counters, int32_t *bsum, int block_items, const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets);
