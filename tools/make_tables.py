@@ -141,7 +141,7 @@ def scaling():
     d = load(f"{R}_predicted_scaling.json")
     if not d:
         return f"(profiles/{R}_predicted_scaling.json missing)"
-    rows = ["| config | ranks | front: shard / replicate / hybrid (compute + modelled exchange, ring) | prune: setup + partitioned (local / close) + row tiles (local / close) + small | per-pass collectives ring - all links | step (best front) ring - all links | speed-up vs one rank |",
+    rows = ["| config | ranks | front: shard / replicate / hybrid (compute + modelled exchange, ring) | prune: setup (a run that builds its descriptors; `hybrid` leaves them beside the heavy atoms) + partitioned (local / close) + row tiles (local / close) + small | per-pass collectives ring - all links | step (best front) ring - all links | speed-up vs one rank |",
             "|---|---|---|---|---|---|---|"]
     for cfg, rws in d["configs"].items():
         for r in rws:
@@ -151,9 +151,13 @@ def scaling():
             g = lambda k, w: bk.get(k, {}).get(w, 0.0)
             best = min(fr.values(), key=lambda v: v["predicted_ms_per_step"])
             best_al = min(fr.values(), key=lambda v: v["predicted_ms_per_step_all_links"])
-            rows.append(f"| {cfg} | {r['n_ranks']} | {fs} | {r['setup_ms']:.2f} + ({g('partitioned', 'local_ms'):.2f} / {g('partitioned', 'close_ms'):.2f}) + "
+            sb = r.get("setup_borrowed_ms")
+            setup = f"{r['setup_ms']:.2f}" + (f" (hybrid: {sb:.2f})" if (sb is not None and r["n_ranks"] > 1) else "")
+            names = {id(v): k for k, v in fr.items()}
+            rows.append(f"| {cfg} | {r['n_ranks']} | {fs} | {setup} + ({g('partitioned', 'local_ms'):.2f} / {g('partitioned', 'close_ms'):.2f}) + "
                         f"({g('row_tiles', 'local_ms'):.2f} / {g('row_tiles', 'close_ms'):.2f}) + {g('replicated', 'local_ms'):.2f} | {r['pass_comm_ms_ring']:.2f} - {r['pass_comm_ms_all_links']:.2f} | "
-                        f"**{best['predicted_ms_per_step']:.2f}** - {best_al['predicted_ms_per_step_all_links']:.2f} | {best['speedup_vs_1_rank_protocol']:.2f} - {best_al['speedup_vs_1_rank_protocol_all_links']:.2f} x |")
+                        f"**{best['predicted_ms_per_step']:.2f}** ({names[id(best)]}) - {best_al['predicted_ms_per_step_all_links']:.2f} ({names[id(best_al)]}) | "
+                        f"{best['speedup_vs_1_rank_protocol']:.2f} - {best_al['speedup_vs_1_rank_protocol_all_links']:.2f} x |")
     return "\n".join(rows) + (f"\n\n(ms per step; from `profiles/{R}_predicted_scaling.json`, `tools/predict_scaling.py`: every rank's library calls timed on ONE GPU, collectives modelled: "
                               f"{d['model']['xgmi_link_GBs']} GB/s per link x {d['model']['link_efficiency']}, {d['model']['collective_fixed_us']} us fixed per collective)")
 

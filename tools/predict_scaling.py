@@ -85,7 +85,7 @@ def measure_front(ens, n_ranks, reps):
     return front, counts, clash_only
 
 
-def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
+def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None, setup_borrowed_ms=None):
     ens = make_config(cfg)
     front, counts, clash_only = measure_front(ens, n_ranks, reps)
     # the prune over the whole survivor list: one backend holding everything (world 1 = the whole pose axis)
@@ -112,6 +112,16 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
             be.clash_block_into_all()
             ts.append(tm(be.embed_masked_all)[0])
         embed_all_ms = min(ts)
+        # ... and the prune run that follows it BORROWS the descriptors and the float32 copy that embed_masked_all wrote beside the heavy atoms
+        # (tsc_prune_create on the same array): its set-up, not the one measured below on runs that build their own from heavy_all
+        tb = []
+        for _ in range(reps + 1):          # (the first creation also pays the run's allocations, which later ones take from the context's cache)
+            be.clash_block_into_all()      # (forks the basis that embed_masked_all's descriptors are written in: the order of _front_hybrid)
+            n_all = int(be.embed_masked_all())
+            t_b, st_b = tm(lambda: be.eng.prune_stepper(be.heavy_all, n_all, be.h, 0.5, 0))
+            st_b.close()
+            tb.append(t_b)
+        setup_borrowed_ms = min(tb)
         n_pass = int(be.embed_clash_block())
         with torch.cuda.stream(be.stream):
             be.heavy_all[:n_pass].copy_(be.heavy_local[:n_pass])
@@ -216,12 +226,19 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
     fronts["replicate"] = {"compute_ms": fa, "comm_ms": [0.0, 0.0]}
     # hybrid: this rank's clash verdicts, the mask summed over the ranks (one byte per pose), every survivor embedded on every rank
     if embed_all_ms is not None:
+        # (the set-up of the prune run behind it is the borrowing one: the descriptors and the float32 copy are in embed_all_ms already)
         fronts["hybrid"] = {"compute_ms": max(clash_only) + embed_all_ms,
+                            "setup_ms": setup_borrowed_ms if (n_ranks > 1 and setup_borrowed_ms is not None) else best["setup_ms"],
                             "comm_ms": [allreduce_ms(ens.n_poses, n_ranks, al) for al in (False, True)] if n_ranks > 1 else [0.0, 0.0]}
     out_fronts = {}
     for name, f in fronts.items():
-        ring, fast = f["compute_ms"] + f["comm_ms"][0] + prune_ms + pass_comm(False), f["compute_ms"] + f["comm_ms"][1] + prune_ms + pass_comm(True)
+        # the prune's set-up depends on the front: `shard` and `replicate` leave heavy atoms only (the run builds descriptors and the float32 copy
+        # from them: the set-up measured on the emulated ranks), `hybrid` leaves both beside the heavy atoms (the run borrows them)
+        setup_f = f.get("setup_ms", best["setup_ms"])
+        body = prune_ms - best["setup_ms"] + setup_f
+        ring, fast = f["compute_ms"] + f["comm_ms"][0] + body + pass_comm(False), f["compute_ms"] + f["comm_ms"][1] + body + pass_comm(True)
         out_fronts[name] = {"front_compute_ms": f["compute_ms"], "front_comm_ms_ring": f["comm_ms"][0], "front_comm_ms_all_links": f["comm_ms"][1],
+                            "prune_setup_ms": setup_f,
                             "predicted_ms_per_step": ring, "predicted_ms_per_step_all_links": fast}
     by_kind = {}
     for p in best["passes"]:
@@ -232,11 +249,11 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None):
         d["comm_ms_ring"] += allreduce_ms(p["bytes"], n_ranks, False) if p["bytes"] else 0.0
         d["comm_ms_all_links"] += allreduce_ms(p["bytes"], n_ranks, True) if p["bytes"] else 0.0
     return {"n_ranks": n_ranks, "partition_min_chunks": chunks, "fronts": out_fronts, "front_ms_per_rank": front, "clash_only_ms_per_rank": clash_only,
-            "embed_all_survivors_ms": embed_all_ms, "setup_ms": best["setup_ms"], "tail_ms": best["tail_ms"], "prune_compute_ms": prune_ms,
+            "embed_all_survivors_ms": embed_all_ms, "setup_ms": best["setup_ms"], "setup_borrowed_ms": setup_borrowed_ms, "tail_ms": best["tail_ms"], "prune_compute_ms": prune_ms,
             "pass_comm_ms_ring": pass_comm(False), "pass_comm_ms_all_links": pass_comm(True), "by_kind": by_kind,
             "passes": [{"k": p["k"], "kind": p["kind"], "max_local_ms": max(p["local_ms_per_rank"]), "sum_local_ms": sum(p["local_ms_per_rank"]),
                         "close_ms": p["close_ms"], "bytes": p["bytes"]} for p in best["passes"]],
-            "allgather_bytes": gather_bytes, "pass_counts_per_rank": counts, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}, embed_all_ms
+            "allgather_bytes": gather_bytes, "pass_counts_per_rank": counts, "n_pass_clash": n_pass, "n_survivors": best["n_keep"]}, embed_all_ms, setup_borrowed_ms
 
 
 OPTIONS = []
@@ -269,10 +286,10 @@ def main():
            "measured_on": torch.cuda.get_device_name(0), "configs": {}}
     for cfg in cfgs:
         rows = []
-        front_all = embed_all = None
+        front_all = embed_all = setup_b = None
         for n in ranks:
             t0 = time.time()
-            row, embed_all = measure(cfg, n, chunks, front_all_ms=front_all, embed_all_ms=embed_all)
+            row, embed_all, setup_b = measure(cfg, n, chunks, front_all_ms=front_all, embed_all_ms=embed_all, setup_borrowed_ms=setup_b)
             rows.append(row)
             if n == ranks[0]:
                 front_all = max(rows[0]["front_ms_per_rank"])          # one rank's front half IS the whole pose list
