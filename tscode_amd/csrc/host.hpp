@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "common.hpp"
 #include "embed_clash.hpp"
@@ -83,6 +84,7 @@ static inline size_t basis_spread_offset(int h) { return size_t(KD) * (n_feature
 constexpr size_t PINNED_SPREAD_OFFSET = 8192;  // where a basis' two spread values land in the context's pinned buffer
 constexpr size_t PINNED_FLAG_OFFSET = PINNED_SPREAD_OFFSET + 128;  // ... and the culled-or-walked verdicts of the context's runs, one 64-byte line each
 constexpr int PINNED_FLAG_SLOTS = 64;
+constexpr size_t PINNED_COUNT_OFFSET = PINNED_FLAG_OFFSET + 64 * size_t(PINNED_FLAG_SLOTS);  // ... and the pipeline's count of passing poses (scan.hpp: total_host)
 constexpr int64_t AUTO_TILE_MIN_N = 30000;     // a prune of its own (no pipeline around it) spends a synchronisation on the question from here on
 
 // "Would the screen let (almost) every pair through?"  Two structures of the sample lie 2 sum_k lambda_k apart, on average, in a

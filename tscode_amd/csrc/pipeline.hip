@@ -348,11 +348,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     if (timed) TSC_HIP(hipEventRecord(ev[1], st));
     if (d_basis && c->clash_first) TSC_TRY(enqueue_basis_chain());
     // ordered compaction: embed only the passing poses, all atoms + heavy atoms
-    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total));
+    // (the count goes to the host through pinned memory the scan kernel writes itself: an event record + a copy on a second stream in front
+    // of the next launch cost the stream two packets, about 6 us each)
+    volatile int32_t *count_host = reinterpret_cast<volatile int32_t *>(static_cast<char *>(c->pinned) + PINNED_COUNT_OFFSET);
+    *count_host = -1;
+    TSC_TRY(scan_mask(st, clash_mask, n_poses, bsum, nullptr, act, nullptr, total, nullptr, false, const_cast<int32_t *>(count_host)));
     // the passing poses are embedded (all atoms + heavy atoms) by a launch sized for every pose that reads the count on the
     // device: it runs while the host fetches the count it needs to set up the prune (the schedule depends on it)
     TSC_TRY(s.get(size_t(n_poses) * n_heavy * 3, &d_heavy));
-    TSC_TRY(read_i32_begin(c, total));
     if (ext.D) {
         const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
         TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));  // the basis (and the cleared maximum) from the side stream
@@ -364,8 +367,17 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
                            (const int32_t *)act, int64_t(0), structures, (const int32_t *)d_slot, n_heavy, d_heavy, (const int32_t *)total);
     }
     TSC_HIP(hipGetLastError());
-    int32_t n_pass = 0;
-    TSC_TRY(read_i32_finish(c, &n_pass));
+    int32_t n_pass = -1;
+    {   // the host looks until the scan kernel has written (a device that never does -- a fault -- is left to the copy path's error after 5 s)
+        const auto t_look = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; (n_pass = *count_host) < 0; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xffffu) == 0xffffu && std::chrono::steady_clock::now() - t_look > std::chrono::seconds(5)) {
+                TSC_TRY(read_i32(c, total, &n_pass));
+                break;
+            }
+        }
+    }
     if (n_pass_host) *n_pass_host = n_pass;
     int64_t n_keep = 0;
     int np = 0;

@@ -47,7 +47,7 @@ inline __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const u
 // (the work of one block; s_w, s_o: SCAN_THREADS / WAVE ints of LDS each)
 __device__ inline void scan_write_block(const uint8_t *__restrict__ mask, int64_t n, const int32_t *__restrict__ bsum,
                                         int32_t *__restrict__ pos, int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
-                                        int32_t *__restrict__ total_out, int *s_w, int *s_o) {
+                                        int32_t *__restrict__ total_out, int *s_w, int *s_o, volatile int32_t *total_host = nullptr) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // exclusive offset of this block = sum of the counts of the blocks before it (a few hundred values at most)
     int part = 0;
@@ -84,17 +84,22 @@ __device__ inline void scan_write_block(const uint8_t *__restrict__ mask, int64_
     if (base <= n && n < base + SCAN_ITEMS) {  // the thread owning the tail knows the total
         if (pos) pos[n] = run;
         if (total_out) *total_out = run;
+        if (total_host) {  // (pinned host memory the host is looking at: no copy command, no event in the stream)
+            *total_host = run;
+            __threadfence_system();
+        }
     }
 }
 
 inline __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_t *__restrict__ mask, int64_t n,
                                                               const int32_t *__restrict__ bsum, int32_t *__restrict__ pos,
                                                               int32_t *__restrict__ act_idx, uint8_t *__restrict__ mbit_bytes,
-                                                              int32_t *__restrict__ total_out, const int *__restrict__ gate) {
+                                                              int32_t *__restrict__ total_out, const int *__restrict__ gate,
+                                                              int32_t *total_host = nullptr) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
     __shared__ int s_o[SCAN_THREADS / WAVE];
     if (gate && *gate == 0) return;
-    scan_write_block(mask, n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o);
+    scan_write_block(mask, n, bsum, pos, act_idx, mbit_bytes, total_out, s_w, s_o, total_host);
 }
 
 // Enqueue the two passes.  bsum must hold ceil(n / SCAN_TILE) + 1 ints.  pos may be null (then only
@@ -104,10 +109,10 @@ inline __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(const uint8_
 inline int scan_grid_blocks(int64_t n) { return int(ceil_div<int64_t>(n + 1, SCAN_TILE)); }
 
 inline int scan_mask(hipStream_t st, const uint8_t *mask, int64_t n, int32_t *bsum, int32_t *pos, int32_t *act_idx,
-                     uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr, bool bsum_current = false) {
+                     uint8_t *mbit_bytes, int32_t *total_dev, const int *gate = nullptr, bool bsum_current = false, int32_t *total_host = nullptr) {
     int nb = int(ceil_div<int64_t>(n + 1, SCAN_TILE));  // n + 1: some thread always owns index n (writes pos[n])
     if (!bsum_current) hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, bsum, gate);
-    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, (const int32_t *)bsum, pos, act_idx, mbit_bytes, total_dev, gate);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, st, mask, n, (const int32_t *)bsum, pos, act_idx, mbit_bytes, total_dev, gate, total_host);
     TSC_HIP(hipGetLastError());
     return 0;
 }
