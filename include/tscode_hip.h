@@ -374,6 +374,10 @@ int tsc_prune_rmsd_dev(tsc_ctx *ctx, const double *heavy, int64_t n, int h, doub
  *                            <all-reduce MIN over tsc_prune_best_ptr, n_active int32 entries>   (RCCL)
  *                            tsc_prune_pass_finish; }                 // identical mask/cache update on every rank
  *   tsc_prune_mask_dev gives the device mask; tsc_prune_destroy frees the state. */
+/* A context serves at most 64 live runs at a time (each owns a word of the context's pinned memory; the 65th tsc_prune_create fails with
+ * TSC_ERR_STATE).  tsc_prune_create / tsc_prune_destroy take the context's scratch cache: calls of them on ONE context must not overlap
+ * (a context is for one thread at a time, see above); runs that exist may then be stepped from different threads.  Runs still alive
+ * when their context is destroyed are destroyed with it -- do not hand them to tsc_prune_destroy afterwards. */
 int tsc_prune_create(tsc_ctx *ctx, const double *heavy_dev, int64_t n, int h, double rmsd_thr, int mode, tsc_prune **out);
 int tsc_prune_next_pass(tsc_prune *p, int64_t *k_out);            /* 0 when the schedule is exhausted; does not wait:
                                                                       the gate of rmsd_pruning.py:192 is evaluated on the
@@ -459,6 +463,32 @@ typedef struct tsc_exchange_record {
 } tsc_exchange_record;
 int tsc_prune_run_sharded(tsc_prune *run, int rank, int world_size, int min_chunks_per_rank, int64_t min_pairs, void *exch_dev, int64_t exch_words,
                           tsc_exchange_fn exchange, void *user, tsc_exchange_record *log, int log_cap, int *n_log);
+/* ---- the exchange inside the library (optional): a one-shot all-reduce over memory the ranks map into each other ----
+ * For the small per-pass messages above a collective library's fixed cost (and, from a scripting host, a frame of the host language per
+ * collective) is most of what an exchange costs.  A tsc_xchg gives every rank a receive area of FINE-GRAINED device memory that the other
+ * ranks of the node map (hipIpcGetMemHandle / hipIpcOpenMemHandle): an exchange is then one kernel that writes this rank's contribution
+ * into every peer and raises a flag there, and one that waits for the peers' flags and folds what they delivered into the caller's buffer
+ * -- enqueued on the context's stream, no host in between.  The library still opens no communicator: the HOST carries the 64-byte
+ * handles from rank to rank, once, over whatever it has (in this repository torch.distributed.all_gather_object).
+ *   tsc_xchg_slot_bytes   bytes a slot must hold for runs over up to n structures (the largest message of tsc_prune_run_sharded)
+ *   tsc_xchg_create       allocates the area (header + 2 x world slots of slot_bytes) and returns its IPC handle (TSC_XCHG_HANDLE_BYTES bytes)
+ *   tsc_xchg_connect      handles = world x TSC_XCHG_HANDLE_BYTES bytes, in rank order (the own entry is ignored): maps the peers.  Call it on
+ *                         every rank after all have created; ranks may share a device (other PROCESSES; tests do)
+ *   tsc_xchg_allreduce    has the signature of tsc_exchange_fn with user = the tsc_xchg: pass it to tsc_prune_run_sharded as the exchange
+ *                         function, or call it directly (buf 8-byte aligned; count elements of int64 / int32 as `kind` says)
+ *   tsc_xchg_status       exchanges made so far and how many of them gave up waiting for a peer (tsc_xchg_set_timeout, default 5 s: a
+ *                         rank that died must not hang the others' GPUs); after a timeout the reduced buffers are NOT valid -- check after
+ *                         the run's synchronisation.  Every rank must make the same sequence of exchanges (tsc_prune_run_sharded does).
+ * What these messages are: tscode/rmsd_pruning.py:149-157 (disjoint out_mask[first:last] per chunk), :92,101-113 (rows independent). */
+typedef struct tsc_xchg tsc_xchg;
+#define TSC_XCHG_HANDLE_BYTES 64
+int tsc_xchg_slot_bytes(int64_t n, int mode, int64_t *bytes);
+int tsc_xchg_create(tsc_ctx *ctx, int rank, int world_size, int64_t slot_bytes, tsc_xchg **out, void *handle_out);
+int tsc_xchg_connect(tsc_xchg *x, const void *handles);
+int tsc_xchg_set_timeout(tsc_xchg *x, double seconds);
+int tsc_xchg_allreduce(void *xchg, int kind, void *buf_dev, int64_t count);
+int tsc_xchg_status(tsc_xchg *x, int64_t *n_exchanges, int *n_timeouts);
+int tsc_xchg_destroy(tsc_xchg *x);
 int tsc_prune_mask_dev(tsc_prune *p, const uint8_t **mask_dev);
 int tsc_prune_copy_mask_dev(tsc_prune *p, uint8_t *dst_dev); /* dst[0..n) <- mask, asynchronous on the stream */
 int tsc_prune_stats(tsc_prune *p, tsc_pass_stats *stats, int *n_passes); /* synchronises */

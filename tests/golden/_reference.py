@@ -109,7 +109,46 @@ def install_standins(full=False):
         typed = types.ModuleType("numba.typed")
 
         class List(list):
-            pass
+            """numba.typed.List as a plain list.  Membership (`key in cache`, rmsd_pruning.py:65) is answered from a set kept
+            beside the items -- the same answers as the list scan, without its O(len) cost, which is what lets the reference's
+            own code run ensembles of 40 000 - 105 000 structures here (G16 / G17).  A List of Lists (unhashable items,
+            rmsd_pruning.py:128) falls back to the scan."""
+
+            def __init__(self, it=()):
+                super().__init__(it)
+                try:
+                    self._set = set(self)
+                except TypeError:
+                    self._set = None
+
+            def append(self, x):
+                super().append(x)
+                if self._set is not None:
+                    try:
+                        self._set.add(x)
+                    except TypeError:
+                        self._set = None
+
+            def extend(self, it):
+                it = list(it)
+                super().extend(it)
+                if self._set is not None:
+                    try:
+                        self._set.update(it)
+                    except TypeError:
+                        self._set = None
+
+            def __contains__(self, x):
+                if self._set is not None:
+                    try:
+                        return x in self._set
+                    except TypeError:
+                        pass
+                return super().__contains__(x)
+
+            def __setitem__(self, i, v):           # computed_pairs[chunk] = ...: item assignment invalidates the set
+                super().__setitem__(i, v)
+                self._set = None
 
         typed.List = List
         nb.typed = typed

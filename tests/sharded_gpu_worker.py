@@ -66,6 +66,25 @@ def main():
         loops_agree = bool(d3 == digest and [s["pairs_evaluated"] for s in r3["stats"]] == evals and r3["exchanges"] == res["exchanges"]
                            and r3["partitioned"] == res["partitioned"])
         be.python_pass_loop = False
+    # the per-pass exchanges INSIDE the library (tsc_xchg_*: every rank's receive area mapped into the others with hipIpcGetMemHandle /
+    # hipIpcOpenMemHandle -- here the ranks are processes sharing one card, which exercises the whole mechanism) against the callback form
+    # (torch.distributed collectives) that every step above used: same survivors, evaluation counts and sequence of exchanges, with the
+    # pass loop inside the library and driven from the host
+    ipc_agrees, ipc_status = None, None
+    if be is not None and world > 1:
+        be.connect_exchange(dist, None)
+        ok = True
+        for host_loop in (False, True):
+            be.python_pass_loop = host_loop
+            r4 = pipe.step()
+            torch.cuda.synchronize()
+            d4 = hashlib.sha256(np.packbits(pipe.h_keep[:r4["n_pass"]].numpy().astype(bool)).tobytes()).hexdigest()[:16]
+            ok = ok and bool(r4["exchange"] == "ipc" and d4 == digest and [s["pairs_evaluated"] for s in r4["stats"]] == evals
+                             and r4["exchanges"] == res["exchanges"] and r4["partitioned"] == res["partitioned"])
+        be.python_pass_loop = False
+        ipc_status = list(be.xchg.status())
+        ipc_agrees = bool(ok and ipc_status[1] == 0 and ipc_status[0] > 0 and res["exchange"] == "callback")
+        be.disconnect_exchange()
     flags = torch.tensor([res["n_pass"], res["n_keep"], int(digest[:12], 16)], dtype=torch.int64, device="cuda:0" if backend == "nccl" else "cpu")
     gathered = [torch.zeros_like(flags) for _ in range(world)]
     dist.all_gather(gathered, flags)
@@ -78,7 +97,7 @@ def main():
         print(json.dumps({"world": world, "n_pass": res["n_pass"], "n_keep": res["n_keep"], "n_conformers": res.get("n_conformers"),
                           "keep_sha256_16": digest, "steps_that_differ": unstable,
                           "ranks_agree": all(torch.equal(g, flags) for g in gathered), "counts": res["counts"], "forms_agree": forms_agree,
-                          "loops_agree": loops_agree, "exchanges": res["exchanges"], "partitioned": res["partitioned"],
+                          "loops_agree": loops_agree, "ipc_agrees": ipc_agrees, "ipc_status": ipc_status, "exchanges": res["exchanges"], "partitioned": res["partitioned"],
                           "front_tuning": pipe.front_tuning,
                           "pairs_evaluated": [s["pairs_evaluated"] for s in res["stats"]], "global_path_passes": sharded_passes}), flush=True)
     dist.barrier()

@@ -252,3 +252,26 @@ def test_dropins_read_from_duck_types_what_they_read_from_the_reference_objects(
             assert set(got[dropin][kind]) == set(want[dropin][kind]), (dropin, kind, sorted(got[dropin][kind]), sorted(want[dropin][kind]))
             for name, held in want[dropin][kind].items():
                 assert same(got[dropin][kind][name], held), (dropin, kind, name, got[dropin][kind][name], held)
+
+
+def test_rotate_dihedral_single_structure_is_host_side():
+    """The one-structure drop-in of rotate_dihedral (tscode/utils.py:389-414) computes on the host like the other single 3x3 helpers
+    (no library call: the reference's search loops call it per torsion and per 5-degree walk-back step, torsion_module.py:482-489) and
+    matches G15 -- masks, `dihedral[0]` alone, and the rotate / undo trail of torsion_module.py:984-1005."""
+    from tscode_amd.torsion_module import rotate_dihedral
+    g = load_golden("G15_rotate_dihedral_fractional")
+    coords, dih, mask = g["coords"], g["dihedral"], g["mask"].astype(bool)
+    for a, rm, rf in zip(g["angles"], g["out_mask"], g["out_first"]):
+        c = coords.copy()
+        assert rotate_dihedral(c, dih, float(a), mask=mask) is c and np.abs(c - rm).max() < 1e-12
+        assert np.abs(rotate_dihedral(coords.copy(), dih, float(a)) - rf).max() < 1e-12
+        moved = list(np.flatnonzero(mask))
+        assert np.abs(rotate_dihedral(coords.copy(), dih, float(a), indices_to_be_moved=moved) - rm).max() < 1e-12
+    seq, q = coords.copy(), 0
+    for a in g["angles"][:4]:
+        for sign in (1.0, -1.0):
+            seq = rotate_dihedral(seq, dih, sign * float(a), mask=mask)
+            assert np.abs(seq - g["trail"][q]).max() < 1e-12
+            q += 1
+    same = coords.copy()
+    assert rotate_dihedral(same, dih, 0.0, mask=mask) is same and np.array_equal(same, coords)

@@ -8,7 +8,7 @@ a regression shows long before the stated bar).
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import LARGE_PRUNE_CASES, load_golden, load_large_prune
 
 pytestmark = pytest.mark.gpu
 
@@ -213,6 +213,60 @@ def algo(request, eng):
     eng.set_option("sieve_trim", SIEVE_TRIM_DEFAULT)
     eng.set_option("fused_apply", 1)
     eng.set_option("open_lds_blocks", 2 ** 30)
+
+
+@pytest.mark.parametrize("name", LARGE_PRUNE_CASES)
+def test_prune_large_golden(eng, algo, name):
+    """G16a / G16b / G17: the reference's own run of prune_conformers_rmsd on 40 023 / 41 999 / 104 999 structures -- the passes
+    k = 5000 (G17), 2000, 1000, 500, 200 of the headline's schedule and their cache-key collisions with the coarse passes
+    (rmsd_pruning.py:65-67, 131-144, 186-204) -- on every route through the prune: final mask, which passes ran, the active
+    count after every pass, cumulative key counts."""
+    import tscode_amd
+    fx = load_large_prune(name)
+    g = fx.g
+    pruned, mask = tscode_amd.prune_conformers_rmsd(fx.structures, fx.atomnos, fx.thr)
+    assert np.array_equal(np.packbits(mask), g["mask_bits"]), (int(mask.sum()), int(np.unpackbits(g["mask_bits"])[:fx.n].sum()))
+    assert np.array_equal(pruned, fx.structures[mask])
+    stats = tscode_amd.last_prune_stats()
+    assert [s["k"] for s in stats] == g["ks"].tolist()
+    assert [s["n_active_after"] for s in stats] == [int(np.unpackbits(b)[:fx.n].sum()) for b in g["pass_mask_bits"]]
+    assert np.cumsum([s["new_keys"] for s in stats]).tolist() == g["pass_nkeys"].tolist()
+    assert all(s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo) for s in stats)
+
+
+@pytest.mark.parametrize("name", LARGE_PRUNE_CASES)
+def test_prune_large_golden_every_pass_mask(eng, name):
+    """The same runs pass by pass (the stepping API): the mask after EVERY pass against the mask the reference's own
+    _similarity_mask_rmsd_group returned for it."""
+    import ctypes as C
+
+    from tscode_amd import _lib
+    fx = load_large_prune(name)
+    g = fx.g
+    lib = eng.lib
+    d_heavy = C.c_void_p()
+    _lib.check(lib.tsc_malloc(eng._h, fx.heavy.nbytes, C.byref(d_heavy)))
+    _lib.check(lib.tsc_memcpy_h2d(eng._h, d_heavy, _lib.ptr(fx.heavy), fx.heavy.nbytes))
+    st = eng.prune_stepper(d_heavy.value, fx.n, fx.heavy.shape[1], fx.thr, 0)
+    after = {}
+    try:
+        while True:
+            k = st.next_pass()
+            if k == 0:
+                break
+            st.pass_local(0, 1)
+            st.pass_finish()
+            m = np.empty(fx.n, dtype=np.uint8)
+            _lib.check(lib.tsc_memcpy_d2h(eng._h, _lib.ptr(m), C.c_void_p(st.mask_ptr()), m.nbytes))
+            after[int(k)] = np.packbits(m.astype(bool))
+        ran = [s["k"] for s in st.stats()]
+    finally:
+        st.close()
+        _lib.check(lib.tsc_free(eng._h, d_heavy))
+    assert ran == g["ks"].tolist()
+    for k, bits in zip(ran, g["pass_mask_bits"]):
+        assert np.array_equal(after[k], bits), f"{name}: the mask after the k = {k} pass differs from the reference's"
+    assert np.array_equal(after[1], g["mask_bits"])
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -1839,6 +1893,10 @@ def test_sharded_protocol_on_gpu_ranks(oracle, world, cfg, n_poses, min_pairs):
     # every step above ran its pass loop INSIDE the library (tsc_prune_run_sharded, the host called back for the collectives only);
     # the same loop driven from the host call by call gives the same survivors, evaluation counts and sequence of exchanges
     assert got["loops_agree"] is True
+    # ... and with the per-pass exchanges inside the library (areas the ranks map into each other over hipIpc*, one-shot all-reduce kernels) in
+    # place of the torch.distributed collectives: identical survivors, evaluation counts and exchange sequence, no exchange timed out
+    if world > 1:
+        assert got["ipc_agrees"] is True, got["ipc_status"]
     if world > 1 and cfg in ("C3", "C4"):
         assert len(got["partitioned"]) >= 3 and len(got["exchanges"]) >= 2, (got["partitioned"], got["exchanges"])
     if world > 1:           # (a world of one does not time the forms: it has nothing to choose)

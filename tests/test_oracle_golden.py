@@ -5,7 +5,7 @@ the HIP path with the oracle."""
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import LARGE_PRUNE_CASES, load_golden, load_large_prune
 
 TOL = 1e-9
 
@@ -84,6 +84,31 @@ def test_g3_prune(oracle, row_parallel):
         assert np.cumsum([s["new_keys"] for s in res["stats"]]).tolist() == g[f"pass_nkeys{c}"].tolist()
         keys = np.array(sorted(set(map(tuple, res["keys"].tolist()))), dtype=np.int64).reshape(-1, 2)
         assert np.array_equal(keys, g[f"keys{c}"])
+
+
+@pytest.mark.parametrize("row_parallel", [False, True])
+@pytest.mark.parametrize("name", LARGE_PRUNE_CASES)
+def test_g16_g17_prune_large(oracle, name, row_parallel):
+    """The FINE passes of the schedule (k = 5000 ... 200) and their cache-key collisions with the coarse ones, pinned by the
+    reference's own prune_conformers_rmsd (rmsd_pruning.py:65-67, 131-144, 186-204) on ensembles large enough for them to run:
+    final mask, every per-pass mask, which passes ran, cumulative key counts and the key set itself."""
+    fx = load_large_prune(name)
+    g = fx.g
+    res = oracle.prune_heavy(fx.heavy, fx.thr, trace=True, row_parallel=row_parallel)
+    assert [s["k"] for s in res["stats"]] == g["ks"].tolist()
+    assert max(g["ks"]) >= (5000 if name == "G17" else 2000) and {1000, 500, 200} <= set(g["ks"].tolist())
+    assert np.array_equal(np.packbits(res["mask"]), g["mask_bits"]), (int(res["mask"].sum()), int(np.unpackbits(g["mask_bits"])[:fx.n].sum()))
+    assert np.array_equal(np.packbits(res["pass_masks"], axis=1), g["pass_mask_bits"])
+    assert np.cumsum([s["new_keys"] for s in res["stats"]]).tolist() == g["pass_nkeys"].tolist()
+    keys = np.array(sorted(set(map(tuple, res["keys"].tolist()))), dtype=np.int64).reshape(-1, 2)
+    assert np.array_equal(keys, g["keys"].astype(np.int64))
+    # N is divisible by no k that ran: the last chunk took a remainder in every pass (rmsd_pruning.py:141-142)
+    assert all(fx.n % int(k) for k in g["ks"] if k > 1)
+    if not row_parallel:          # the call the reference's callers make: (structures[mask], mask) from ALL atoms + atomnos
+        pruned, mask = oracle.prune_conformers_rmsd(fx.structures, fx.atomnos, fx.thr)
+        assert np.array_equal(np.packbits(mask), g["mask_bits"]) and np.array_equal(pruned, fx.structures[mask])
+        mr, mm = oracle.prune_margins(fx.heavy, fx.thr, 0)
+        assert mr > 1e-6 and mm > 1e-6, "guard band (SURVEY 8d): an evaluated pair lies within 1e-6 of a threshold"
 
 
 def test_g3_cache_free_mode_differs(oracle):

@@ -46,6 +46,7 @@ class ExchangeRecord(C.Structure):
 
 
 XCHG_SUM_I64, XCHG_MIN_I32 = 1, 2
+XCHG_HANDLE_BYTES = 64
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)     # tsc_exchange_fn(user, kind, buf_dev, count)
 
 # name -> (restype, argtypes); mirrors include/tscode_hip.h one to one
@@ -124,6 +125,13 @@ _SIGNATURES = {
     "tsc_prune_mask_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "tsc_prune_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, C.c_int64, EXCHANGE_FN, _vp, C.POINTER(ExchangeRecord), C.c_int,
                                         C.POINTER(C.c_int)]),
+    "tsc_xchg_slot_bytes": (C.c_int, [C.c_int64, C.c_int, c_i64p]),
+    "tsc_xchg_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, C.POINTER(_vp), _vp]),
+    "tsc_xchg_connect": (C.c_int, [_vp, _vp]),
+    "tsc_xchg_set_timeout": (C.c_int, [_vp, C.c_double]),
+    "tsc_xchg_allreduce": (C.c_int, [_vp, C.c_int, _vp, C.c_int64]),
+    "tsc_xchg_status": (C.c_int, [_vp, c_i64p, C.POINTER(C.c_int)]),
+    "tsc_xchg_destroy": (C.c_int, [_vp]),
     "tsc_prune_copy_mask_dev": (C.c_int, [_vp, _vp]),
     "tsc_prune_stats": (C.c_int, [_vp, C.POINTER(PassStats), C.POINTER(C.c_int)]),
     "tsc_prune_destroy": (C.c_int, [_vp]),

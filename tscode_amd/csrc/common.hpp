@@ -11,6 +11,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -130,7 +131,12 @@ struct tsc_ctx {
     const double *xd_heavy = nullptr;     // the heavy-atom array they describe
     bool xd_valid = false;
     int xd_borrowers = 0;                 // live prune runs that read the xd_* buffers (tsc_prune_create borrowed them): no release / regrow meanwhile
-    int next_flag_slot = 0;               // pinned flag words handed to prune runs, round robin (host.hpp: PINNED_FLAG_OFFSET)
+    // Bookkeeping that runs of one context driven from DIFFERENT host threads touch (tsc_prune_create / tsc_prune_destroy): the pinned flag
+    // words handed to runs (host.hpp: PINNED_FLAG_OFFSET; bit s set = word s is some live run's) and the list of live runs, which
+    // tsc_ctx_destroy destroys with the context -- a host whose finalisers run in no particular order cannot leak a run's events.
+    std::mutex runs_mutex;
+    unsigned long long flag_slots_used = 0;
+    std::vector<tsc_prune *> live_runs;
     std::vector<int32_t> sample_host;     // pose indices of the basis sample of the last tsc_pipeline_dev call and their device copy
     int32_t *sample_dev = nullptr;
     double *mom_acc = nullptr;            // moment accumulators of the pipeline's basis chain (k_sample_moments adds, k_descriptor_basis clears)

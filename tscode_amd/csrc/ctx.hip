@@ -76,6 +76,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_destroy(tsc_ctx *c
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->basis_stream) (void)hipStreamSynchronize(c->basis_stream);
+    // runs that are still alive go with their context (their blocks are the context's, their events join its pool below): a host whose
+    // finalisers come in no particular order -- Python collecting a run and its engine in one cycle -- must not hand a run to
+    // tsc_prune_destroy after this
+    while (!c->live_runs.empty()) (void)tsc_prune_destroy(c->live_runs.back());
     for (auto &kv : c->cache) (void)hipFree(kv.second);
     for (auto &kv : c->live) (void)hipFree(kv.first);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

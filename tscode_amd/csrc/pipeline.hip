@@ -383,9 +383,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
     int np = 0;
     if (d_basis) TSC_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
     // automatic kernel choice: where the sample's descriptors hardly differ the screen separates nothing and the all-pairs kernel is the
-    // faster route (screen_is_useless).  The side chain finished long ago (it runs beside the clash kernel): no wait in practice
+    // faster route (screen_is_useless).  The basis kernel writes the two spreads to pinned memory; the HOST has to wait for that kernel
+    // itself -- the stream-side wait above orders only the stream, and since round 4 the chain (about 37 us + its event's way across
+    // queues) is no shorter than the clash kernel + scan it runs beside: the count can be there before the spreads are.  A read of the
+    // pre-set +inf would not change a verdict, only the kernel choice (sieve where the all-pairs kernel is 5x faster) -- from run to run.
     int force_algo = -1;
     if (d_basis && c->prune_algo == ALGO_AUTO && mode == 1 && n_heavy <= MAX_HP) {
+        TSC_HIP(hipEventSynchronize(c->ev_join));
         const volatile double *sh = reinterpret_cast<const volatile double *>(static_cast<const char *>(c->pinned) + PINNED_SPREAD_OFFSET);
         const double spread[NFAM] = {sh[0], sh[1]};
         if (screen_is_useless(spread, n_heavy, rmsd_thr)) force_algo = ALGO_TILE;

@@ -46,7 +46,13 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prun
     TSC_API_GUARD_BEGIN
     if (!p) return 0;
     DeviceGuard guard(p->ctx->device);
-    if (p->borrows_xd && p->ctx->xd_borrowers > 0) --p->ctx->xd_borrowers;
+    {
+        std::lock_guard<std::mutex> lock(p->ctx->runs_mutex);
+        if (p->borrows_xd && p->ctx->xd_borrowers > 0) --p->ctx->xd_borrowers;
+        if (p->flag_slot >= 0) p->ctx->flag_slots_used &= ~(1ull << p->flag_slot);
+        auto &lr = p->ctx->live_runs;
+        lr.erase(std::remove(lr.begin(), lr.end(), p), lr.end());
+    }
     for (void *q : p->blocks) p->ctx->release(q);
     for (auto &slot : p->ev)
         for (hipEvent_t e : slot)
@@ -152,7 +158,19 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
     p->mode = mode;
     p->algo = (c->prune_algo == ALGO_TILE) ? ALGO_TILE : ALGO_SIEVE;
     p->det_desc = c->deterministic_basis != 0;
-    p->flag_slot = c->next_flag_slot++ % PINNED_FLAG_SLOTS;
+    {   // this run's word of pinned memory (the culled-or-walked verdict of a candidate pass): its own for as long as it lives
+        std::lock_guard<std::mutex> lock(c->runs_mutex);
+        static_assert(PINNED_FLAG_SLOTS == 64, "one bit per flag word");
+        const int slot = ~c->flag_slots_used ? __builtin_ctzll(~c->flag_slots_used) : -1;
+        if (slot < 0) {
+            delete p;
+            return fail(TSC_ERR_STATE, "tsc_prune_create: %d prune runs are alive on this context, the most it serves at a time (destroy some, or use a "
+                                       "context per thread)", PINNED_FLAG_SLOTS);
+        }
+        c->flag_slots_used |= 1ull << slot;
+        p->flag_slot = slot;
+        c->live_runs.push_back(p);
+    }
     Scratch s_basis(c);
     if (force_algo >= 0) {
         p->algo = force_algo;
@@ -172,7 +190,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             else basis = q;  // (the sieve's descriptors are built from it further down)
         }
         if (rc0) {
-            delete p;
+            tsc_prune_destroy(p);
             return rc0;
         }
     }
@@ -280,6 +298,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_create(tsc_ctx *
         ext.heavy32 = c->xd_h32_valid ? c->xd_heavy32 : nullptr;
         c->xd_valid = false;
         TSC_TRY(prune_create_impl(c, heavy_dev, n, h, rmsd_thr, mode, nullptr, out, nullptr, &ext));
+        std::lock_guard<std::mutex> lock(c->runs_mutex);
         (*out)->borrows_xd = true;   // (tsc_embed_masked_dev will not release or regrow the buffers under this run)
         ++c->xd_borrowers;
         return 0;

@@ -83,7 +83,7 @@ struct tsc_prune {
     bool det_desc = false;     // the descriptors were built with fixed-order sums ("deterministic_basis"): every rank of a sharded run that fed
                                // its run the same sample holds the same bits -- what row tiles of a SORTED layout dealt among ranks rely on
     bool auto_tile = false;    // ALGO_TILE was this run's own choice (screen_is_useless on its own basis estimate), not the caller's
-    int flag_slot = 0;         // this run's word in the context's pinned buffer (the culled-or-walked verdict of a candidate pass)
+    int flag_slot = -1;        // this run's word in the context's pinned buffer (the culled-or-walked verdict of a candidate pass)
 };
 
 template <typename T>

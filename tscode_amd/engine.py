@@ -105,12 +105,14 @@ class Engine:
         check(self.lib.tsc_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
-        self._runs = weakref.WeakSet()      # live PruneSteppers: they hold blocks and events of this context
+        self._runs = weakref.WeakSet()      # live PruneSteppers / IpcExchanges: they hold blocks and events of this context
 
     def close(self):
         if getattr(self, "_h", None):
             # (a run and its engine can become garbage together -- e.g. both held by the traceback of an exception -- and the
-            # collector finalises them in no particular order: the runs go first, whichever finaliser is called first)
+            # collector finalises them in no particular order: the runs go first, whichever finaliser is called first.  When they die
+            # in ONE collection CPython has cleared the weak references before any finaliser runs and this set is already empty:
+            # tsc_ctx_destroy then destroys the runs the context still lists itself, and their close() finds the engine closed)
             for run in list(getattr(self, "_runs", ())):
                 run.close()
             self.lib.tsc_ctx_destroy(self._h)
@@ -501,6 +503,71 @@ class Engine:
         return run
 
 
+class IpcExchange:
+    """The exchange inside the library (include/tscode_hip.h, tsc_xchg_*): a receive area of fine-grained device memory per rank, mapped
+    into every other rank of the node; an all-reduce is one kernel that writes into all peers and one that waits for their flags and
+    folds what they delivered.  ``handle`` (64 bytes) has to reach every other rank -- the caller's business (``connect_over`` does it
+    with torch.distributed) -- then ``connect(handles in rank order)``."""
+
+    def __init__(self, engine: Engine, rank, world, slot_bytes):
+        self.e, self.rank, self.world = engine, int(rank), int(world)
+        x = C.c_void_p()
+        buf = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
+        check(engine.lib.tsc_xchg_create(engine._h, C.c_int(rank), C.c_int(world), C.c_int64(int(slot_bytes)), C.byref(x), buf))
+        self._x, self.handle = x, bytes(buf.raw)
+        engine._runs.add(self)               # closed with the engine, before its context goes
+
+    @staticmethod
+    def slot_bytes(lib, n, mode=0) -> int:
+        b = C.c_int64()
+        check(lib.tsc_xchg_slot_bytes(C.c_int64(int(n)), C.c_int(mode), C.byref(b)))
+        return b.value
+
+    def connect(self, handles):
+        handles = [bytes(h) for h in handles]
+        if len(handles) != self.world or any(len(h) != _lib.XCHG_HANDLE_BYTES for h in handles):
+            raise ValueError("connect() takes the 64-byte handle of every rank, in rank order")
+        check(self.e.lib.tsc_xchg_connect(self._x, C.c_char_p(b"".join(handles))))
+
+    def connect_over(self, dist, group=None):
+        """All-gather the handles over a torch.distributed process group and map the peers."""
+        handles = [None] * self.world
+        dist.all_gather_object(handles, self.handle, group=group)
+        self.connect(handles)
+        dist.barrier(group=group)            # every rank has mapped every area before the first exchange writes into one
+
+    def set_timeout(self, seconds):
+        check(self.e.lib.tsc_xchg_set_timeout(self._x, C.c_double(seconds)))
+
+    def allreduce(self, kind, buf_dev, count):
+        """In place over the ranks, enqueued on the engine's stream: kind = XCHG_SUM_I64 / XCHG_MIN_I32 (tscode_amd._lib)."""
+        check(self.e.lib.tsc_xchg_allreduce(self._x, C.c_int(kind), ptr(buf_dev), C.c_int64(int(count))))
+
+    def status(self):
+        """(exchanges made, exchanges that gave up waiting for a peer).  Read it after a synchronisation."""
+        n, t = C.c_int64(), C.c_int()
+        check(self.e.lib.tsc_xchg_status(self._x, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def check_status(self):
+        n, t = self.status()
+        if t:
+            raise _lib.TscodeHipError(-5, f"{t} of {n} in-library exchanges gave up waiting for a peer rank (tsc_xchg_set_timeout): the results of "
+                                     "the runs they belonged to are not valid")
+
+    def close(self):
+        if getattr(self, "_x", None):
+            if getattr(self.e, "_h", None):
+                self.e.lib.tsc_xchg_destroy(self._x)
+            self._x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PruneStepper:
     """Stepping form of one prune run (tsc_prune_*), used to shard a pass over ranks."""
 
@@ -591,19 +658,26 @@ class PruneStepper:
         aborts the run and is re-raised here."""
         from ._lib import EXCHANGE_FN, ExchangeRecord
         failure = []
-
-        def _cb(_user, kind, buf, count):
-            try:
-                exchange(int(kind), int(buf), int(count))
-                return 0
-            except BaseException as exc:  # noqa: BLE001  (must not propagate through the C frames)
-                failure.append(exc)
-                return 1
-        cb = EXCHANGE_FN(_cb) if exchange is not None else C.cast(None, EXCHANGE_FN)     # (no callback: a world of one needs none)
+        user = None
+        if isinstance(exchange, IpcExchange):
+            # the library's own exchange (tsc_xchg_allreduce has the signature of tsc_exchange_fn): the pass loop calls it directly,
+            # no Python frame per collective
+            cb, user = C.cast(self.e.lib.tsc_xchg_allreduce, EXCHANGE_FN), exchange._x
+        elif exchange is not None:
+            def _cb(_user, kind, buf, count):
+                try:
+                    exchange(int(kind), int(buf), int(count))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001  (must not propagate through the C frames)
+                    failure.append(exc)
+                    return 1
+            cb = EXCHANGE_FN(_cb)
+        else:
+            cb = C.cast(None, EXCHANGE_FN)     # (no callback: a world of one needs none)
         log = (ExchangeRecord * (2 * TSC_MAX_PASSES + 2))()
         n_log = C.c_int()
         rc = self.e.lib.tsc_prune_run_sharded(self._p, C.c_int(rank), C.c_int(world), C.c_int(min_chunks_per_rank), C.c_int64(int(min_pairs)),
-                                              ptr(exch_dev), C.c_int64(exch_dev.numel() if exch_dev is not None else 0), cb, None, log,
+                                              ptr(exch_dev), C.c_int64(exch_dev.numel() if exch_dev is not None else 0), cb, user, log,
                                               C.c_int(len(log)), C.byref(n_log))
         if failure:
             raise failure[0]

@@ -51,7 +51,10 @@ PARTITION_MIN_CHUNKS = 2
 
 # A sharded run culls a pass (cull.hpp: sorted layout + bounding boxes) from this many pairs of a rank's SHARE on, where one GPU on its own
 # waits for 2e9 ("cull_min_pairs"): the walk's cost falls with the share, a layout's does not, but the shares of C4's five largest passes on
-# eight ranks (0.3 - 1.5e9 pairs) still lie where the layout pays -- 0.5 ms of a 4.4 ms step in the same model.
+# eight ranks (0.3 - 1.5e9 pairs) still lie where the layout pays -- 0.5 ms of a 4.4 ms step in the same model.  The share of a pass
+# PARTITIONED BY CHUNKS is compared with this number as it stands; for a pass dealt by ROW TILES the library doubles it
+# (csrc/prune.hip, pass_launch: every rank lays the whole pass out for its fraction of the tiles), i.e. such a pass is culled from 1e9 pairs
+# of a rank's share on.
 SHARDED_CULL_MIN_PAIRS = 5.0e8
 
 
@@ -180,10 +183,26 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
         in_library = hasattr(st, "run_sharded") and not getattr(backend, "python_pass_loop", False)
         if can_partition and not in_library:
             st.set_partition(rank, world, partition_chunks)
+        # The per-pass exchanges: the library's own (backend.xchg: areas the ranks map into each other, one-shot all-reduce kernels on the
+        # step's stream -- IpcExchange) where the backend has connected one, else torch.distributed collectives (RCCL) on the same buffers
+        xchg = getattr(backend, "xchg", None) if world > 1 else None
+
+        def reduce_sum(t):
+            if xchg is not None:
+                xchg.allreduce(XCHG_SUM_I64, t, t.numel())
+            else:
+                _all_reduce(dist, t, dist.ReduceOp.SUM, group)
+
+        def reduce_min(t):
+            if xchg is not None:
+                xchg.allreduce(XCHG_MIN_I32, t, t.numel())
+            else:
+                _all_reduce(dist, t, dist.ReduceOp.MIN, group)
         try:
             if in_library:
                 # the product backend: the pass loop lives behind the C ABI (tsc_prune_run_sharded); the host is called back for the
-                # collectives only -- one Python frame per collective instead of three library calls + this loop per pass
+                # collectives only -- one Python frame per collective instead of three library calls + this loop per pass -- or, with
+                # the library's own exchange, not at all
                 def exchange(kind, addr, count):
                     if kind == XCHG_SUM_I64:
                         off = (addr - backend.exch.data_ptr()) // 8
@@ -191,7 +210,7 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
                     else:
                         assert addr == backend.best.data_ptr()
                         _all_reduce(dist, backend.best[:count], dist.ReduceOp.MIN, group)
-                for k, kind, count in st.run_sharded(rank, world, partition_chunks if can_partition else 0, limit, exchange):
+                for k, kind, count in st.run_sharded(rank, world, partition_chunks if can_partition else 0, limit, xchg if xchg is not None else exchange):
                     if kind == XCHG_MIN_I32:
                         exchanges.append((int(k), int(count)))
                     elif k > 0:
@@ -213,7 +232,7 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
                     # the whole pass on this rank's chunks; what the ranks tell each other is which rows they removed
                     st.pass_range()
                     words = st.exchange_words()
-                    _all_reduce(dist, backend.exch[:words], dist.ReduceOp.SUM, group)
+                    reduce_sum(backend.exch[:words])
                     st.pass_merge()
                     partitioned.append((int(k), int(words)))
                     continue
@@ -221,13 +240,13 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
                     # first pass after the partitioned ones: every rank needs every rank's cache keys from here on
                     off, words = st.views_range()
                     if words:
-                        _all_reduce(dist, backend.exch[off:off + words], dist.ReduceOp.SUM, group)
+                        reduce_sum(backend.exch[off:off + words])
                         views_words += int(words)
                     st.views_merged()
                 if shard:
                     st.pass_local(rank, world)          # this rank's row tiles only ...
                     n_best = st.n_active()
-                    _all_reduce(dist, backend.best[:n_best], dist.ReduceOp.MIN, group)   # ... merged
+                    reduce_min(backend.best[:n_best])   # ... merged
                     exchanges.append((int(k), int(n_best)))
                 else:
                     st.pass_local(0, 1)                 # small pass: replicated, no exchange
@@ -236,13 +255,16 @@ def _sharded_step(backend, rank: int, world: int, dist, group, min_pairs, front=
             if getattr(backend, "keep_host", None) is not None:      # verdicts back to the host before the run's one sync
                 backend.keep_host[:n_pass].copy_(backend.keep[:n_pass], non_blocking=True)
             stats = st.stats()
+            if xchg is not None:
+                xchg.check_status()                     # (after the run's synchronisation: did every exchange hear from every peer?)
         finally:
             st.close()
     n_keep = stats[-1]["n_active_after"] if stats else 0
     return {"n_pass": n_pass, "n_pass_local": n_pass_local, "n_keep": int(n_keep), "stats": stats, "counts": counts, "exchanges": exchanges,
             "partitioned": partitioned, "front": front, "allgather_bytes": gathered_bytes,
             "allreduce_bytes": 4 * sum(n for _, n in exchanges) + 8 * sum(w for _, w in partitioned) + 8 * views_words
-                               + (8 * world if front == "shard" else 0) + mask_bytes}
+                               + (8 * world if front == "shard" else 0) + mask_bytes,
+            "exchange": "ipc" if (world > 1 and getattr(backend, "xchg", None) is not None) else "callback"}
 
 
 class _HipStepper:
@@ -310,6 +332,7 @@ class HipShardBackend:
     def __init__(self, ens, device_index, rank, world, clash_thresh, max_clashes, rmsd_thr, mode):
         import torch
         self.torch, self.ens = torch, ens
+        self.xchg = None                       # the library's own per-pass exchange (connect_exchange); None: torch.distributed collectives
         self.clash_thresh, self.max_clashes, self.rmsd_thr, self.mode = clash_thresh, max_clashes, rmsd_thr, mode
         self.dev = torch.device(f"cuda:{device_index}")
         torch.cuda.set_device(self.dev)
@@ -356,6 +379,25 @@ class HipShardBackend:
 
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
+
+    def connect_exchange(self, dist, group=None):
+        """The per-pass exchanges of the prune inside the library from here on (engine.IpcExchange: every rank's receive area mapped into
+        every other rank of the node, one-shot all-reduce kernels on this backend's stream).  Collective: every rank calls it.  The
+        process group only carries the 64-byte handles, once.  Returns the exchange; on failure nothing changes and the error
+        propagates (the caller may stay with the callback form)."""
+        from .engine import IpcExchange
+        if self.world <= 1 or self.xchg is not None:
+            return self.xchg
+        x = IpcExchange(self.eng, dist.get_rank(group), self.world, IpcExchange.slot_bytes(self.eng.lib, max(self.ens.n_poses, 1), self.mode))
+        x.connect_over(dist, group)
+        self.xchg = x
+        return x
+
+    def disconnect_exchange(self):
+        if self.xchg is not None:
+            self.torch.cuda.synchronize(self.dev)
+            self.xchg.close()
+            self.xchg = None
 
     def embed_clash_block(self):
         # fused verdicts, then only the passing poses are embedded: straight into `structures` and into the padded send
@@ -445,8 +487,12 @@ def time_fronts(torch, dev, pg, steps, step):
 
 class DevicePipeline:
     def __init__(self, ens, device_index=0, rank=0, world=1, clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0,
-                 process_group=None, force_sharded=False, shard_min_pairs=None, front="auto", partition_chunks=PARTITION_MIN_CHUNKS):
-        """``front`` (multi-rank runs): "shard" = pose blocks + all-gather of the survivors' coordinates, "replicate" = every rank
+                 process_group=None, force_sharded=False, shard_min_pairs=None, front="auto", partition_chunks=PARTITION_MIN_CHUNKS,
+                 exchange="callback"):
+        """``exchange`` (multi-rank runs): "callback" = the per-pass collectives are torch.distributed all-reduces (RCCL) the library calls back
+        for; "ipc" = the library's own exchange over areas the ranks map into each other (``HipShardBackend.connect_exchange``; the process
+        group only carries the handles).  Same results either way.
+        ``front`` (multi-rank runs): "shard" = pose blocks + all-gather of the survivors' coordinates, "replicate" = every rank
         computes the whole front half and only best[] travels, "auto" = ``tune_front()`` decides on the node at hand (called by
         the first ``step()`` unless the caller did; one rank: "shard", there is nothing to choose)."""
         import torch
@@ -463,6 +509,10 @@ class DevicePipeline:
         self.front_tuning = None
         if self.sharded:
             self.backend = HipShardBackend(ens, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
+            if exchange not in ("callback", "ipc"):
+                raise ValueError(f"exchange must be 'callback' or 'ipc', got {exchange!r}")
+            if exchange == "ipc" and self.world > 1:
+                self.backend.connect_exchange(torch.distributed, process_group)
             self.d_keep, self.d_clash, self.d_structures = self.backend.keep, self.backend.clash, self.backend.structures
             self.h_keep = self.backend.keep_host
             return

@@ -119,7 +119,12 @@ class Ensemble:
 
 def make_ensemble(n_poses: int, atoms_per_frag, seed: int, children: int = 10,
                   sigma_rot_deg: float = 1.0, sigma_t: float = 0.03,
-                  shell=(4.0, 9.0)) -> Ensemble:
+                  shell=(4.0, 9.0), local_spread: float | None = None) -> Ensemble:
+    """``local_spread`` = None: the children of all parents are shuffled over the whole array (every BASELINE config).
+    A number S > 1: a LOCAL shuffle -- every family gets a home position, uniform over the array, and each child lands at
+    home +- a log-uniform offset in [1, S]: a few siblings share a chunk of 20, more share a chunk of 200, the rest only meet in
+    the coarse passes.  The prune's fine passes (k = 5000 ... 200, rmsd_pruning.py:186-192) then each find duplicates to remove
+    while more than 20 k structures stay active, which a global shuffle never gives them (golden fixtures G16 / G17)."""
     rng = np.random.default_rng(seed)
     atoms_per_frag = [int(a) for a in atoms_per_frag]
     n_mols = len(atoms_per_frag)
@@ -143,7 +148,12 @@ def make_ensemble(n_poses: int, atoms_per_frag, seed: int, children: int = 10,
         d_t = sigma_t * rng.normal(size=(n_poses, 3))
         rot[:, m] = np.einsum("pij,pjk->pik", pr[parent_of], d_rot)
         pos[:, m] = pt[parent_of] + d_t
-    perm = rng.permutation(n_poses)
+    if local_spread is None:
+        perm = rng.permutation(n_poses)
+    else:
+        home = rng.uniform(0.0, n_poses, size=n_par)
+        off = np.exp(rng.uniform(0.0, np.log(float(local_spread)), size=n_poses)) * rng.choice([-1.0, 1.0], size=n_poses)
+        perm = np.argsort(home[parent_of] + off, kind="stable")
     rot, pos, parent_of = rot[perm], pos[perm], parent_of[perm]
     return Ensemble(
         frag_coords=frags,
@@ -151,7 +161,7 @@ def make_ensemble(n_poses: int, atoms_per_frag, seed: int, children: int = 10,
         rot=np.ascontiguousarray(rot), pos=np.ascontiguousarray(pos),
         ids=np.asarray(atoms_per_frag, dtype=np.int64), atomnos=atomnos, seed=seed,
         meta={"children": children, "sigma_rot_deg": sigma_rot_deg, "sigma_t": sigma_t,
-              "shell": tuple(shell), "parent_of": parent_of},
+              "shell": tuple(shell), "parent_of": parent_of, "local_spread": local_spread},
     )
 
 

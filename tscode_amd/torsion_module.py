@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .algebra import rot_mat_from_pointer
 from .engine import get_engine
 
 __all__ = ["rotate_dihedral", "rotate_dihedral_batch", "torsion_comp_check", "csearch_rotate", "csearch_candidates"]
@@ -62,9 +63,14 @@ def rotate_dihedral(coords, dihedral, angle, mask=None, indices_to_be_moved=None
     mask = np.asarray(mask, dtype=bool)
     if float(angle) == 0.0:
         return coords                                    # (the identity; the candidate loop never rotates by zero, :482)
-    # one structure, one rotation by any real angle (tscode/torsion_module.py:984-1005 passes fractional corrections): no clash check
-    out = get_engine().rotate_dihedral_batch(coords_arr[None], [int(i) for i in dihedral], mask, [float(angle)])
-    coords_arr[...] = out[0]
+    # ONE structure, one rotation: on the host, like the other single 3x3 helpers of the path (algebra.py) -- the
+    # reference's search loops call this once per torsion and candidate and once per 5-degree walk-back step
+    # (tscode/torsion_module.py:482-489, :756-763), and a GPU call per molecule-sized rotation (three uploads, a launch, a download, a
+    # synchronisation: 50 us and more) would slow them down.  Whole tables of rotations belong on rotate_dihedral_batch / csearch_rotate.
+    _, i2, i3, _ = (int(i) for i in dihedral)
+    mat = rot_mat_from_pointer(coords_arr[i2] - coords_arr[i3], float(angle))
+    center = coords_arr[i3].copy()
+    coords_arr[mask] = (mat @ (coords_arr[mask] - center).T).T + center
     return coords
 
 
