@@ -27,7 +27,12 @@ what crossed xGMI.  `replicas` beside it (`"scaling": "weak"`): every GPU runs t
 data-path collective -- how a batch of independent embeds uses a node.  The 100k x 50 pipeline is a 0.9 ms chain of dependent
 launches of which about 0.5 ms shards (the Amdahl ceiling of C3 is stated there); `--config C4` (1M x 50)
 is the workload on which sharding one ensemble pays.  Should the sharded leg fail or hang (180 s watchdog), the line falls
-back to the replicas figure, says so in `error`, and the process exits non-zero.
+back to the replicas figure, says so in `error`, and the process exits non-zero -- also when the sharded leg was only the side figure.
+At N > 1 BOTH figures stand at top level whichever of them `value` is: `value_strong` / `ms_per_step_strong` (one ensemble sharded, with
+`rccl_world`, `collectives_per_step`, `exchange`) and `value_weak` / `ms_per_step_weak` (replicas).  Before any leg the collectives meet the
+step's real buffers once (`selftest_collectives`: all-reduce SUM of int64, all-reduce MIN of int32, all-gather, each checked, timed and under
+a 30 s watchdog that names the collective that hung; then the library's own exchange over memory the ranks map into each other,
+`--exchange`: used for the per-pass messages when it connects and agrees).
 
 The timed region (K steps between barrier + synchronize) carries the HIP start/stop events of every pair-kernel dispatch that
 `roofline.avg_launch_us` needs; the same K steps with those events off follow (`events_off`), then three steps with every
@@ -95,6 +100,13 @@ def parse():
                     help="multi-rank front half: pose blocks + all-gather of the survivors' coordinates, every rank computing all "
                          "poses itself, clash verdicts per block + every rank embedding all survivors (hybrid), or whichever is fastest on "
                          "this node (timed before the warm-up)")
+    ap.add_argument("--exchange", choices=("auto", "ipc", "callback"), default="auto",
+                    help="N > 1: the per-pass exchanges of the sharded prune -- 'callback' = torch.distributed all-reduces (RCCL) the library calls back "
+                         "for, 'ipc' = the library's own exchange over areas the ranks map into each other (hipIpc*; the process group only carries "
+                         "the handles), 'auto' (default) = ipc if the collective self-test finds it connected and correct on this node, else callback")
+    ap.add_argument("--no-selftest", action="store_true",
+                    help="N > 1: skip the collective self-test (one all-reduce SUM of int64, one all-reduce MIN of int32 and one all-gather on the "
+                         "step's real buffers, each under a 30 s watchdog, before any leg)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-rank protocol (sharded_step + torch.distributed collectives) even with one rank")
     ap.add_argument("--pass-timing", type=int, default=1,
@@ -238,6 +250,165 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def collectives_selftest():
+        """First contact of the node's collectives with the step's REAL buffers, before any leg: all-reduce(SUM) of int64 on the exchange
+        buffer of the partitioned passes, all-reduce(MIN) of int32 on best[], all-gather on the heavy-atom send / receive buffers -- each
+        checked against what every rank can compute for itself and timed (5 calls between stream events), under a 30 s watchdog that
+        prints a line NAMING the collective that did not return and ends the process (exit code 4).  Then the same two reductions through
+        the library's own exchange (tsc_xchg_*): connected?  equal to what the process group's gave?  Returns the record for the line."""
+        from tscode_amd._lib import XCHG_MIN_I32, XCHG_SUM_I64
+        from tscode_amd.pipeline import HipShardBackend
+        rec = {"watchdog_s": 30, "backend": dist.get_backend()}
+        now = {"what": "setup"}
+
+        def hung():
+            if rank == 0:
+                line = {"metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)", "value": None,
+                        "unit": "conformers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": f"{args.config}: {ens.n_poses} conformers x {ens.n_atoms} atoms"},
+                        "error": f"collective self-test: `{now['what']}` did not return within 30 s on {world} ranks ({dist.get_backend()})",
+                        "selftest_collectives": rec}
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            os._exit(4)
+
+        def guarded(name, fn):
+            now["what"] = name
+            t = threading.Timer(30.0, hung)
+            t.daemon = True
+            t.start()
+            try:
+                return fn()
+            finally:
+                t.cancel()
+        be = guarded("buffers of the sharded backend", lambda: HipShardBackend(ens, local_rank, rank, world, 1.5, 0, 0.5, args.mode))
+        n = ens.n_poses
+        words = n // 64 + 48
+        staged = args.backend != "nccl"
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(be.stream):
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+
+        def ar(t, op):
+            with torch.cuda.stream(be.stream):
+                if staged:
+                    c = t.cpu()
+                    dist.all_reduce(c, op=op)
+                    t.copy_(c)
+                else:
+                    dist.all_reduce(t, op=op)
+        idx64 = torch.arange(words, dtype=torch.int64, device=be.dev)
+        idx32 = torch.arange(n, dtype=torch.int32, device=be.dev)
+
+        def fill():                                   # rank-dependent patterns every rank can predict for all ranks
+            with torch.cuda.stream(be.stream):
+                be.exch[:words].copy_(idx64 * (rank + 1) + 7)
+                be.best[:n].copy_((idx32 * 31 + rank * 1009) % 65521 - rank)
+        want64 = idx64 * (world * (world + 1) // 2) + 7 * world
+        want32 = torch.stack([(idx32 * 31 + r * 1009) % 65521 - r for r in range(world)]).amin(0)
+
+        def check_sum():
+            fill()
+            ar(be.exch[:words], dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            return bool(torch.equal(be.exch[:words], want64))
+
+        def check_min():
+            fill()
+            ar(be.best[:n], dist.ReduceOp.MIN)
+            torch.cuda.synchronize()
+            return bool(torch.equal(be.best[:n], want32))
+        ok = guarded("all-reduce SUM of int64 (removed-row bits + statistics)", check_sum)
+        rec["allreduce_sum_i64"] = {"count": words, "ok": ok,
+                                    "us_per_call": guarded("all-reduce SUM of int64, timed", lambda: timed(lambda: ar(be.exch[:words], dist.ReduceOp.SUM)))}
+        ok = guarded("all-reduce MIN of int32 (best[])", check_min)
+        rec["allreduce_min_i32"] = {"count": n, "ok": ok,
+                                    "us_per_call": guarded("all-reduce MIN of int32, timed", lambda: timed(lambda: ar(be.best[:n], dist.ReduceOp.MIN)))}
+        rows = min(be.max_local, 4096)
+        row_elems = be.heavy_pad[0].numel()
+
+        def ag():
+            with torch.cuda.stream(be.stream):
+                out_t, in_t = be.gather.view(-1)[:world * rows * row_elems], be.heavy_pad.view(-1)[:rows * row_elems]
+                if staged:
+                    co, ci = out_t.cpu(), in_t.cpu()
+                    dist.all_gather_into_tensor(co, ci)
+                    out_t.copy_(co)
+                else:
+                    dist.all_gather_into_tensor(out_t, in_t)
+
+        def check_gather():
+            with torch.cuda.stream(be.stream):
+                be.heavy_pad.view(-1)[:rows * row_elems].fill_(float(rank + 1))
+            ag()
+            torch.cuda.synchronize()
+            got = be.gather.view(-1)[:world * rows * row_elems].view(world, -1)
+            return bool(all(float(got[r].min()) == float(got[r].max()) == float(r + 1) for r in range(world)))
+        ok = guarded("all-gather of float64 (heavy-atom shards)", check_gather)
+        rec["allgather_f64"] = {"bytes_per_rank": rows * row_elems * 8, "ok": ok, "us_per_call": guarded("all-gather, timed", lambda: timed(ag))}
+        # the library's own exchange: may fail to connect (no peer access, IPC refused) -- that is a result, not an error
+        ipc = {"connected": False}
+        try:
+            guarded("tsc_xchg connect (hipIpcGetMemHandle / hipIpcOpenMemHandle + handles over the process group)", lambda: be.connect_exchange(dist, None))
+            ipc["connected"] = be.xchg is not None
+        except Exception as exc:   # noqa: BLE001
+            ipc["error"] = f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([1 if ipc["connected"] else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # one rank without it: nobody uses it
+        if ipc["connected"] and not bool(flag.item()):
+            ipc["connected"], ipc["error"] = False, "another rank could not connect"
+            be.disconnect_exchange()
+        if ipc["connected"]:
+            be.xchg.set_timeout(20.0)
+
+            def x_sum():
+                with torch.cuda.stream(be.stream):
+                    be.xchg.allreduce(XCHG_SUM_I64, be.exch[:words], words)
+
+            def x_min():
+                with torch.cuda.stream(be.stream):
+                    be.xchg.allreduce(XCHG_MIN_I32, be.best[:n], n)
+
+            def check_x():
+                fill()
+                x_sum()
+                x_min()
+                torch.cuda.synchronize()
+                return bool(torch.equal(be.exch[:words], want64)), bool(torch.equal(be.best[:n], want32))
+            ipc["sum_ok"], ipc["min_ok"] = guarded("tsc_xchg_allreduce (SUM int64 + MIN int32)", check_x)
+            ipc["sum_us_per_call"] = guarded("tsc_xchg_allreduce SUM, timed", lambda: timed(x_sum))
+            ipc["min_us_per_call"] = guarded("tsc_xchg_allreduce MIN, timed", lambda: timed(x_min))
+            ipc["timeouts"] = be.xchg.status()[1]
+            good = torch.tensor([1 if (ipc["sum_ok"] and ipc["min_ok"] and ipc["timeouts"] == 0) else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            ipc["usable"] = bool(good.item())
+            be.disconnect_exchange()
+        rec["ipc_exchange"] = ipc
+        rec["all_ok"] = bool(rec["allreduce_sum_i64"]["ok"] and rec["allreduce_min_i32"]["ok"] and rec["allgather_f64"]["ok"])
+        del be
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return rec
+
+    selftest = None
+    if world > 1 and not args.no_selftest:
+        selftest = collectives_selftest()
+    if args.exchange == "auto":
+        use_ipc = bool(selftest and selftest.get("ipc_exchange", {}).get("usable"))
+    else:
+        use_ipc = args.exchange == "ipc" and world > 1
+    exchange_form = "ipc" if use_ipc else "callback"
+
     def configure(pipe, pass_timing):
         pipe.set_option("prune_algo", args.algo)
         pipe.set_option("pass_timing", pass_timing)
@@ -316,12 +487,12 @@ def main():
             angle_table = np.random.default_rng(6).choice(np.array([0, 0, 60, 120, 180, 240, 300, 25]), size=(CHAIN_CANDIDATES, 8)).astype(np.int32)
             if sharded:
                 pipe = ShardedCsearchChain(ens, torsions, tmasks, angle_table, rank, world, process_group=pg, thresh=1.4, device_index=local_rank,
-                                           mode=args.mode, seed=7, front=args.front)
+                                           mode=args.mode, seed=7, front=args.front, exchange=exchange_form)
             else:
                 pipe = CsearchChain(ens, torsions, tmasks, angle_table, thresh=1.4, device_index=local_rank, mode=args.mode, seed=7)
         elif sharded:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=rank, world=world, mode=args.mode, process_group=pg,
-                                  force_sharded=args.force_sharded or world == 1, front=args.front)
+                                  force_sharded=args.force_sharded or world == 1, front=args.front, exchange=exchange_form)
         else:
             pipe = DevicePipeline(ens, device_index=local_rank, rank=0, world=1, mode=args.mode)
         configure(pipe, args.pass_timing)
@@ -359,7 +530,18 @@ def main():
                "scaling": "strong" if leg["sharded"] else "weak", "conformers_per_step_all_ranks": leg["units_per_step"],
                "n_survivors": int(res["n_keep"]), "keep_sha256_16": leg["digest"], "parity_vs_recorded_oracle": leg["parity"],
                "events_off": leg["events_off"], "what": what}
+        if leg["sharded"]:
+            out["rccl_world"] = dist.get_world_size() if use_dist else 1
+            out["collectives_per_step"] = collectives_of(res)
+            out["exchange"] = res.get("exchange")
+            out["front"] = res.get("front")
         return out
+
+    def collectives_of(res):
+        """Exchanges of one sharded step: counts all-reduce + coordinates all-gather (front = shard) or the clash mask (front = hybrid), one
+        all-reduce per pass that is partitioned by chunks or dealt by row tiles, one for the cache views between the two kinds."""
+        return ({"shard": 2, "hybrid": 1}.get(res.get("front"), 0) + len(res.get("exchanges", [])) + len(res.get("partitioned", []))
+                + (1 if res.get("partitioned") and args.mode == 0 else 0))
 
     SHARDED_WHAT = ("ONE ensemble sharded over the ranks: passes with >= 2 chunks per rank partitioned by chunks (all-reduce SUM of one bit "
                     "per structure + statistics), the later ones by row tiles (all-reduce MIN over best[]); the front half as `front` says -- "
@@ -398,7 +580,7 @@ def main():
                         s = leg_summary(replicas, REPLICAS_WHAT)
                         line.update(value=s["value"], ms_per_step=s["ms_per_step"], replicas=s)
                     os.write(real_stdout, (json.dumps(line) + "\n").encode())
-                os._exit(3 if main_sharded else 0)
+                os._exit(3)      # (also when the sharded leg was only the side figure: a hung collective is never a clean run)
             watchdog = threading.Timer(180.0, bail)
             watchdog.daemon = True
             watchdog.start()
@@ -406,10 +588,9 @@ def main():
                 sharded_leg = run_leg(True)
             except Exception as exc:
                 error = f"sharded single-ensemble leg failed: {type(exc).__name__}: {exc}" + ("; value = replicas leg" if main_sharded else "")
-                if main_sharded:
-                    exit_code = 3
-                    if replicas is None:
-                        raise
+                exit_code = 3        # (also when the sharded leg was only the side figure: the RCCL path gates every N > 1 run)
+                if main_sharded and replicas is None:
+                    raise
             watchdog.cancel()
         if main_sharded and sharded_leg is not None:
             leg = sharded_leg
@@ -422,6 +603,9 @@ def main():
     else:
         leg = run_leg(main_sharded)
 
+    if selftest is not None and not selftest["all_ok"]:
+        error = ((error + "; ") if error else "") + "collective self-test: a collective returned wrong data on the step's buffers (selftest_collectives)"
+        exit_code = exit_code or 4
     res, acc, dt = leg["res"], leg["acc"], leg["dt"]
     tile_ms, evals, computed, screened = acc["tile_ms"], acc["evals"], acc["computed"], acc["screened"]
     stage_ms, pass_ms = leg["stage_ms"], leg["pass_ms"]
@@ -582,11 +766,26 @@ def main():
             out["partitioned_passes"] = [{"k": k, "int64_words": w} for k, w in res.get("partitioned", [])]
             # counts all-reduce and coordinates all-gather (front = shard), the clash mask (front = hybrid), one all-reduce per pass that
             # is partitioned by chunks or sharded by row tiles, one for the cache views between the two kinds
-            out["collectives_per_step"] = ({"shard": 2, "hybrid": 1}.get(res.get("front"), 0) + len(res.get("exchanges", []))
-                                           + len(res.get("partitioned", [])) + (1 if res.get("partitioned") and args.mode == 0 else 0))
+            out["collectives_per_step"] = collectives_of(res)
+            out["exchange"] = res.get("exchange")
         if world > 1:
             out["multi"] = {"value_is": "sharded_single_ensemble" if sharded_mode else "replicas", "why": multi_reason,
                             "beside_it": side[0] if side is not None else None}
+            # both figures at top level, whichever of them `value` is: `value_strong` = ONE ensemble sharded over the ranks (RCCL / the library's
+            # exchange in the data path; what north_star's ">= 6x further at 8 GPUs" speaks of), `value_weak` = one whole ensemble per GPU
+            strong = ({"value": out["value"], "ms_per_step": ms_per_step, "res": res} if sharded_mode else
+                      ({"value": side[1]["value"], "ms_per_step": side[1]["ms_per_step"], "res": sharded_leg["res"]} if side is not None and sharded_leg is not None else None))
+            weak = ({"value": out["value"], "ms_per_step": ms_per_step} if not sharded_mode else
+                    ({"value": side[1]["value"], "ms_per_step": side[1]["ms_per_step"]} if side is not None else None))
+            out["value_strong"] = strong["value"] if strong else None
+            out["ms_per_step_strong"] = strong["ms_per_step"] if strong else None
+            out["value_weak"] = weak["value"] if weak else None
+            out["ms_per_step_weak"] = weak["ms_per_step"] if weak else None
+            if strong:
+                out["rccl_world"] = dist.get_world_size()
+                out["collectives_per_step"] = collectives_of(strong["res"])
+                out["exchange"] = strong["res"].get("exchange")
+            out["selftest_collectives"] = selftest
         if side is not None:
             out[side[0]] = side[1]
         if error is not None:

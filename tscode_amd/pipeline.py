@@ -691,7 +691,7 @@ class ShardedCsearchChain:
 
     def __init__(self, ens, torsions, masks, angles, rank, world, process_group=None, n_out=None, fragment=0, thresh=1.5, device_index=0,
                  clash_thresh=1.5, max_clashes=0, rmsd_thr=0.5, mode=0, seed=0, front="auto", shard_min_pairs=None,
-                 partition_chunks=PARTITION_MIN_CHUNKS):
+                 partition_chunks=PARTITION_MIN_CHUNKS, exchange="callback"):
         import copy
 
         import torch
@@ -710,6 +710,10 @@ class ShardedCsearchChain:
         e2.ids, e2.atomnos = np.asarray(ens.ids)[order], np.asarray(ens.atomnos)[atom_order]
         self.ens = e2
         self.backend = be = HipShardBackend(e2, device_index, self.rank, self.world, clash_thresh, max_clashes, rmsd_thr, mode)
+        if exchange not in ("callback", "ipc"):
+            raise ValueError(f"exchange must be 'callback' or 'ipc', got {exchange!r}")
+        if exchange == "ipc" and self.world > 1:
+            be.connect_exchange(torch.distributed, process_group)
         self.eng, self.dev, self.stream = be.eng, be.dev, be.stream
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         base = np.ascontiguousarray(e2.frag_coords[0][0], dtype=np.float64)
