@@ -1,0 +1,34 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): L2 (TCC) counters per kernel -- hit / miss, requests by kind, what leaves the L2 towards the fabric
+# (reads, writes, atomics, write-backs) -- three --pmc passes of a short bench run.  Written for the question "where do the culled pair
+# kernel's 4.65 GB per launch come from" (VERDICT r4, weak 3).
+# usage: tools/pmc_tcc.sh OUTDIR [bench.py arguments]        (outputs under gpurun_out/OUTDIR, summary tcc_counters.json)
+set -e
+P=gpurun_out/$1; shift
+mkdir -p "$P"
+export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --no-cpu --no-side-leg $*"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$P/p1" -- python3 bench.py $ARGS > "$P/b1.json" 2> "$P/p1.err"
+rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d "$P/p2" -- python3 bench.py $ARGS > "$P/b2.json" 2> "$P/p2.err"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_WRITEBACK_sum --output-format csv -d "$P/p3" -- python3 bench.py $ARGS > "$P/b3.json" 2> "$P/p3.err"
+python3 - "$P" <<'PY'
+import csv, glob, sys, collections, json
+P = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in glob.glob(f"{P}/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+out = {}
+for k, v in agg.items():
+    out[k] = {c: {"total": x, "calls": len(calls[k][c]), "per_call": x / max(1, len(calls[k][c]))} for c, x in v.items()}
+json.dump(out, open(f"{P}/tcc_counters.json", "w"), indent=1)
+for k in sorted(out, key=lambda k: -out[k].get("TCC_REQ_sum", out[k].get("TCC_READ_sum", {"total": 0}))["total"])[:8]:
+    print(k)
+    for c, x in sorted(out[k].items()):
+        print(f"    {c:28s} per call {x['per_call']:.4g}  ({x['calls']} calls)")
+PY

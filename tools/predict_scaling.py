@@ -33,6 +33,12 @@ from tscode_amd.pipeline import PARTITION_MIN_CHUNKS, SHARD_MIN_PAIRS, SHARDED_C
 from tscode_amd.synthetic import make_config
 
 LINK_GBS, LINK_EFF, COLL_FIXED_US = 153.0, 0.7, 20.0
+# The fixed cost of a collective is the model's least certain number: 20 us is what a world of ONE shows for an RCCL all-reduce from
+# torch.distributed; eight ranks, a Python frame per collective and torch's own work in between can make it 40 - 80 us.  Every predicted
+# step is therefore ALSO given at these fixed costs (`by_collective_fixed_us`); a step makes `collectives_per_step` of them.  The library's own
+# exchange (csrc/xchg.hip, profiles/r05_ipc_exchange.json: 6.5 - 10.5 us up to 230 KB, 25 us at 1.9 MB, two processes sharing one GPU) lies below
+# the first of them.
+SENSITIVITY_FIXED_US = (10.0, 20.0, 50.0, 100.0)
 
 
 class Timer:
@@ -237,9 +243,13 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None, 
         setup_f = f.get("setup_ms", best["setup_ms"])
         body = prune_ms - best["setup_ms"] + setup_f
         ring, fast = f["compute_ms"] + f["comm_ms"][0] + body + pass_comm(False), f["compute_ms"] + f["comm_ms"][1] + body + pass_comm(True)
+        # collectives of a step: the front's (shard: counts + coordinates; hybrid: the clash mask) + one per pass that exchanges anything
+        n_coll = 0 if n_ranks == 1 else {"shard": 2, "hybrid": 1}.get(name, 0) + sum(1 for p in best["passes"] if p["bytes"])
         out_fronts[name] = {"front_compute_ms": f["compute_ms"], "front_comm_ms_ring": f["comm_ms"][0], "front_comm_ms_all_links": f["comm_ms"][1],
-                            "prune_setup_ms": setup_f,
-                            "predicted_ms_per_step": ring, "predicted_ms_per_step_all_links": fast}
+                            "prune_setup_ms": setup_f, "collectives_per_step": n_coll,
+                            "predicted_ms_per_step": ring, "predicted_ms_per_step_all_links": fast,
+                            "by_collective_fixed_us": {str(int(us)): {"ring": ring + n_coll * (us - COLL_FIXED_US) / 1e3,
+                                                                      "all_links": fast + n_coll * (us - COLL_FIXED_US) / 1e3} for us in SENSITIVITY_FIXED_US}}
     by_kind = {}
     for p in best["passes"]:
         d = by_kind.setdefault(p["kind"], {"passes": 0, "local_ms": 0.0, "close_ms": 0.0, "comm_ms_ring": 0.0, "comm_ms_all_links": 0.0})
@@ -279,6 +289,7 @@ def main():
     cfgs = [a for a in args if a.startswith("C")] or ["C3", "C4"]
     out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
            "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
+                     "sensitivity_fixed_us": list(SENSITIVITY_FIXED_US),
                      "ring (predicted_ms_per_step)": "per-link bound: all-gather = (N-1) steps of one shard over one link; all-reduce = reduce-scatter + all-gather of that pattern",
                      "all_links (predicted_ms_per_step_all_links)": "the fully connected xGMI mesh used at once: every shard straight to its N-1 peers, one link each",
                      "shard_min_pairs": SHARD_MIN_PAIRS, "partition_min_chunks": chunks,
@@ -301,6 +312,8 @@ def main():
             for f in r["fronts"].values():
                 f["speedup_vs_1_rank_protocol"] = base / f["predicted_ms_per_step"]
                 f["speedup_vs_1_rank_protocol_all_links"] = base / f["predicted_ms_per_step_all_links"]
+                for v in f["by_collective_fixed_us"].values():
+                    v["speedup_ring"], v["speedup_all_links"] = base / v["ring"], base / v["all_links"]
         out["configs"][cfg] = rows
     print(json.dumps(out, indent=1))
 

@@ -113,6 +113,8 @@ struct tsc_ctx {
     int cull = 1;                         // large passes of the sieve lay their structures out along a Morton curve and skip tile pairs by bounding box (cull.hpp)
     double cull_min_pairs = 2.0e9;        // ... passes of at least this many pairs (n * (n / k) / 2)
     int64_t cull_grid = 1 << 30;          // workgroups of the culled pair kernel at most (each walks work items with that stride)
+    int cull_xcd = 1;                     // 1 (default): the culled pair kernel keys runs of 32 row groups to XCDs (workgroup b runs on XCD b % 8): the workgroups an
+                                          // XCD has in flight share their column windows in its L2 (cull.hpp; an experiment of round 5)
     int pass_timing = 0;                  // HIP events per pass: 0 none, 1 on the pair kernel's dispatch, 2 also around the whole pass
     // basis estimated by tsc_embed_clash_compact_dev beside its clash kernel, for the tsc_prune_create that follows (consumed once)
     double *eb_block = nullptr;           // [sample coordinates | moment accumulators | basis]

@@ -268,6 +268,10 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->cull_grid = int64_t(value);
         return 0;
     }
+    if (strcmp(name, "cull_xcd") == 0) {
+        c->cull_xcd = value != 0.0 ? 1 : 0;
+        return 0;
+    }
     if (strcmp(name, "cull_tile_block") == 0) {
         TSC_REQUIRE(value >= 1 && value <= 65536, "cull_tile_block must be in [1, 65536]");
         c->cull_tile_block = int(value);

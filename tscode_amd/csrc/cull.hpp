@@ -30,6 +30,10 @@ constexpr int CULL_BUCKETS = 1 << (CULL_MORTON_BITS * CULL_MORTON_DIMS);   // 32
 constexpr int CULL_MAX_CHUNKS = 64;                         // passes with more chunks are not culled (their chunks are short anyway)
 constexpr int CULL_COLS = 128;                              // columns per tile (the pair kernel's CPL = 2)
 constexpr int CULL_BOX = 2 * DW;                            // floats per bounding box: lo[16], hi[16]
+#ifndef TSC_CULL_XCD_RUN
+#define TSC_CULL_XCD_RUN 32
+#endif
+constexpr int CULL_XCD_RUN = TSC_CULL_XCD_RUN;              // option "cull_xcd": consecutive row groups (of 4 tiles) that stay on one XCD
 
 // ---- once per run: the structures in (coarse) Morton order of their descriptors ---------------------------------------------
 __device__ inline unsigned morton_cell(const float *__restrict__ d, float inv_dmax) {
@@ -347,6 +351,7 @@ struct CullArgs {
     const float *cbox, *rbox;
     int k;                  // chunks of the pass
     int tile_block;         // row tiles are dealt to the ranks in runs of this many consecutive tiles of the sorted layout (1: one by one)
+    int xcd_seg;            // 1: runs of row groups keyed to XCDs inside every column segment (k_rmsd_sieve_sorted), one work item per workgroup
 };
 
 // The pair kernel of a culled pass: one wavefront = (16 consecutive positions of the sorted layout) x (one segment of the
@@ -606,6 +611,30 @@ inline __global__ __launch_bounds__(256, TSC_SORTED_OCC) void k_rmsd_sieve_sorte
     // one segment (the same column tiles: one trip through the caches), segment after segment
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int groups = (my_tiles + 3) / 4;
+    if (ca.xcd_seg) {
+        // Row-group RUNS keyed to XCDs.  Workgroups go to the XCDs round-robin (workgroup b runs on XCD b % 8), each XCD has an L2 of its own,
+        // and a work item's columns are the 4096-position window behind its rows: with the items in plain order (below) the ~1 300
+        // workgroups in flight are consecutive row groups of ONE segment spread over all eight XCDs -- every L2 sees the whole
+        // 80 000-position window of descriptors (5 MB against its 4 MB; measured L2 hit rate 64 %).  Here, inside a segment, runs of
+        // CULL_XCD_RUN consecutive row groups go to the XCDs in turn: the workgroups an XCD has in flight come from a few runs and share
+        // their windows.  (Whole SEGMENTS keyed to XCDs -- round 5's first form -- took the L2 hit rate to 92 % and the fabric reads
+        // down 4.6x, and the pass 2.3 - 5x up: in a culled pass the work sits in the segments next to the diagonal, which two XCDs then
+        // did alone; profiles/r05_xcd_study.)
+        const int x = int(blockIdx.x & 7u);
+        const long long j = (long long)(blockIdx.x >> 3);
+        const int runs_per_xcd = (((groups + CULL_XCD_RUN - 1) / CULL_XCD_RUN) + 7) / 8;
+        const long long per_seg = (long long)runs_per_xcd * CULL_XCD_RUN;
+        const int seg = int(j / per_seg);
+        const int rem = int(j - (long long)seg * per_seg);
+        const int grp = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
+        if (seg < n_seg && grp < groups) sieve_item_sorted<16, F32>(heavy, act, Gall, cend, best, counters, st, a, ca, grp * 4 + wid, seg);
+        return;
+    }
+    if ((long long)gridDim.x >= (long long)groups * n_seg) {  // (the usual launch: a workgroup per item -- no loop to carry state across)
+        const int seg = int(blockIdx.x / unsigned(groups)), grp = int(blockIdx.x - unsigned(seg) * unsigned(groups));
+        if (seg < n_seg) sieve_item_sorted<16, F32>(heavy, act, Gall, cend, best, counters, st, a, ca, grp * 4 + wid, seg);
+        return;
+    }
     for (long long item = blockIdx.x; item < (long long)groups * n_seg; item += gridDim.x) {
         const int seg = int(item / groups), slot = int(item - (long long)seg * groups) * 4 + wid;
         sieve_item_sorted<16, F32>(heavy, act, Gall, cend, best, counters, st, a, ca, slot, seg);

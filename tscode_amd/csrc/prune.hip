@@ -553,7 +553,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         int nxt = -1;
         const StepArgs sa = p->cur_fused ? next_step_args(p, &nxt) : StepArgs{-1, -1, 0ll, 0, -1};
         static_assert(SCAN_TILE == 64 * SCAN_BLOCK_WORDS && DW == DESC_WORDS, "k_open_rows");
-        hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 4)), dim3(256), 0, st, g, oa, step_ctx(p, range), sa, p->act, p->cend, p->best, p->tile_cmax,
+        hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 16)), dim3(256), 0, st, g, oa, step_ctx(p, range), sa, p->act, p->cend, p->best, p->tile_cmax,
                            (const float *)p->Dall, p->Dc);
     }
     if (p->algo == ALGO_TILE) {
@@ -620,7 +620,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         a.heavy32 = p->heavy32;
         a.drain_min = c->drain_min;
         const int tb = world > 1 ? std::max(1, c->cull_tile_block) : 1;
-        CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k), tb};
+        CullArgs ca{p->Ds, p->crank, p->cbase, p->cbox, p->rbox, int(k), tb, c->cull_xcd};
         const int n_tiles = ceil_div(A, TILE_ROWS);
         // (slots of this rank: one by one, or whole runs of tb tiles -- an upper bound; slots beyond the last tile leave at once)
         const int my_tiles = tb <= 1 ? (n_tiles - rank + world - 1) / world : (n_tiles / (tb * world) + 1) * tb;
@@ -628,7 +628,9 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const int n_seg = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, a.seg_cols);
         hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
         const int64_t items = int64_t(ceil_div(my_tiles, 4)) * n_seg;
-        const dim3 sgrid(unsigned(std::max<int64_t>(1, std::min<int64_t>(items, c->cull_grid))));
+        // ("cull_xcd": one work item per workgroup, runs of row groups keyed to XCDs -- 8 XCDs x segments x the runs an XCD holds of a segment)
+        const int64_t xitems = int64_t(8) * n_seg * ceil_div(ceil_div(ceil_div(my_tiles, 4), CULL_XCD_RUN), 8) * CULL_XCD_RUN;
+        const dim3 sgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : std::min<int64_t>(items, c->cull_grid))));
         TSC_TRY(launch_rmsd_sieve_sorted(a.heavy32 != nullptr, st, sgrid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend,
                                          p->best, p->counters, (const PruneState *)p->state, a, ca, my_tiles, n_seg));
         if (range) {

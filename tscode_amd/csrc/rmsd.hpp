@@ -609,25 +609,29 @@ __device__ inline int select64(unsigned long long w, int k) {
     return p;
 }
 
-// Everything a pass needs per ROW, in one launch with no kernel in front of it: OPEN_LPR lanes per active row r, one
-// wavefront per 16 rows = one row tile of the pair kernel, four tiles per block.
+// Everything a pass needs per ROW, in one launch with no kernel in front of it: ONE LANE per active row r, one wavefront per 64 rows
+// = four row tiles of the pair kernel, four wavefronts per block.
 //   * which structure is the r-th active one: the scan block from the prefix of the block counts (boff, kept current by
 //     the kernel that closed the previous pass), the bit inside the block from the 32 words of the mask's bit copy --
-//     an ordered compaction without a scan pass over the whole mask;
+//     an ordered compaction without a scan pass over the whole mask.  The 64 rows of a wavefront are consecutive ranks, so they lie
+//     in one or two scan blocks: the wavefront stages a block's 32 words and their running popcounts in LDS ONCE (stage_block) and
+//     every row of that block finds its word by search and its bit by select;
 //   * cend[r] = rank of the first active column j in (i, last) with (first + (j - i)) in the cache view of this pass (the
 //     row returns "not similar" there, :66-67), else rank of `last`.  Columns of compacted rank in (r, cend[r]) are the
-//     ones the reference may still evaluate for row r;
+//     ones the reference may still evaluate for row r.  Ranks of positions come from staged blocks too: the rows of a wavefront
+//     share their chunk's end (one or two distinct targets), a cache hit lies a few positions behind its row;
 //   * act[r], best[r] = none, the row's descriptor copied to position r of Dc (the pair kernel reads rows and columns by
-//     position), the largest stop column of the tile;
+//     position), the largest stop column of every tile;
 //   * the other bit copy of the mask brought up to date (the rows this pass removes are cleared THERE, so that every row of
 //     the pass sees the mask as it was when the pass began, rmsd_pruning.py:151-157, whatever order the tiles finish in).
 // fused != 0: the pair kernel applies the verdicts of a row tile itself when the tile's last work item finishes, and the
 // last tile closes the pass.  A tile without work (no row with columns to look at; beyond the active count; the pass gated
 // off) has nothing to apply and arrives here.
+// (Rounds 2 - 4 gave a row 16, then 4 lanes: at a million structures 30 000 wavefronts each waited out the same memory round trips and
+// the kernel was bound by instruction issue -- 45 us per pass at C4, 12 at C3.  A lane per row is a quarter of the wavefronts and of
+// the wave-instructions per row.)
 constexpr int OPEN_LDS_BLOCKS = 2048;  // scan blocks whose prefix is staged in LDS (4 M structures); beyond: read from memory
-constexpr int OPEN_LPR = 4;            // lanes per row (measured: with 16, a million structures need 30 000 blocks that each
-                                       // wait out the same three memory round trips -- 86 us per pass)
-constexpr int OPEN_WPL = 32 / OPEN_LPR;  // words of a 2048-bit scan block per lane
+constexpr int OPEN_ROWS = 64;          // rows per wavefront
 struct OpenArgs {
     int use_cache, fused, lds_cap;
     const unsigned long long *view;  // cache view of this pass and its summary (bit_words behind it)
@@ -654,10 +658,13 @@ struct OpenArgs {
 inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs oa, StepCtx sc, StepArgs next, int32_t *__restrict__ act,
                                                     int32_t *__restrict__ cend, int32_t *__restrict__ best, int32_t *__restrict__ tile_cmax,
                                                     const float *__restrict__ D, float *__restrict__ Dc) {
-    static_assert(SCAN_BLOCK_WORDS == 32 && 64 / OPEN_LPR == 16 && DESC_WORDS == 4 * OPEN_LPR, "one wavefront = one row tile; a float4 of the descriptor per lane");
+    static_assert(SCAN_BLOCK_WORDS == 32 && OPEN_ROWS == 64 && DESC_WORDS == 16, "one wavefront = 64 rows = four row tiles; a block's 32 words on 32 lanes");
     __shared__ int s_boff[OPEN_LDS_BLOCKS + 1];
+    __shared__ unsigned long long s_w[4][SCAN_BLOCK_WORDS];   // per wavefront: the words of the scan block staged last ...
+    __shared__ int s_pre[4][SCAN_BLOCK_WORDS];                // ... and the set bits below each of them
     const PruneState *st = sc.st;
-    const int lane = threadIdx.x & 63, sub = lane / OPEN_LPR, sl = lane % OPEN_LPR;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (the first 256 entries of the prefix are requested together with the state block: one round trip for both)
     const bool in_lds = oa.n_blocks <= oa.lds_cap;
     const int boff_mine = (in_lds && int(threadIdx.x) <= oa.n_blocks) ? oa.boff[threadIdx.x] : 0;
@@ -667,102 +674,82 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
     // One read of the state per WORKGROUP: in a fused pass that is gated off the last tile to arrive -- possibly a wavefront of this
     // very launch -- opens the NEXT pass and rewrites the state block, and a wavefront of this block that started late would then
     // see the next pass's gate while its siblings saw this one's (a barrier below is conditional on it)
-#ifndef TSC_DBG_NO_STATE_LDS
     __shared__ int s_state[5];
     if (threadIdx.x == 0) s_state[0] = st->pass_on, s_state[1] = st->A, s_state[2] = st->bitsel, s_state[3] = st->row_lo, s_state[4] = st->n_active;
     __syncthreads();
     const int pass_on = s_state[0], A = s_state[1], sel = s_state[2], row_lo = s_state[3], n_all = s_state[4];
-#else   // (measurement hook: every wavefront reads the state block itself, as in round 2)
-    const int pass_on = st->pass_on, A = st->A, sel = st->bitsel, row_lo = st->row_lo, n_all = st->n_active;
-#endif
     const unsigned long long *X = oa.bits + size_t(sel) * oa.bit_words;
-    const unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int r0 = int(tile) * 16;
+    const unsigned wave = blockIdx.x * 4 + wid;          // rows 64 wave .. 64 wave + 63, tiles 4 wave .. 4 wave + 3
+    const int R0 = int(wave) * OPEN_ROWS;
+    const unsigned tile = wave * 4 + unsigned(lane >> 4);
     if (pass_on) {
         unsigned long long *Xo = oa.bits + size_t(sel ^ 1) * oa.bit_words;
         for (int w = blockIdx.x * 256 + threadIdx.x; w < oa.bit_words; w += gridDim.x * 256) Xo[w] = X[w];
     }
-    if (pass_on && in_lds && int(blockIdx.x) * 64 < A) {  // (block-uniform)
+    if (pass_on && in_lds && int(blockIdx.x) * 4 * OPEN_ROWS < A) {  // (block-uniform)
         if (int(threadIdx.x) <= oa.n_blocks) s_boff[threadIdx.x] = boff_mine;
         for (int e = threadIdx.x + 256; e <= oa.n_blocks; e += 256) s_boff[e] = oa.boff[e];
         __syncthreads();
     }
-    if (tile >= oa.n_tiles) return;  // (padding of the last block)
+    if (wave * 4 >= oa.n_tiles) return;  // (padding of the last block)
     TSC_OPEN_STAMP(1);  // bit copy made, prefix staged
-    bool dead = true;
-    if (pass_on && r0 < A) {
+    int my_c = 0;        // stop column of this lane's row (0 for lanes without one: the tile maxima below)
+    if (pass_on && R0 < A) {
         auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
-        const int r_true = r0 + sub;
+        unsigned long long *sw = s_w[wid];
+        int *sp = s_pre[wid];
+        // the 32 words of scan block b and the set bits below each of them -> this wavefront's LDS area (zeros beyond the last block)
+        auto stage_block = [&](int b) {
+            __builtin_amdgcn_wave_barrier();   // (everybody has finished with the block staged before)
+            unsigned long long w = 0ull;
+            if (lane < SCAN_BLOCK_WORDS && b < oa.n_blocks) w = X[size_t(b) * SCAN_BLOCK_WORDS + lane];
+            const int c = __popcll(w);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < SCAN_BLOCK_WORDS; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (lane < SCAN_BLOCK_WORDS) sw[lane] = w, sp[lane] = incl - c;
+            __builtin_amdgcn_wave_barrier();
+        };
+        const int r_true = R0 + lane;
         const bool mine = r_true < A;
-        const int r = mine ? r_true : A - 1;  // (idle groups walk along with the last row: the shuffles below stay convergent)
+        const int r = mine ? r_true : A - 1;  // (idle lanes walk along with the last row: the loops below stay convergent)
         const int rg = r + row_lo;            // its rank among ALL active structures
         // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg)
         int lo = 0, hi = oa.n_blocks;
-        while (hi - lo > 1) {
+        while (__ballot(hi - lo > 1)) {
             const int mid = (lo + hi) >> 1;
-            if (before(mid) <= rg) lo = mid;
-            else hi = mid;
-        }
-        int64_t i;
-        {
-            const int rem = rg - before(lo);
-            unsigned long long w[OPEN_WPL];
-            int c = 0;
-#pragma unroll
-            for (int u = 0; u < OPEN_WPL; ++u) w[u] = X[size_t(lo) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u], c += __popcll(w[u]);
-            int incl = c;
-#pragma unroll
-            for (int off = 1; off < OPEN_LPR; off <<= 1) {
-                const int t = __shfl_up(incl, off, OPEN_LPR);
-                if (sl >= off) incl += t;
+            if (hi - lo > 1) {
+                if (before(mid) <= rg) lo = mid;
+                else hi = mid;
             }
-            int t = rem - (incl - c);  // index of the wanted bit among this lane's; exactly one lane of the row holds it
-            const bool here = t >= 0 && t < c;
-            int pos = 0;
-            if (here) {
-#pragma unroll
-                for (int u = 0; u < OPEN_WPL; ++u) {
-                    const int cu = __popcll(w[u]);
-                    if (t >= 0 && t < cu) pos = 64 * (OPEN_WPL * sl + u) + select64(w[u], t);
-                    t -= cu;  // (negative from here on, or still to come)
-                }
-            }
-            const unsigned hit = unsigned(__ballot(here) >> (OPEN_LPR * sub)) & ((1u << OPEN_LPR) - 1u);
-            pos = __shfl(pos, OPEN_LPR * sub + (__ffs(hit) - 1));
-            i = int64_t(lo) * oa.block_items + pos;
         }
+        const int rem = rg - before(lo);      // the row is the rem-th active structure of its scan block
+        int pos = 0;
+        for (unsigned long long pending = __ballot(true); pending;) {   // the (one or two) distinct scan blocks of this wavefront's rows
+            const int b = __builtin_amdgcn_readlane(lo, __ffsll((long long)pending) - 1);
+            stage_block(b);
+            if (lo == b) {
+                int u = 0;                     // the last word with sp[u] <= rem
+#pragma unroll
+                for (int s = SCAN_BLOCK_WORDS / 2; s > 0; s >>= 1)
+                    if (sp[u + s] <= rem) u += s;
+                pos = 64 * u + select64(sw[u], rem - sp[u]);
+            }
+            pending &= ~__ballot(lo == b);
+        }
+        const int64_t i = int64_t(lo) * oa.block_items + pos;
         int64_t first, last;
         chunk_of(g, i, first, last);
-        f32x4 dval = {0.0f, 0.0f, 0.0f, 0.0f};
         TSC_OPEN_STAMP(2);  // the row's structure found
-        if (D) dval = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * sl);
-        // rank of a position = active structures before it: the prefix of its scan block + the set bits of the block below it
-        // (OPEN_WPL words per lane, summed over the row's lanes)
-        auto block_words = [&](int64_t pos, unsigned long long (&w)[OPEN_WPL]) {
-            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
+        f32x4 dval[4];
+        if (D) {
 #pragma unroll
-            for (int u = 0; u < OPEN_WPL; ++u) {
-                const int wlo = 64 * (OPEN_WPL * sl + u);
-                w[u] = (bf < oa.n_blocks && wlo < off) ? X[size_t(bf) * SCAN_BLOCK_WORDS + OPEN_WPL * sl + u] : 0ull;
-            }
-        };
-        auto rank_of = [&](int64_t pos, const unsigned long long (&w)[OPEN_WPL]) {
-            const int bf = int(pos / oa.block_items), off = int(pos - int64_t(bf) * oa.block_items);
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < OPEN_WPL; ++u) {
-                const int below = off - 64 * (OPEN_WPL * sl + u);  // bits of this word that lie below the position
-                const unsigned long long m = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1ull : 0ull);
-                cnt += __popcll(w[u] & m);
-            }
-#pragma unroll
-            for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-            return (bf < oa.n_blocks ? before(bf) : n_all) + cnt - row_lo;
-        };
-        // the stop column is the end of the chunk unless the cache view has a hit (rare): its words are requested now, with
-        // the descriptor and the view's summary, not after the walk through the view
-        unsigned long long wr[OPEN_WPL];
-        block_words(last, wr);
+            for (int q = 0; q < 4; ++q) dval[q] = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * q);
+        }
+        // the stop column is the end of the chunk unless the cache view has a hit (rare)
         int64_t found = last;
         if (oa.use_cache) {
             // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
@@ -774,75 +761,85 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             int64_t B = p_lo >> 10;
             const int64_t B_hi = p_hi >> 10;
             bool scanning = len > 0;
-            while (__ballot(scanning) != 0) {
-                if (scanning) {  // next non-empty block at or after B (the lanes of a row agree)
-                    bool any = false;
-                    while (B <= B_hi) {
-                        const unsigned long long sw = dsum[B >> 6] >> (B & 63);
-                        if (sw) {
-                            B += __ffsll((long long)sw) - 1;
-                            any = B <= B_hi;
-                            break;
-                        }
-                        B = ((B >> 6) + 1) << 6;
+            while (scanning) {
+                bool any = false;            // next non-empty block at or after B
+                while (B <= B_hi) {
+                    const unsigned long long sb = dsum[B >> 6] >> (B & 63);
+                    if (sb) {
+                        B += __ffsll((long long)sb) - 1;
+                        any = B <= B_hi;
+                        break;
                     }
-                    scanning = any;
+                    B = ((B >> 6) + 1) << 6;
                 }
-                // the 16 words of the block, 16 / OPEN_LPR per lane: first cached column this lane sees (mask position), or none
-                int64_t cand = INT64_MAX;
-                if (scanning) {
-#pragma unroll
-                    for (int u = 16 / OPEN_LPR - 1; u >= 0; --u) {
-                        const int64_t p0 = (B * 16 + (16 / OPEN_LPR) * sl + u) * 64;  // first position of this word
-                        if (p0 <= p_hi && p0 + 63 >= p_lo) {
-                            unsigned long long w = dbit[p0 >> 6] & extract64(X, p0 + shift);
-                            if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
-                            if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
-                            if (w) cand = p0 + (__ffsll((long long)w) - 1) + shift;
+                if (!any) break;
+                // the 16 words of the block in ascending order: the first cached column (mask position) ends the walk
+                for (int u = 0; u < 16 && scanning; ++u) {
+                    const int64_t p0 = (B * 16 + u) * 64;  // first position of this word
+                    if (p0 <= p_hi && p0 + 63 >= p_lo) {
+                        unsigned long long w = dbit[p0 >> 6];
+                        if (w) w &= extract64(X, p0 + shift);
+                        if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
+                        if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
+                        if (w) {
+                            found = p0 + (__ffsll((long long)w) - 1) + shift;
+                            scanning = false;
                         }
                     }
                 }
-#pragma unroll
-                for (int o = OPEN_LPR / 2; o > 0; o >>= 1) cand = min(cand, (int64_t)__shfl_xor((long long)cand, o));
-                if (scanning && cand != INT64_MAX) {
-                    found = cand;
-                    scanning = false;
-                } else {
-                    ++B;
-                    if (B > B_hi) scanning = false;
-                }
+                ++B;
+                if (B > B_hi) scanning = false;
             }
         }
-        if (found != last) block_words(found, wr);  // (the lanes of a row agree)
-        int my_c = rank_of(found, wr);
+        // rank of the stop position = active structures before it: the prefix of its scan block + the set bits of the block below it.
+        // The rows of a wavefront share their targets' scan blocks (the chunk's end; a hit a few positions behind its row): one staging
+        // per distinct block
+        {
+            const int bf = int(found / oa.block_items), off = int(found - int64_t(bf) * oa.block_items);
+            for (unsigned long long pending = __ballot(true); pending;) {
+                const int b = __builtin_amdgcn_readlane(bf, __ffsll((long long)pending) - 1);
+                stage_block(b);
+                if (bf == b) {
+                    const int u = off >> 6, below = off & 63;
+                    const int cnt = sp[u] + __popcll(sw[u] & (below ? (~0ull >> (64 - below)) : 0ull));
+                    my_c = (b < oa.n_blocks ? before(b) : n_all) + cnt - row_lo;
+                }
+                pending &= ~__ballot(bf == b);
+            }
+        }
         TSC_OPEN_STAMP(3);  // stop column and its rank
-        if (mine && D) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * sl) = dval;
-        if (mine && sl == 0) {
+        if (mine) {
+            if (D) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * q) = dval[q];
+            }
             act[r] = int32_t(i);
             cend[r] = my_c;
             best[r] = INT_MAX;  // atomicMin target of the pair kernel: no similar column found yet
             if (oa.rank_of) oa.rank_of[i] = r;
         }
         if (oa.rank_of) {  // a pass that may be culled: how many pairs lie inside the rows' ranges (what the ordered walk would look at)
-            long long w = (mine && sl == 0) ? (long long)max(0, my_c - r - 1) : 0ll;
+            long long w = mine ? (long long)max(0, my_c - r - 1) : 0ll;
             for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
-            if (lane == 0) count_add(sc.cnt, tile, CNT_WALK, (unsigned long long)w);
+            if (lane == 0) count_add(sc.cnt, wave, CNT_WALK, (unsigned long long)w);
         }
-        // largest stop column of the 16 rows of this tile: lets a work item of the pair kernel whose column segment lies
-        // beyond it leave after one scalar load
         if (!mine) my_c = 0;
-        for (int off = 32; off > 0; off >>= 1) my_c = max(my_c, __shfl_xor(my_c, off));
-        if (lane == 0) tile_cmax[tile] = my_c;
-        dead = my_c <= ((r0 + 1) & ~63);  // no work item of the pair kernel will find a column for this tile
         TSC_OPEN_STAMP(4);  // everything written
-    } else if (lane == 0) {
-        tile_cmax[tile] = 0;  // every work item of this tile leaves at its first test
     }
-    if (!oa.fused || !dead) return;
+    // largest stop column of the 16 rows of every tile: lets a work item of the pair kernel whose column segment lies
+    // beyond it leave after one scalar load (0: every work item of the tile leaves at its first test -- also for a pass that is
+    // gated off and for tiles beyond the active count)
+    int cmax = my_c;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    const bool tile_lane = (lane & 15) == 0 && tile < oa.n_tiles;
+    if (tile_lane) tile_cmax[tile] = cmax;
+    // no work item of the pair kernel will find a column for this tile: it has nothing to apply and arrives here
+    const bool dead = tile_lane && cmax <= ((int(tile) * 16 + 1) & ~63);
+    if (!oa.fused || !__ballot(dead)) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int fin = 0;
-    if (lane == 0) fin = tickets_arrive(oa.tickets, tile, oa.n_tiles, PT_GROUPS) ? 1 : 0;
-    if (__builtin_amdgcn_readfirstlane(fin)) pass_step_wave(sc, next);
+    const bool fin = dead && tickets_arrive(oa.tickets, tile, oa.n_tiles, PT_GROUPS);
+    if (__ballot(fin)) pass_step_wave(sc, next);
 }
 
 // The verdicts of up to 64 rows of a finished pass, one row per lane (a whole wavefront calls this): rows with a similar
