@@ -632,6 +632,7 @@ __device__ inline int select64(unsigned long long w, int k) {
 // the wave-instructions per row.)
 constexpr int OPEN_LDS_BLOCKS = 2048;  // scan blocks whose prefix is staged in LDS (4 M structures); beyond: read from memory
 constexpr int OPEN_ROWS = 64;          // rows per wavefront
+constexpr int OPEN_LIST_CAP = 64 + 1024;  // a refill stops once it holds 64 entries; the block that takes it there adds 1024 at most
 struct OpenArgs {
     int use_cache, fused, lds_cap;
     const unsigned long long *view;  // cache view of this pass and its summary (bit_words behind it)
@@ -662,6 +663,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
     __shared__ int s_boff[OPEN_LDS_BLOCKS + 1];
     __shared__ unsigned long long s_w[4][SCAN_BLOCK_WORDS];   // per wavefront: the words of the scan block staged last ...
     __shared__ int s_pre[4][SCAN_BLOCK_WORDS];                // ... and the set bits below each of them
+    __shared__ int s_list[4][OPEN_LIST_CAP];                  // per wavefront: deltas of the cache view's set bits inside its chunk, ascending
     const PruneState *st = sc.st;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -695,14 +697,18 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
     TSC_OPEN_STAMP(1);  // bit copy made, prefix staged
     int my_c = 0;        // stop column of this lane's row (0 for lanes without one: the tile maxima below)
     if (pass_on && R0 < A) {
+        // The kernel is a chain of dependent memory round trips (a light pass is bound by it, not by work): loads that do not depend on
+        // each other are issued TOGETHER -- (1) state + prefix, above; (2) the words of the rows' scan blocks; (3) descriptors, the cache
+        // view's summary and the words of the stop positions' scan block; then the stores.
         auto before = [&](int b) { return in_lds ? s_boff[b] : oa.boff[b]; };
         unsigned long long *sw = s_w[wid];
         int *sp = s_pre[wid];
-        // the 32 words of scan block b and the set bits below each of them -> this wavefront's LDS area (zeros beyond the last block)
-        auto stage_block = [&](int b) {
+        auto load_block = [&](int b) -> unsigned long long {   // word `lane` of scan block b (zeros beyond the last block)
+            return (lane < SCAN_BLOCK_WORDS && b < oa.n_blocks) ? X[size_t(b) * SCAN_BLOCK_WORDS + lane] : 0ull;
+        };
+        // a block's 32 words and the set bits below each of them -> this wavefront's LDS area
+        auto stage_words = [&](unsigned long long w) {
             __builtin_amdgcn_wave_barrier();   // (everybody has finished with the block staged before)
-            unsigned long long w = 0ull;
-            if (lane < SCAN_BLOCK_WORDS && b < oa.n_blocks) w = X[size_t(b) * SCAN_BLOCK_WORDS + lane];
             const int c = __popcll(w);
             int incl = c;
 #pragma unroll
@@ -717,54 +723,155 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
         const bool mine = r_true < A;
         const int r = mine ? r_true : A - 1;  // (idle lanes walk along with the last row: the loops below stay convergent)
         const int rg = r + row_lo;            // its rank among ALL active structures
-        // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg)
-        int lo = 0, hi = oa.n_blocks;
-        while (__ballot(hi - lo > 1)) {
-            const int mid = (lo + hi) >> 1;
-            if (hi - lo > 1) {
-                if (before(mid) <= rg) lo = mid;
-                else hi = mid;
+        // scan block of rank rg: the last b with boff[b] <= rg  (boff[0] = 0, boff[n_blocks] = n_all > rg).  The wavefront's rows are
+        // consecutive ranks: the block of its FIRST row by a 64-way search (the lanes test 64 boundaries at once, coarse then fine --
+        // three trips to LDS for up to 262 144 blocks instead of one per halving), the others a boundary or two further on
+        int lo;
+        {
+            const int rg0 = __builtin_amdgcn_readfirstlane(rg);
+            int base = 0, span = oa.n_blocks;   // invariant: boff[base] <= rg0 < boff[base + span]
+            while (span > 1) {
+                const int step = (span + 63) >> 6;
+                const int b = base + lane * step;
+                const unsigned long long le = __ballot(b < base + span && before(b) <= rg0);   // lane 0 always (the invariant)
+                const int q = __popcll(le) - 1;           // boundaries are ascending: the set lanes are 0 .. q
+                base += q * step;
+                span = min(step, oa.n_blocks - base);
             }
+            lo = base;
+            while (__ballot(lo + 1 < oa.n_blocks && before(lo + 1) <= rg))
+                if (lo + 1 < oa.n_blocks && before(lo + 1) <= rg) ++lo;
         }
         const int rem = rg - before(lo);      // the row is the rem-th active structure of its scan block
         int pos = 0;
-        for (unsigned long long pending = __ballot(true); pending;) {   // the (one or two) distinct scan blocks of this wavefront's rows
-            const int b = __builtin_amdgcn_readlane(lo, __ffsll((long long)pending) - 1);
-            stage_block(b);
-            if (lo == b) {
-                int u = 0;                     // the last word with sp[u] <= rem
+        {
+            // the (one or two, on sparse masks more) distinct scan blocks of this wavefront's rows: the first and the last are requested
+            // together
+            const int b_first = __builtin_amdgcn_readfirstlane(lo), b_last = __builtin_amdgcn_readlane(lo, 63);
+            const unsigned long long w_first = load_block(b_first);
+            const unsigned long long w_last = b_last != b_first ? load_block(b_last) : 0ull;
+            for (unsigned long long pending = __ballot(true); pending;) {
+                const int b = __builtin_amdgcn_readlane(lo, __ffsll((long long)pending) - 1);
+                stage_words(b == b_first ? w_first : (b == b_last ? w_last : load_block(b)));
+                if (lo == b) {
+                    int u = 0;                     // the last word with sp[u] <= rem
 #pragma unroll
-                for (int s = SCAN_BLOCK_WORDS / 2; s > 0; s >>= 1)
-                    if (sp[u + s] <= rem) u += s;
-                pos = 64 * u + select64(sw[u], rem - sp[u]);
+                    for (int s2 = SCAN_BLOCK_WORDS / 2; s2 > 0; s2 >>= 1)
+                        if (sp[u + s2] <= rem) u += s2;
+                    pos = 64 * u + select64(sw[u], rem - sp[u]);
+                }
+                pending &= ~__ballot(lo == b);
             }
-            pending &= ~__ballot(lo == b);
         }
         const int64_t i = int64_t(lo) * oa.block_items + pos;
         int64_t first, last;
         chunk_of(g, i, first, last);
         TSC_OPEN_STAMP(2);  // the row's structure found
+        // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
+        // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
+        // blocks of it, found through the summary bitmap, instead of every block of its chunk
+        const unsigned long long *dbit = oa.view, *dsum = oa.view + oa.bit_words;
+        const int64_t len = mine ? last - i - 1 : 0;
+        const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
+        const bool walk = oa.use_cache != 0 && len > 0;
+        // one batch of requests: the descriptor, the first summary word of the cache view, the scan block of the chunk's end
         f32x4 dval[4];
         if (D) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) dval[q] = *reinterpret_cast<const f32x4 *>(D + i * 16 + 4 * q);
         }
-        // the stop column is the end of the chunk unless the cache view has a hit (rare)
+        const unsigned long long sum_first = walk ? dsum[(p_lo >> 10) >> 6] : 0ull;
+        const int bl_first = __builtin_amdgcn_readfirstlane(int(last / oa.block_items));
+        const unsigned long long wl_first = load_block(bl_first);
+        // The stop column is the end of the chunk unless the cache view has a hit: the first delta d >= 1 whose key (first, first + d) is in the
+        // view AND whose column i + d is active (rmsd_pruning.py:65-67).
+        // Rows of ONE chunk (every wavefront of a late pass) look at the same view bits, shifted against the mask by their own position: the
+        // wavefront lists the view's set bits once (in LDS, ascending, 64 or more at a time, walking the non-empty 1024-bit blocks through the
+        // summary) and every row tests ITS mask bit behind each of them, eight at a time.  A hit comes after a few tests -- a row's
+        // column is active more often than not -- where a walk word by word and row by row was as long as the unluckiest of the 64 rows
+        // (the k = 1 pass of C3: 68 us for 21 000 rows).  Wavefronts whose rows lie in several chunks (early passes: short chunks, nearly empty
+        // views) walk lane by lane, below.
+        const bool one_chunk = __ballot(first != __shfl(first, 0)) == 0;
         int64_t found = last;
-        if (oa.use_cache) {
-            // candidate deltas d = 1 .. len, i.e. cache-view positions P = first + d in [p_lo, p_hi]; the view is sparse (a
-            // key applies to a pass only when its chunk start is one of this pass's), so the row walks the NON-EMPTY 1024-bit
-            // blocks of it, found through the summary bitmap, instead of every block of its chunk
-            const unsigned long long *dbit = oa.view, *dsum = oa.view + oa.bit_words;
-            const int64_t len = mine ? last - i - 1 : 0;
-            const int64_t p_lo = first + 1, p_hi = first + len, shift = i - first;  // mask position of P is P + shift
-            int64_t B = p_lo >> 10;
-            const int64_t B_hi = p_hi >> 10;
+        if (oa.use_cache != 0 && one_chunk) {
+            int *list = s_list[wid];
+            const int64_t dmax = __shfl(len, 0);              // rows ascend: lane 0 has the longest range (and is always a row of the pass)
+            const unsigned long long sum0 = (unsigned long long)__shfl((long long)sum_first, 0);   // (lanes without a range of their own loaded none)
+            int64_t Bc = (first + 1) >> 10;
+            const int64_t Bh = (first + dmax) >> 10;
             bool scanning = len > 0;
+            while (__ballot(scanning)) {
+                int n_list = 0;
+                while (n_list < 64 && Bc <= Bh) {             // (wave-uniform: every lane holds the same first, dmax, Bc)
+                    const unsigned long long sb = ((Bc >> 6) == ((p_lo >> 10) >> 6) ? sum0 : dsum[Bc >> 6]) >> (Bc & 63);
+                    if (!sb) {
+                        Bc = ((Bc >> 6) + 1) << 6;
+                        continue;
+                    }
+                    Bc += __ffsll((long long)sb) - 1;
+                    if (Bc > Bh) break;
+                    const int64_t p0 = (Bc * 16 + (lane & 15)) * 64;
+                    unsigned long long w = 0ull;
+                    if (lane < 16 && p0 <= first + dmax && p0 + 63 >= first + 1) {
+                        w = dbit[p0 >> 6];
+                        if (p0 < first + 1) w &= (first + 1 - p0 < 64) ? (~0ull << (first + 1 - p0)) : 0ull;
+                        if (first + dmax - p0 < 63) w &= (2ull << (first + dmax - p0)) - 1ull;
+                    }
+                    const int c = __popcll(w);
+                    int incl = c;
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        const int t = __shfl_up(incl, off);
+                        if (lane >= off) incl += t;
+                    }
+                    const int total = __builtin_amdgcn_readlane(incl, 15);
+                    int kk = n_list + incl - c;
+                    while (w) {
+                        list[kk++] = int(p0 + (__ffsll((long long)w) - 1) - first);
+                        w &= w - 1;
+                    }
+                    n_list += total;
+                    ++Bc;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (n_list == 0) break;                        // the view has no further key inside the chunk: no row stops early
+                int kidx = 0;
+                while (__ballot(scanning && kidx < n_list)) {
+                    if (scanning && kidx < n_list) {
+                        int dd[8];
+                        unsigned long long mw[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) dd[t] = kidx + t < n_list ? list[kidx + t] : INT_MAX;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) mw[t] = int64_t(dd[t]) <= len ? X[(i + dd[t]) >> 6] : 0ull;
+                        int hit = -1;
+#pragma unroll
+                        for (int t = 7; t >= 0; --t)
+                            if (int64_t(dd[t]) <= len && ((mw[t] >> ((i + dd[t]) & 63)) & 1ull)) hit = dd[t];
+                        bool beyond = false;                   // the (ascending) list has left this row's range
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) beyond = beyond || (dd[t] != INT_MAX && int64_t(dd[t]) > len);
+                        if (hit >= 0) found = i + hit, scanning = false;
+                        else if (beyond) scanning = false;
+                        kidx += 8;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();               // (before the list is refilled)
+                // a row still scanning here has used up this list: on to the next non-empty blocks (none left: n_list = 0 above)
+                if (Bc > Bh) {
+                    // (the range is exhausted: rows that have not hit anything keep found = last)
+                    break;
+                }
+            }
+        }
+        if (walk && !one_chunk) {
+            int64_t B = p_lo >> 10;
+            const int64_t B_hi = p_hi >> 10, S_first = (p_lo >> 10) >> 6;
+            bool scanning = true;
             while (scanning) {
                 bool any = false;            // next non-empty block at or after B
                 while (B <= B_hi) {
-                    const unsigned long long sb = dsum[B >> 6] >> (B & 63);
+                    const unsigned long long sb = ((B >> 6) == S_first ? sum_first : dsum[B >> 6]) >> (B & 63);
                     if (sb) {
                         B += __ffsll((long long)sb) - 1;
                         any = B <= B_hi;
@@ -773,19 +880,23 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
                     B = ((B >> 6) + 1) << 6;
                 }
                 if (!any) break;
-                // the 16 words of the block in ascending order: the first cached column (mask position) ends the walk
-                for (int u = 0; u < 16 && scanning; ++u) {
+                // the 16 words of the block: requested together (one round trip, not one per word), then the mask words behind the
+                // non-empty ones; in ascending order the first cached column (mask position) ends the walk
+                unsigned long long vw[16], xw[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
                     const int64_t p0 = (B * 16 + u) * 64;  // first position of this word
-                    if (p0 <= p_hi && p0 + 63 >= p_lo) {
-                        unsigned long long w = dbit[p0 >> 6];
-                        if (w) w &= extract64(X, p0 + shift);
-                        if (p0 < p_lo) w &= ~0ull << (p_lo - p0);
-                        if (p_hi - p0 < 63) w &= (2ull << (p_hi - p0)) - 1ull;
-                        if (w) {
-                            found = p0 + (__ffsll((long long)w) - 1) + shift;
-                            scanning = false;
-                        }
-                    }
+                    unsigned long long w = (p0 <= p_hi && p0 + 63 >= p_lo) ? dbit[p0 >> 6] : 0ull;
+                    if (p0 < p_lo) w &= (p_lo - p0 < 64) ? (~0ull << (p_lo - p0)) : 0ull;
+                    if (p_hi - p0 < 63) w &= p_hi >= p0 ? ((2ull << (p_hi - p0)) - 1ull) : 0ull;
+                    vw[u] = w;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) xw[u] = vw[u] ? extract64(X, (B * 16 + u) * 64 + shift) : 0ull;
+#pragma unroll
+                for (int u = 15; u >= 0; --u) {
+                    const unsigned long long w = vw[u] & xw[u];
+                    if (w) found = (B * 16 + u) * 64 + (__ffsll((long long)w) - 1) + shift, scanning = false;
                 }
                 ++B;
                 if (B > B_hi) scanning = false;
@@ -798,7 +909,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             const int bf = int(found / oa.block_items), off = int(found - int64_t(bf) * oa.block_items);
             for (unsigned long long pending = __ballot(true); pending;) {
                 const int b = __builtin_amdgcn_readlane(bf, __ffsll((long long)pending) - 1);
-                stage_block(b);
+                stage_words(b == bl_first ? wl_first : load_block(b));
                 if (bf == b) {
                     const int u = off >> 6, below = off & 63;
                     const int cnt = sp[u] + __popcll(sw[u] & (below ? (~0ull >> (64 - below)) : 0ull));
