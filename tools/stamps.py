@@ -49,12 +49,17 @@ print("phase (us)                                    min     p50     p90     p99
 print("wavefront start after the first one        ", pct(s[started, 0] - t_start))
 names = ["prologue (start -> data arrived)", "screen", "drains (candidates evaluated)", "-> arrived at the tile counter", "apply the tile",
          "-> arrived at the pass counter", "close the pass"]
-if k < 0:      # k_open_rows of pass -k: 0 started, 1 bit copy made and prefix staged, 2 structure of the row found, 3 stop column and rank, 4 written
-    names = ["bit copy, prefix -> LDS", "search + select (the row's structure)", "descriptor, cache view, rank of the stop column", "stores"]
+if k < 0:      # k_open_rows of pass -k: 0 started, 1 bit copy made and prefix staged, 2 structure of the row found, 3 cache view walked, 4 rank of the stop column, 5 written
+    names = ["bit copy, prefix -> LDS", "search + select (the row's structure)", "descriptor requested, cache view walked", "rank of the stop column", "stores"]
 for i, nm in enumerate(names, start=1):
     m = (s[:, i] > 0) & (s[:, i - 1] > 0)
     if m.any():
         print(f"{nm:43s}", pct(s[m, i] - s[m, i - 1]), f"  ({int(m.sum())} wavefronts)")
+if k < 0:      # (inside the cooperative walk: 6 = the list refilled (last time), 7 = the list tested (last time))
+    for a, b, nm in ((2, 6, "row found -> list refilled (last refill)"), (6, 7, "list refilled -> tested (last round)"), (7, 3, "tested -> walk done")):
+        m = (s[:, a] > 0) & (s[:, b] > 0)
+        if m.any():
+            print(f"{nm:43s}", pct(s[m, b] - s[m, a]), f"  ({int(m.sum())} wavefronts)")
 for i in (1, 2, 3, 4, 5, 6, 7):
     m = s[:, i] > 0
     if m.any():

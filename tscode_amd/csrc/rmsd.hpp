@@ -802,38 +802,62 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             bool scanning = len > 0;
             while (__ballot(scanning)) {
                 int n_list = 0;
-                while (n_list < 64 && Bc <= Bh) {             // (wave-uniform: every lane holds the same first, dmax, Bc)
-                    const unsigned long long sb = ((Bc >> 6) == ((p_lo >> 10) >> 6) ? sum0 : dsum[Bc >> 6]) >> (Bc & 63);
+                while (n_list < 64 && Bc <= Bh) {             // (wave-uniform: every lane holds the same first, dmax, Bc, n_list)
+                    // up to 16 of the next non-empty blocks at once, four lanes per block and four words per lane: a sparse view (C3's
+                    // last pass: 96 keys over 30 blocks) is listed in one round trip, not one per block
+                    const unsigned long long sb = ((Bc >> 6) == ((p_lo >> 10) >> 6) ? sum0 : dsum[Bc >> 6]) >> (Bc & 63);   // bit t: block Bc + t
                     if (!sb) {
                         Bc = ((Bc >> 6) + 1) << 6;
                         continue;
                     }
-                    Bc += __ffsll((long long)sb) - 1;
-                    if (Bc > Bh) break;
-                    const int64_t p0 = (Bc * 16 + (lane & 15)) * 64;
-                    unsigned long long w = 0ull;
-                    if (lane < 16 && p0 <= first + dmax && p0 + 63 >= first + 1) {
-                        w = dbit[p0 >> 6];
-                        if (p0 < first + 1) w &= (first + 1 - p0 < 64) ? (~0ull << (first + 1 - p0)) : 0ull;
-                        if (first + dmax - p0 < 63) w &= (2ull << (first + dmax - p0)) - 1ull;
+                    const int j = lane >> 2, q = lane & 3;
+                    int64_t Bj = -1;
+                    if (j < __popcll(sb)) {
+                        Bj = Bc + select64(sb, j);
+                        if (Bj > Bh) Bj = -1;
                     }
-                    const int c = __popcll(w);
+                    unsigned long long w4[4] = {0ull, 0ull, 0ull, 0ull};
+                    int c = 0;
+                    if (Bj >= 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t p0 = (Bj * 16 + 4 * q + u) * 64;
+                            unsigned long long w = 0ull;
+                            if (p0 <= first + dmax && p0 + 63 >= first + 1) {
+                                w = dbit[p0 >> 6];
+                                if (p0 < first + 1) w &= (first + 1 - p0 < 64) ? (~0ull << (first + 1 - p0)) : 0ull;
+                                if (first + dmax - p0 < 63) w &= (2ull << (first + dmax - p0)) - 1ull;
+                            }
+                            w4[u] = w;
+                            c += __popcll(w);
+                        }
+                    }
                     int incl = c;
 #pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) {
+                    for (int off = 1; off < 64; off <<= 1) {
                         const int t = __shfl_up(incl, off);
                         if (lane >= off) incl += t;
                     }
-                    const int total = __builtin_amdgcn_readlane(incl, 15);
-                    int kk = n_list + incl - c;
-                    while (w) {
-                        list[kk++] = int(p0 + (__ffsll((long long)w) - 1) - first);
-                        w &= w - 1;
+                    // whole blocks, in order, as long as the list has room (the first always fits: a block holds 1024 keys at most)
+                    const bool fits = Bj >= 0 && __shfl(incl, lane | 3) <= OPEN_LIST_CAP - n_list;
+                    const int n_valid = __popcll(__ballot(Bj >= 0 && q == 3)), n_fit = __popcll(__ballot(fits && q == 3));
+                    if (fits) {
+                        int kk = n_list + incl - c;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t p0 = (Bj * 16 + 4 * q + u) * 64;
+                            for (unsigned long long w = w4[u]; w; w &= w - 1) list[kk++] = int(p0 + (__ffsll((long long)w) - 1) - first);
+                        }
                     }
-                    n_list += total;
-                    ++Bc;
+                    if (n_valid == 0) {
+                        Bc = Bh + 1;                            // the summary's next blocks lie beyond the chunk
+                    } else {
+                        n_list += __shfl(incl, 4 * n_fit - 1);
+                        Bc = __shfl(Bj, 4 * n_fit - 1) + 1;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
+                TSC_OPEN_STAMP(6);  // (the list refilled)
                 if (n_list == 0) break;                        // the view has no further key inside the chunk: no row stops early
                 int kidx = 0;
                 while (__ballot(scanning && kidx < n_list)) {
@@ -857,6 +881,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
                     }
                 }
                 __builtin_amdgcn_wave_barrier();               // (before the list is refilled)
+                TSC_OPEN_STAMP(7);  // (the list tested)
                 // a row still scanning here has used up this list: on to the next non-empty blocks (none left: n_list = 0 above)
                 if (Bc > Bh) {
                     // (the range is exhausted: rows that have not hit anything keep found = last)
@@ -902,6 +927,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
                 if (B > B_hi) scanning = false;
             }
         }
+        TSC_OPEN_STAMP(3);  // the cache view walked
         // rank of the stop position = active structures before it: the prefix of its scan block + the set bits of the block below it.
         // The rows of a wavefront share their targets' scan blocks (the chunk's end; a hit a few positions behind its row): one staging
         // per distinct block
@@ -918,7 +944,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
                 pending &= ~__ballot(bf == b);
             }
         }
-        TSC_OPEN_STAMP(3);  // stop column and its rank
+        TSC_OPEN_STAMP(4);  // stop column's rank
         if (mine) {
             if (D) {
 #pragma unroll
@@ -935,7 +961,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             if (lane == 0) count_add(sc.cnt, wave, CNT_WALK, (unsigned long long)w);
         }
         if (!mine) my_c = 0;
-        TSC_OPEN_STAMP(4);  // everything written
+        TSC_OPEN_STAMP(5);  // everything written
     }
     // largest stop column of the 16 rows of every tile: lets a work item of the pair kernel whose column segment lies
     // beyond it leave after one scalar load (0: every work item of the tile leaves at its first test -- also for a pass that is
