@@ -74,8 +74,12 @@ if STEP_TIMES:      # debugging aid: every garbage collection with its generatio
         else:
             print(f"gc gen {info['generation']}: {(time.perf_counter() - _gc_t[0]) * 1e3:.2f} ms, collected {info['collected']}", file=sys.stderr)
     gc.callbacks.append(_gc_note)
-PMC_PROFILES = ("r04_pmc_hbm_counters.json", "r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
-PMC_PROFILES_C4 = ("r04_pmc_hbm_counters_C4.json",)
+SQ_PROFILES = {"C3": ("r05_sq_counters_c3.json",), "C4": ("r05_sq_counters_c4.json",)}   # tools/pmc_sq.sh summaries (profiles/): VALU issue of the pair kernels
+GPU_CLOCK_GHZ = 2.4              # MI355X engine clock: CU-cycles of a launch = duration x clock x 256 CUs
+SCREEN_FLOP_PER_PAIR = 36        # the screen as executed: 18 v_pk_fma_f32 per (row, 128 columns) = 2 families x 9 FMA per pair (8 of the dot product
+                                 # + 1 that turns it into the squared distance); DESIGN.md section 4 counts the same
+PMC_PROFILES = ("r05_pmc_hbm_counters.json", "r04_pmc_hbm_counters.json", "r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json", "r01_final_pmc_hbm_counters.json")   # newest first (profiles/)
+PMC_PROFILES_C4 = ("r05_pmc_hbm_counters_C4.json", "r04_pmc_hbm_counters_C4.json")
 
 
 def parse():
@@ -658,8 +662,8 @@ def main():
                                    f"rocprofv3 --pmc, separate passes")
                 break
         hbm_achieved = b_launch / avg_launch_s / 1e9 if avg_launch_s else None
-        # What the instructions execute (the PRIMARY compute figure): the fp32 screen (2 families x (8 fma + add + fma) = 34 flop
-        # per screened pair, packed fp32) and fp64 H + quartic tests (18 h + 110 flop per pair that reaches them; register-tiled
+        # What the instructions execute (the PRIMARY compute figure): the fp32 screen (2 families x 9 FMA = 36 flop per screened pair:
+        # 18 v_pk_fma_f32 per row and 128 columns) and fp64 H + quartic tests (18 h + 110 flop per pair that reaches them; register-tiled
         # kernel: every computed pair, h padded to a multiple of 4).  Beside it SURVEY.md 8(d)'s accounting: the reference's own
         # pair evaluations x (46 h + 500) flop each over the kernel time -- the sieve reaches the reference's verdicts without
         # forming H for most pairs, so that ratio exceeds 1 and is NOT a roofline fraction.
@@ -667,7 +671,7 @@ def main():
         screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
         ref_equiv = evals_big * flops_per_eval / (tile_s / ev_steps) / 1e12 if tile_s > 0 else None
         if screened_big:
-            f32_flops = screened_big * 34        # dot-product form: 2 families x (8 fma + add + fma) per pair
+            f32_flops = screened_big * SCREEN_FLOP_PER_PAIR
             f64_flops = computed_big * (18 * h + 110)
         else:
             f32_flops = 0.0
@@ -685,6 +689,31 @@ def main():
                               "bound": "hbm", "algorithmic_bytes": b_k12, "ms": front_ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS,
                               "what": "B_K12 = N n_mols 96 + N_pass n 24 + N (SURVEY.md 8d) over the embed_clash + compact stages' HIP events"}
+        # VALU issue of the dominant kernel from the committed SQ-counter summary of this same command (tools/pmc_sq.sh: SQ_INSTS_VALU and
+        # SQ_BUSY_CU_CYCLES over every launch of the kernel): a CU issues one wave64 VALU instruction per cycle (4 SIMDs x 4 cycles), so
+        # `issue_frac` = instructions / (CU-cycles of the kernel's launches) is the fraction of the VALU issue ceiling the kernel reaches --
+        # the resource that bounds it.  Only while the profile was taken from the kernels that run now (digest), like `traffic`.
+        issue = None
+        for name in SQ_PROFILES.get(args.config, ()):
+            sq_path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(sq_path) or args.n_poses is not None or world != 1:
+                continue
+            sq = json.load(open(sq_path))
+            run = sq.get("_run", {})
+            if run.get("csrc_sha256_16") != now or built != now:
+                issue = {"source": f"profiles/{name} is STALE (taken from csrc {run.get('csrc_sha256_16')}, the kernels now are {now}): withheld; re-run tools/pmc_sq.sh"}
+                break
+            kk = next((v for k_, v in sq.items() if k_ != "_run" and kernel in k_ and "sorted" not in k_), None)
+            if kk and kk.get("SQ_BUSY_CU_CYCLES") and avg_launch_s:
+                all_cu_cycles = kk["launches"] * avg_launch_s * GPU_CLOCK_GHZ * 1e9 * 256
+                issue = {"valu_insts": kk["SQ_INSTS_VALU"], "busy_cu_cycles": kk["SQ_BUSY_CU_CYCLES"], "launches": kk["launches"],
+                         "issue_frac_while_busy": kk["SQ_INSTS_VALU"] / kk["SQ_BUSY_CU_CYCLES"],
+                         "issue_frac": kk["SQ_INSTS_VALU"] / all_cu_cycles,
+                         "fma_f32_share_of_valu": kk.get("SQ_INSTS_VALU_FMA_F32", 0.0) / kk["SQ_INSTS_VALU"],
+                         "wait_share_of_wave_cycles": kk.get("SQ_WAIT_ANY", 0.0) / kk["SQ_WAVE_CYCLES"] if kk.get("SQ_WAVE_CYCLES") else None,
+                         "source": f"profiles/{name} (csrc {now}, the kernels of this run): rocprofv3 --pmc SQ_*, separate passes; CU-cycles of the "
+                                   f"launches = launches x avg_launch_us (this run) x {GPU_CLOCK_GHZ} GHz x 256 CUs"}
+            break
         out = {
             "metric": "conformers/sec, 100k x 50-atom prune_conformers pipeline (embed -> clash mask -> RMSD prune)",
             "value": units_per_step * args.steps / dt,
@@ -714,7 +743,13 @@ def main():
                        "library_events_in_timed_region": args.pass_timing},
             "roofline": {
                 "kernel": kernel + " (all-pairs Kabsch RMSD of one pass; one launch per pass)",
-                "bound": "hbm",
+                # what binds the kernel -- NOT HBM: its 33 MB per launch sit in the infinity cache.  `achieved` / `peak` / `frac`
+                # below stay the bench contract's HBM figure (algorithmic bytes over the launch against 8 TB/s); `issue_frac` is the kernel against
+                # the roof that does bind it
+                "bound": "valu_issue",
+                "frac_resource": "hbm",
+                "issue_frac": issue.get("issue_frac") if issue else None,
+                "issue": issue,
                 "achieved": hbm_achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

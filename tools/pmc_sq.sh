@@ -24,7 +24,24 @@ for f in glob.glob(f"{P}/p*/**/*counter_collection.csv", recursive=True):
         if key not in seen:
             seen.add(key)
 out = {k: dict(v) for k, v in agg.items() if "sieve" in k or "open_rows" in k or "apply" in k or "pass_chunks" in k}
+# launches of every kernel in one pass (the passes run the same command) and the digest of the binary that ran: what issue_frac is computed from
+launches = collections.defaultdict(set)
+for f in glob.glob(f"{P}/p1/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        launches[r["Kernel_Name"].split("(")[0].split("<")[0]].add(r["Dispatch_Id"])
+for k in out:
+    out[k]["launches"] = len(launches.get(k, ()))
+try:
+    line = [l for l in open(f"{P}/b1.json").read().strip().splitlines() if l.startswith("{")][-1]
+    b = json.loads(line)
+    out["_run"] = {"csrc_sha256_16": b["roofline"].get("binary_csrc_sha256_16"), "workload": b["config"]["workload"],
+                   "what": "SQ counters summed over every launch of the kernel in `bench.py --steps 2 --warmup 1` (8 steps with the events-off and detail "
+                           "steps); VALU issue: SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES (a CU issues one wave64 VALU instruction per cycle: four SIMDs, "
+                           "four cycles each)"}
+except Exception as exc:
+    out["_run"] = {"error": str(exc)}
 json.dump(out, open(f"{P}/sq_counters.json", "w"), indent=1)
+out.pop("_run", None)
 for k, v in out.items():
     print(k)
     for c, x in sorted(v.items()):

@@ -39,6 +39,17 @@ LINK_GBS, LINK_EFF, COLL_FIXED_US = 153.0, 0.7, 20.0
 # exchange (csrc/xchg.hip, profiles/r05_ipc_exchange.json: 6.5 - 10.5 us up to 230 KB, 25 us at 1.9 MB, two processes sharing one GPU) lies below
 # the first of them.
 SENSITIVITY_FIXED_US = (10.0, 20.0, 50.0, 100.0)
+# The library's own exchange (tsc_xchg_*): a rank writes its whole contribution into every peer (one link each, all at once) and folds
+# what it received: fixed cost from profiles/r05_ipc_exchange.json (two launches: 6.5 - 10.5 us measured up to 230 KB with two processes
+# sharing one GPU; 8 us taken) + bytes over ONE link.  Used for the per-pass messages (`predicted_ms_per_step_ipc`); the front half's
+# collectives stay with the collective library in the model as in the code.
+IPC_FIXED_US = 8.0
+
+
+def ipc_allreduce_ms(nbytes, n):
+    if n == 1:
+        return 0.0
+    return IPC_FIXED_US / 1e3 + nbytes / (LINK_GBS * LINK_EFF * 1e9) * 1e3
 
 
 class Timer:
@@ -245,9 +256,11 @@ def measure(cfg, n_ranks, chunks, reps=3, front_all_ms=None, embed_all_ms=None, 
         ring, fast = f["compute_ms"] + f["comm_ms"][0] + body + pass_comm(False), f["compute_ms"] + f["comm_ms"][1] + body + pass_comm(True)
         # collectives of a step: the front's (shard: counts + coordinates; hybrid: the clash mask) + one per pass that exchanges anything
         n_coll = 0 if n_ranks == 1 else {"shard": 2, "hybrid": 1}.get(name, 0) + sum(1 for p in best["passes"] if p["bytes"])
+        pass_ipc = sum(ipc_allreduce_ms(p["bytes"], n_ranks) for p in best["passes"] if p["bytes"])
         out_fronts[name] = {"front_compute_ms": f["compute_ms"], "front_comm_ms_ring": f["comm_ms"][0], "front_comm_ms_all_links": f["comm_ms"][1],
                             "prune_setup_ms": setup_f, "collectives_per_step": n_coll,
                             "predicted_ms_per_step": ring, "predicted_ms_per_step_all_links": fast,
+                            "predicted_ms_per_step_ipc": f["compute_ms"] + f["comm_ms"][1] + body + pass_ipc, "pass_comm_ms_ipc": pass_ipc,
                             "by_collective_fixed_us": {str(int(us)): {"ring": ring + n_coll * (us - COLL_FIXED_US) / 1e3,
                                                                       "all_links": fast + n_coll * (us - COLL_FIXED_US) / 1e3} for us in SENSITIVITY_FIXED_US}}
     by_kind = {}
@@ -289,7 +302,7 @@ def main():
     cfgs = [a for a in args if a.startswith("C")] or ["C3", "C4"]
     out = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
            "model": {"xgmi_link_GBs": LINK_GBS, "link_efficiency": LINK_EFF, "collective_fixed_us": COLL_FIXED_US,
-                     "sensitivity_fixed_us": list(SENSITIVITY_FIXED_US),
+                     "sensitivity_fixed_us": list(SENSITIVITY_FIXED_US), "ipc_exchange_fixed_us": IPC_FIXED_US,
                      "ring (predicted_ms_per_step)": "per-link bound: all-gather = (N-1) steps of one shard over one link; all-reduce = reduce-scatter + all-gather of that pattern",
                      "all_links (predicted_ms_per_step_all_links)": "the fully connected xGMI mesh used at once: every shard straight to its N-1 peers, one link each",
                      "shard_min_pairs": SHARD_MIN_PAIRS, "partition_min_chunks": chunks,
@@ -304,7 +317,7 @@ def main():
             rows.append(row)
             if n == ranks[0]:
                 front_all = max(rows[0]["front_ms_per_rank"])          # one rank's front half IS the whole pose list
-            print(f"{cfg} N={n}: " + " | ".join(f"{name} {f['predicted_ms_per_step']:.3f} (all links {f['predicted_ms_per_step_all_links']:.3f})"
+            print(f"{cfg} N={n}: " + " | ".join(f"{name} {f['predicted_ms_per_step']:.3f} (all links {f['predicted_ms_per_step_all_links']:.3f}, ipc {f['predicted_ms_per_step_ipc']:.3f})"
                                                 for name, f in row["fronts"].items()) + f"  prune compute {row['prune_compute_ms']:.3f} [{time.time() - t0:.0f} s]",
                   file=sys.stderr)
         base = min(f["predicted_ms_per_step"] for f in rows[0]["fronts"].values())
@@ -312,6 +325,7 @@ def main():
             for f in r["fronts"].values():
                 f["speedup_vs_1_rank_protocol"] = base / f["predicted_ms_per_step"]
                 f["speedup_vs_1_rank_protocol_all_links"] = base / f["predicted_ms_per_step_all_links"]
+                f["speedup_vs_1_rank_protocol_ipc"] = base / f["predicted_ms_per_step_ipc"]
                 for v in f["by_collective_fixed_us"].values():
                     v["speedup_ring"], v["speedup_all_links"] = base / v["ring"], base / v["all_links"]
         out["configs"][cfg] = rows

@@ -126,6 +126,34 @@ static int launch_clash(tsc_ctx *c, const ClashArgs &a, const double *coords, co
         TSC_HIP(hipGetLastError());
         return 0;
     }
+    if (minmode && FUSED && c->clash_lanes != 0 && (a.n_mols == 2 || a.n_mols == 3) && ft.n_mols == a.n_mols && a.n == ft.n_total &&
+        a.atom_off[1] == ft.atom_off[1] && (a.n_mols == 2 || a.atom_off[2] == ft.atom_off[2])) {
+        // one pose per lane for fragments of any size and for three of them: the "A" fragment of every pair in register tiles, the poses
+        // packed again between the fragment pairs (embed_clash.hpp, k_clash_lanes_multi).  The tile size that wastes the fewest padded
+        // distances over the pairs (numba_functions.py:87-105: (m2, m1), (m3, m2), (m1, m3)), the B atoms embedded once per tile counted in
+        auto cost = [&](int na2) {
+            int64_t w = 0;
+            const int n_pairs = a.n_mols == 2 ? 1 : 3;
+            for (int pr = 0; pr < n_pairs; ++pr) {
+                const int mA = a.n_mols == 2 ? 1 : (pr == 0 ? 1 : (pr == 1 ? 2 : 0)), mB = a.n_mols == 2 ? 0 : (pr == 0 ? 0 : (pr == 1 ? 1 : 2));
+                const int64_t tiles = ceil_div(ft.n_atoms[mA], 2 * na2);
+                w += tiles * ft.n_atoms[mB] * (2 * na2 + 4);
+            }
+            return w;
+        };
+        int best = 12;
+        for (int na2 : {16, 18})
+            if (cost(na2) < cost(best)) best = na2;
+        const dim3 grid(unsigned(grid_for(ceil_div<int64_t>(a.n_poses, CLM_POSES), 1, 256 * 32)));
+#define TSC_LAUNCH_CLASH_MULTI(N)                                                                                                          \
+    hipLaunchKernelGGL(k_clash_lanes_multi<N>, grid, dim3(256), 0, c->stream, a.n_poses, frags, ft, conf_idx, rot, pos, a.sq_bound, mask)
+        if (best == 12) TSC_LAUNCH_CLASH_MULTI(12);
+        else if (best == 16) TSC_LAUNCH_CLASH_MULTI(16);
+        else TSC_LAUNCH_CLASH_MULTI(18);
+#undef TSC_LAUNCH_CLASH_MULTI
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
     if (minmode) return launch_clash_impl<FUSED, false, true>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
     return launch_clash_impl<FUSED, false, false>(c, a, coords, frags, ft, conf_idx, rot, pos, mask, counts);
 }

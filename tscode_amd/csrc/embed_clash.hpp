@@ -407,6 +407,166 @@ inline __global__ __launch_bounds__(256) void k_clash_lanes(int64_t n_poses, con
     }
 }
 
+// K1 + K2 fused, one pose per lane, ANY two or three fragments (verdict only, no clash allowed): what k_clash_lanes does for two fragments with
+// a small one, for fragments of any size and for the three fragment pairs of a trimolecular pose (numba_functions.py:87-105: (m2, m1), (m3, m2),
+// (m1, m3); with max_clashes = 0 the verdict is "no distance of any pair below thresh", whatever the order and the reference's early exits).
+//   * the "A" fragment of a pair goes through the registers 2 NA2 atoms at a time (packed fp32 pairs); for every such tile the atoms of
+//     the "B" fragment are embedded one after the other (fp64, 15 instructions against the tile's 3.5 per distance) and each meets the
+//     whole tile -- registers only, two running minima;
+//   * a WORKGROUP owns CLM_POSES poses and takes the fragment pairs one after the other: after a pair the poses that certainly clash
+//     (minimum below the band) leave, the others are packed again (their number, running minimum and coordinate bound in LDS), so that the
+//     wavefronts of the next pair are full of poses still worth looking at.  On C5 (500k poses of 70 + 70 + 60 atoms, 75 % of them
+//     clashing) that is a quarter less work than three pairs for every pose; what a lane of a clashing pose would otherwise still do cannot
+//     be skipped inside a wavefront, 64 poses wide;
+//   * same rigorous band as k_clash's MINMODE (fp32_min_band with the POSE's own largest coordinate so far: the bound only has to cover
+//     the atoms that entered the minimum); a pose that ends inside the band is recounted in fp64 by a whole wavefront.
+#ifndef TSC_CLM_OCC
+#define TSC_CLM_OCC 2
+#endif
+#ifndef TSC_CLM_POSES
+#define TSC_CLM_POSES 512
+#endif
+constexpr int CLM_POSES = TSC_CLM_POSES;   // poses per workgroup and round (two per thread in the first pair)
+template <int NA2>
+inline __global__ __launch_bounds__(256, TSC_CLM_OCC) void k_clash_lanes_multi(int64_t n_poses, const double *__restrict__ frags, FragTable ft,
+                                                            const int32_t *__restrict__ conf_idx, const double *__restrict__ rot,
+                                                            const double *__restrict__ pos, double sq_bound, uint8_t *__restrict__ mask) {
+    __shared__ int s_id[2][CLM_POSES];        // poses still undecided, packed (two lists: the one being read, the one being made)
+    __shared__ float s_m[2][CLM_POSES];       // ... their running minimum of squared distances
+    __shared__ float s_c[2][CLM_POSES];       // ... and the largest |coordinate| met so far (rounded up)
+    __shared__ int s_n[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nm = ft.n_mols, n_pairs = nm == 2 ? 1 : 3;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int64_t base = int64_t(blockIdx.x) * CLM_POSES; base < n_poses; base += int64_t(gridDim.x) * CLM_POSES) {
+        const int n0 = int(min<int64_t>(CLM_POSES, n_poses - base));
+        __syncthreads();                       // (the lists of the round before are no longer read)
+        if (tid == 0) s_n[0] = n0, s_n[1] = 0;
+        for (int e = tid; e < n0; e += 256) s_id[0][e] = e, s_m[0][e] = __builtin_inff(), s_c[0][e] = 0.0f;
+        __syncthreads();
+        for (int pr = 0; pr < n_pairs; ++pr) {
+            const int cur = pr & 1, nxt = cur ^ 1;
+            // numba_functions.py:87-105: (m2, m1), (m3, m2), (m1, m3); two fragments: (m2, m1)
+            const int mA = nm == 2 ? 1 : (pr == 0 ? 1 : (pr == 1 ? 2 : 0)), mB = nm == 2 ? 0 : (pr == 0 ? 0 : (pr == 1 ? 1 : 2));
+            const int nA = ft.n_atoms[mA], nB = ft.n_atoms[mB];
+            const int n_cur = s_n[cur];
+            const bool last_pair = pr == n_pairs - 1;
+            for (int e0 = wid * 64; e0 < n_cur; e0 += 256) {        // (wave-uniform: 64 packed poses per trip)
+                const bool valid = e0 + lane < n_cur;
+                const int e = valid ? e0 + lane : n_cur - 1;          // (idle lanes walk along with the last pose)
+                const int lid = s_id[cur][e];
+                const int64_t s = base + lid;
+                float m = s_m[cur][e];
+                double cmax = double(s_c[cur][e]);
+                double RA[9], tA[3], RB[9], tB[3];
+                {
+                    const double *r = rot + (s * nm + mA) * 9, *t = pos + (s * nm + mA) * 3;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) RA[q] = r[q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) tA[q] = t[q];
+                    r = rot + (s * nm + mB) * 9, t = pos + (s * nm + mB) * 3;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) RB[q] = r[q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) tB[q] = t[q];
+                }
+                const double *XA = frags + ft.frag_off[mA] + int64_t(conf_idx[s * nm + mA]) * nA * 3;
+                const double *XB = frags + ft.frag_off[mB] + int64_t(conf_idx[s * nm + mB]) * nB * 3;
+                for (int a0 = 0; a0 < nA; a0 += 2 * NA2) {           // the A fragment, a register tile at a time
+                    clash_f32x2 ax[NA2], ay[NA2], az[NA2];
+#pragma unroll
+                    for (int k = 0; k < NA2; ++k) {
+                        float v[2][3];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int a = a0 + 2 * k + u;
+                            if (a < nA) {
+                                const double x0 = XA[3 * a], x1 = XA[3 * a + 1], x2 = XA[3 * a + 2];
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) {
+                                    const double w = RA[3 * i] * x0 + RA[3 * i + 1] * x1 + RA[3 * i + 2] * x2 + tA[i];  // embed_atom
+                                    cmax = fmax(cmax, fabs(w));
+                                    v[u][i] = float(w);
+                                }
+                            } else {
+                                v[u][0] = v[u][1] = v[u][2] = 1.0e18f;  // (padding: an atom far from everything; its squared distances stay finite in fp32)
+                            }
+                        }
+                        ax[k] = clash_f32x2{v[0][0], v[1][0]}, ay[k] = clash_f32x2{v[0][1], v[1][1]}, az[k] = clash_f32x2{v[0][2], v[1][2]};
+                    }
+                    for (int b = 0; b < nB; ++b) {
+                        const double x0 = XB[3 * b], x1 = XB[3 * b + 1], x2 = XB[3 * b + 2];
+                        float bf[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const double w = RB[3 * i] * x0 + RB[3 * i + 1] * x1 + RB[3 * i + 2] * x2 + tB[i];
+                            cmax = fmax(cmax, fabs(w));
+                            bf[i] = float(w);
+                        }
+                        const clash_f32x2 bx = {bf[0], bf[0]}, by = {bf[1], bf[1]}, bz = {bf[2], bf[2]};
+                        float m0 = m, m1 = __builtin_inff();           // two running minima: consecutive pairs of A do not wait for each other
+#pragma unroll
+                        for (int k = 0; k < NA2; ++k) {
+                            const clash_f32x2 dx = bx - ax[k], dy = by - ay[k], dz = bz - az[k];
+                            clash_f32x2 s2 = dx * dx;
+                            s2 = __builtin_elementwise_fma(dy, dy, s2);
+                            s2 = __builtin_elementwise_fma(dz, dz, s2);
+                            if (k & 1) m1 = fminf(m1, fminf(s2.x, s2.y));
+                            else m0 = fminf(m0, fminf(s2.x, s2.y));
+                        }
+                        m = fminf(m0, m1);
+                    }
+                }
+                // after this pair: certainly a clash -> the pose leaves with verdict 0; else it goes on to the next pair, or to its verdict
+                float lo, hi;
+                const bool banded = fp32_min_band(sq_bound, cmax, &lo, &hi);
+                const bool clash = valid && banded && m < lo;           // some distance certainly < thresh (a NaN minimum: never certain)
+                if (clash) mask[s] = 0;
+                const bool goes_on = valid && !clash;
+                if (!last_pair) {
+                    const unsigned long long go = __builtin_amdgcn_ballot_w64(goes_on);
+                    int slot0 = 0;
+                    if (lane == 0 && go) slot0 = atomicAdd(&s_n[nxt], __popcll(go));
+                    slot0 = __builtin_amdgcn_readfirstlane(slot0);
+                    if (goes_on) {
+                        const int d = slot0 + __popcll(go & lt_mask);
+                        s_id[nxt][d] = lid, s_m[nxt][d] = m;
+                        s_c[nxt][d] = __double2float_ru(cmax);
+                    }
+                } else {
+                    // every distance certainly >= thresh: passes.  Inside the band (a few poses in 10^4), or without a usable band: every
+                    // distance of every pair in fp64, by the whole wavefront
+                    bool decided = !goes_on;
+                    if (goes_on && banded && m >= hi) decided = true, mask[s] = 1;
+                    for (unsigned long long und = __builtin_amdgcn_ballot_w64(!decided); und; und &= und - 1) {
+                        const int l = __ffsll((long long)und) - 1;
+                        const int64_t sp = base + __builtin_amdgcn_readlane(lid, l);
+                        bool hit = false;
+                        for (int q = 0; q < n_pairs; ++q) {
+                            const int qa = nm == 2 ? 1 : (q == 0 ? 1 : (q == 1 ? 2 : 0)), qb = nm == 2 ? 0 : (q == 0 ? 0 : (q == 1 ? 1 : 2));
+                            const int na = ft.n_atoms[qa], nb = ft.n_atoms[qb];
+                            for (int el = lane; el < na * nb; el += 64) {
+                                const int a = el / nb, b = el - a * nb;
+                                double p3[3], q3[3];
+                                embed_atom(frags, ft, conf_idx, rot, pos, sp, ft.atom_off[qa] + a, p3);
+                                embed_atom(frags, ft, conf_idx, rot, pos, sp, ft.atom_off[qb] + b, q3);
+                                const double dx = q3[0] - p3[0], dy = q3[1] - p3[1], dz = q3[2] - p3[2];
+                                hit = hit || (dx * dx + dy * dy + dz * dz < sq_bound);
+                            }
+                        }
+                        const bool any = __builtin_amdgcn_ballot_w64(hit) != 0;
+                        if (lane == l) mask[sp] = any ? 0 : 1;          // count(D < thresh) <= 0
+                    }
+                }
+            }
+            __syncthreads();                   // the list of the next pair is complete
+            if (tid == 0) s_n[cur] = 0;        // (it becomes the list the pair after next fills)
+            __syncthreads();
+        }
+    }
+}
+
 // all_dists (algebra.py:98-157): out[i, j] = sqrt(sum_k (A[i,k] - B[j,k])^2)
 inline __global__ __launch_bounds__(256) void k_all_dists(const double *__restrict__ A, int na, const double *__restrict__ B, int nb,
                                                     double *__restrict__ out) {
