@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-R = "r04"
+R = "r05"
 
 
 def last_json_line(name):
@@ -141,8 +141,8 @@ def scaling():
     d = load(f"{R}_predicted_scaling.json")
     if not d:
         return f"(profiles/{R}_predicted_scaling.json missing)"
-    rows = ["| config | ranks | front: shard / replicate / hybrid (compute + modelled exchange, ring) | prune: setup (a run that builds its descriptors; `hybrid` leaves them beside the heavy atoms) + partitioned (local / close) + row tiles (local / close) + small | per-pass collectives ring - all links | step (best front) ring - all links | speed-up vs one rank |",
-            "|---|---|---|---|---|---|---|"]
+    rows = ["| config | ranks | front: shard / replicate / hybrid (compute + modelled exchange, ring) | prune: setup (a run that builds its descriptors; `hybrid` leaves them beside the heavy atoms) + partitioned (local / close) + row tiles (local / close) + small | per-pass collectives ring - all links | step (best front) ring - all links | speed-up vs one rank | the per-pass messages through the library's own exchange (`tsc_xchg_*`) | the ring figure at 50 / 100 us fixed per collective (`collectives_per_step` of them) |",
+            "|---|---|---|---|---|---|---|---|---|"]
     for cfg, rws in d["configs"].items():
         for r in rws:
             fr = r["fronts"]
@@ -157,7 +157,10 @@ def scaling():
             rows.append(f"| {cfg} | {r['n_ranks']} | {fs} | {setup} + ({g('partitioned', 'local_ms'):.2f} / {g('partitioned', 'close_ms'):.2f}) + "
                         f"({g('row_tiles', 'local_ms'):.2f} / {g('row_tiles', 'close_ms'):.2f}) + {g('replicated', 'local_ms'):.2f} | {r['pass_comm_ms_ring']:.2f} - {r['pass_comm_ms_all_links']:.2f} | "
                         f"**{best['predicted_ms_per_step']:.2f}** ({names[id(best)]}) - {best_al['predicted_ms_per_step_all_links']:.2f} ({names[id(best_al)]}) | "
-                        f"{best['speedup_vs_1_rank_protocol']:.2f} - {best_al['speedup_vs_1_rank_protocol_all_links']:.2f} x |")
+                        f"{best['speedup_vs_1_rank_protocol']:.2f} - {best_al['speedup_vs_1_rank_protocol_all_links']:.2f} x | "
+                        + (lambda bi: f"{bi['predicted_ms_per_step_ipc']:.2f} ({names[id(bi)]}; {bi.get('speedup_vs_1_rank_protocol_ipc', 0):.2f} x)")(min(fr.values(), key=lambda v: v.get("predicted_ms_per_step_ipc", 1e9)))
+                        + " | " + (f"{best['by_collective_fixed_us']['50']['ring']:.2f} / {best['by_collective_fixed_us']['100']['ring']:.2f} ({best['collectives_per_step']})"
+                                   if "by_collective_fixed_us" in best else "—") + " |")
     return "\n".join(rows) + (f"\n\n(ms per step; from `profiles/{R}_predicted_scaling.json`, `tools/predict_scaling.py`: every rank's library calls timed on ONE GPU, collectives modelled: "
                               f"{d['model']['xgmi_link_GBs']} GB/s per link x {d['model']['link_efficiency']}, {d['model']['collective_fixed_us']} us fixed per collective)")
 
