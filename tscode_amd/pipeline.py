@@ -144,7 +144,14 @@ def _front_hybrid(backend, rank, world, dist, group):
     """Clash verdicts of this rank's block -> the verdicts of all blocks (one byte per pose: all-reduce SUM of a mask that is zero
     outside the rank's block) -> every rank embeds the heavy atoms of ALL passing poses itself.  Returns (n_pass, mask bytes moved)."""
     backend.clash_block_into_all()            # (also forks the descriptor basis onto the side stream, embeds this block's survivors)
-    _all_reduce(dist, backend.clash_all, dist.ReduceOp.SUM, group)
+    xchg = getattr(backend, "xchg", None) if world > 1 else None
+    words = getattr(backend, "clash_all_words", None)
+    if xchg is not None and words is not None:
+        # the library's own exchange: the byte mask is zero outside this rank's block, so the SUM of its 8-byte words over the ranks is
+        # the union of the blocks' verdicts -- the one collective of this front then needs no collective library either
+        xchg.allreduce(XCHG_SUM_I64, words, words.numel())
+    else:
+        _all_reduce(dist, backend.clash_all, dist.ReduceOp.SUM, group)
     return int(backend.embed_masked_all()), int(backend.clash_all.numel())
 
 
@@ -427,7 +434,9 @@ class HipShardBackend:
             torch, ens = self.torch, self.ens
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
             self.d_ci_all, self.d_rot_all, self.d_pos_all = t(ens.conf_idx), t(ens.rot), t(ens.pos)
-            self.clash_all = torch.zeros(ens.n_poses, dtype=torch.uint8, device=self.dev)
+            # (padded to whole 8-byte words: the library's exchange sums the mask as int64 -- clash_all_words is the same memory)
+            self.clash_all_words = torch.zeros((ens.n_poses + 7) // 8, dtype=torch.int64, device=self.dev)
+            self.clash_all = self.clash_all_words.view(torch.uint8)[:ens.n_poses]
 
     def clash_block(self):
         """The clash verdicts of this rank's block alone (no pose is written)."""
