@@ -69,6 +69,8 @@ def roofline():
             f"| achieved / peak | {r['achieved']:.0f} / {r['peak']:.0f} GB/s = **{r['frac']:.4f}** |",
             f"| HBM traffic per launch (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE) | {f(r['traffic'] / 1e6 if r.get('traffic') else None, 1)} MB"
             + (f" = {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f} x the algorithmic bytes" if r.get("traffic") else f" ({r.get('traffic_source')})") + " |",
+            f"| what binds the kernel (`roofline.bound`) and how close it comes (`roofline.issue_frac`: wave64 VALU instructions per CU-cycle of its launches, ceiling 1; SQ counters) | {r.get('bound')}: "
+            + (f"{r['issue_frac']:.3f} ({r['issue']['issue_frac_while_busy']:.3f} of the cycles a CU is busy; {r['issue']['fma_f32_share_of_valu']:.2f} of the instructions are `v_pk_fma_f32`)" if r.get('issue_frac') else f"— ({(r.get('issue') or {}).get('source', 'no SQ profile of these kernels')})") + " |",
             f"| what the instructions execute | {ex.get('fp32_TFLOPs', 0):.1f} TFLOP/s packed fp32 = {ex.get('fp32_frac', 0):.3f} of {ex.get('fp32_peak_TFLOPs')} + {ex.get('fp64_TFLOPs', 0):.2f} TFLOP/s fp64 |",
             f"| pairs screened / H formed per step | {ex.get('pairs_screened_per_step', 0):.3g} / {ex.get('pairs_with_H_formed_per_step', 0):.3g} |"]
     fr = b.get("roofline_front")
