@@ -504,7 +504,12 @@ int tsc_prune_destroy(tsc_prune *p);
  *   clash_mask u8[n_poses]; structures f64[n_pass, n_atoms, 3] (poses that pass the clash check, in order);
  *   keep_mask u8[n_pass] (prune verdict on those); keep_mask_host (optional, host, n_poses bytes) receives a copy of
  *   keep_mask[0 .. n_pass) before the call returns; n_pass_host / n_keep_host scalars on the host.
- * timings_ms (optional, host) float[4] = {embed+clash, compaction, prune, total} from HIP events. */
+ * timings_ms (optional, host) float[4] = {embed+clash, compaction, prune, total} from HIP events.
+ * HOST COST: the call returns after ONE synchronisation at its end, but in the middle it needs the number of poses that passed the clash
+ * check to size the prune (the schedule depends on it).  The scan kernel writes that count into the context's pinned memory and the calling
+ * thread SPINS on it (a pause instruction per look: x86; about 40 us per call at 100k poses -- the clash kernel + the scan -- with a fall-back
+ * to a copy + synchronise after 5 s): a host core per context is busy for that long in every call.  A caller that keeps several contexts in
+ * flight from one thread each pays it per context. */
 int tsc_pipeline_dev(tsc_ctx *ctx, const double *frags, const int64_t *frag_off_host, const int32_t *n_atoms_host,
                      const int32_t *n_conf_host, int n_mols, const int32_t *conf_idx, const double *rot, const double *pos,
                      int64_t n_poses, const int32_t *heavy_idx_host, int n_heavy, double clash_thresh, int64_t max_clashes,
