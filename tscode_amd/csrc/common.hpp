@@ -101,7 +101,6 @@ struct tsc_ctx {
     int stage1_f32 = 1;                   // stage 1 of the pair kernels reads a float32 copy of the coordinates first (sieve.hpp: pair_stage1)
     int local_max_chunk = 384;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
-    int local_short = 1;                  // ... their regular chunks of at most 128 structures one per wavefront, every structure a lane (short_chunk)
     void *dbg_buf = nullptr;              // -DTSC_DBG_STAMPS builds: time stamps of the pair kernel's wavefronts
     size_t dbg_bytes = 0;
     int64_t dbg_waves = 0, dbg_stamp_k = -1;

@@ -268,10 +268,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->cull_grid = int64_t(value);
         return 0;
     }
-    if (strcmp(name, "local_short") == 0) {
-        c->local_short = value != 0.0 ? 1 : 0;
-        return 0;
-    }
     if (strcmp(name, "cull_xcd") == 0) {
         c->cull_xcd = value != 0.0 ? 1 : 0;
         return 0;

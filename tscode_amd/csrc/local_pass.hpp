@@ -43,7 +43,6 @@ struct LocalPassArgs {
     int c_lo;        // first chunk of this launch and how many regular chunks (not the last one of the pass) follow it: 0 and k - 1,
     int n_reg;       // unless the pass is partitioned over ranks (rmsd.hpp, k_pass_merge): then this rank's chunks; blocks beyond
                      // n_reg * nb_regular belong to the last chunk of the pass
-    int short_sets;  // k_pass_short only: 1 / 2 = the regular chunks hold at most 64 / 128 structures (one or two per lane)
     unsigned long long *exch;  // rank-partitioned pass (else null): removed rows are noted here and applied by k_pass_merge
     double thr, maxdev_thr, half_h_thr2, two_thr2, desc_limit;
     const unsigned *dmax_bits;
@@ -60,278 +59,6 @@ __device__ inline unsigned long long lds_extract64(const unsigned long long *bit
     const unsigned long long lo = bits[w] >> sh;
     const unsigned long long hi = sh ? (bits[w + 1] << (64 - sh)) : 0ull;
     return lo | hi;
-}
-
-// A chunk of at most 64 S structures run by ONE wavefront with every structure on a lane (S = 1, 2 structures per lane): the mask and
-// the cache view of the chunk are S words, a row's stop column is a shift and an AND, the columns' descriptors stay in registers for all
-// rows of the chunk and a row's comes to them by readlane -- no ranking, no LDS staging, no gathers by position: about 40 instructions per
-// row and 64 columns.  What passes the screen (0.2 %) goes through the same two evaluation stages as below, a wavefront's lanes shared
-// among the queued pairs.  Same verdicts, same statistics, same cache keys as the general path (the reference's semantics: :43-157).
-// The passes this takes were chains of seven dependent phases in one workgroup per chunk (30 us for C3's k = 1000 and 500).
-template <int S>
-__device__ __forceinline__ void short_chunk(const PassGeom &g, const LocalPassArgs &a, int c, const unsigned long long *__restrict__ mbit,
-                                            unsigned long long *__restrict__ mbit_next, uint8_t *__restrict__ mask, const unsigned long long *__restrict__ dbit,
-                                            const double *__restrict__ heavy, const double *__restrict__ Gall, const float *__restrict__ D, const CacheViews &cv,
-                                            int32_t *__restrict__ bsum, int block_items, int *s_best, unsigned short *queue, unsigned short *exq,
-                                            unsigned long long (&stat)[5]) {
-    static_assert(S == 1 || S == 2, "one or two structures per lane");
-    const int lane = threadIdx.x & 63;
-    const int first = c * g.cs, L = g.cs;                          // a regular chunk (:140-144), L <= 64 S
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long M[2] = {0ull, 0ull}, V[2] = {0ull, 0ull};
-#pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int rem = L - 64 * q;
-        if (rem > 0) {
-            const unsigned long long keep = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-            M[q] = extract64(mbit, int64_t(first) + 64 * q) & keep;
-            V[q] = a.use_cache ? (extract64(dbit, int64_t(first) + 64 * q) & keep) : 0ull;
-        }
-        // (the same words on every lane: into scalar registers, so that the row loop below -- its lane selects, shifts and branches -- is
-        // scalar code and a readlane by the row's lane is one instruction, not a loop over the lanes' values)
-        M[q] = (unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(M[q])))) | ((unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(M[q] >> 32)))) << 32);
-        V[q] = (unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(V[q])))) | ((unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(V[q] >> 32)))) << 32);
-    }
-    // the other bit copy may lag one pass behind (a superset of this one): this chunk's words brought up to date (commutes with the bits cleared below)
-    if (!a.exch)
-        for (int w = (first >> 6) + lane; w <= ((first + L - 1) >> 6); w += 64) atomicAnd(&mbit_next[w], mbit[w]);
-    const int A = __popcll(M[0]) + __popcll(M[1]);
-    if (A < 2) return;
-    const int h3 = a.h * 3;
-    const float limit32 = screen_limit32(__uint_as_float(*a.dmax_bits), a.desc_limit);
-    // ---- the columns: structure 64 q + lane of the chunk, its descriptor in registers
-    f32x2 dq[S][KD];
-    bool act[S];
-#pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int pcol = 64 * q + lane;
-        act[q] = pcol < L && ((M[q] >> lane) & 1ull);
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(D + int64_t(first + min(pcol, L - 1)) * DW);
-#pragma unroll
-        for (int k = 0; k < KD / 2; ++k) {
-            const f32x4 v = src[k];
-            dq[q][2 * k] = f32x2{v.x, v.y};
-            dq[q][2 * k + 1] = f32x2{v.z, v.w};
-        }
-    }
-    for (int e = lane; e < 64 * S; e += 64) s_best[e] = INT_MAX;
-    __builtin_amdgcn_wave_barrier();
-    int qn = 0, qe = 0;
-    unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
-
-    auto decode = [&](unsigned e, int &t, int &col, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
-        t = int(e >> 7);
-        col = int(e & 127u);
-        const int64_t i = first + t, jj = first + col;
-        pp = heavy + i * h3, pq = heavy + jj * h3;
-        Gi = Gall[i], Gj = Gall[jj];
-    };
-    auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
-        int lpp = 64;
-        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
-        const int grp = lane / lpp, sub = lane - grp * lpp;
-        if (grp < cnt) {
-            int t, col;
-            const double *pp, *pq;
-            double Gi, Gj, H[9], rm, md;
-            decode(exq[base + grp], t, col, pp, pq, Gi, Gj);
-            pair_H(pp, pq, a.h, sub, lpp, H);
-            exact_rmsd_maxdev(pp, pq, a.h, H, Gi, Gj, rm, md, sub, lpp);
-            if (sub == 0 && rm < a.thr && md < a.maxdev_thr) atomicMin(&s_best[t], col);  // rmsd_pruning.py:75
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto sign_stage = [&](int base, int cnt) __attribute__((always_inline)) {
-        int lpp = 64;
-        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
-        const int grp = lane / lpp, sub = lane - grp * lpp;
-        bool cand = false;
-        unsigned e = 0;
-        if (grp < cnt) {
-            e = queue[base + grp];
-            int t, col;
-            const double *pp, *pq;
-            double Gi, Gj, H[9];
-            decode(e, t, col, pp, pq, Gi, Gj);
-            pair_H(pp, pq, a.h, sub, lpp, H);
-            const int verdict = pair_verdict(H, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, a.h);
-            cand = sub == 0 && verdict == PAIR_UNDECIDED;
-            if (sub == 0 && verdict == PAIR_SIMILAR) atomicMin(&s_best[t], col);
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-        if (m) {
-            if (cand) exq[qe + __popcll(m & lt_mask)] = (unsigned short)e;
-            qe += __popcll(m);
-        }
-        n_eval += cnt;
-        n_exact += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (qe >= 64) {
-            exact_stage(qe - 64, 64);
-            qe -= 64;
-        }
-    };
-
-    // ---- the rows: every active structure but the last, in order
-#pragma unroll
-    for (int qr = 0; qr < S; ++qr) {
-        for (unsigned long long rows = M[qr]; rows; rows &= rows - 1) {
-            const int tl = __ffsll((long long)rows) - 1, t = 64 * qr + tl;   // (wave-uniform)
-            // its stop position: the first d >= 1 with the key (first, first + d) cached and column t + d active (:65-67), else the chunk's end
-            int cpos = L;
-            {
-                unsigned long long m0, m1 = 0ull;                   // the mask from position t on, 128 bits
-                if (S == 1) {
-                    m0 = M[0] >> tl;
-                } else if (qr == 0) {
-                    m0 = (M[0] >> tl) | (tl ? (M[1] << (64 - tl)) : 0ull);
-                    m1 = M[1] >> tl;
-                } else {
-                    m0 = M[1] >> tl;
-                }
-                const unsigned long long h0 = m0 & V[0] & ~1ull, h1 = (S == 2) ? (m1 & V[1]) : 0ull;
-                if (h0) cpos = t + (__ffsll((long long)h0) - 1);
-                else if (h1) cpos = t + 64 + (__ffsll((long long)h1) - 1);
-            }
-            if (cpos <= t + 1) continue;                            // (nothing between the row and its stop column; also the last active row of the chunk)
-            // the row's descriptor: from the registers of the lane that holds it
-            f32x2 dr[KD];
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-                dr[k].x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dq[qr][k].x), tl));
-                dr[k].y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dq[qr][k].y), tl));
-            }
-#pragma unroll
-            for (int qc = qr; qc < S; ++qc) {
-                if (64 * qc >= cpos) continue;
-                const int col = 64 * qc + lane;
-                const bool inside = act[qc] && col > t && col < cpos;
-                f32x2 s2 = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < KD; ++k) {
-                    const f32x2 d = dr[k] - dq[qc][k];
-                    s2 = __builtin_elementwise_fma(d, d, s2);
-                }
-                const bool pass = inside && !(fmaxf(s2.x, s2.y) > limit32);
-                n_screened += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(inside));
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                if (m) {
-                    if (pass) queue[qn + __popcll(m & lt_mask)] = (unsigned short)((unsigned(t) << 7) | unsigned(col));
-                    qn += __popcll(m);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            while (qn >= 64) {
-                sign_stage(qn - 64, 64);
-                qn -= 64;
-            }
-        }
-    }
-    if (qn > 0) sign_stage(0, qn);
-    if (qe > 0) exact_stage(0, qe);
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- apply: one row per lane and set -- mask, the bit in the copy the next pass reads, scan counts, one cache key per removed row
-    // (:69-73), the number of pair evaluations the reference's scan makes (:70)
-    unsigned long long n_evaluated = 0, n_removed = 0;
-#pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int prow = 64 * q + lane;
-        bool removed = false;
-        int my_block = -1, delta = 0;
-        unsigned long long ev = 0;
-        if (act[q]) {
-            const int b = s_best[prow];
-            // active structures in (prow, upto): what the reference evaluates for this row
-            auto active_between = [&](int upto_excl) {             // positions prow + 1 .. upto_excl - 1
-                int cnt = 0;
-#pragma unroll
-                for (int w = 0; w < S; ++w) {
-                    const int lo = max(prow + 1 - 64 * w, 0), hi = min(upto_excl - 64 * w, 64);
-                    if (hi > lo) {
-                        const unsigned long long mk = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                        cnt += __popcll(M[w] & mk);
-                    }
-                }
-                return cnt;
-            };
-            if (b != INT_MAX) {
-                if (a.exch) {
-                    atomicOr(&a.exch[(first + prow) >> 6], 1ull << ((first + prow) & 63));
-                } else {
-                    mask[first + prow] = 0;
-                    atomicAnd(&mbit_next[(first + prow) >> 6], ~(1ull << ((first + prow) & 63)));
-                    my_block = (first + prow) / block_items;
-                }
-                delta = b - prow;
-                removed = true;
-                ev = (unsigned long long)active_between(b + 1);    // columns up to and including the similar one were evaluated
-            } else {
-                // every active column before the stop column (recomputed: the row loop's value lived in scalar registers)
-                int cpos = L;
-                {
-                    const int tl = lane;
-                    unsigned long long m0, m1 = 0ull;
-                    if (S == 1) {
-                        m0 = M[0] >> tl;
-                    } else if (q == 0) {
-                        m0 = (M[0] >> tl) | (tl ? (M[1] << (64 - tl)) : 0ull);
-                        m1 = M[1] >> tl;
-                    } else {
-                        m0 = M[1] >> tl;
-                    }
-                    const unsigned long long h0 = m0 & V[0] & ~1ull, h1 = (S == 2) ? (m1 & V[1]) : 0ull;
-                    if (h0) cpos = prow + (__ffsll((long long)h0) - 1);
-                    else if (h1) cpos = prow + 64 + (__ffsll((long long)h1) - 1);
-                }
-                ev = (unsigned long long)active_between(cpos);
-            }
-        }
-        for (unsigned long long left = __builtin_amdgcn_ballot_w64(removed && my_block >= 0); left;) {
-            const int l = __ffsll((long long)left) - 1;
-            const int blk = __shfl(my_block, l);
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(removed && my_block == blk);
-            if (lane == l) atomicSub(&bsum[blk], __popcll(same));
-            left &= ~same;
-        }
-        n_removed += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(removed));
-        views_insert_wave(cv, removed, first, first + delta);      // the cache keys (:69-73), where later passes will look for them
-        for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
-        n_evaluated += ev;
-    }
-    stat[CNT_FORMED] += n_eval, stat[CNT_EXACT] += n_exact, stat[CNT_SCREENED] += n_screened;
-    stat[CNT_EVALUATED] += n_evaluated, stat[CNT_REMOVED] += n_removed;   // (n_evaluated: lane 0 holds the sum)
-}
-
-// The regular chunks c_lo .. c_lo + n_reg - 1 of a pass, one per wavefront (short_chunk), four to a block.  Applies its verdicts and adds its
-// statistics; does NOT close the pass: the launch behind it (k_pass_chunks on the last chunk alone, n_reg = 0) does, when ITS blocks are done.
-template <int S>
-inline __global__ __launch_bounds__(LP_THREADS) void k_pass_short(PassGeom g, LocalPassArgs a, const PruneState *__restrict__ st, uint8_t *__restrict__ mask,
-                                                            unsigned long long *__restrict__ bits, int bit_words, const unsigned long long *__restrict__ dbit,
-                                                            const double *__restrict__ heavy, const double *__restrict__ Gall, const float *__restrict__ D,
-                                                            CacheViews cv, PassCounters *__restrict__ cnt, int32_t *__restrict__ bsum, int block_items) {
-    __shared__ int s_best[LP_WAVES][128];
-    __shared__ unsigned short s_queue[LP_WAVES][256], s_exq[LP_WAVES][128];
-    __shared__ unsigned long long s_stat[8];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (st->pass_on == 0) return;
-    const unsigned long long *mbit = bits + size_t(st->bitsel) * bit_words;
-    unsigned long long *mbit_next = bits + size_t(st->bitsel ^ 1) * bit_words;
-    if (tid < 8) s_stat[tid] = 0;
-    __syncthreads();
-    const int cw = int(blockIdx.x) * LP_WAVES + wid;
-    if (cw < a.n_reg) {
-        unsigned long long stat[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-        short_chunk<S>(g, a, a.c_lo + cw, mbit, mbit_next, mask, dbit, heavy, Gall, D, cv, bsum, block_items, s_best[wid], s_queue[wid], s_exq[wid], stat);
-        if (lane == 0) {
-#pragma unroll
-            for (int w = 0; w < 5; ++w)
-                if (stat[w]) atomicAdd(&s_stat[w], stat[w]);
-        }
-    }
-    __syncthreads();
-    if (tid < 5) count_add(cnt, blockIdx.x, tid, s_stat[tid]);
 }
 
 inline __global__ __launch_bounds__(LP_THREADS, LP_OCCUPANCY) void k_pass_chunks(PassGeom g, LocalPassArgs a, PruneState *__restrict__ st, uint8_t *__restrict__ mask,

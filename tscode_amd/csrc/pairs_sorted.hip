@@ -19,14 +19,3 @@ int launch_pass_chunks(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_
     TSC_HIP(hipGetLastError());
     return 0;
 }
-
-int launch_pass_short(int sets, hipStream_t st, unsigned blocks, const PassGeom &g, const LocalPassArgs &a, const PruneState *state, uint8_t *mask, unsigned long long *bits,
-                      int bit_words, const unsigned long long *view, const double *heavy, const double *Gall, const float *Dall, const CacheViews &cv,
-                      PassCounters *counters, int32_t *bsum, int block_items) {
-    if (sets == 1)
-        hipLaunchKernelGGL(k_pass_short<1>, dim3(blocks), dim3(LP_THREADS), 0, st, g, a, state, mask, bits, bit_words, view, heavy, Gall, Dall, cv, counters, bsum, block_items);
-    else
-        hipLaunchKernelGGL(k_pass_short<2>, dim3(blocks), dim3(LP_THREADS), 0, st, g, a, state, mask, bits, bit_words, view, heavy, Gall, Dall, cv, counters, bsum, block_items);
-    TSC_HIP(hipGetLastError());
-    return 0;
-}

@@ -476,9 +476,6 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         a.nb_regular = std::max(1, ceil_div(ceil_div(g.cs, LP_TI), LP_TILES_PER_BLOCK));
         a.nb_last = c_hi == k ? std::max(1, ceil_div(ceil_div(int(n - (k - 1) * g.cs), LP_TI), LP_TILES_PER_BLOCK)) : 0;
         a.c_lo = int(c_lo), a.n_reg = int(std::min<int64_t>(c_hi, k - 1) - c_lo);
-        // regular chunks of at most 128 structures (a single-rank pass): one per wavefront, every structure a lane, in a launch of their own
-        // (local_pass.hpp: k_pass_short); the chunk-local kernel then runs the last chunk alone and closes the pass
-        a.short_sets = (c->local_short != 0 && !range && a.n_reg >= 1 && a.nb_last >= 1 && g.cs <= 128) ? (g.cs <= 64 ? 1 : 2) : 0;
         a.exch = range ? p->exch : nullptr;
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
@@ -487,11 +484,6 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         a.dmax_bits = p->dmax_bits;
         int nxt = -1;
         const StepArgs sa = next_step_args(p, &nxt);
-        if (a.short_sets) {
-            TSC_TRY(launch_pass_short(a.short_sets, st, unsigned(ceil_div(a.n_reg, LP_WAVES)), g, a, p->state, p->mask, p->bits, int(p->bit_words), view_of_open_pass(p), p->heavy,
-                                      (const double *)p->Gall, (const float *)p->Dall, later_views(p), p->counters, p->bsum, SCAN_TILE));
-            a.n_reg = 0;       // (what is left for the launch below: the last chunk)
-        }
         const int64_t blocks = int64_t(a.n_reg) * a.nb_regular + a.nb_last;
         // (its own events only at pass_timing 2: level 1 is what a timed region carries for the PAIR kernel's durations, and a pair of
         // events costs a small pass about 6 us)

@@ -171,7 +171,3 @@ int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0,
 int launch_pass_chunks(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_t e1, const PassGeom &g, const LocalPassArgs &a, PruneState *state, uint8_t *mask,
                        unsigned long long *bits, int bit_words, const unsigned long long *view, const double *heavy, const double *Gall, const float *Dall,
                        const CacheViews &cv, PassCounters *counters, int32_t *bsum, int block_items, const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets);
-// k_pass_short<sets> (pairs_sorted.hip): the regular chunks of a pass with short chunks, one per wavefront
-int launch_pass_short(int sets, hipStream_t st, unsigned blocks, const PassGeom &g, const LocalPassArgs &a, const PruneState *state, uint8_t *mask, unsigned long long *bits,
-                      int bit_words, const unsigned long long *view, const double *heavy, const double *Gall, const float *Dall, const CacheViews &cv,
-                      PassCounters *counters, int32_t *bsum, int block_items);
