@@ -427,6 +427,127 @@ def string_embed(coords1, coords2, centers1, orb_vecs1, centers2, orb_vecs2, ang
     return (cands, ok, kept, margin) if return_margin else (cands, ok, kept)
 
 
+def _vec_angle_padded(v1, v2):
+    """algebra.py:58-62 vec_angle with 2-vectors padded by z = 0: what embeds.py:297-299 means (as shipped it reads vec[2] of a
+    2-vector, algebra.py:87 -- undefined).  Degrees."""
+    a, b = np.zeros(3), np.zeros(3)
+    a[:len(v1)], b[:len(v2)] = v1, v2
+    a, b = a / np.sqrt((a * a).sum()), b / np.sqrt((b * b).sum())
+    return float(np.degrees(np.arccos(np.clip(np.dot(a, b), -1.0, 1.0))))
+
+
+def _triangle_vertices(norms):
+    """embeds.py:256-267 / :332-343: the triangle with sides norms[0], norms[1], norms[2], first vertex at the origin, first side along x."""
+    a, b, c = norms[0] ** 2, norms[1] ** 2, norms[2] ** 2
+    x = (a - b + c) / (2 * a ** 0.5)
+    y = (c - x ** 2) ** 0.5
+    return np.array([[0.0, 0.0], [norms[0], 0.0], [x, y]])
+
+
+def get_directions3(norms):
+    """embeds.py:244-310 _get_directions for three molecules (vec_angle as _vec_angle_padded).  `norms` may be nudged in place (:285-290)."""
+    vertices = _triangle_vertices(norms)
+    a, b, c = vertices[1, 0], vertices[2, 0], vertices[2, 1]
+    cc = np.array([a / 2, (b ** 2 + c ** 2 - a * b) / (2 * c)])                       # circumcentre, :269-275
+    v0, v1, v2 = vertices
+    d1, d2, d3 = cc - (v0 + v1) / 2, cc - (v1 + v2) / 2, cc - (v2 + v0) / 2             # :279-285
+    if any(np.all(d == 0) for d in (d1, d2, d3)):                                     # a right triangle: nudged, :287-293
+        norms[0] += 1e-5
+        d1, d2, d3 = [t[:-1] for t in get_directions3(norms)]
+    if _vec_angle_padded(v0 - v2, v1 - v2) > 90:                                      # angle2 obtuse -> dir1, :295-301
+        d1 = -d1
+    if _vec_angle_padded(v1 - v0, v2 - v0) > 90:
+        d2 = -d2
+    if _vec_angle_padded(v0 - v1, v2 - v1) > 90:
+        d3 = -d3
+    out = np.zeros((3, 3))
+    for i, d in enumerate((d1, d2, d3)):
+        out[i, :2] = d
+        out[i] /= np.sqrt((out[i] * out[i]).sum())                                    # :306-308
+    return out
+
+
+def adjust_directions3(coords, reactive, reactive_cumnums, norms, directions, ids, vecs, pvt, conf_ids):
+    """embeds.py:312-465 _adjust_directions: the three molecules pre-aligned with `directions`, the 7^3 combinations of -30 .. 30 degree
+    turns about their pivots scored by how parallel the facing orbitals come out, the best one's displacement vectors returned.
+    pvt[m] = (pivot, meanpoint) of molecule m; coords[m] f64[n_conf, n, 3]; reactive_cumnums[m] = [[atom index, cumnum], ...]."""
+    p = [vecs[i][1] - vecs[i][0] for i in range(3)]
+    p_mean = [(vecs[i][1] + vecs[i][0]) / 2 for i in range(3)]
+    tri = _triangle_vertices(norms)
+    v = [np.array([tri[i, 0], tri[i, 1], 0.0]) for i in range(3)]
+    rot, pos = [], []
+    for i in range(3):
+        start, end = vecs[i]
+        mol_direction = pvt[i][1] - coords[i][conf_ids[i]][reactive[i]].mean(axis=0)
+        if np.all(mol_direction == 0.0):
+            mol_direction = pvt[i][1]
+        r_i = align_vec_pair(np.array([end - start, directions[i]]), np.array([pvt[i][0], mol_direction]))   # :368-369
+        rot.append(r_i), pos.append((start + end) / 2 - r_i @ pvt[i][1])
+    r = np.zeros((3, 3), dtype=int)                                                    # r[m, partner]: m's reactive atom that faces `partner`, :376-397
+    for c in ids:
+        found = [None, None]
+        for m in range(3):
+            for index, cum in reactive_cumnums[m]:
+                if cum == c[0]:
+                    found[0] = (m, int(index))
+                if cum == c[1]:
+                    found[1] = (m, int(index))
+        (m0, i0), (m1, i1) = found
+        r[m0, m1], r[m1, m0] = i0, i1
+    at = lambda m, partner: rot[m] @ coords[m][0][r[m, partner]] + pos[m]              # (conformer 0, as the reference, :403-411)
+    a01, a02, a10, a12, a20, a21 = at(0, 1), at(0, 2), at(1, 0), at(1, 2), at(2, 0), at(2, 1)
+    best = None
+    for ang in np.array(cartesian_product(7, 7, 7)) * 10.0 - 30.0:                     # :415-420
+        r0, r1, r2 = (rot_mat_from_pointer(p[i], ang[i]) for i in range(3))
+        n01, n02, n10, n12, n20, n21 = r0 @ a01, r0 @ a02, r1 @ a10, r1 @ a12, r2 @ a20, r2 @ a21
+        cost = (_vec_angle_padded(v[0] - n02, n20 - v[0]) + _vec_angle_padded(v[1] - n01, n10 - v[1])
+                + _vec_angle_padded(v[2] - n21, n12 - v[2]))                          # :441-444
+        if best is None or cost < best[0]:                                             # (sorted(...)[0] is stable: the first of the smallest)
+            best = (cost, np.array([p_mean[0] - (n01 + n02) / 2, p_mean[1] - (n10 + n12) / 2, p_mean[2] - (n20 + n21) / 2]))
+    return best[1]
+
+
+def cyclical_embed3(coords, reactive, pivots, reactive_cumnums, angles, clash_thresh, rmsd_thr=1):
+    """embeds.py:470-732 for THREE molecules under RIGID (impossible triangles are skipped, :527-573), vec_angle padded as in
+    _vec_angle_padded: (candidates, group_of, clash_ok, kept, ids per group).  pivots[m][c] = (pivot [P,3], meanpoint [P,3], cumnums [P,2])."""
+    SW = [(0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1)]        # :886-893
+    ids_len = [c.shape[1] for c in coords]
+    cands, group_of, ok, kept, gids = [], [], [], [], []
+    for conf_ids in cartesian_product(*[len(c) for c in coords]):
+        pv = [pivots[m][conf_ids[m]] for m in range(3)]
+        for pi in cartesian_product(*[len(q[0]) for q in pv]):
+            norms = np.array([float(np.sqrt((np.asarray(pv[m][0][pi[m]]) ** 2).sum())) for m in range(3)])
+            if not all(norms[i] < norms[i - 1] + norms[i - 2] for i in (0, 1, 2)):      # :499-503 -> :527-573 under RIGID: skipped
+                continue
+            poly = polygonize(norms)
+            directions = get_directions3(norms)
+            pvt = [(np.asarray(pv[m][0][pi[m]], dtype=np.float64), np.asarray(pv[m][1][pi[m]], dtype=np.float64)) for m in range(3)]
+            for v in range(8):
+                cum = [list(pv[m][2][pi[m]]) for m in range(3)]
+                cum = [c[::-1] if SW[v][m] else c for m, c in enumerate(cum)]
+                ids = [sorted([cum[0][1], cum[1][0]]), sorted([cum[1][1], cum[2][0]]), sorted([cum[2][1], cum[0][0]])]      # :895-897
+                gids.append(ids)
+                g = len(gids) - 1
+                directions = adjust_directions3(coords, reactive, reactive_cumnums, norms, directions, ids, poly[v], pvt, conf_ids)    # :650-655 (carried over)
+                group_poses = []
+                for ang in angles:
+                    rot, pos = np.empty((1, 3, 3, 3)), np.empty((1, 3, 3))
+                    for m in range(3):
+                        r = coords[m][conf_ids[m]][reactive[m]]
+                        rm, pm = cyclical_embed_params([poly[v, m, 0]], [poly[v, m, 1]], [directions[m]], [pvt[m][0]], [pvt[m][1]], [r[0]],
+                                                       [r[1] if len(r) == 2 else r[0]], [len(r)], [ang[m]])
+                        rot[0, m], pos[0, m] = rm[0], pm[0]
+                    pose = transform_batch(coords, [list(conf_ids)], rot, pos)[0]
+                    good = bool(compenetration_mask(pose[None], ids_len, clash_thresh, 0)[0])
+                    keep = False
+                    if good:
+                        keep = not _rmsd_similarity(pose, group_poses, rmsd_thr)
+                        if keep:
+                            group_poses.append(pose)
+                    cands.append(pose), group_of.append(g), ok.append(good), kept.append(keep)
+    return np.array(cands), np.array(group_of), np.array(ok, dtype=bool), np.array(kept, dtype=bool), np.array(gids)
+
+
 def cyclical_embed(coords, reactive, pivots, angles, clash_thresh, rigid_shortcut=True, max_norm_delta=5, rmsd_thr=1):
     """embeds.py:470-732 / :734-860 for two molecules, one group at a time: (candidates, group_of, clash_ok, kept, ids per group).
     pivots[m][c] = (pivot [P,3], meanpoint [P,3], cumnums [P,2])."""

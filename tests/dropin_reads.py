@@ -125,18 +125,21 @@ def duck_string_embedder(g11, k, logs):
                                  options=types.SimpleNamespace(clash_thresh=float(g11[f"clash_thresh_{k}"])), log=lambda *a, **kw: logs.append(a))
 
 
-def duck_cyclical_embedder(g12, k, logs):
-    """Embedder + two molecules carrying the recorded inputs of G12 case k."""
+def duck_cyclical_embedder(g12, k, logs, n_mols=2):
+    """Embedder + two (G12) or three (G18) molecules carrying the recorded inputs of case k."""
     import types
     mols = []
-    for m in range(2):
+    for m in range(n_mols):
         coords = g12[f"coords{m}_{k}"]
         piv = []
         for c in range(len(coords)):
             vec, mean, cum = g12[f"pivot_vec{m}_{c}_{k}"], g12[f"pivot_mean{m}_{c}_{k}"], g12[f"pivot_cumnums{m}_{c}_{k}"]
             piv.append([types.SimpleNamespace(pivot=vec[i], meanpoint=mean[i], start_atom=types.SimpleNamespace(cumnum=int(cum[i, 0])),
                                               end_atom=types.SimpleNamespace(cumnum=int(cum[i, 1]))) for i in range(len(vec))])
-        mols.append(types.SimpleNamespace(atomcoords=coords, reactive_indices=g12[f"reactive_indices{m}_{k}"], pivots=piv))
+        mol = types.SimpleNamespace(atomcoords=coords, reactive_indices=g12[f"reactive_indices{m}_{k}"], pivots=piv)
+        if f"reactive_cumnums{m}_{k}" in g12.files:      # (three molecules: which reactive atom carries which cumulative number)
+            mol.reactive_atoms_classes_dict = {0: {int(i): types.SimpleNamespace(cumnum=int(cn)) for i, cn in g12[f"reactive_cumnums{m}_{k}"]}}
+        mols.append(mol)
     return types.SimpleNamespace(objects=mols, ids=g12[f"ids_{k}"], systematic_angles=g12[f"angles_{k}"], candidates=len(g12[f"candidates_{k}"]),
                                  embed="cyclical", pairings_table={}, internal_constraints=[],
                                  options=types.SimpleNamespace(clash_thresh=float(g12[f"clash_thresh_{k}"]), rigid=bool(g12[f"rigid_{k}"])),

@@ -365,6 +365,63 @@ def gen_g12():
     _save("G12_cyclical_embed", **flat)
 
 
+# --------------------------------------------------------------------------- G18
+def gen_g18():
+    """cyclical_embed for THREE molecules (tscode/embeds.py:244-465, 470-732) -- with ONE change to the reference: `vec_angle` as
+    `_get_directions` calls it on 2-vectors (:297-299) pads them with z = 0.  As shipped that call is undefined (algebra.norm reads vec[2]
+    of a 2-vector, tscode/algebra.py:87: an IndexError as plain NumPy, an unchecked out-of-bounds read under Numba); the padded form is the
+    mathematically intended one (an angle between two plane vectors).  Everything else -- polygonize, _get_directions, _adjust_directions
+    (its carry-over of `directions` from one orientation to the next, its use of conformer 0 for the reactive atoms), the pose loop -- is the
+    reference's own code, run here.  Fixtures made this way are labelled "reference patched: unpinned where the reference is undefined"."""
+    print("G18 cyclical_embed, three molecules (vec_angle of 2-vectors padded with z = 0)")
+    flat = {"seed": 9118, "patch": "tscode.embeds.vec_angle pads 2-vectors with z = 0 (embeds.py:297-299 / algebra.py:87)"}
+    real_va = ref_embeds.vec_angle
+
+    def va(v1, v2):
+        v1, v2 = np.asarray(v1, dtype=np.float64), np.asarray(v2, dtype=np.float64)
+        if v1.shape[0] == 2:
+            v1 = np.concatenate((v1, [0.0]))
+        if v2.shape[0] == 2:
+            v2 = np.concatenate((v2, [0.0]))
+        return real_va(v1, v2)
+    CH3Cl, HCOOH = (os.path.join(TESTS, f) for f in ("CH3Cl.xyz", "HCOOH.xyz"))
+    rng = np.random.default_rng(9118)
+    scratch = "/tmp/tscode_amd_golden"
+    os.makedirs(scratch, exist_ok=True)
+    ph = os.path.join(scratch, "HCOOH_confs3.xyz")
+    zh, ch_ = R.read_xyz_data(HCOOH)
+    _write_xyz(ph, zh, _conformers(zh, ch_[0], rng, 2, (0, 3), [4]))
+    cases = [
+        # tests/trimolecular.txt: CH3Cl 0A 4y + HCOOH 1A 4x + HCOOH 1x 4y (one DIST for all pairings here), STEPS=1 ROTRANGE=10
+        dict(files=[(CH3Cl, [0, 4]), (HCOOH, [1, 4]), (HCOOH, [1, 4])], dist=2.3, steps=1, rot_range=10, thresh=1.3),
+        # more angle sets per group, a tighter clash threshold
+        dict(files=[(CH3Cl, [0, 4]), (HCOOH, [1, 4]), (HCOOH, [1, 4])], dist=2.6, steps=2, rot_range=20, thresh=1.2),
+        # a conformer ensemble on one side: the order of conf_indices / pivots_indices
+        dict(files=[(CH3Cl, [0, 4]), (ph, [1, 4]), (HCOOH, [1, 4])], dist=2.4, steps=1, rot_range=15, thresh=1.25),
+    ]
+    ref_embeds.vec_angle = va
+    try:
+        for k, cs in enumerate(cases):
+            mols = [_molecule(f, r, cs["dist"]) for f, r in cs["files"]]
+            e = _embedder(mols, "cyclical", clash_thresh=cs["thresh"], rigid=True)
+            for m in mols:
+                ref_embedder.Embedder._set_pivots(e, m)
+            steps, rr = cs["steps"], cs["rot_range"]
+            e.systematic_angles = ref_utils.cartesian_product(*[range(steps + 1) for _ in mols]) * 2 * rr / steps - rr
+            inp = _cyclical_inputs(e)
+            for m, mol in enumerate(mols):     # which reactive atom carries which cumulative number (_adjust_directions pairs them up, :378-385)
+                inp[f"reactive_cumnums{m}"] = np.array([[int(i), int(a.cumnum)] for i, a in mol.reactive_atoms_classes_dict[0].items()]).reshape(-1, 2)
+            tr = _trace_cyclical_embed(e)
+            for key, v in {**inp, **tr}.items():
+                flat[f"{key}_{k}"] = v
+            print(f"  case {k}: pivots {[len(m.pivots[0]) for m in mols]}, {len(tr['candidates'])} candidates in {len(tr['group_ids'])} groups, "
+                  f"{int(tr['clash_ok'].sum())} pass the clash check, {len(tr['poses'])} kept")
+    finally:
+        ref_embeds.vec_angle = real_va
+    flat["n_cases"] = len(cases)
+    _save("G18_cyclical_embed_trimolecular", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["G10", "G11", "G12"]
     for g in which:

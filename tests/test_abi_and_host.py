@@ -275,3 +275,34 @@ def test_rotate_dihedral_single_structure_is_host_side():
             q += 1
     same = coords.copy()
     assert rotate_dihedral(same, dih, 0.0, mask=mask) is same and np.array_equal(same, coords)
+
+
+def test_trimolecular_groups_host_logic_vs_g18(oracle):
+    """The host side of the three-molecule cyclical embed (tscode_amd.embeds._trimolecular_groups: polygonize, _get_directions with the
+    plane-vector reading of vec_angle, _adjust_directions with its carry-over from orientation to orientation) against G18, the
+    reference's own code run with that one change: the groups and their facing atoms, and -- the groups' records pushed through the
+    oracle's per-row pose parameters and embedding on the CPU -- every candidate pose."""
+    from tscode_amd.embeds import _trimolecular_groups
+    g = load_golden("G18_cyclical_embed_trimolecular")
+    for k in range(int(g["n_cases"])):
+        coords = [np.ascontiguousarray(g[f"coords{m}_{k}"], dtype=np.float64) for m in range(3)]
+        reactive = [np.atleast_1d(g[f"reactive_indices{m}_{k}"]).astype(np.int64) for m in range(3)]
+        pivots = [[(g[f"pivot_vec{m}_{c}_{k}"], g[f"pivot_mean{m}_{c}_{k}"], g[f"pivot_cumnums{m}_{c}_{k}"]) for c in range(len(coords[m]))] for m in range(3)]
+        cumnums = [g[f"reactive_cumnums{m}_{k}"] for m in range(3)]
+        blocks, gids, meta = _trimolecular_groups(coords, reactive, pivots, cumnums, None, ())
+        assert np.array_equal(gids, g[f"group_ids_{k}"]) and len(meta) == len(gids)
+        angles = g[f"angles_{k}"]
+        A = len(angles)
+        assert len(blocks) * A == len(g[f"candidates_{k}"])
+        worst = 0.0
+        for gi in range(0, len(blocks), max(1, len(blocks) // 12)):          # a dozen groups spread over the list, all their angle sets
+            rec = blocks[gi]
+            for ai, ang in enumerate(angles):
+                rot, pos = np.empty((1, 3, 3, 3)), np.empty((1, 3, 3))
+                for m in range(3):
+                    rm, pm = oracle.cyclical_embed_params([rec[m, 0:3]], [rec[m, 3:6]], [rec[m, 6:9]], [rec[m, 9:12]], [rec[m, 12:15]], [rec[m, 15:18]],
+                                                          [rec[m, 18:21]], [int(rec[m, 21])], [ang[m]])
+                    rot[0, m], pos[0, m] = rm[0], pm[0]
+                pose = oracle.transform_batch(coords, [[int(rec[m, 22]) for m in range(3)]], rot, pos)[0]
+                worst = max(worst, float(np.abs(pose - g[f"candidates_{k}"][gi * A + ai]).max()))
+        assert worst < 1e-9, (k, worst)

@@ -1610,6 +1610,29 @@ def test_cyclical_embed_golden(eng, oracle):
         tscode_amd.cyclical_embed_batch(_cyclical_case(g, 0) * 2, g["angles_0"])           # not two molecules
 
 
+def test_cyclical_embed_trimolecular_golden(eng, oracle):
+    """THREE molecules (tests/trimolecular.txt's CH3Cl + 2 HCOOH and variants), G18: the reference's own cyclical_embed run with the one change
+    that makes it defined (vec_angle pads the 2-vectors of _get_directions with z = 0; embeds.py:297-299 / algebra.py:87) -- "reference
+    patched", unpinned where the reference is undefined -- against ONE call of the product driver: triangle, directions and their
+    adjustment on the host, pose parameters -> embed of three fragments -> compenetration mask -> greedy per-group filter on the device."""
+    import tscode_amd
+    g = load_golden("G18_cyclical_embed_trimolecular")
+    for k in range(int(g["n_cases"])):
+        mols = []
+        for m in range(3):
+            coords = g[f"coords{m}_{k}"]
+            mols.append(dict(coords=coords, reactive_indices=g[f"reactive_indices{m}_{k}"], reactive_cumnums=g[f"reactive_cumnums{m}_{k}"],
+                             pivots=[(g[f"pivot_vec{m}_{c}_{k}"], g[f"pivot_mean{m}_{c}_{k}"], g[f"pivot_cumnums{m}_{c}_{k}"]) for c in range(len(coords))]))
+        poses, cons, tr = tscode_amd.cyclical_embed_batch(mols, g[f"angles_{k}"], clash_thresh=float(g[f"clash_thresh_{k}"]), return_trace=True)
+        assert np.array_equal(tr.group_of, g[f"group_of_{k}"])
+        assert np.array_equal(np.array([grp[3] for grp in tr.groups]), g[f"group_ids_{k}"])
+        assert oracle.clash_margin(g[f"candidates_{k}"], g[f"ids_{k}"], float(g[f"clash_thresh_{k}"])) > 1e-9
+        assert np.array_equal(tr.clash_ok, g[f"clash_ok_{k}"])
+        assert np.array_equal(tr.kept, g[f"kept_{k}"]), (k, tr.kept.sum(), g[f"kept_{k}"].sum())
+        assert poses.shape == g[f"poses_{k}"].shape and np.abs(poses - g[f"poses_{k}"]).max() < VAL_TOL
+        assert np.array_equal(cons, g[f"constrained_indices_{k}"]) and cons.shape[1:] == (3, 2)
+
+
 def test_cyclical_embed_wide_groups(eng, oracle):
     """STEPS = 36: (36 + 1)^2 = 1369 poses per (conformers, pivots, orientation) group -- beyond the 1024 the group filter took in round 2
     (ADVICE r2).  The product driver against the oracle's loop on the molecules of G12's first case."""
@@ -1666,7 +1689,17 @@ def test_embed_dropins_with_the_reference_signatures(eng):
             poses = E.cyclical_embed(emb)
             assert poses.shape == g12[f"poses_{k}"].shape and np.abs(poses - g12[f"poses_{k}"]).max() < VAL_TOL
             assert np.array_equal(emb.constrained_indices, g12[f"constrained_indices_{k}"])
-        # three molecules: handed to the reference's own function (recorded by install())
+        # three molecules with the switch on: the batch driver (G18: the reference's own code with vec_angle's plane vectors padded)
+        g18 = load_golden("G18_cyclical_embed_trimolecular")
+        E.TRIMOLECULAR = True
+        try:
+            emb3 = dropin_reads.duck_cyclical_embedder(g18, 0, logs, n_mols=3)
+            poses3 = E.cyclical_embed(emb3)
+            assert poses3.shape == g18["poses_0"].shape and np.abs(poses3 - g18["poses_0"]).max() < VAL_TOL
+            assert np.array_equal(emb3.constrained_indices, g18["constrained_indices_0"])
+        finally:
+            E.TRIMOLECULAR = False
+        # three molecules by default: handed to the reference's own function (recorded by install())
         done = tscode_amd.install()
         assert ("tscode.embeds", "string_embed") in done and ("tscode.embeds", "cyclical_embed") in done
         assert standin.cyclical_embed is E.cyclical_embed

@@ -395,3 +395,29 @@ def test_g15_rotate_dihedral_fractional_angles(oracle):
             seq = oracle.rotate_dihedral(seq, g["dihedral"], sign * float(a), g["mask"])
             assert np.abs(seq - g["trail"][q]).max() < 1e-12
             q += 1
+
+
+def _cyclical_case3(g, k):
+    coords = [g[f"coords{m}_{k}"] for m in range(3)]
+    reactive = [g[f"reactive_indices{m}_{k}"] for m in range(3)]
+    pivots = [[(g[f"pivot_vec{m}_{c}_{k}"], g[f"pivot_mean{m}_{c}_{k}"], g[f"pivot_cumnums{m}_{c}_{k}"]) for c in range(len(coords[m]))] for m in range(3)]
+    cumnums = [g[f"reactive_cumnums{m}_{k}"] for m in range(3)]
+    return coords, reactive, pivots, cumnums
+
+
+def test_g18_cyclical_embed_trimolecular(oracle):
+    """The reference's cyclical_embed for THREE molecules (tests/trimolecular.txt's molecules and variants), run with `vec_angle` padding the
+    2-vectors of _get_directions with z = 0 -- as shipped that call is undefined (embeds.py:297-299 / algebra.py:87), so this fixture is
+    "reference patched", unpinned where the reference is undefined -- against the oracle's restatement of _get_directions,
+    _adjust_directions (the carry-over of `directions` from orientation to orientation, conformer 0 for the reactive atoms) and the pose loop."""
+    g = load_golden("G18_cyclical_embed_trimolecular")
+    for k in range(int(g["n_cases"])):
+        coords, reactive, pivots, cumnums = _cyclical_case3(g, k)
+        cands, group_of, ok, kept, gids = oracle.cyclical_embed3(coords, reactive, pivots, cumnums, g[f"angles_{k}"], float(g[f"clash_thresh_{k}"]))
+        assert np.array_equal(group_of, g[f"group_of_{k}"]) and np.array_equal(gids, g[f"group_ids_{k}"])
+        assert cands.shape == g[f"candidates_{k}"].shape and np.abs(cands - g[f"candidates_{k}"]).max() < 1e-9
+        assert oracle.clash_margin(g[f"candidates_{k}"], g[f"ids_{k}"], float(g[f"clash_thresh_{k}"])) > 1e-9
+        assert np.array_equal(ok, g[f"clash_ok_{k}"])
+        assert np.array_equal(kept, g[f"kept_{k}"]), (k, kept.sum(), g[f"kept_{k}"].sum())
+        assert np.abs(cands[kept] - g[f"poses_{k}"]).max() < 1e-9
+        assert np.array_equal(gids[group_of[kept]], g[f"constrained_indices_{k}"])

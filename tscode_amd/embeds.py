@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .algebra import rot_mat_from_pointer, rotation_matrix_from_vectors  # noqa: F401  (host-side singles, re-exported)
+from .algebra import align_vec_pair, norm, rot_mat_from_pointer, rotation_matrix_from_vectors, vec_angle  # noqa: F401  (host-side singles, re-exported)
 from .engine import FragmentSet, get_engine
 from .utils import cartesian_product, polygonize
 
@@ -138,6 +138,141 @@ def _in_constraints(pair, internal_constraints):
     return bool((np.asarray(internal_constraints) == np.asarray(pair)).any())
 
 
+# ---- three molecules (tscode/embeds.py:244-465).  UNPINNED WHERE THE REFERENCE IS UNDEFINED: _get_directions calls vec_angle on 2-vectors
+# (:297-299) and algebra.norm reads vec[2] of them (tscode/algebra.py:87) -- an IndexError as plain NumPy, an out-of-bounds read under Numba.
+# What follows takes the mathematically intended reading (a plane vector has z = 0); with that one change the reference's own code runs, and
+# fixture G18 records it ("reference patched").  Everything else below is the reference's behaviour, quirks included.
+_ORIENT3 = np.array([(0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1)], dtype=bool)      # :886-893
+_SWAPS3 = ((1, 2), (2, 1), (3, 1), (3, 2), (4, 0), (5, 0), (5, 1), (6, 0), (6, 2), (7, 0), (7, 1), (7, 2))                       # tscode/utils.py:255
+_ADJUST_ANGLES = cartesian_product(np.arange(7), np.arange(7), np.arange(7)) * 10.0 - 30.0                                      # :415-420
+
+
+def _plane_angle(v1, v2):
+    """vec_angle (tscode/algebra.py:58-62) of two vectors with up to three components, the missing ones zero.  Degrees."""
+    a, b = np.zeros(3), np.zeros(3)
+    a[:len(v1)], b[:len(v2)] = v1, v2
+    return vec_angle(a, b)
+
+
+def _triangle3(norms):
+    """Vertices of the triangle with sides norms (first vertex at the origin, first side along x): tscode/utils.py:240-250, embeds.py:256-267."""
+    a, b, c = norms[0] ** 2, norms[1] ** 2, norms[2] ** 2
+    x = (a - b + c) / (2 * a ** 0.5)
+    y = (c - x ** 2) ** 0.5
+    return np.array([[0.0, 0.0, 0.0], [norms[0], 0.0, 0.0], [x, y, 0.0]])
+
+
+def _polygonize3(norms):
+    """tscode/utils.py:234-261: the eight orientations of the three (start, end) pairs, f64[8, 3, 2, 3]."""
+    v = _triangle3(norms)
+    arr = np.zeros((3, 2, 3))
+    arr[0, 1] = arr[1, 0] = v[1]
+    arr[1, 1] = arr[2, 0] = v[2]
+    out = np.repeat(arr[None], 8, axis=0)
+    for t, m in _SWAPS3:
+        out[t, m] = out[t, m][::-1].copy()
+    return out
+
+
+def _directions3(norms):
+    """_get_directions for three molecules (embeds.py:244-310): from the middle of every side towards the circumcentre, away from it where
+    the opposite angle is obtuse.  `norms` is nudged in place for a right triangle, as the reference does (:287-293)."""
+    v = _triangle3(norms)[:, :2]
+    a, b, c = v[1, 0], v[2, 0], v[2, 1]
+    cc = np.array([a / 2, (b ** 2 + c ** 2 - a * b) / (2 * c)])
+    d = [cc - (v[0] + v[1]) / 2, cc - (v[1] + v[2]) / 2, cc - (v[2] + v[0]) / 2]
+    if any(np.all(x == 0) for x in d):
+        norms[0] += 1e-5
+        d = [t[:-1] for t in _directions3(norms)]
+    obtuse = (_plane_angle(v[1] - v[0], v[2] - v[0]) > 90, _plane_angle(v[0] - v[1], v[2] - v[1]) > 90, _plane_angle(v[0] - v[2], v[1] - v[2]) > 90)
+    flip = (obtuse[2], obtuse[0], obtuse[1])                                                          # :299-301
+    out = np.zeros((3, 3))
+    for i in range(3):
+        out[i, :2] = -d[i] if flip[i] else d[i]
+        out[i] = norm(out[i])
+    return out
+
+
+def _adjust_directions3(coords, reactive, cumnums, norms, directions, ids, vecs, pivot, meanpoint, conf_ids):
+    """_adjust_directions (embeds.py:312-465): the molecules pre-aligned with `directions`; every combination of -30 .. 30 degree turns of the
+    three about their pivots (7^3) scored by the angles between the facing orbitals; the displacement vectors of the best one (the first
+    of the smallest cost).  All 343 candidates at once."""
+    p = vecs[:, 1] - vecs[:, 0]
+    p_mean = vecs.mean(axis=1)
+    tri = _triangle3(norms)
+    rot, pos = [], []
+    for i in range(3):
+        mol_direction = meanpoint[i] - coords[i][conf_ids[i]][reactive[i]].mean(axis=0)
+        if np.all(mol_direction == 0.0):
+            mol_direction = meanpoint[i]
+        r_i = align_vec_pair(np.array([p[i], directions[i]]), np.array([pivot[i], mol_direction]))     # :368-369
+        rot.append(r_i), pos.append(p_mean[i] - r_i @ meanpoint[i])
+    facing = np.zeros((3, 3), dtype=np.int64)            # facing[m, partner] = m's reactive atom that faces `partner` (:376-397)
+    for c in ids:
+        found = [None, None]
+        for m in range(3):
+            for index, cum in cumnums[m]:
+                if cum == c[0]:
+                    found[0] = (m, int(index))
+                if cum == c[1]:
+                    found[1] = (m, int(index))
+        (m0, i0), (m1, i1) = found
+        facing[m0, m1], facing[m1, m0] = i0, i1
+    at = lambda m, partner: rot[m] @ coords[m][0][facing[m, partner]] + pos[m]                        # (conformer 0: as the reference, :403-411)
+    # R(axis, angle) for the 7 angles of every molecule, then the 343 combinations by indexing
+    steps = np.arange(7) * 10.0 - 30.0
+    turn = [np.array([rot_mat_from_pointer(p[i], a) for a in steps]) for i in range(3)]               # [7, 3, 3] each
+    idx = ((_ADJUST_ANGLES + 30.0) / 10.0).round().astype(np.int64)                                   # [343, 3]
+    new = {}
+    for m, partner in ((0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)):
+        new[m, partner] = turn[m][idx[:, m]] @ at(m, partner)                                         # [343, 3]
+
+    def ang(u, w):                                                                                    # vec_angle row by row
+        un = u / np.sqrt((u * u).sum(axis=1, keepdims=True))
+        wn = w / np.sqrt((w * w).sum(axis=1, keepdims=True))
+        return np.degrees(np.arccos(np.clip((un * wn).sum(axis=1), -1.0, 1.0)))
+    cost = ang(tri[0] - new[0, 2], new[2, 0] - tri[0]) + ang(tri[1] - new[0, 1], new[1, 0] - tri[1]) + ang(tri[2] - new[2, 1], new[1, 2] - tri[2])
+    best = int(np.argmin(cost))                                                                       # (the first of the smallest: sorted() is stable)
+    return np.array([p_mean[0] - (new[0, 1][best] + new[0, 2][best]) / 2, p_mean[1] - (new[1, 0][best] + new[1, 2][best]) / 2,
+                     p_mean[2] - (new[2, 0][best] + new[2, 1][best]) / 2])
+
+
+def _trimolecular_groups(coords, reactive, pivots, cumnums, pairings, internal_constraints):
+    """The (conformers, pivots, orientation) groups of a three-molecule cyclical embed under RIGID (embeds.py:470-655): one 23-field record
+    per molecule and group, the facing atoms of every group, and (conformers, pivots, orientations) per pivot triple for the trace."""
+    blocks, group_ids, group_meta = [], [], []
+    for conf_ids in cartesian_product(*[np.arange(len(c)) for c in coords]):
+        pv = [pivots[m][conf_ids[m]] for m in range(3)]
+        vec = [np.asarray(q[0], dtype=np.float64).reshape(-1, 3) for q in pv]
+        mean = [np.asarray(q[1], dtype=np.float64).reshape(-1, 3) for q in pv]
+        cum = [np.asarray(q[2]).reshape(-1, 2) for q in pv]
+        for pi in cartesian_product(*[np.arange(len(v)) for v in vec]):
+            pivot = [vec[m][pi[m]] for m in range(3)]
+            meanpoint = [mean[m][pi[m]] for m in range(3)]
+            norms = np.array([np.linalg.norm(q) for q in pivot])                                     # :487
+            if not all(norms[i] < norms[i - 1] + norms[i - 2] for i in (0, 1, 2)):                    # an impossible triangle: skipped under RIGID (:527-573)
+                continue
+            poly = _polygonize3(norms)
+            directions = _directions3(norms)
+            for v in range(8):
+                c3 = [cum[m][pi[m]][::-1] if _ORIENT3[v][m] else cum[m][pi[m]] for m in range(3)]
+                ids = [sorted([int(c3[0][1]), int(c3[1][0])]), sorted([int(c3[1][1]), int(c3[2][0])]), sorted([int(c3[2][1]), int(c3[0][0])])]   # :895-897
+                if pairings and not all((list(pair) in ids) or _in_constraints(pair, internal_constraints) for pair in pairings):                 # :642
+                    continue
+                # (carried over from orientation to orientation, as the reference's loop does: `directions` is rebound inside it, :650-655)
+                directions = _adjust_directions3(coords, reactive, cumnums, norms, directions, ids, poly[v], pivot, meanpoint, conf_ids)
+                rec = np.zeros((3, 23))
+                for m in range(3):
+                    r = coords[m][conf_ids[m]][reactive[m]]
+                    rec[m, 0:3], rec[m, 3:6], rec[m, 6:9] = poly[v, m, 0], poly[v, m, 1], directions[m]
+                    rec[m, 9:12], rec[m, 12:15] = pivot[m], meanpoint[m]
+                    rec[m, 15:18], rec[m, 18:21] = r[0], (r[1] if len(r) == 2 else r[0])
+                    rec[m, 21], rec[m, 22] = len(r), conf_ids[m]
+                blocks.append(rec), group_ids.append(ids)
+                group_meta.append((tuple(int(c) for c in conf_ids), tuple(int(i) for i in pi), v))
+    return (np.array(blocks).reshape(-1, 3, 23), np.array(group_ids, dtype=np.int64).reshape(-1, 3, 2), group_meta)
+
+
 def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=0, rigid_shortcut=True, max_norm_delta=5, pairings=None,
                          internal_constraints=(), rmsd_thr=1, return_trace=False):
     """The loops of a BImolecular ``cyclical_embed`` (tscode/embeds.py:470-732, rigid shortcut :734-860) in one GPU call.
@@ -163,20 +298,29 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
     Returns ``(poses f64[n_kept, n_total, 3], constrained_indices int[n_kept, 2, 2])`` -- the reference's return value and
     ``embedder.constrained_indices`` -- plus an EmbedTrace with ``return_trace``.
 
-    Trimolecular embeds are not offered: the reference's ``_get_directions`` calls ``vec_angle`` on 2-vectors (:297-299) and
-    ``algebra.norm`` reads ``vec[2]`` of them (tscode/algebra.py:87) -- an unchecked out-of-bounds read under Numba, an
-    IndexError as plain NumPy: what it computes is undefined in the reference itself.
+    THREE molecules (RIGID: triangles that cannot be closed are skipped, the reference bends them otherwise): each molecule also brings
+    ``reactive_cumnums`` int[R, 2] = (atom index, cumnum) of its reactive atoms (``[(i, a.cumnum) for i, a in
+    mol.reactive_atoms_classes_dict[0].items()]``).  UNPINNED WHERE THE REFERENCE IS UNDEFINED: its ``_get_directions`` calls ``vec_angle``
+    on 2-vectors (:297-299) and ``algebra.norm`` reads ``vec[2]`` of them (tscode/algebra.py:87) -- an unchecked out-of-bounds read under
+    Numba, an IndexError as plain NumPy.  This driver takes the intended reading (z = 0); fixture G18 is the reference's own code run with
+    that one change.  ``rigid_shortcut`` / ``max_norm_delta`` do not apply to three molecules.
     """
     get = lambda m, k: m[k] if isinstance(m, dict) else getattr(m, k)
-    if len(mols) != 2:
-        raise ValueError("cyclical_embed_batch embeds two molecules (the reference's trimolecular path reads out of bounds: see the docstring)")
+    if len(mols) not in (2, 3):
+        raise ValueError("cyclical_embed_batch embeds two or three molecules")
+    n_mols = len(mols)
     coords = [np.ascontiguousarray(get(m, "coords"), dtype=np.float64) for m in mols]
     reactive = [np.atleast_1d(np.asarray(get(m, "reactive_indices"), dtype=np.int64)) for m in mols]
     pivots = [get(m, "pivots") for m in mols]
-    angles = np.asarray(systematic_angles, dtype=np.float64).reshape(-1, 2)
+    angles = np.asarray(systematic_angles, dtype=np.float64).reshape(-1, n_mols)
     A = len(angles)
     if A > MAX_GROUP_POSES:
-        raise ValueError(f"{A} angle pairs per group: tsc_cyclical_embed takes groups of up to {MAX_GROUP_POSES} poses (rotation steps up to 89)")
+        raise ValueError(f"{A} angle sets per group: tsc_cyclical_embed takes groups of up to {MAX_GROUP_POSES} poses (rotation steps up to 89)")
+    if n_mols == 3:
+        cumnums = [np.asarray(get(m, "reactive_cumnums"), dtype=np.int64).reshape(-1, 2) for m in mols]
+        blocks3, group_ids3, meta3 = _trimolecular_groups(coords, reactive, pivots, cumnums, pairings, internal_constraints)
+        return _run_cyclical_groups(coords, blocks3, group_ids3, [(c, p, np.array([v])) for c, p, v in meta3], angles, clash_thresh, max_clashes, rmsd_thr,
+                                    return_trace, flat_meta=True)
     directions = np.array([[0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])                                      # _get_directions for two, :252-253 / :768
     conf_indices = cartesian_product(*[np.arange(len(c)) for c in coords])                           # :470-471
     blocks, group_ids, group_meta = [], [], []
@@ -268,13 +412,22 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
         group_ids.append(ids[take])
         qs, vs = np.nonzero(take)
         group_meta.append((np.asarray(conf_ids, dtype=np.int64), pi[qs], vs))
-    n_total = sum(c.shape[1] for c in coords)
     n_groups = sum(len(b) for b in blocks)
+    blocks = np.concatenate(blocks) if n_groups else np.zeros((0, 2, 23))                            # [group, molecule, field]
+    group_ids = np.concatenate(group_ids) if n_groups else np.zeros((0, 2, 2), dtype=np.int64)
+    return _run_cyclical_groups(coords, blocks, group_ids, group_meta, angles, clash_thresh, max_clashes, rmsd_thr, return_trace)
+
+
+def _run_cyclical_groups(coords, blocks, group_ids, group_meta, angles, clash_thresh, max_clashes, rmsd_thr, return_trace, flat_meta=False):
+    """The groups' records -> one row per (pose, molecule) -> ONE library call (tsc_cyclical_embed): pose parameters, embedding, clash
+    verdicts, the greedy per-group similarity filter; the kept poses and the facing atoms of their groups."""
+    n_mols = len(coords)
+    A = len(angles)
+    n_total = sum(c.shape[1] for c in coords)
+    n_groups = len(blocks)
     if not n_groups:
-        out = (np.zeros((0, n_total, 3)), np.zeros((0, 2, 2), dtype=np.int64))
+        out = (np.zeros((0, n_total, 3)), np.zeros((0, n_mols, 2), dtype=np.int64))
         return (*out, EmbedTrace(clash_ok=np.zeros(0, bool), kept=np.zeros(0, bool), group_of=np.zeros(0, np.int64), groups=[])) if return_trace else out
-    blocks = np.concatenate(blocks)                                                                  # [group, molecule, field]
-    group_ids = np.concatenate(group_ids)
     # one row per (pose, molecule): a group's A poses share everything but the angles.  Every field is expanded straight into the
     # contiguous array the library takes (expanding the whole 23-field record and slicing it afterwards copied everything twice)
     expand = lambda lo, hi, dtype=np.float64: np.repeat(np.ascontiguousarray(blocks[:, :, lo:hi], dtype=dtype), A, axis=0).reshape(-1, hi - lo)
@@ -284,12 +437,12 @@ def cyclical_embed_batch(mols, systematic_angles, clash_thresh=1.5, max_clashes=
                                                   expand(15, 18), expand(18, 21), expand(21, 22, np.int32).reshape(-1), angle_rows,
                                                   expand(22, 23, np.int32).reshape(-1), group_off, clash_thresh, max_clashes, rmsd_thr)
     group_of = np.repeat(np.arange(n_groups), A)
-    constrained = group_ids[group_of[kept]].reshape(-1, 2, 2)                                        # :718
+    constrained = group_ids[group_of[kept]].reshape(-1, n_mols, 2)                                   # :718
     if return_trace:
         groups, g = [], 0
         for conf, pis, vs in group_meta:                                                             # (conformers, pivots, orientation, facing atoms) per group
             for q in range(len(vs)):
-                groups.append((tuple(int(c) for c in conf), tuple(int(i) for i in pis[q]), int(vs[q]), group_ids[g].tolist()))
+                groups.append((tuple(int(c) for c in conf), tuple(int(i) for i in (pis if flat_meta else pis[q])), int(vs[q]), group_ids[g].tolist()))
                 g += 1
         return poses, constrained, EmbedTrace(clash_ok=ok, kept=kept, group_of=group_of, groups=groups)
     return poses, constrained
@@ -340,14 +493,40 @@ def string_embed(embedder):
     return poses
 
 
+# Three molecules through this driver?  False (default): handed to the reference's own function, which is undefined there (vec_angle on 2-vectors,
+# embeds.py:297-299 / algebra.py:87: an IndexError as plain NumPy, an out-of-bounds read under Numba).  True: the batch driver with the
+# intended reading (z = 0), for RIGID runs -- what fixture G18 records; the result is then this package's, labelled so in the log.
+TRIMOLECULAR = False
+
+
 def cyclical_embed(embedder, max_norm_delta=5):
     """Drop-in for tscode/embeds.py:234-860 ``cyclical_embed(embedder)`` for two molecules (the rigid shortcut, and the general
-    loop where it bends nothing); trimolecular embeds and pivot pairs the reference would bend go to the reference's own
-    function."""
+    loop where it bends nothing); pivot pairs the reference would bend go to the reference's own function, and so do trimolecular
+    embeds unless ``tscode_amd.embeds.TRIMOLECULAR`` is set (see there)."""
     ref = _reference_embeds()
     original = _originals.get("cyclical_embed")
     mols = embedder.objects
     rigid = bool(embedder.options.rigid)
+    if len(mols) == 3 and TRIMOLECULAR and rigid and len(embedder.systematic_angles) <= MAX_GROUP_POSES:
+        packed = []
+        for mol in mols:
+            pivots = [(np.array([p.pivot for p in pv]).reshape(-1, 3), np.array([p.meanpoint for p in pv]).reshape(-1, 3),
+                       np.array([[p.start_atom.cumnum, p.end_atom.cumnum] for p in pv]).reshape(-1, 2)) for pv in mol.pivots]
+            packed.append(dict(coords=np.asarray(mol.atomcoords), reactive_indices=np.asarray(mol.reactive_indices), pivots=pivots,
+                               reactive_cumnums=np.array([[int(i), int(a.cumnum)] for i, a in mol.reactive_atoms_classes_dict[0].items()]).reshape(-1, 2)))
+        embedder.log(f"\n--> Performing {embedder.embed} embed of three molecules ({ref.pretty_num(embedder.candidates)} candidates, MI355X engine; "
+                     "vec_angle of plane vectors read with z = 0: the reference is undefined there)")
+        pairings = [list(p) for p in embedder.pairings_table.values()] if embedder.pairings_table else None
+        poses, constrained = cyclical_embed_batch(packed, embedder.systematic_angles, clash_thresh=embedder.options.clash_thresh, pairings=pairings,
+                                                  internal_constraints=getattr(embedder, "internal_constraints", ()))
+        embedder.constrained_indices = constrained
+        if not len(poses):
+            msg = ("\n--> Cyclical embed did not find any suitable disposition of molecules.\n"
+                   "    This is probably because one molecule has two reactive centers at a great distance,\n"
+                   "    preventing the other two molecules from forming a closed, cyclical structure.")
+            embedder.log(msg, p=False)
+            raise ref.ZeroCandidatesError(msg)
+        return poses
 
     def theirs():
         if original is None:
