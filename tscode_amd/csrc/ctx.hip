@@ -268,11 +268,6 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->cull_grid = int64_t(value);
         return 0;
     }
-    if (strcmp(name, "sieve_near_segs") == 0) {
-        TSC_REQUIRE(value >= 1 && value <= 1e6, "sieve_near_segs must be at least 1");
-        c->sieve_near_segs = int(value);
-        return 0;
-    }
     if (strcmp(name, "cull_xcd") == 0) {
         c->cull_xcd = value != 0.0 ? 1 : 0;
         return 0;

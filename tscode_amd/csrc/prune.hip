@@ -386,13 +386,6 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
         // and arrive at the pass's counter as a tile that does not exist)
         a.n = A, a.h = p->h;
         a.tile_begin = rank, a.tile_stride = world, a.seg_cols = seg_cols;
-        // the first "sieve_near_segs" segments of a row tile at seg_cols columns, the rest at 4096 (sieve.hpp, SieveArgs): the grid of a pass
-        // whose rows could reach far but mostly do not is then small
-        a.n_near = std::min(n_seg, std::max(1, c->sieve_near_segs));
-        a.far_cols = 4096;
-        a.n_far = (seg_cols < a.far_cols && n_seg > a.n_near) ? ceil_div(max_range + 64 - a.n_near * seg_cols, a.far_cols) : 0;
-        if (a.n_far == 0) a.n_near = n_seg;
-        grid.y = unsigned(a.n_near + a.n_far);
         a.thr = p->thr, a.maxdev_thr = 2 * p->thr;  // :95
         a.half_h_thr2 = 0.5 * double(p->h) * p->thr * p->thr;
         a.two_thr2 = p->h >= 4 ? 2.0 * p->thr * p->thr : -1.0;

@@ -670,13 +670,6 @@ struct SieveArgs {
     int tile_begin;
     int tile_stride;
     int seg_cols;
-    // Column segments of a row tile, in the order of blockIdx.y: first n_far FAR segments of far_cols columns each, behind the near ones,
-    // then n_near NEAR segments of seg_cols (sieve_segment).  The grid is sized for the longest possible range; in the late passes of a
-    // run most rows stop after a few hundred columns and nearly every work item behind them leaves at its first test -- but a workgroup
-    // that leaves at once still has to be dispatched: C3's last pass launched 100 000 workgroups for 430 with work, and dispatching them
-    // WAS the kernel (24 us).  Far segments eight times as long make the empty part of the grid eight times smaller; where they do have
-    // work (the heavy passes) an item is 32 column tiles instead of 4, launched first.
-    int n_near, n_far, far_cols;
     double thr, maxdev_thr;
     double half_h_thr2;   // h * thr^2 / 2
     double two_thr2;      // 2 thr^2 when the near-duplicate test applies (h >= 4), else -1
@@ -687,24 +680,6 @@ struct SieveArgs {
     const float *heavy32;       // float32 copy of the heavy atoms (heavy32_pitch(h) floats per structure), or null: stage 1 in float64 only
     unsigned long long *dbg;    // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront of the launch (tools/stamps.py), else null
 };
-
-// columns [lo, hi) of segment y (= blockIdx.y) of a row tile whose first column tile starts at seg_base
-__device__ __forceinline__ void sieve_segment(const SieveArgs &a, int seg_base, int y, int &lo, int &hi) {
-    if (y < a.n_far) {
-        lo = seg_base + a.n_near * a.seg_cols + y * a.far_cols;
-        hi = lo + a.far_cols;
-    } else {
-        lo = seg_base + (y - a.n_far) * a.seg_cols;
-        hi = lo + a.seg_cols;
-    }
-}
-// segments of a row tile that begin before column `lim` (> seg_base): the work items that will arrive at the tile's counter
-__device__ __forceinline__ int sieve_live_segments(const SieveArgs &a, int seg_base, int lim) {
-    const int near = min(a.n_near, (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
-    const int far_base = seg_base + a.n_near * a.seg_cols;
-    const int far = lim > far_base ? min(a.n_far, (lim - far_base + a.far_cols - 1) / a.far_cols) : 0;
-    return near + far;
-}
 
 #ifdef TSC_DBG_STAMPS   // measurement hook: where a wavefront of the pair kernel spends its time (100 MHz wall clock)
 #define TSC_STAMP(i)                                                                                                                  \
@@ -853,8 +828,8 @@ __device__ __forceinline__ void sieve_item(const double *__restrict__ heavy, con
     const int slot = blockIdx.x * 4 + wid;
     const int tile = a.tile_begin + slot * a.tile_stride;
     const int r0 = tile * TI;
-    int seg_lo, seg_hi;
-    sieve_segment(a, (r0 + 1) & ~63, int(blockIdx.y), seg_lo, seg_hi);
+    const int seg_lo = ((r0 + 1) & ~63) + int(blockIdx.y) * a.seg_cols;
+    const int seg_hi = seg_lo + a.seg_cols;
 
     // ---- prologue in one memory round trip: the state, this item's 16 stop columns / best columns (they decide whether
     // it has work at all: most items of a late pass have none) and the descriptors of its rows and first column tile.
@@ -1231,8 +1206,7 @@ inline __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OC
     const int tile = a.tile_begin + slot * a.tile_stride;
     const int r0 = tile * TI;
     const int seg_base = (r0 + 1) & ~63;
-    int seg_lo, seg_hi_unused;
-    sieve_segment(a, seg_base, int(blockIdx.y), seg_lo, seg_hi_unused);
+    const int seg_lo = seg_base + int(blockIdx.y) * a.seg_cols;
     TSC_STAMP(0);  // the wavefront has started
     if (r0 >= a.n || seg_lo >= a.n) return;  // beyond the upper bound the grid was sized for: nothing to read
     // most items of a pass with long chunks start beyond every stop column of their row tile (0 for a tile without rows or
@@ -1245,7 +1219,7 @@ inline __global__ __launch_bounds__(256, CPL == 4 ? 4 : (CPL == 2 ? TSC_SIEVE_OC
         // this item's atomicMin's on best[] are at the L2 before its arrival is
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const int lim = min(a.n, tcm);
-        const int n_live = sieve_live_segments(a, seg_base, lim);
+        const int n_live = min(int(gridDim.y), (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
         // (the tail of a light pass is a chain of dependent round trips -- arrival, state, best[], act[], the atomics' way out, the pass's
         // counter -- and its length is the pass: the only item of its tile needs no arrival, and the state block was read in the prologue)
         if (n_live > 1) {
