@@ -202,6 +202,13 @@ int tsc_rmsd_pairs(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, 
 int tsc_rmsd_pairs_dev(tsc_ctx *ctx, const double *heavy, int64_t n_structs, int h, const int32_t *pairs, int64_t n_pairs,
                        double *rmsd, double *maxdev);
 
+/* The descriptor screen of the prune's pair kernel as the matrix cores compute it (csrc/mm.hpp), for tests: the screen values
+ * S[fam][r][c] (two feature families, rows r < 64, columns c < n) of the first 64 of n descriptors against all n, in the units the
+ * kernel compares them in -- out_scale^2 times |D_fam[r] - D_fam[c]|^2 up to the error bound of mm.hpp -- and the limit the kernel
+ * holds them against for a squared-distance limit `limit` = h thr^2 (as a float's bit pattern; INT32_MAX - 1: nothing is dropped).
+ *   D f32[n, 16] host (component 2 k + fam, as the library stores descriptors); S f32[2, 64, n] host. */
+int tsc_screen_mm_values(tsc_ctx *ctx, const float *D, int64_t n, double limit, float *S, int32_t *limit_bits, float *out_scale);
+
 /* Torsion-fingerprint pruning (tscode/numba_functions.py:142-264).
  * tsc_torsion_fingerprints: _get_tf_mat -- out f32[n_structs, n_quads] of dihedral angles in degrees (tscode/algebra.py:24-55)
  * over quads i32[n_quads, 4]; coords f64[n_structs, n_atoms, 3].

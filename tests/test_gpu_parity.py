@@ -162,6 +162,44 @@ def test_dropin_embed_functions(eng):
 
 
 # ----------------------------------------------------------------------------- prune
+@pytest.mark.parametrize("spread, scale", [(0.05, 1.0), (0.4, 1.0), (0.4, 37.0), (3.0, 0.02), (0.0, 1.0)])
+def test_matrix_core_screen_values_and_limit(eng, spread, scale):
+    """Level 1 of the descriptor screen as v_mfma_f32_16x16x16_f16 computes it (csrc/mm.hpp: components rounded to float16, norms folded
+    into the product): every value against the exact squared distance of the stored fp32 descriptors, within the error the limit allows
+    for, and the property everything rests on -- no pair whose exact distance is within h thr^2 lies above the kernel's limit."""
+    import ctypes as C
+
+    from tscode_amd import _lib
+    rng = np.random.default_rng(int(spread * 100) + int(scale * 7))
+    n = 1000
+    centres = rng.normal(size=(40, 16)) * 4.0
+    D = (centres[rng.integers(0, 40, n)] + rng.normal(size=(n, 16)) * spread) * scale
+    D = D.astype(np.float32)
+    limit = 30 * 0.5 ** 2 * scale ** 2        # h thr^2 in the descriptors' units
+    S = np.empty((2, 64, n), dtype=np.float32)
+    lim_bits, sigma = C.c_int32(), C.c_float()
+    _lib.check(eng.lib.tsc_screen_mm_values(eng._h, _lib.ptr(D), n, C.c_double(limit), _lib.ptr(S), C.byref(lim_bits), C.byref(sigma)))
+    sg = float(sigma.value)
+    dmax = float(np.abs(D).max())
+    assert dmax == 0.0 or 32.0 <= dmax * sg < 64.0
+    D64 = D.astype(np.float64)
+    exact = np.stack([((D64[:64, None, f::2] - D64[None, :, f::2]) ** 2).sum(axis=2) for f in (0, 1)]) * sg * sg     # [fam][r][c]
+    M = dmax * sg
+    # what the limit allows for besides the descriptors' own storage rounding: both operands rounded to float16 (2^-11 of M' each, per
+    # component), the norm pieces, the accumulation at 2^-20 of the term sum
+    err = np.abs(S.astype(np.float64) - exact)
+    delta = np.sqrt(8.0) * 2 * (2.0 ** -11 * M + 2.0 ** -25)
+    allowed = 2 * np.sqrt(exact) * delta + delta ** 2 + 2 * 2.0 ** -14 + 2.0 ** -20 * 4 * 8 * 64.0 * 64.0
+    assert (err <= allowed).all(), float((err / allowed).max())
+    lim = np.array([lim_bits.value], dtype=np.int32).view(np.float32)[0]
+    worst = np.maximum(S[0], S[1])
+    inside = np.maximum(exact[0], exact[1]) <= limit * sg * sg
+    assert (worst[inside].view(np.int32) <= lim_bits.value).all()
+    assert float(lim) <= (np.sqrt(limit) * sg + 2 * np.sqrt(8.0) * 2 * 2.0 ** -11 * M * 1.01 + 1e-3) ** 2 + 0.3, (float(lim), limit * sg * sg)
+    if spread == 0.4 and scale == 1.0:
+        assert inside.sum() > 500 and (~inside).sum() > 10000    # (the case has pairs on both sides)
+
+
 def test_prune_golden(eng, algo):
     import tscode_amd
     g = load_golden("G3_prune")
@@ -180,9 +218,10 @@ SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixtu
 
 
 @pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3),
-                        (2, 0, False, 4), (2, 0, False, 5)],
+                        (2, 0, False, 4), (2, 0, False, 5), (2, 0, False, 6), (0, 1, False, 7), (2, 0, False, 8)],
                 ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen", "algo-sieve-separate-apply", "algo-auto-ranks-from-memory",
-                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1"])
+                     "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1", "algo-sieve-vector-screen", "algo-auto-vector-screen-f32-stage1",
+                     "algo-sieve-culled-vector-screen"])
 def algo(request, eng):
     """Runs a test once per route through the prune: automatic choice (descriptor sieve whose pair kernel applies the verdicts
     tile by tile; passes with short chunks in the chunk-local kernel), register-tiled all-pairs (its passes are applied by
@@ -191,20 +230,25 @@ def algo(request, eng):
     multi-rank pass does), the automatic choice with k_open_rows reading the scan-block prefix from memory (the path of
     ensembles beyond 4 M structures), the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
     what the large passes of C4 / C5 run by default), and the last two again with stage 1 of the pair kernels reading the float32 copy
-    of the coordinates (what runs of 128 MB of heavy atoms and more do by default)."""
+    of the coordinates (what runs of 128 MB of heavy atoms and more do by default).  Since round 5 the walked passes of the sieve
+    screen on the matrix cores (mm.hpp, option sieve_mm = 1, the default): every sieve route above takes that kernel -- fused and with
+    its own apply launch, walked and culled (cull_mm.hpp), with stage 1 in float64 and on the float32 copy; "other-screen" and the three
+    "vector-screen" routes switch it off and run the packed-fp32 screen of sieve.hpp (what row tiles dealt to several ranks still use)."""
     eng.set_option("prune_algo", request.param[0])
+    eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 1)
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
         eng.set_option("sieve_trim", 1 - SIEVE_TRIM_DEFAULT)
     eng.set_option("fused_apply", 1 if request.param[3] else 0)
     if request.param[3] == 2:
         eng.set_option("open_lds_blocks", 0)
-    if request.param[3] in (3, 5):      # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
+    if request.param[3] in (3, 5, 8):      # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
         eng.set_option("cull_min_pairs", 0)
         eng.set_option("cull", 2)
-    if request.param[3] in (4, 5):      # H of stage 1 from the float32 copy, its own rounding bound (sieve.hpp: pair_stage1)
+    if request.param[3] in (4, 5, 7):      # H of stage 1 from the float32 copy, its own rounding bound (sieve.hpp: pair_stage1)
         eng.set_option("stage1_f32", 2)
     yield request.param[0]
+    eng.set_option("sieve_mm", 1)
     eng.set_option("stage1_f32", 1)
     eng.set_option("cull_min_pairs", 2.0e9)
     eng.set_option("cull", 1)

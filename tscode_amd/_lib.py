@@ -77,6 +77,7 @@ _SIGNATURES = {
     "tsc_compact_rows_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, c_i64p]),
     "tsc_gather_heavy_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, c_i32p, C.c_int, _vp, c_i64p]),
     "tsc_rmsd_pairs": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "tsc_screen_mm_values": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, _vp, _vp, _vp]),
     "tsc_rmsd_pairs_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "tsc_embed_clash_compact_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_double, C.c_int64,
                                                _vp, _vp, _vp, _vp]),

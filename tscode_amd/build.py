@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")           # object files and their dependency lists (git-ignored; travels to the GPU box, unused there)
 OUT = os.path.join(HERE, "libtscode_hip.so")
 # One translation unit per kernel family: an edit rebuilds the units that include what changed (hipcc -MD), side by side.
-SOURCES = ["ctx.hip", "embed.hip", "prune.hip", "pairs_tile.hip", "pairs_sieve.hip", "pairs_sieve_plain.hip", "pairs_sorted.hip", "adjacent.hip", "pipeline.hip", "xchg.hip"]
+SOURCES = ["ctx.hip", "embed.hip", "prune.hip", "pairs_tile.hip", "pairs_sieve.hip", "pairs_sieve_plain.hip", "pairs_sorted.hip", "pairs_mm.hip", "adjacent.hip", "pipeline.hip", "xchg.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "tscode_hip.h")]
 DIGEST_UNIT = "ctx.hip"                     # the unit that bakes the digest in (tsc_build_digest): rebuilt whenever anything changes
 

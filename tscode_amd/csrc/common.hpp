@@ -92,6 +92,9 @@ struct tsc_ctx {
     int drain_min = 32;                   // sieve: queued pairs that trigger an evaluation batch between column tiles (swept 16..64 after the row
                                           // loop was trimmed: 32 is 1.3 % ahead of 64 at 1M structures, level elsewhere)
     int sieve_trim = 1;                   // pair kernel: the screen with fewer vector instructions per (row, tile) (norms folded into the fma chain, per-family compares)
+    int sieve_mm = 1;                     // pair kernel of the walked passes of a one-rank run: the screen on the matrix cores, 64 rows per work item (mm.hpp); 0: the
+                                          // packed-fp32 screen of sieve.hpp
+    int mm_seg_cols = 256;                // ... columns per work item of that kernel
     int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
     int64_t pca_min_n = 6000;             // below this many structures the descriptors use the identity basis (no principal-axis estimate)
     int fuse_descriptors = 1;             // ... and the descriptors by the kernel that embeds the passing poses (needs early_basis)

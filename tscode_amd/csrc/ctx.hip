@@ -223,6 +223,16 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->sieve_trim = int(value);
         return 0;
     }
+    if (strcmp(name, "sieve_mm") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "sieve_mm must be 0 or 1");
+        c->sieve_mm = int(value);
+        return 0;
+    }
+    if (strcmp(name, "mm_seg_cols") == 0) {
+        TSC_REQUIRE(value >= 64 && value <= 1024 && int(value) % 64 == 0, "mm_seg_cols must be a multiple of 64 in [64, 1024]");
+        c->mm_seg_cols = int(value);
+        return 0;
+    }
     if (strcmp(name, "sieve_cpl") == 0) {
         TSC_REQUIRE(value == 1 || value == 2 || value == 4, "sieve_cpl must be 1, 2 or 4");
         c->sieve_cpl = int(value);

@@ -272,7 +272,10 @@ inline __global__ __launch_bounds__(64) void k_layout_scan(const PruneState *__r
 inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, LayoutRange lr, const PruneState *__restrict__ st, const int32_t *__restrict__ order,
                                                         const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
                                                         const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
-                                                        int32_t *__restrict__ crank) {
+                                                        int32_t *__restrict__ crank, const _Float16 *__restrict__ Dh = nullptr,
+                                                        const _Float16 *__restrict__ Dn = nullptr, _Float16 *__restrict__ Dhs = nullptr,
+                                                        _Float16 *__restrict__ Dns = nullptr) {
+    // Dh / Dn -> Dhs / Dns (optional): the float16 records of the matrix-core screen (mm_record.hpp) move along with the descriptors
     __shared__ int s_cnt[CULL_LAYOUT_SLOTS][CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
     const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
@@ -307,6 +310,13 @@ inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, Layou
         f32x4 *dst = reinterpret_cast<f32x4 *>(Ds + int64_t(pos) * DW);
 #pragma unroll
         for (int q = 0; q < DW / 4; ++q) dst[q] = src[q];
+        if (Dhs) {
+            const f32x4 *hs = reinterpret_cast<const f32x4 *>(Dh + int64_t(r) * MM_REC_HALVES);
+            f32x4 *hd = reinterpret_cast<f32x4 *>(Dhs + int64_t(pos) * MM_REC_HALVES);
+#pragma unroll
+            for (int q = 0; q < MM_REC_HALVES / 8; ++q) hd[q] = hs[q];
+            *reinterpret_cast<f32x4 *>(Dns + int64_t(pos) * MM_ROWN_HALVES) = *reinterpret_cast<const f32x4 *>(Dn + int64_t(r) * MM_ROWN_HALVES);
+        }
     }
 }
 

@@ -1,0 +1,281 @@
+// cull_mm.hpp -- the pair kernel of a culled pass (cull.hpp) with the descriptor screen on the matrix cores (mm.hpp).
+//
+// cull.hpp's work items and culling (16 rows of the sorted layout x a segment of 4096 columns; column tiles whose box lies beyond the
+// limit of the row tile's box are never loaded); what is loaded goes through level 1 of mm.hpp -- 16 MFMAs per column tile -- and
+// level 2 with everything cull.hpp's decode tests (visited once, inside the row's range, before the similar column the row already
+// has) where a pair is decoded.
+#pragma once
+#include "cull.hpp"
+#include "mm.hpp"
+
+namespace tsc {
+
+constexpr int CMM_SEG = 4096;             // columns per work item, as in cull.hpp (queue entries: row 4 bits | column offset 12 bits)
+constexpr int CMM_BLOCKS = CULL_COLS / MM_STEP;   // 16-column blocks of a column tile
+
+struct CullMmArgs {
+    const _Float16 *Dhs, *Dns;   // the float16 records (mm_record.hpp) by sorted position, like CullArgs::Ds
+};
+
+#ifndef TSC_CMM_OCC
+#define TSC_CMM_OCC 4
+#endif
+
+// One wavefront = (16 consecutive positions of the sorted layout) x (one segment of 4096 columns at or behind them): cull.hpp's work
+// item.  In a sorted layout a column tile is rarely within the limit of more than one of four neighbouring row tiles (measured on
+// C4's k = 2 pass: 1.03 row tiles per visited column tile), so rows are not grouped; what a needed tile pair costs is the trip of the
+// column tile's records (8 KB) from the caches -- requested one needed tile AHEAD, whole -- 16 MFMAs and 64 sign-bit shifts.
+template <bool F32>
+__device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
+                                                     const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                     const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const CullMmArgs cm, const int slot,
+                                                     const int seg) {
+    constexpr int TI = 16;
+    constexpr int QCAP = TI * CULL_COLS + 64;
+    static_assert(CULL_COLS == 128 && CMM_BLOCKS == 8 && DW == 16 && CMM_SEG / CULL_COLS == 32, "tile shapes");
+    __shared__ unsigned short s_queue[4][QCAP];
+    __shared__ unsigned short s_exq[4][128];
+    __shared__ double s_jacobi[4][32];
+    const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = slot;
+    const int p0 = tile * TI;
+    const int pass_on = st->pass_on, A = st->A;
+    TSC_STAMP(0);  // started
+    if (pass_on == 0 || p0 >= A) return;
+    const int nrows = min(TI, A - p0);
+    // the chunk of the tile's LAST row ends the column range (a tile may straddle a chunk boundary; a pair across it fails the
+    // range test at decode time: the higher rank lies at or beyond the lower one's stop column)
+    int col_end;
+    {
+        const int cb = lane <= ca.k ? ca.cbase[lane] : INT_MAX;            // (k <= 63 chunks + the end)
+        const unsigned long long le = __ballot(cb <= p0 + nrows - 1);
+        const int c_last = __popcll(le) - 1;
+        col_end = __builtin_amdgcn_readlane(cb, c_last + 1);
+    }
+    const int seg_lo = (p0 & ~(CULL_COLS - 1)) + seg * CMM_SEG;
+    const int seg_hi = min(seg_lo + CMM_SEG, col_end);
+    if (seg_lo >= seg_hi) return;
+    // which column tiles of the segment lie within the limit of this row tile: one lane per column tile, one round trip
+    const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
+    unsigned need;
+    {
+        const int n_ct = (seg_hi - seg_lo + CULL_COLS - 1) / CULL_COLS;    // <= 32
+        bool near = false;
+        if (lane < n_ct) {
+            const f32x4 *rb = reinterpret_cast<const f32x4 *>(ca.rbox + int64_t(tile) * CULL_BOX);
+            const f32x4 *cb = reinterpret_cast<const f32x4 *>(ca.cbox + int64_t(seg_lo / CULL_COLS + lane) * CULL_BOX);
+            float g0 = 0.0f, g1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < DW / 4; ++q) {
+                const f32x4 rl = rb[q], rh = rb[DW / 4 + q], cl = cb[q], ch = cb[DW / 4 + q];
+                const float gx = fmaxf(0.0f, fmaxf(cl.x - rh.x, rl.x - ch.x)), gy = fmaxf(0.0f, fmaxf(cl.y - rh.y, rl.y - ch.y));
+                const float gz = fmaxf(0.0f, fmaxf(cl.z - rh.z, rl.z - ch.z)), gw = fmaxf(0.0f, fmaxf(cl.w - rh.w, rl.w - ch.w));
+                g0 = fmaf(gx, gx, fmaf(gz, gz, g0));  // components 4q, 4q + 2: family 0
+                g1 = fmaf(gy, gy, fmaf(gw, gw, g1));  // components 4q + 1, 4q + 3: family 1
+            }
+            near = fmaxf(g0, g1) <= limit32 * 1.001f;   // (cull.hpp: every pair of the two tiles is at least sqrt(g) apart in that family)
+        }
+        need = unsigned(__ballot(near));
+    }
+    TSC_STAMP(1);  // boxes tested
+    if (!need) return;
+    const float limit_mm = screen_limit_mm(*a.dmax_bits, a.desc_limit);
+
+    // the rows' operands; rows beyond the active count carry +inf in the n0 slot of family 0 (mm.hpp): they never pass
+    f16x4 Ar[NFAM];
+    {
+        const int64_t row = min(p0 + rc, A - 1);
+#pragma unroll
+        for (int fam = 0; fam < NFAM; ++fam) Ar[fam] = mm_load_A(cm.Dhs + row * MM_REC_HALVES, cm.Dns + row * MM_ROWN_HALVES, fam, g);
+        if (g == 2 && rc >= nrows) Ar[0][0] = _Float16(__builtin_inff());
+    }
+    // a column tile's records: block b of 16 columns, this lane's k group of column 16 b + rc
+    auto load_tile = [&](int c_tile, f16x4 (&B)[CMM_BLOCKS][NFAM]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < CMM_BLOCKS; ++b) {
+            const _Float16 *rec = cm.Dhs + int64_t(min(c_tile + MM_STEP * b + rc, A - 1)) * MM_REC_HALVES;
+#pragma unroll
+            for (int fam = 0; fam < NFAM; ++fam) B[b][fam] = mm_load_B(rec, fam, g);
+        }
+    };
+
+    const int h3 = a.h * 3;
+    unsigned short *queue = s_queue[wid], *exq = s_exq[wid];
+    int qn = 0, qe = 0;
+    unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // an entry = (row of the tile, 4 bits | column position inside the segment, 12 bits); the pair = the two structures at those
+    // positions, the one with the lower active rank playing the reference's `ref` (rmsd_pruning.py:92: the row), the other its column
+    int64_t si = 0, sj = 0;
+    auto decode = [&](unsigned e, int &lo, int &hi, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
+        const int prow = p0 + int(e >> 12), pcol = seg_lo + int(e & 0xfffu);
+        const int r1 = ca.crank[prow], r2 = ca.crank[pcol];
+        lo = min(r1, r2), hi = max(r1, r2);
+        const int64_t i = act[lo], j = act[hi];
+        si = i, sj = j;
+        pp = heavy + i * h3, pq = heavy + j * h3;
+        Gi = Gall[i], Gj = Gall[j];
+        // visited once (from the earlier position), inside the segment; the column inside the row's range (rows of another chunk, or
+        // behind a cache hit, are not) and before the similar column the row already has; within the fp32 screen's limit (level 2)
+        return pcol > prow && pcol < seg_hi && hi < cend[lo] && hi < __hip_atomic_load(&best[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+               mm_pair_within32(ca.Ds + int64_t(prow) * DW, ca.Ds + int64_t(pcol) * DW, limit32);
+    };
+    auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int gq = lane / lpp, sub = lane - gq * lpp;
+        bool degenerate = false;
+        unsigned ent = 0;
+        if (gq < cnt) {
+            int lo, hi;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], e[4];
+            ent = exq[base + gq];
+            (void)decode(ent, lo, hi, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, sub, lpp, H);
+            if (rotation_quaternion_fast(H, Gi, Gj, e)) {
+                double rm, md;
+                residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, sub, lpp);
+                if (sub == 0 && rm < a.thr && md < a.maxdev_thr) atomicMin(&best[lo], hi);  // rmsd_pruning.py:75
+            } else {
+                degenerate = sub == 0;
+            }
+        }
+        for (unsigned long long dm = __builtin_amdgcn_ballot_w64(degenerate); dm; dm &= dm - 1) {  // (sieve.hpp: the Jacobi fallback, one pair per wavefront)
+            const unsigned e1 = unsigned(__builtin_amdgcn_readlane(int(ent), __ffsll((long long)dm) - 1));
+            int lo, hi;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], e[4], rm, md;
+            (void)decode(e1, lo, hi, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, lane, 64, H);
+            double *jac = s_jacobi[wid];
+            if (lane == 0) {
+                horn_matrix(H, jac);
+                top_eigvec4_mem(jac, jac + 16, e);
+                jac[0] = e[0], jac[1] = e[1], jac[2] = e[2], jac[3] = e[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+            e[0] = jac[0], e[1] = jac[1], e[2] = jac[2], e[3] = jac[3];
+            __builtin_amdgcn_wave_barrier();
+            residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, lane, 64);
+            if (rm < a.thr && md < a.maxdev_thr && lane == 0) atomicMin(&best[lo], hi);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto sign_stage = [&](int base, int cnt) __attribute__((always_inline)) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int gq = lane / lpp, sub = lane - gq * lpp;
+        bool cand = false, counted = false;
+        unsigned e = 0;
+        if (gq < cnt) {
+            e = queue[base + gq];
+            int lo, hi;
+            const double *pp, *pq;
+            double Gi, Gj;
+            if (decode(e, lo, hi, pp, pq, Gi, Gj)) {  // (the lanes of a group hold the same pair: they branch together)
+                const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
+                cand = sub == 0 && verdict == PAIR_UNDECIDED;
+                counted = sub == 0;
+                if (sub == 0 && verdict == PAIR_SIMILAR) atomicMin(&best[lo], hi);
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (m) {
+            if (cand) exq[qe + __popcll(m & lt_mask)] = (unsigned short)e;
+            qe += __popcll(m);
+        }
+        n_eval += __popcll(__builtin_amdgcn_ballot_w64(counted));
+        n_exact += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (qe >= 64) {
+            exact_stage(qe - 64, 64);
+            qe -= 64;
+        }
+    };
+    // One column tile against the 16 rows.  Every accumulator starts at -limit: a pair is kept iff both families come out negative; the sign
+    // bits go into a mask per family (mm.hpp), value j = 4 b + i of the tile -- row 4 g + i, column 16 b + rc -- at bit 31 - j.
+    auto screen_tile = [&](int c_tile, const f16x4 (&B)[CMM_BLOCKS][NFAM]) __attribute__((always_inline)) {
+        unsigned m0 = 0, m1 = 0;
+#pragma unroll
+        for (int b = 0; b < CMM_BLOCKS; ++b) {
+            const f32x4 z = {-limit_mm, -limit_mm, -limit_mm, -limit_mm};
+            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[0], B[b][0], z, 0, 0, 0);
+            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[1], B[b][1], z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(s0[i]), 31);
+                m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(s1[i]), 31);
+            }
+        }
+        n_screened += (unsigned long long)nrows * (unsigned long long)max(0, min(CULL_COLS, seg_hi - c_tile));
+        unsigned hits = m0 & m1;
+        for (unsigned long long hm = __builtin_amdgcn_ballot_w64(hits != 0u); hm; hm = __builtin_amdgcn_ballot_w64(hits != 0u)) {
+            if (hits) {   // one pair per lane and turn
+                const int j = __builtin_clz(hits);
+                hits &= ~(0x80000000u >> j);
+                queue[qn + __popcll(hm & lt_mask)] = (unsigned short)((unsigned(4 * g + (j & 3)) << 12) | unsigned(c_tile + MM_STEP * (j >> 2) + rc - seg_lo));
+            }
+            qn += __popcll(hm);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 64) {
+            sign_stage(qn - 64, 64);
+            qn -= 64;
+        }
+    };
+
+    TSC_STAMP(2);  // the rows' operands
+    // the needed column tiles one after the other, two register sets in turn: the next needed tile is on its way while this one is multiplied
+    f16x4 Bx[CMM_BLOCKS][NFAM], By[CMM_BLOCKS][NFAM];
+    load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), Bx);
+    while (need) {
+        const int cx = seg_lo + CULL_COLS * (__ffs(need) - 1);
+        need &= need - 1;
+        if (need) load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), By);
+        screen_tile(cx, Bx);
+        if (!need) break;
+        const int cy = seg_lo + CULL_COLS * (__ffs(need) - 1);
+        need &= need - 1;
+        if (need) load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), Bx);
+        screen_tile(cy, By);
+    }
+    TSC_STAMP(3);  // screened (evaluation batches of 64 included)
+    if (qn > 0) sign_stage(0, qn);
+    if (qe > 0) exact_stage(0, qe);
+    TSC_STAMP(4);  // the rest evaluated
+    if (lane == 0) {
+        count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
+        count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
+        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+    }
+}
+
+// grid and work-item numbering: cull.hpp's k_rmsd_sieve_sorted (a workgroup per item; with xcd_seg runs of row groups keyed to XCDs)
+template <bool F32>
+inline __global__ __launch_bounds__(256, TSC_CMM_OCC) void k_rmsd_sieve_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                                                            const double *__restrict__ Gall, const int32_t *__restrict__ cend,
+                                                                            int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, CullMmArgs cm, int my_tiles,
+                                                                            int n_seg) {
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = (my_tiles + 3) / 4;
+    int seg, grp;
+    if (ca.xcd_seg) {
+        const int x = int(blockIdx.x & 7u);
+        const long long j = (long long)(blockIdx.x >> 3);
+        const int runs_per_xcd = (((groups + CULL_XCD_RUN - 1) / CULL_XCD_RUN) + 7) / 8;
+        const long long per_seg = (long long)runs_per_xcd * CULL_XCD_RUN;
+        seg = int(j / per_seg);
+        const int rem = int(j - (long long)seg * per_seg);
+        grp = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
+    } else {
+        seg = int(blockIdx.x / unsigned(groups)), grp = int(blockIdx.x - unsigned(seg) * unsigned(groups));
+    }
+    if (seg >= n_seg || grp >= groups) return;
+    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, grp * 4 + wid, seg);
+}
+
+}  // namespace tsc

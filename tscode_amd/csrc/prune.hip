@@ -42,6 +42,40 @@ extern "C" __attribute__((visibility("default"))) int tsc_rmsd_pairs(tsc_ctx *c,
     TSC_API_GUARD_END
 }
 
+extern "C" __attribute__((visibility("default"))) int tsc_screen_mm_values(tsc_ctx *c, const float *D, int64_t n, double limit, float *S, int32_t *limit_bits,
+                                                                           float *out_scale) {
+    TSC_API_GUARD_BEGIN
+    TSC_REQUIRE(c && D && S && limit_bits && out_scale, "tsc_screen_mm_values: null argument");
+    TSC_REQUIRE(n >= 1 && n <= (1 << 20), "n = %lld not supported", (long long)n);
+    DeviceGuard guard(c->device);
+    Scratch s(c);
+    float dmax = 0.0f;
+    for (int64_t e = 0; e < n * DW; ++e) dmax = std::fabs(D[e]) > dmax || std::isnan(D[e]) ? (std::isnan(D[e]) ? NAN : std::fabs(D[e])) : dmax;
+    unsigned bits;
+    memcpy(&bits, &dmax, sizeof(bits));
+    if (std::isnan(dmax)) bits = NONFINITE_BITS;
+    float *d_D, *d_S;
+    unsigned *d_bits;
+    int *d_lim;
+    _Float16 *d_rec, *d_rown;
+    TSC_TRY(upload(c, s, D, size_t(n) * DW, &d_D));
+    TSC_TRY(upload(c, s, &bits, 1, &d_bits));
+    TSC_TRY(s.get(size_t(n) * MM_REC_HALVES, &d_rec));
+    TSC_TRY(s.get(size_t(n) * MM_ROWN_HALVES, &d_rown));
+    TSC_TRY(s.get(size_t(NFAM) * MM_ROWS * n, &d_S));
+    TSC_TRY(s.get(1, &d_lim));
+    hipLaunchKernelGGL(k_mm_records, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const float *)d_D, n, (const unsigned *)d_bits, d_rec, d_rown);
+    hipLaunchKernelGGL(k_mm_screen_dump, dim3(unsigned(ceil_div<int64_t>(n, MM_STEP))), dim3(64), 0, c->stream, (const _Float16 *)d_rec, (const _Float16 *)d_rown, int(n), (const unsigned *)d_bits,
+                       limit, d_S, d_lim);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipMemcpyAsync(S, d_S, size_t(NFAM) * MM_ROWS * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipMemcpyAsync(limit_bits, d_lim, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TSC_HIP(hipStreamSynchronize(c->stream));
+    *out_scale = mm_scale(bits);
+    return 0;
+    TSC_API_GUARD_END
+}
+
 extern "C" __attribute__((visibility("default"))) int tsc_prune_destroy(tsc_prune *p) {
     TSC_API_GUARD_BEGIN
     if (!p) return 0;
@@ -230,6 +264,8 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
         }
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
+        if (!rc && c->sieve_mm) rc = palloc(p, size_t(n) * MM_REC_HALVES, &p->Dh);
+        if (!rc && c->sieve_mm) rc = palloc(p, size_t(n) * MM_ROWN_HALVES, &p->Dn);
         // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
         // (it pays where the gathers come from HBM: 41 MB of heavy atoms at C3 sit in the 256 MB infinity cache and the conversions cost the
         // VALU-bound kernel 2 %; at C4's 348 MB a step goes from 12.1 to 10.6 ms.  "stage1_f32": 0 never, 1 from 128 MB on, 2 always)
@@ -366,9 +402,12 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     // (measured on MI355X, tools/sweep.py: 512 columns at 57k structures, 1024 at 126k, 4096 at 483k; "seg_cols" overrides)
     int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
+    // the screen on the matrix cores (mm.hpp): one rank, 64 rows per work item and segments of their own length
+    const bool mm = p->algo == ALGO_SIEVE && p->Dh && world == 1 && c->sieve_mm;
+    if (mm) seg_cols = c->mm_seg_cols;
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
-    dim3 grid(std::max(1, ceil_div(my_tiles, 4)), n_seg);
+    dim3 grid(std::max(1, mm ? ceil_div(ceil_div(A, MM_ROWS), 4) : ceil_div(my_tiles, 4)), n_seg);
     // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
     // hipEventRecord before and after it costs about 4 us each on MI355X)
     hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -421,6 +460,11 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
             }
         }
         const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
+        if (mm) {
+            TSC_TRY(launch_rmsd_sieve_mm(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                                         (const float *)p->Dc, (const _Float16 *)p->Dh, (const _Float16 *)p->Dn, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, fa));
+            return 0;
+        }
         // (stage 1 on the float32 copy exists for the default shape of the kernel only)
         TSC_TRY((p->cur_fused ? launch_rmsd_sieve_fused : launch_rmsd_sieve_plain)(
             c->sieve_cpl, trim, trim && a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall, (const float *)p->Dc,
@@ -523,6 +567,8 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cfill);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_LAYOUT_ITEMS + 2) * CULL_MAX_CHUNKS, &p->blk_cnt);
         if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
+        if (!rc && p->Dh) rc = palloc(p, (size_t(n) + 256) * MM_REC_HALVES, &p->Dhs);
+        if (!rc && p->Dh) rc = palloc(p, (size_t(n) + 256) * MM_ROWN_HALVES, &p->Dns);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
@@ -536,6 +582,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
         oa.rank_of = culled ? p->rank_of : nullptr;
+        oa.Dh = (p->Dh && world == 1 && c->sieve_mm) ? p->Dh : nullptr, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
         oa.dbg = nullptr;
 #ifdef TSC_DBG_STAMPS
         if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
@@ -597,6 +644,9 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         TSC_HIP(hipGetLastError());
         p->morton_sorted = true;
     }
+    // (the culled pass with the screen on the matrix cores: one rank's own pass -- row tiles of a layout dealt to several ranks keep the
+    // kernel of cull.hpp, whose items are single row tiles)
+    const bool cull_mm = run_culled && p->Dhs && c->sieve_mm && world == 1;
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
         const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));
@@ -606,7 +656,8 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         hipLaunchKernelGGL(k_layout_scan, dim3(unsigned(k)), dim3(64), 0, st, (const PruneState *)p->state, n_lb, (const int32_t *)p->cbase, p->blk_cnt);
         hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, lr, (const PruneState *)p->state, (const int32_t *)p->morton_order,
                            (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of, (const float *)p->Dc,
-                           (const int32_t *)p->blk_cnt, p->Ds, p->crank);
+                           (const int32_t *)p->blk_cnt, p->Ds, p->crank, (const _Float16 *)(cull_mm ? p->Dh : nullptr), (const _Float16 *)p->Dn,
+                           cull_mm ? p->Dhs : nullptr, p->Dns);
         hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
                            p->cbox, p->rbox);
         SieveArgs a;
@@ -631,6 +682,26 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         // ("cull_xcd": one work item per workgroup, runs of row groups keyed to XCDs -- 8 XCDs x segments x the runs an XCD holds of a segment)
         const int64_t xitems = int64_t(8) * n_seg * ceil_div(ceil_div(ceil_div(my_tiles, 4), CULL_XCD_RUN), 8) * CULL_XCD_RUN;
         const dim3 sgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : std::min<int64_t>(items, c->cull_grid))));
+        if (cull_mm) {
+#ifdef TSC_DBG_STAMPS
+            if (c->dbg_stamp_k == k) {
+                const size_t bytes = size_t(sgrid.x) * 32 * sizeof(unsigned long long);
+                if (c->dbg_bytes < bytes) {
+                    if (c->dbg_buf) (void)hipFree(c->dbg_buf);
+                    TSC_HIP(hipMalloc(&c->dbg_buf, bytes));
+                    c->dbg_bytes = bytes;
+                }
+                TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
+                c->dbg_waves = int64_t(sgrid.x) * 4;
+                a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
+            }
+#endif
+            // (the same items and grid as the kernel of cull.hpp: 16 rows x 4096 columns)
+            const dim3 mgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : items)));
+            CullMmArgs cm{p->Dhs, p->Dns};
+            TSC_TRY(launch_rmsd_sieve_sorted_mm(a.heavy32 != nullptr, st, mgrid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                                                (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, cm, my_tiles, n_seg));
+        } else
         TSC_TRY(launch_rmsd_sieve_sorted(a.heavy32 != nullptr, st, sgrid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend,
                                          p->best, p->counters, (const PruneState *)p->state, a, ca, my_tiles, n_seg));
         if (range) {

@@ -7,6 +7,8 @@
 #include "scan.hpp"
 #include "local_pass.hpp"
 #include "cull.hpp"
+#include "mm.hpp"
+#include "cull_mm.hpp"
 
 // --------------------------------------------------------------------------------------------------
 // K3: prune_conformers_rmsd
@@ -43,6 +45,7 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     float *Dc = nullptr;     // ... in active order, rewritten by k_open_rows every pass: what the pair kernel reads
+    _Float16 *Dh = nullptr, *Dn = nullptr;  // ... and as the float16 records of the matrix-core screen (mm.hpp), in active order too ("sieve_mm")
     double *Gall = nullptr;
     struct Tickets {
         PassTickets pass;
@@ -52,6 +55,7 @@ struct tsc_prune {
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
+    _Float16 *Dhs = nullptr, *Dns = nullptr;   // the float16 records of the matrix-core screen by sorted position (cull_mm.hpp)
     float *heavy32 = nullptr;            // float32 copy of the heavy atoms for stage 1 of the pair kernels (sieve.hpp: pair_stage1)
     bool morton_sorted = false;          // the run's Morton order exists (made when the first pass is really culled)
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
@@ -164,10 +168,18 @@ int launch_rmsd_sieve_fused(int cpl, bool trim, bool f32, hipStream_t st, dim3 g
 int launch_rmsd_sieve_plain(int cpl, bool trim, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act,
                             const double *Gall, const float *Dc, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
                             const SieveArgs &a, const FusedApply &fa);
+// k_rmsd_sieve_mm<fused, f32> (pairs_mm.hip): the screen on the matrix cores, 64 rows per work item
+int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
+                         const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
+                         const FusedApply &fa);
 // k_rmsd_sieve_sorted<f32> and k_pass_chunks (pairs_sorted.hip)
 int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                              const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
                              int my_tiles, int n_seg);
+// k_rmsd_sieve_sorted_mm<f32> (pairs_mm.hip): the culled pass with the screen on the matrix cores
+int launch_rmsd_sieve_sorted_mm(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
+                                const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
+                                const CullMmArgs &cm, int n_groups, int n_seg);
 int launch_pass_chunks(hipStream_t st, unsigned blocks, hipEvent_t e0, hipEvent_t e1, const PassGeom &g, const LocalPassArgs &a, PruneState *state, uint8_t *mask,
                        unsigned long long *bits, int bit_words, const unsigned long long *view, const double *heavy, const double *Gall, const float *Dall,
                        const CacheViews &cv, PassCounters *counters, int32_t *bsum, int block_items, const StepCtx &sc, const StepArgs &sa, LocalTickets *tickets);

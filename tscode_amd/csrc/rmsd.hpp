@@ -23,6 +23,7 @@
 // inner loop is 9 v_fma_f64 per atom with one SGPR operand each.
 #pragma once
 #include "common.hpp"
+#include "mm_record.hpp"
 #include "scan.hpp"
 
 namespace tsc {
@@ -643,6 +644,8 @@ struct OpenArgs {
     unsigned n_tiles;                // row tiles of the pass (arrival count of a fused pass)
     PassTickets *tickets;
     int32_t *rank_of;                // (optional) rank_of[structure] = its active rank: what a culled pass (cull.hpp) lays its sorted order out from
+    _Float16 *Dh, *Dn;               // (optional) the float16 records of the matrix-core screen (mm.hpp: columns, row-side norms), by position like Dc
+    const unsigned *dmax_bits;       // ... and the largest |descriptor component| of the run that scales them
     unsigned long long *dbg;         // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront (tools/stamps.py), else null
 };
 #ifdef TSC_DBG_STAMPS
@@ -949,6 +952,12 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             if (D) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * q) = dval[q];
+                if (oa.Dh) {
+                    float dv[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dv[4 * q] = dval[q].x, dv[4 * q + 1] = dval[q].y, dv[4 * q + 2] = dval[q].z, dv[4 * q + 3] = dval[q].w;
+                    mm_write_record(dv, mm_scale(*oa.dmax_bits), oa.Dh + int64_t(r) * MM_REC_HALVES, oa.Dn + int64_t(r) * MM_ROWN_HALVES);
+                }
             }
             act[r] = int32_t(i);
             cend[r] = my_c;
