@@ -231,11 +231,12 @@ def algo(request, eng):
     ensembles beyond 4 M structures), the sieve with every pass of fewer than 64 chunks culled (sorted layout + bounding boxes:
     what the large passes of C4 / C5 run by default), and the last two again with stage 1 of the pair kernels reading the float32 copy
     of the coordinates (what runs of 128 MB of heavy atoms and more do by default).  Since round 5 the walked passes of the sieve
-    screen on the matrix cores (mm.hpp, option sieve_mm = 1, the default): every sieve route above takes that kernel -- fused and with
+    screen on the matrix cores in runs of 150 000 structures and more (mm.hpp, option sieve_mm = 1, the default; 2 = always, what the
+    fixture sets): every sieve route above takes that kernel -- fused and with
     its own apply launch, walked and culled (cull_mm.hpp), with stage 1 in float64 and on the float32 copy; "other-screen" and the three
     "vector-screen" routes switch it off and run the packed-fp32 screen of sieve.hpp (what row tiles dealt to several ranks still use)."""
     eng.set_option("prune_algo", request.param[0])
-    eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 1)
+    eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 2)
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
         eng.set_option("sieve_trim", 1 - SIEVE_TRIM_DEFAULT)
@@ -278,13 +279,16 @@ def test_prune_large_golden(eng, algo, name):
     assert all(s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo) for s in stats)
 
 
+@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
 @pytest.mark.parametrize("name", LARGE_PRUNE_CASES)
-def test_prune_large_golden_every_pass_mask(eng, name):
+def test_prune_large_golden_every_pass_mask(eng, name, mm):
     """The same runs pass by pass (the stepping API): the mask after EVERY pass against the mask the reference's own
-    _similarity_mask_rmsd_group returned for it."""
+    _similarity_mask_rmsd_group returned for it -- with the packed-fp32 screen (what runs of this size take) and with the screen on the
+    matrix cores (csrc/mm.hpp; sieve_mm = 2 forces it)."""
     import ctypes as C
 
     from tscode_amd import _lib
+    eng.set_option("sieve_mm", mm)
     fx = load_large_prune(name)
     g = fx.g
     lib = eng.lib
@@ -307,6 +311,7 @@ def test_prune_large_golden_every_pass_mask(eng, name):
     finally:
         st.close()
         _lib.check(lib.tsc_free(eng._h, d_heavy))
+        eng.set_option("sieve_mm", 1)
     assert ran == g["ks"].tolist()
     for k, bits in zip(ran, g["pass_mask_bits"]):
         assert np.array_equal(after[k], bits), f"{name}: the mask after the k = {k} pass differs from the reference's"

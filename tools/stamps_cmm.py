@@ -32,6 +32,6 @@ for a, b, nm in ((0, 1, "start -> boxes tested"), (1, 2, "-> rows' operands"), (
     m = (s[:, a] > 0) & (s[:, b] > 0)
     if m.any():
         print(f"{nm:28s}", pct(s[m, b] - s[m, a]), f" ({int(m.sum())})   total {float((s[m, b] - s[m, a]).sum()) / 100.0 / 1e3:.1f} ms*wave")
-tl, nd = s[work, 7] // 16, s[work, 7] % 16
-print("column tiles visited per item: mean %.2f; (row tile, column tile) pairs needed per item: mean %.2f -> %.2f row tiles per visited tile" % (tl.mean(), (s[work, 7] % 16).mean(), 0))
+tl, nd = s[work, 7] // 64, s[work, 7] % 64
+print("column tiles visited per item: mean %.2f; (row tile, column tile) pairs needed per item: mean %.2f -> %.2f row tiles per visited tile" % (tl.mean(), nd.mean(), nd.sum() / tl.sum()))
 print("last stamp after first start: %.1f us" % ((s[s > 0].max() - t0) / 100.0))

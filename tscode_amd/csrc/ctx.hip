@@ -224,12 +224,17 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         return 0;
     }
     if (strcmp(name, "sieve_mm") == 0) {
-        TSC_REQUIRE(value == 0 || value == 1, "sieve_mm must be 0 or 1");
+        TSC_REQUIRE(value == 0 || value == 1 || value == 2, "sieve_mm must be 0 (never), 1 (large runs) or 2 (always)");
         c->sieve_mm = int(value);
         return 0;
     }
+    if (strcmp(name, "mm_min_n") == 0) {
+        TSC_REQUIRE(value >= 0 && value <= 4e9, "mm_min_n must be in [0, 4e9]");
+        c->mm_min_n = int64_t(value);
+        return 0;
+    }
     if (strcmp(name, "mm_seg_cols") == 0) {
-        TSC_REQUIRE(value >= 64 && value <= 1024 && int(value) % 64 == 0, "mm_seg_cols must be a multiple of 64 in [64, 1024]");
+        TSC_REQUIRE(value == 0 || (value >= 64 && value <= 1024 && int(value) % 64 == 0), "mm_seg_cols must be 0 (automatic) or a multiple of 64 in [64, 1024]");
         c->mm_seg_cols = int(value);
         return 0;
     }

@@ -1,17 +1,16 @@
 // cull_mm.hpp -- the pair kernel of a culled pass (cull.hpp) with the descriptor screen on the matrix cores (mm.hpp).
 //
-// cull.hpp's work items and culling (16 rows of the sorted layout x a segment of 4096 columns; column tiles whose box lies beyond the
-// limit of the row tile's box are never loaded); what is loaded goes through level 1 of mm.hpp -- 16 MFMAs per column tile -- and
-// level 2 with everything cull.hpp's decode tests (visited once, inside the row's range, before the similar column the row already
-// has) where a pair is decoded.
+// cull.hpp's culling (row tiles of 16 and column tiles of 128 positions of the sorted layout, each with its bounding box; a tile pair
+// whose boxes lie beyond the limit is never multiplied) in front of level 1 of mm.hpp; level 2 and everything cull.hpp's decode tests
+// (visited once, inside the row's range, before the similar column the row already has) where a pair is decoded.
 #pragma once
 #include "cull.hpp"
 #include "mm.hpp"
 
 namespace tsc {
 
-constexpr int CMM_SEG = 4096;             // columns per work item, as in cull.hpp (queue entries: row 4 bits | column offset 12 bits)
-constexpr int CMM_BLOCKS = CULL_COLS / MM_STEP;   // 16-column blocks of a column tile
+constexpr int CMM_SEG = 1024;             // columns per work item (queue entries keep the column offset in 10 bits)
+constexpr int CMM_TILES = CMM_SEG / CULL_COLS;
 
 struct CullMmArgs {
     const _Float16 *Dhs, *Dns;   // the float16 records (mm_record.hpp) by sorted position, like CullArgs::Ds
@@ -21,30 +20,28 @@ struct CullMmArgs {
 #define TSC_CMM_OCC 4
 #endif
 
-// One wavefront = (16 consecutive positions of the sorted layout) x (one segment of 4096 columns at or behind them): cull.hpp's work
-// item.  In a sorted layout a column tile is rarely within the limit of more than one of four neighbouring row tiles (measured on
-// C4's k = 2 pass: 1.03 row tiles per visited column tile), so rows are not grouped; what a needed tile pair costs is the trip of the
-// column tile's records (8 KB) from the caches -- requested one needed tile AHEAD, whole -- 16 MFMAs and 64 sign-bit shifts.
+// One wavefront = 64 consecutive positions of the sorted layout (four row tiles of 16, each with its bounding box) x one segment of
+// 1024 columns (eight column tiles of 128, each with its box) at or behind them, to the end of the rows' chunk.  A (row tile, column
+// tile) pair whose boxes lie further apart than the screen's limit is never multiplied; a column tile that no row tile needs is never
+// loaded.  (16-row items with 4096-column segments and a whole column tile requested ahead -- cull.hpp's shape -- were measured too:
+// C4's k = 2 pass 2.57 ms against 1.98 in this form; the commit before this one.)
 template <bool F32>
 __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
                                                      const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                     const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const CullMmArgs cm, const int slot,
+                                                     const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const CullMmArgs cm, const int grp,
                                                      const int seg) {
-    constexpr int TI = 16;
-    constexpr int QCAP = TI * CULL_COLS + 64;
-    static_assert(CULL_COLS == 128 && CMM_BLOCKS == 8 && DW == 16 && CMM_SEG / CULL_COLS == 32, "tile shapes");
-    __shared__ unsigned short s_queue[4][QCAP];
+    static_assert(CULL_COLS == 128 && CMM_TILES == 8 && DW == 16, "tile shapes");
+    __shared__ unsigned short s_queue[4][MM_QCAP];
     __shared__ unsigned short s_exq[4][128];
     __shared__ double s_jacobi[4][32];
     const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = slot;
-    const int p0 = tile * TI;
+    const int p0 = grp * MM_ROWS;
     const int pass_on = st->pass_on, A = st->A;
     TSC_STAMP(0);  // started
     if (pass_on == 0 || p0 >= A) return;
-    const int nrows = min(TI, A - p0);
-    // the chunk of the tile's LAST row ends the column range (a tile may straddle a chunk boundary; a pair across it fails the
+    const int nrows = min(MM_ROWS, A - p0);
+    // the chunk of the group's LAST row ends the column range (a group may straddle a chunk boundary; a pair across it fails the
     // range test at decode time: the higher rank lies at or beyond the lower one's stop column)
     int col_end;
     {
@@ -56,15 +53,16 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
     const int seg_lo = (p0 & ~(CULL_COLS - 1)) + seg * CMM_SEG;
     const int seg_hi = min(seg_lo + CMM_SEG, col_end);
     if (seg_lo >= seg_hi) return;
-    // which column tiles of the segment lie within the limit of this row tile: one lane per column tile, one round trip
+    // which (row tile, column tile) pairs lie within the limit: lane = (column tile, row tile), one round trip
     const float limit32 = screen_limit32_dot(__uint_as_float(*a.dmax_bits), a.desc_limit);
-    unsigned need;
+    unsigned need;   // bit 4 ct + rt
     {
-        const int n_ct = (seg_hi - seg_lo + CULL_COLS - 1) / CULL_COLS;    // <= 32
+        const int n_ct = (seg_hi - seg_lo + CULL_COLS - 1) / CULL_COLS;    // <= 8
+        const int ct = lane >> 2, rt = lane & 3;
         bool near = false;
-        if (lane < n_ct) {
-            const f32x4 *rb = reinterpret_cast<const f32x4 *>(ca.rbox + int64_t(tile) * CULL_BOX);
-            const f32x4 *cb = reinterpret_cast<const f32x4 *>(ca.cbox + int64_t(seg_lo / CULL_COLS + lane) * CULL_BOX);
+        if (ct < n_ct && p0 + 16 * rt < A) {
+            const f32x4 *rb = reinterpret_cast<const f32x4 *>(ca.rbox + int64_t(p0 / 16 + rt) * CULL_BOX);
+            const f32x4 *cb = reinterpret_cast<const f32x4 *>(ca.cbox + int64_t(seg_lo / CULL_COLS + ct) * CULL_BOX);
             float g0 = 0.0f, g1 = 0.0f;
 #pragma unroll
             for (int q = 0; q < DW / 4; ++q) {
@@ -76,28 +74,25 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
             }
             near = fmaxf(g0, g1) <= limit32 * 1.001f;   // (cull.hpp: every pair of the two tiles is at least sqrt(g) apart in that family)
         }
-        need = unsigned(__ballot(near));
+        need = unsigned(__ballot(near));   // (lanes 32..63 hold no tile pair)
     }
     TSC_STAMP(1);  // boxes tested
     if (!need) return;
     const float limit_mm = screen_limit_mm(*a.dmax_bits, a.desc_limit);
 
     // the rows' operands; rows beyond the active count carry +inf in the n0 slot of family 0 (mm.hpp): they never pass
-    f16x4 Ar[NFAM];
-    {
-        const int64_t row = min(p0 + rc, A - 1);
+    f16x4 Ar[4][NFAM];
 #pragma unroll
-        for (int fam = 0; fam < NFAM; ++fam) Ar[fam] = mm_load_A(cm.Dhs + row * MM_REC_HALVES, cm.Dns + row * MM_ROWN_HALVES, fam, g);
-        if (g == 2 && rc >= nrows) Ar[0][0] = _Float16(__builtin_inff());
+    for (int rt = 0; rt < 4; ++rt) {
+        const int64_t row = min(p0 + 16 * rt + rc, A - 1);
+#pragma unroll
+        for (int fam = 0; fam < NFAM; ++fam) Ar[rt][fam] = mm_load_A(cm.Dhs + row * MM_REC_HALVES, cm.Dns + row * MM_ROWN_HALVES, fam, g);
+        if (g == 2 && 16 * rt + rc >= nrows) Ar[rt][0][0] = _Float16(__builtin_inff());
     }
-    // a column tile's records: block b of 16 columns, this lane's k group of column 16 b + rc
-    auto load_tile = [&](int c_tile, f16x4 (&B)[CMM_BLOCKS][NFAM]) __attribute__((always_inline)) {
+    auto load_B = [&](int c0, f16x4 (&B)[NFAM]) __attribute__((always_inline)) {
+        const _Float16 *rec = cm.Dhs + int64_t(min(c0 + rc, A - 1)) * MM_REC_HALVES;
 #pragma unroll
-        for (int b = 0; b < CMM_BLOCKS; ++b) {
-            const _Float16 *rec = cm.Dhs + int64_t(min(c_tile + MM_STEP * b + rc, A - 1)) * MM_REC_HALVES;
-#pragma unroll
-            for (int fam = 0; fam < NFAM; ++fam) B[b][fam] = mm_load_B(rec, fam, g);
-        }
+        for (int fam = 0; fam < NFAM; ++fam) B[fam] = mm_load_B(rec, fam, g);
     };
 
     const int h3 = a.h * 3;
@@ -106,11 +101,11 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
     unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // an entry = (row of the tile, 4 bits | column position inside the segment, 12 bits); the pair = the two structures at those
+    // an entry = (row of the group, 6 bits | column position inside the segment, 10 bits); the pair = the two structures at those
     // positions, the one with the lower active rank playing the reference's `ref` (rmsd_pruning.py:92: the row), the other its column
     int64_t si = 0, sj = 0;
     auto decode = [&](unsigned e, int &lo, int &hi, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
-        const int prow = p0 + int(e >> 12), pcol = seg_lo + int(e & 0xfffu);
+        const int prow = p0 + int(e >> 10), pcol = seg_lo + int(e & 0x3ffu);
         const int r1 = ca.crank[prow], r2 = ca.crank[pcol];
         lo = min(r1, r2), hi = max(r1, r2);
         const int64_t i = act[lo], j = act[hi];
@@ -195,74 +190,100 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
             qe -= 64;
         }
     };
-    // One column tile against the 16 rows.  Every accumulator starts at -limit: a pair is kept iff both families come out negative; the sign
-    // bits go into a mask per family (mm.hpp), value j = 4 b + i of the tile -- row 4 g + i, column 16 b + rc -- at bit 31 - j.
-    auto screen_tile = [&](int c_tile, const f16x4 (&B)[CMM_BLOCKS][NFAM]) __attribute__((always_inline)) {
-        unsigned m0 = 0, m1 = 0;
+    // the column tiles some row tile needs, one after the other; a step = 32 columns (two blocks of 16), its operands requested a step
+    // ahead (the first step of the next needed tile behind the last one of this)
+    unsigned tiles = 0;   // bit ct: some row tile needs column tile ct
 #pragma unroll
-        for (int b = 0; b < CMM_BLOCKS; ++b) {
-            const f32x4 z = {-limit_mm, -limit_mm, -limit_mm, -limit_mm};
-            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[0], B[b][0], z, 0, 0, 0);
-            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[1], B[b][1], z, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(s0[i]), 31);
-                m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(s1[i]), 31);
-            }
-        }
-        n_screened += (unsigned long long)nrows * (unsigned long long)max(0, min(CULL_COLS, seg_hi - c_tile));
-        unsigned hits = m0 & m1;
-        for (unsigned long long hm = __builtin_amdgcn_ballot_w64(hits != 0u); hm; hm = __builtin_amdgcn_ballot_w64(hits != 0u)) {
-            if (hits) {   // one pair per lane and turn
-                const int j = __builtin_clz(hits);
-                hits &= ~(0x80000000u >> j);
-                queue[qn + __popcll(hm & lt_mask)] = (unsigned short)((unsigned(4 * g + (j & 3)) << 12) | unsigned(c_tile + MM_STEP * (j >> 2) + rc - seg_lo));
-            }
-            qn += __popcll(hm);
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (qn >= 64) {
-            sign_stage(qn - 64, 64);
-            qn -= 64;
-        }
-    };
-
+    for (int ct = 0; ct < CMM_TILES; ++ct) tiles |= ((need >> (4 * ct)) & 0xfu) ? (1u << ct) : 0u;
     TSC_STAMP(2);  // the rows' operands
-    // the needed column tiles one after the other, two register sets in turn: the next needed tile is on its way while this one is multiplied
-    f16x4 Bx[CMM_BLOCKS][NFAM], By[CMM_BLOCKS][NFAM];
-    load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), Bx);
-    while (need) {
-        const int cx = seg_lo + CULL_COLS * (__ffs(need) - 1);
-        need &= need - 1;
-        if (need) load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), By);
-        screen_tile(cx, Bx);
-        if (!need) break;
-        const int cy = seg_lo + CULL_COLS * (__ffs(need) - 1);
-        need &= need - 1;
-        if (need) load_tile(seg_lo + CULL_COLS * (__ffs(need) - 1), Bx);
-        screen_tile(cy, By);
+#ifdef TSC_DBG_STAMPS
+    if (a.dbg && lane == 0) a.dbg[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wid * 8 + 7] = (unsigned long long)(__popc(tiles) * 64 + __popc(need));
+#endif
+    f16x4 Bn[2][NFAM];
+    {
+        const int c_first = seg_lo + CULL_COLS * (__ffs(tiles) - 1);
+        load_B(c_first, Bn[0]);
+        load_B(c_first + MM_STEP, Bn[1]);
+    }
+    for (; tiles; tiles &= tiles - 1) {
+        const int ct = __ffs(tiles) - 1;
+        const unsigned rts = (need >> (4 * ct)) & 0xfu;   // the row tiles that need this column tile
+        const unsigned rest = tiles & (tiles - 1);
+        const int c_tile = seg_lo + CULL_COLS * ct;
+        const int c_next_tile = rest ? seg_lo + CULL_COLS * (__ffs(rest) - 1) : -1;
+        n_screened += (unsigned long long)(16 * __popc(rts)) * (unsigned long long)max(0, min(CULL_COLS, seg_hi - c_tile));
+        for (int sub = 0; sub < CULL_COLS / (2 * MM_STEP); ++sub) {
+            const int c0 = c_tile + 2 * MM_STEP * sub;
+            f16x4 Bc[2][NFAM];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int fam = 0; fam < NFAM; ++fam) Bc[u][fam] = Bn[u][fam];
+            const int c_pre = sub + 1 < CULL_COLS / (2 * MM_STEP) ? c0 + 2 * MM_STEP : c_next_tile;
+            if (c_pre >= 0) {
+                load_B(c_pre, Bn[0]);
+                load_B(c_pre + MM_STEP, Bn[1]);
+            }
+            // every accumulator starts at -limit: a pair is kept iff both families come out negative; sign bits into a mask per family,
+            // value j = 16 u + 4 rt + i of the step at bit 31 - j (mm.hpp)
+            unsigned m0 = 0, m1 = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    if ((rts >> rt) & 1u) {
+                        const f32x4 z = {-limit_mm, -limit_mm, -limit_mm, -limit_mm};
+                        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[rt][0], Bc[u][0], z, 0, 0, 0);
+                        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[rt][1], Bc[u][1], z, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(s0[i]), 31);
+                            m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(s1[i]), 31);
+                        }
+                    } else {
+                        m0 <<= 4, m1 <<= 4;
+                    }
+                }
+            }
+            unsigned hits = m0 & m1;
+            for (unsigned long long hm = __builtin_amdgcn_ballot_w64(hits != 0u); hm; hm = __builtin_amdgcn_ballot_w64(hits != 0u)) {
+                if (hits) {   // one pair per lane and turn
+                    const int j = __builtin_clz(hits);
+                    hits &= ~(0x80000000u >> j);
+                    const int u = j >> 4, rt = (j >> 2) & 3, i = j & 3;
+                    queue[qn + __popcll(hm & lt_mask)] = (unsigned short)((unsigned(16 * rt + 4 * g + i) << 10) | unsigned(c0 + MM_STEP * u + rc - seg_lo));
+                }
+                qn += __popcll(hm);
+            }
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= 64) {
+                sign_stage(qn - 64, 64);
+                qn -= 64;
+            }
+        }
     }
     TSC_STAMP(3);  // screened (evaluation batches of 64 included)
     if (qn > 0) sign_stage(0, qn);
     if (qe > 0) exact_stage(0, qe);
     TSC_STAMP(4);  // the rest evaluated
     if (lane == 0) {
-        count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
-        count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
-        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+        count_add(counters, unsigned(grp), CNT_FORMED, n_eval);
+        count_add(counters, unsigned(grp), CNT_EXACT, n_exact);
+        count_add(counters, unsigned(grp), CNT_SCREENED, n_screened);
     }
 }
 
-// grid and work-item numbering: cull.hpp's k_rmsd_sieve_sorted (a workgroup per item; with xcd_seg runs of row groups keyed to XCDs)
+// grid: a workgroup per (four consecutive groups of 64 rows, column segment); with xcd_seg the workgroups of a segment are dealt so that
+// runs of CULL_XCD_RUN consecutive workgroups' rows stay on one XCD (cull.hpp: k_rmsd_sieve_sorted)
 template <bool F32>
 inline __global__ __launch_bounds__(256, TSC_CMM_OCC) void k_rmsd_sieve_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                             const double *__restrict__ Gall, const int32_t *__restrict__ cend,
                                                                             int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, CullMmArgs cm, int my_tiles,
+                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, CullMmArgs cm, int n_groups,
                                                                             int n_seg) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int groups = (my_tiles + 3) / 4;
-    int seg, grp;
+    const int groups = (n_groups + 3) / 4;   // workgroups per segment
+    int seg, wg;
     if (ca.xcd_seg) {
         const int x = int(blockIdx.x & 7u);
         const long long j = (long long)(blockIdx.x >> 3);
@@ -270,12 +291,12 @@ inline __global__ __launch_bounds__(256, TSC_CMM_OCC) void k_rmsd_sieve_sorted_m
         const long long per_seg = (long long)runs_per_xcd * CULL_XCD_RUN;
         seg = int(j / per_seg);
         const int rem = int(j - (long long)seg * per_seg);
-        grp = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
+        wg = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
     } else {
-        seg = int(blockIdx.x / unsigned(groups)), grp = int(blockIdx.x - unsigned(seg) * unsigned(groups));
+        seg = int(blockIdx.x / unsigned(groups)), wg = int(blockIdx.x - unsigned(seg) * unsigned(groups));
     }
-    if (seg >= n_seg || grp >= groups) return;
-    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, grp * 4 + wid, seg);
+    if (seg >= n_seg || wg >= groups || wg * 4 + wid >= n_groups) return;
+    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, wg * 4 + wid, seg);
 }
 
 }  // namespace tsc

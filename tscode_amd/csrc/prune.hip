@@ -264,8 +264,9 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
         }
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
-        if (!rc && c->sieve_mm) rc = palloc(p, size_t(n) * MM_REC_HALVES, &p->Dh);
-        if (!rc && c->sieve_mm) rc = palloc(p, size_t(n) * MM_ROWN_HALVES, &p->Dn);
+        const bool want_mm = c->sieve_mm == 2 || (c->sieve_mm == 1 && n >= c->mm_min_n);   // (mm.hpp; decided per run)
+        if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_REC_HALVES, &p->Dh);
+        if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_ROWN_HALVES, &p->Dn);
         // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
         // (it pays where the gathers come from HBM: 41 MB of heavy atoms at C3 sit in the 256 MB infinity cache and the conversions cost the
         // VALU-bound kernel 2 %; at C4's 348 MB a step goes from 12.1 to 10.6 ms.  "stage1_f32": 0 never, 1 from 128 MB on, 2 always)
@@ -403,8 +404,8 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     // the screen on the matrix cores (mm.hpp): one rank, 64 rows per work item and segments of their own length
-    const bool mm = p->algo == ALGO_SIEVE && p->Dh && world == 1 && c->sieve_mm;
-    if (mm) seg_cols = c->mm_seg_cols;
+    const bool mm = p->algo == ALGO_SIEVE && p->Dh && world == 1;
+    if (mm) seg_cols = c->mm_seg_cols > 0 ? c->mm_seg_cols : (max_range >= 2048 ? 1024 : 512);
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     dim3 grid(std::max(1, mm ? ceil_div(ceil_div(A, MM_ROWS), 4) : ceil_div(my_tiles, 4)), n_seg);
@@ -582,7 +583,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
         oa.rank_of = culled ? p->rank_of : nullptr;
-        oa.Dh = (p->Dh && world == 1 && c->sieve_mm) ? p->Dh : nullptr, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
+        oa.Dh = (p->Dh && world == 1) ? p->Dh : nullptr, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
         oa.dbg = nullptr;
 #ifdef TSC_DBG_STAMPS
         if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
@@ -646,7 +647,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     }
     // (the culled pass with the screen on the matrix cores: one rank's own pass -- row tiles of a layout dealt to several ranks keep the
     // kernel of cull.hpp, whose items are single row tiles)
-    const bool cull_mm = run_culled && p->Dhs && c->sieve_mm && world == 1;
+    const bool cull_mm = run_culled && p->Dhs && world == 1;
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
         const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));
@@ -683,24 +684,26 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const int64_t xitems = int64_t(8) * n_seg * ceil_div(ceil_div(ceil_div(my_tiles, 4), CULL_XCD_RUN), 8) * CULL_XCD_RUN;
         const dim3 sgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : std::min<int64_t>(items, c->cull_grid))));
         if (cull_mm) {
+            const int n_groups = ceil_div(A, MM_ROWS), wgs = ceil_div(n_groups, 4);
+            const int n_seg_mm = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, CMM_SEG);
+            const int64_t grid_mm = c->cull_xcd ? int64_t(8) * n_seg_mm * ceil_div(ceil_div(wgs, CULL_XCD_RUN), 8) * CULL_XCD_RUN : int64_t(wgs) * n_seg_mm;
 #ifdef TSC_DBG_STAMPS
             if (c->dbg_stamp_k == k) {
-                const size_t bytes = size_t(sgrid.x) * 32 * sizeof(unsigned long long);
+                const size_t bytes = size_t(grid_mm) * 32 * sizeof(unsigned long long);
                 if (c->dbg_bytes < bytes) {
                     if (c->dbg_buf) (void)hipFree(c->dbg_buf);
                     TSC_HIP(hipMalloc(&c->dbg_buf, bytes));
                     c->dbg_bytes = bytes;
                 }
                 TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
-                c->dbg_waves = int64_t(sgrid.x) * 4;
+                c->dbg_waves = grid_mm * 4;
                 a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
             }
 #endif
-            // (the same items and grid as the kernel of cull.hpp: 16 rows x 4096 columns)
-            const dim3 mgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : items)));
             CullMmArgs cm{p->Dhs, p->Dns};
-            TSC_TRY(launch_rmsd_sieve_sorted_mm(a.heavy32 != nullptr, st, mgrid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                                                (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, cm, my_tiles, n_seg));
+            TSC_TRY(launch_rmsd_sieve_sorted_mm(a.heavy32 != nullptr, st, dim3(unsigned(std::max<int64_t>(1, grid_mm))), e0, e1, p->heavy, (const int32_t *)p->act,
+                                                (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, cm,
+                                                n_groups, n_seg_mm));
         } else
         TSC_TRY(launch_rmsd_sieve_sorted(a.heavy32 != nullptr, st, sgrid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall, (const int32_t *)p->cend,
                                          p->best, p->counters, (const PruneState *)p->state, a, ca, my_tiles, n_seg));
