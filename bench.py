@@ -904,6 +904,9 @@ def main():
             c4 = leg_summary(leg4, SHARDED_WHAT if world > 1 else "the one-call pipeline on one GPU")
             c4["workload"] = f"C4: {ens4.n_poses} conformers x {ens4.n_atoms} atoms ({ens4.n_heavy} heavy), seed {ens4.seed}"
             c4["n_pass_clash"] = int(leg4["res"]["n_pass"])
+            if world == 1:
+                c4["pair_kernels"] = ("k_rmsd_sieve_mm + k_rmsd_sieve_sorted_mm: the descriptor screen on the matrix cores (v_mfma_f32_16x16x16_f16 on float16 "
+                                      "records, the fp32 screen behind it; csrc/mm.hpp, cull_mm.hpp) -- what runs of 150 000 structures and more take")
             # HBM traffic of the pair kernels at C4 against their algorithmic bytes, from the committed PMC passes of `bench.py --config C4`
             # (tools/profile.sh; only while that profile was taken from the kernels that run now)
             st4 = leg4["res"]["stats"]
@@ -918,7 +921,7 @@ def main():
                     c4["traffic_source"] = f"profiles/{name} is STALE (csrc {pmc.get('csrc_sha256_16')}): traffic withheld"
                     break
                 tot = 0.0
-                for kname in ("k_rmsd_sieve_sorted", "k_rmsd_sieve<"):
+                for kname in ("k_rmsd_sieve_sorted", "k_rmsd_sieve<", "k_rmsd_sieve_mm<"):
                     f_ = [v for k_, v in pmc.get("FETCH_SIZE", {}).items() if kname in k_]
                     w_ = [v for k_, v in pmc.get("WRITE_SIZE", {}).items() if kname in k_]
                     tot += sum(2.0 * v["total_KB"] for v in f_) + sum(v["total_KB"] for v in w_)

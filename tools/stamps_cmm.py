@@ -34,4 +34,6 @@ for a, b, nm in ((0, 1, "start -> boxes tested"), (1, 2, "-> rows' operands"), (
         print(f"{nm:28s}", pct(s[m, b] - s[m, a]), f" ({int(m.sum())})   total {float((s[m, b] - s[m, a]).sum()) / 100.0 / 1e3:.1f} ms*wave")
 tl, nd = s[work, 7] // 64, s[work, 7] % 64
 print("column tiles visited per item: mean %.2f; (row tile, column tile) pairs needed per item: mean %.2f -> %.2f row tiles per visited tile" % (tl.mean(), nd.mean(), nd.sum() / tl.sum()))
+dr = s[work, 5] / 100.0
+print("in-loop evaluation batches per item: mean %.2f; their time per item: mean %.2f us (p50 %.2f, p99 %.2f) = %.1f ms*wave in all; per batch %.2f us" % (s[work, 6].mean(), dr.mean(), np.percentile(dr, 50), np.percentile(dr, 99), dr.sum() / 1e3, dr.sum() / max(1, s[work, 6].sum())))
 print("last stamp after first start: %.1f us" % ((s[s > 0].max() - t0) / 100.0))

@@ -31,11 +31,11 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
                                                      const PruneState *__restrict__ st, const SieveArgs a, const CullArgs ca, const CullMmArgs cm, const int grp,
                                                      const int seg) {
     static_assert(CULL_COLS == 128 && CMM_TILES == 8 && DW == 16, "tile shapes");
-    __shared__ unsigned short s_queue[4][MM_QCAP];
-    __shared__ unsigned short s_exq[4][128];
-    __shared__ double s_jacobi[4][32];
+    __shared__ unsigned short s_queue[1][MM_QCAP];
+    __shared__ unsigned short s_exq[1][128];
+    __shared__ double s_jacobi[1][32];
     const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int wid = 0;   // (one wavefront per workgroup: below)
     const int p0 = grp * MM_ROWS;
     const int pass_on = st->pass_on, A = st->A;
     TSC_STAMP(0);  // started
@@ -273,17 +273,18 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
     }
 }
 
-// grid: a workgroup per (four consecutive groups of 64 rows, column segment); with xcd_seg the workgroups of a segment are dealt so that
-// runs of CULL_XCD_RUN consecutive workgroups' rows stay on one XCD (cull.hpp: k_rmsd_sieve_sorted)
+// grid: ONE WAVEFRONT per workgroup = (a group of 64 rows, a column segment).  (Four per workgroup, as in the other pair kernels, kept a
+// workgroup's slot until its longest item was through -- in a sorted layout the near-duplicates sit together and one item of four may
+// carry fifty evaluation batches: measured, 53 % of the wavefront slots in use.)  With xcd_seg the groups of a segment are dealt so that
+// runs of CULL_XCD_RUN consecutive groups stay on one XCD (cull.hpp: k_rmsd_sieve_sorted).
 template <bool F32>
-inline __global__ __launch_bounds__(256, TSC_CMM_OCC) void k_rmsd_sieve_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                                            const double *__restrict__ Gall, const int32_t *__restrict__ cend,
-                                                                            int32_t *__restrict__ best, PassCounters *__restrict__ counters,
-                                                                            const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, CullMmArgs cm, int n_groups,
-                                                                            int n_seg) {
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int groups = (n_groups + 3) / 4;   // workgroups per segment
-    int seg, wg;
+inline __global__ __launch_bounds__(64, TSC_CMM_OCC) void k_rmsd_sieve_sorted_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                                                           const double *__restrict__ Gall, const int32_t *__restrict__ cend,
+                                                                           int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                                           const PruneState *__restrict__ st, SieveArgs a, CullArgs ca, CullMmArgs cm, int n_groups,
+                                                                           int n_seg) {
+    const int groups = n_groups;   // workgroups per segment
+    int seg, grp;
     if (ca.xcd_seg) {
         const int x = int(blockIdx.x & 7u);
         const long long j = (long long)(blockIdx.x >> 3);
@@ -291,12 +292,12 @@ inline __global__ __launch_bounds__(256, TSC_CMM_OCC) void k_rmsd_sieve_sorted_m
         const long long per_seg = (long long)runs_per_xcd * CULL_XCD_RUN;
         seg = int(j / per_seg);
         const int rem = int(j - (long long)seg * per_seg);
-        wg = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
+        grp = ((rem / CULL_XCD_RUN) * 8 + x) * CULL_XCD_RUN + rem % CULL_XCD_RUN;
     } else {
-        seg = int(blockIdx.x / unsigned(groups)), wg = int(blockIdx.x - unsigned(seg) * unsigned(groups));
+        seg = int(blockIdx.x / unsigned(groups)), grp = int(blockIdx.x - unsigned(seg) * unsigned(groups));
     }
-    if (seg >= n_seg || wg >= groups || wg * 4 + wid >= n_groups) return;
-    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, wg * 4 + wid, seg);
+    if (seg >= n_seg || grp >= groups) return;
+    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, grp, seg);
 }
 
 }  // namespace tsc

@@ -128,24 +128,28 @@ inline __global__ __launch_bounds__(64) void k_mm_screen_dump(const _Float16 *__
 #ifndef TSC_MM_OCC
 #define TSC_MM_OCC 4
 #endif
+#ifndef TSC_MM_WAVES
+#define TSC_MM_WAVES 4
+#endif
+constexpr int MM_WAVES = TSC_MM_WAVES;   // wavefronts (work items) per workgroup of the walked passes' kernel
 
 // The pair kernel with the screen on the matrix cores.  Grid (groups of 64 rows / 4, column segments); everything around the screen --
 // queue, evaluation stages, the fused apply and pass closing -- as in k_rmsd_sieve (sieve.hpp), with 64 rows per work item.
 // Dh: the records by POSITION (k_open_rows writes them every pass, like the fp32 copy Dc the other pair kernels read).
 template <bool FUSED, bool F32>
-inline __global__ __launch_bounds__(256, TSC_MM_OCC) void k_rmsd_sieve_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                     const double *__restrict__ Gall, const float *__restrict__ Dc,
                                                                     const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
                                                                     const int32_t *__restrict__ cend, int32_t *__restrict__ best,
                                                                     PassCounters *__restrict__ counters, const PruneState *__restrict__ st, SieveArgs a,
                                                                     FusedApply fa) {
-    __shared__ unsigned short s_queue[4][MM_QCAP];
-    __shared__ unsigned short s_exq[4][128];
-    __shared__ double s_jacobi[4][32];
-    __shared__ __attribute__((aligned(16))) int s_cend[4][MM_ROWS];   // stop column of every row still looking (0: not, or no longer)
+    __shared__ unsigned short s_queue[MM_WAVES][MM_QCAP];
+    __shared__ unsigned short s_exq[MM_WAVES][128];
+    __shared__ double s_jacobi[MM_WAVES][32];
+    __shared__ __attribute__((aligned(16))) int s_cend[MM_WAVES][MM_ROWS];   // stop column of every row that was looking when the item began (else 0)
     const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = blockIdx.x * 4 + wid;
+    const int wid = MM_WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = blockIdx.x * MM_WAVES + wid;
     const int R0 = grp * MM_ROWS;
     const int seg_lo = R0 + int(blockIdx.y) * a.seg_cols, seg_hi = seg_lo + a.seg_cols;
     TSC_STAMP(0);  // the wavefront has started

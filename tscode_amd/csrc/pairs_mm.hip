@@ -5,7 +5,7 @@ int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEve
                          const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
                          const FusedApply &fa) {
 #define TSC_LAUNCH_MM(FUSED, F32) \
-    hipExtLaunchKernelGGL((k_rmsd_sieve_mm<FUSED, F32>), grid, dim3(256), 0, st, e0, e1, 0, heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, state, a, fa)
+    hipExtLaunchKernelGGL((k_rmsd_sieve_mm<FUSED, F32>), grid, dim3(64 * MM_WAVES), 0, st, e0, e1, 0, heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, state, a, fa)
     if (fused && f32) TSC_LAUNCH_MM(true, true);
     else if (fused) TSC_LAUNCH_MM(true, false);
     else if (f32) TSC_LAUNCH_MM(false, true);
@@ -18,8 +18,8 @@ int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEve
 int launch_rmsd_sieve_sorted_mm(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                                 const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
                                 const CullMmArgs &cm, int n_groups, int n_seg) {
-    if (f32) hipExtLaunchKernelGGL(k_rmsd_sieve_sorted_mm<true>, grid, dim3(256), 0, st, e0, e1, 0, heavy, act, Gall, cend, best, counters, state, a, ca, cm, n_groups, n_seg);
-    else hipExtLaunchKernelGGL(k_rmsd_sieve_sorted_mm<false>, grid, dim3(256), 0, st, e0, e1, 0, heavy, act, Gall, cend, best, counters, state, a, ca, cm, n_groups, n_seg);
+    if (f32) hipExtLaunchKernelGGL(k_rmsd_sieve_sorted_mm<true>, grid, dim3(64), 0, st, e0, e1, 0, heavy, act, Gall, cend, best, counters, state, a, ca, cm, n_groups, n_seg);
+    else hipExtLaunchKernelGGL(k_rmsd_sieve_sorted_mm<false>, grid, dim3(64), 0, st, e0, e1, 0, heavy, act, Gall, cend, best, counters, state, a, ca, cm, n_groups, n_seg);
     TSC_HIP(hipGetLastError());
     return 0;
 }

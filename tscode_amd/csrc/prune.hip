@@ -408,7 +408,7 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     if (mm) seg_cols = c->mm_seg_cols > 0 ? c->mm_seg_cols : (max_range >= 2048 ? 1024 : 512);
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
-    dim3 grid(std::max(1, mm ? ceil_div(ceil_div(A, MM_ROWS), 4) : ceil_div(my_tiles, 4)), n_seg);
+    dim3 grid(std::max(1, mm ? ceil_div(ceil_div(A, MM_ROWS), MM_WAVES) : ceil_div(my_tiles, 4)), n_seg);
     // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
     // hipEventRecord before and after it costs about 4 us each on MI355X)
     hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -684,7 +684,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const int64_t xitems = int64_t(8) * n_seg * ceil_div(ceil_div(ceil_div(my_tiles, 4), CULL_XCD_RUN), 8) * CULL_XCD_RUN;
         const dim3 sgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : std::min<int64_t>(items, c->cull_grid))));
         if (cull_mm) {
-            const int n_groups = ceil_div(A, MM_ROWS), wgs = ceil_div(n_groups, 4);
+            const int n_groups = ceil_div(A, MM_ROWS), wgs = n_groups;   // (one wavefront per workgroup)
             const int n_seg_mm = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, CMM_SEG);
             const int64_t grid_mm = c->cull_xcd ? int64_t(8) * n_seg_mm * ceil_div(ceil_div(wgs, CULL_XCD_RUN), 8) * CULL_XCD_RUN : int64_t(wgs) * n_seg_mm;
 #ifdef TSC_DBG_STAMPS
@@ -696,7 +696,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                     c->dbg_bytes = bytes;
                 }
                 TSC_HIP(hipMemsetAsync(c->dbg_buf, 0, bytes, st));
-                c->dbg_waves = grid_mm * 4;
+                c->dbg_waves = grid_mm * 4;   // (8 of every 32 words used: one wavefront per workgroup)
                 a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
             }
 #endif
