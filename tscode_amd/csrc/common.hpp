@@ -94,7 +94,7 @@ struct tsc_ctx {
     int sieve_trim = 1;                   // pair kernel: the screen with fewer vector instructions per (row, tile) (norms folded into the fma chain, per-family compares)
     int sieve_mm = 1;                     // pair kernels of a one-rank run with the screen on the matrix cores, 64 rows per work item (mm.hpp, cull_mm.hpp): 0 never (the
                                           // packed-fp32 screen of sieve.hpp / cull.hpp), 1 for runs of at least mm_min_n structures, 2 always
-    int64_t mm_min_n = 150000;            // (measured: at 57 000 structures a pass is a few thousand work items and bound by their chains of memory round trips, which
+    int64_t mm_min_n = 100000;            // (measured: at 57 000 structures a pass is a few thousand work items and bound by their chains of memory round trips, which
                                           // the longer 64-row items lengthen -- C3 0.80 - 0.89 ms against 0.79; at 483 000 the passes are bound by issue: C4 9.05 -> 7.8 ms)
     int mm_seg_cols = 0;                  // ... columns per work item of the walked passes' kernel (0: 1024 where rows' ranges reach 2048 columns, else 512)
     int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
