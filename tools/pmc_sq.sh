@@ -11,7 +11,7 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d "$P/p3" -- python3 bench.py $ARGS > "$P/b3.json" 2> "$P/p3.err"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F32 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --output-format csv -d "$P/p4" -- python3 bench.py $ARGS > "$P/b4.json" 2> "$P/p4.err"
 # (the matrix-core screen of the large runs, csrc/mm.hpp: how busy the MFMA pipe is; a pass of its own that may fail where a counter is not offered)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES --output-format csv -d "$P/p5" -- python3 bench.py $ARGS > "$P/b5.json" 2> "$P/p5.err" || echo "pass p5 (MFMA counters) failed: see $P/p5.err"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$P/p5" -- python3 bench.py $ARGS > "$P/b5.json" 2> "$P/p5.err" || echo "pass p5 (MFMA counters) failed: see $P/p5.err"
 python3 - "$P" <<'PY'
 import csv, glob, sys, collections, json
 P = sys.argv[1]

@@ -26,7 +26,13 @@ for f in glob.glob(f"{P}/p*/**/*counter_collection.csv", recursive=True):
 out = {}
 for k, v in agg.items():
     out[k] = {c: {"total": x, "calls": len(calls[k][c]), "per_call": x / max(1, len(calls[k][c]))} for c, x in v.items()}
+try:   # the digest of the binary that ran (bench.py reports it): what ties this file to the kernels it describes
+    line = [l for l in open(f"{P}/b1.json").read().strip().splitlines() if l.startswith("{")][-1]
+    out["_run"] = {"csrc_sha256_16": json.loads(line)["roofline"].get("binary_csrc_sha256_16")}
+except Exception as exc:
+    out["_run"] = {"error": str(exc)}
 json.dump(out, open(f"{P}/tcc_counters.json", "w"), indent=1)
+out.pop("_run", None)
 for k in sorted(out, key=lambda k: -out[k].get("TCC_REQ_sum", out[k].get("TCC_READ_sum", {"total": 0}))["total"])[:8]:
     print(k)
     for c, x in sorted(out[k].items()):
