@@ -15,6 +15,15 @@ P = os.path.join(ROOT, "profiles")
 R = "r05"
 
 
+def kernel_name(raw):
+    """rocprofv3's kernel name without arguments; names it could not demangle (a _Float16 parameter: DF16_) as namespace tsc's plain name."""
+    m = re.match(r"_ZN3tsc(\d+)", raw)
+    if m:
+        n = int(m.group(1))
+        return raw[m.end():m.end() + n] + ("<...>" if raw[m.end() + n] == "I" else "")
+    return re.sub(r"\(.*", "", raw).replace("void ", "").replace("tsc::", "")
+
+
 def last_json_line(name):
     path = os.path.join(P, name)
     if not os.path.exists(path):
@@ -99,7 +108,7 @@ def kernels():
         per = int(r["TotalDurationNs"]) / steps / 1e3
         tot += per
         if per >= 3.0:
-            name = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("tsc::", "")
+            name = kernel_name(r["Name"])
             rows.append(f"| `{name}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {per:.1f} |")
     rows.append(f"| sum over all kernels | | | {tot:.0f} |")
     return "\n".join(rows) + f"\n\n(from `profiles/{R}_kernel_stats.csv`)"
@@ -117,7 +126,7 @@ def kernels_c4():
         per = int(r["TotalDurationNs"]) / steps / 1e3
         tot += per
         if per >= 40.0:
-            name = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("tsc::", "")
+            name = kernel_name(r["Name"])
             rows.append(f"| `{name}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {per:.1f} |")
     rows.append(f"| sum over all kernels | | | {tot:.0f} |")
     return "\n".join(rows) + f"\n\n(from `profiles/{R}_kernel_stats_C4.csv`)"
