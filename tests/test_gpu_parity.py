@@ -388,10 +388,14 @@ def test_prune_many_heavy_atoms(eng, oracle):
         assert np.array_equal(mask, ref["mask"]), h
 
 
-def test_prune_sharded_rows_equal_single(eng, oracle):
+@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
+def test_prune_sharded_rows_equal_single(eng, oracle, mm):
     """The stepping API with the row tiles of each pass dealt to 3 'ranks' (run one after the other on
-    this GPU, merging through the atomicMin target) gives the same mask as the one-shot call."""
+    this GPU, merging through the atomicMin target) gives the same mask as the one-shot call -- also with the matrix-core
+    kernel, which deals groups of 64 rows (sieve_mm = 2)."""
     import ctypes as C
+
+    eng.set_option("sieve_mm", mm)
 
     from tscode_amd import _lib
     from tscode_amd.synthetic import make_config
@@ -445,6 +449,7 @@ def test_prune_sharded_rows_equal_single(eng, oracle):
     assert [x["pairs_evaluated"] for x in s.stats()] == [x["pairs_evaluated"] for x in ref_stats]
     s.close()
     _lib.check(lib.tsc_free(eng._h, d_heavy))
+    eng.set_option("sieve_mm", 1)
 
 
 def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
@@ -493,8 +498,9 @@ def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
         assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
 
 
+@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
 @pytest.mark.parametrize("world,n_poses,tile_block,det", [(3, 20_000, 256, 1), (8, 30_000, 256, 1), (5, 9_000, 16, 1), (4, 12_000, 1, 1), (3, 20_000, 256, 0)])
-def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block, det):
+def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block, det, mm):
     """Passes sharded by ROW TILES with every pass culled (sorted layout + bounding boxes, cull.hpp): `world` prune runs over one array stand
     in for the ranks, rank r takes its runs of `cull_tile_block` consecutive tiles of the sorted layout, best[] is min-merged with torch as the
     all-reduce(MIN) would.  Each unordered pair of a pass is visited by exactly one rank -- the layouts of the ranks must be bit-identical for
@@ -514,6 +520,7 @@ def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, t
     eng.set_option("local_pass", 0)
     eng.set_option("cull_tile_block", tile_block)
     eng.set_option("deterministic_basis", det)
+    eng.set_option("sieve_mm", mm)      # (2: the matrix-core kernels, which deal groups of 64 rows -- runs of tile_block / 4 of them)
     try:
         sts = [eng.prune_stepper(d_heavy, len(heavy), heavy.shape[1], 0.5, 0) for _ in range(world)]
         bests = [torch.empty(len(heavy), dtype=torch.int32, device=dev) for _ in range(world)]
@@ -546,6 +553,7 @@ def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, t
         eng.set_option("local_pass", 1)
         eng.set_option("cull_tile_block", 256)
         eng.set_option("deterministic_basis", 0)
+        eng.set_option("sieve_mm", 1)
 
 
 @pytest.mark.parametrize("world,min_chunks,n_poses,mode,cull", [(2, 4, 12_000, 0, 0), (3, 1, 12_000, 0, 0), (8, 4, 40_000, 0, 0), (3, 4, 9_000, 1, 0), (5, 2, 700, 0, 0),

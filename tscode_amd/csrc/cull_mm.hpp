@@ -297,7 +297,10 @@ inline __global__ __launch_bounds__(64, TSC_CMM_OCC) void k_rmsd_sieve_sorted_mm
         seg = int(blockIdx.x / unsigned(groups)), grp = int(blockIdx.x - unsigned(seg) * unsigned(groups));
     }
     if (seg >= n_seg || grp >= groups) return;
-    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, grp, seg);
+    // (several ranks: runs of tile_block / 4 consecutive groups of the sorted layout stay on one rank, as cull.hpp deals its tiles)
+    const int tbg = max(1, ca.tile_block / 4);
+    const int g64 = a.tile_stride <= 1 ? grp : ((grp / tbg) * a.tile_stride + a.tile_begin) * tbg + grp % tbg;
+    sieve_item_sorted_mm<F32>(heavy, act, Gall, cend, best, counters, st, a, ca, cm, g64, seg);
 }
 
 }  // namespace tsc

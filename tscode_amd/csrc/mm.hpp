@@ -149,7 +149,7 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
     __shared__ __attribute__((aligned(16))) int s_cend[MM_WAVES][MM_ROWS];   // stop column of every row that was looking when the item began (else 0)
     const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
     const int wid = MM_WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = blockIdx.x * MM_WAVES + wid;
+    const int grp = a.tile_begin + (int(blockIdx.x) * MM_WAVES + wid) * a.tile_stride;   // (groups of 64 rows dealt round-robin to the ranks; one rank: 0, 1)
     const int R0 = grp * MM_ROWS;
     const int seg_lo = R0 + int(blockIdx.y) * a.seg_cols, seg_hi = seg_lo + a.seg_cols;
     TSC_STAMP(0);  // the wavefront has started

@@ -404,11 +404,12 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     // the screen on the matrix cores (mm.hpp): one rank, 64 rows per work item and segments of their own length
-    const bool mm = p->algo == ALGO_SIEVE && p->Dh && world == 1;
+    const bool mm = p->algo == ALGO_SIEVE && p->Dh;
     if (mm) seg_cols = c->mm_seg_cols > 0 ? c->mm_seg_cols : (max_range >= 2048 ? 1024 : 512);
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
-    dim3 grid(std::max(1, mm ? ceil_div(ceil_div(A, MM_ROWS), MM_WAVES) : ceil_div(my_tiles, 4)), n_seg);
+    // (mm: groups of 64 rows dealt round-robin to the ranks)
+    dim3 grid(std::max(1, mm ? ceil_div((ceil_div(A, MM_ROWS) - rank + world - 1) / world, MM_WAVES) : ceil_div(my_tiles, 4)), n_seg);
     // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
     // hipEventRecord before and after it costs about 4 us each on MI355X)
     hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -583,7 +584,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
         oa.rank_of = culled ? p->rank_of : nullptr;
-        oa.Dh = (p->Dh && world == 1) ? p->Dh : nullptr, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
+        oa.Dh = p->Dh, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
         oa.dbg = nullptr;
 #ifdef TSC_DBG_STAMPS
         if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
@@ -647,7 +648,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     }
     // (the culled pass with the screen on the matrix cores: one rank's own pass -- row tiles of a layout dealt to several ranks keep the
     // kernel of cull.hpp, whose items are single row tiles)
-    const bool cull_mm = run_culled && p->Dhs && world == 1;
+    const bool cull_mm = run_culled && p->Dhs;
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
         const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));
@@ -684,7 +685,9 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const int64_t xitems = int64_t(8) * n_seg * ceil_div(ceil_div(ceil_div(my_tiles, 4), CULL_XCD_RUN), 8) * CULL_XCD_RUN;
         const dim3 sgrid(unsigned(std::max<int64_t>(1, c->cull_xcd ? xitems : std::min<int64_t>(items, c->cull_grid))));
         if (cull_mm) {
-            const int n_groups = ceil_div(A, MM_ROWS), wgs = n_groups;   // (one wavefront per workgroup)
+            // (one wavefront per workgroup; several ranks: this rank's share of the groups, in runs of tile_block / 4 -- an upper bound)
+            const int all_groups = ceil_div(A, MM_ROWS), tbg = std::max(1, tb / 4);
+            const int n_groups = world <= 1 ? all_groups : (all_groups / (tbg * world) + 1) * tbg, wgs = n_groups;
             const int n_seg_mm = ceil_div(int(std::min<int64_t>(A, longest_chunk)) + 2 * CULL_COLS, CMM_SEG);
             const int64_t grid_mm = c->cull_xcd ? int64_t(8) * n_seg_mm * ceil_div(ceil_div(wgs, CULL_XCD_RUN), 8) * CULL_XCD_RUN : int64_t(wgs) * n_seg_mm;
 #ifdef TSC_DBG_STAMPS

@@ -952,7 +952,7 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
             if (D) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * q) = dval[q];
-                if (oa.Dh) {
+                if (oa.Dh) {   // (made here every pass; copying them from records made once per run was measured: no faster, 80 B more per structure)
                     float dv[16];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dv[4 * q] = dval[q].x, dv[4 * q + 1] = dval[q].y, dv[4 * q + 2] = dval[q].z, dv[4 * q + 3] = dval[q].w;
