@@ -34,6 +34,15 @@ for a, b, nm in ((0, 1, "start -> boxes tested"), (1, 2, "-> rows' operands"), (
         print(f"{nm:28s}", pct(s[m, b] - s[m, a]), f" ({int(m.sum())})   total {float((s[m, b] - s[m, a]).sum()) / 100.0 / 1e3:.1f} ms*wave")
 tl, nd = s[work, 7] // 64, s[work, 7] % 64
 print("column tiles visited per item: mean %.2f; (row tile, column tile) pairs needed per item: mean %.2f -> %.2f row tiles per visited tile" % (tl.mean(), nd.mean(), nd.sum() / tl.sum()))
-dr = s[work, 5] / 100.0
-print("in-loop evaluation batches per item: mean %.2f; their time per item: mean %.2f us (p50 %.2f, p99 %.2f) = %.1f ms*wave in all; per batch %.2f us" % (s[work, 6].mean(), dr.mean(), np.percentile(dr, 50), np.percentile(dr, 99), dr.sum() / 1e3, dr.sum() / max(1, s[work, 6].sum())))
+u5, u6 = buf[: n.value, 5][work], buf[: n.value, 6][work]
+pos, ce, be, l2 = int((u5 >> np.uint64(32)).sum()), int((u5 & np.uint64(0xffffffff)).sum()), int((u6 >> np.uint64(32)).sum()), int((u6 & np.uint64(0xffffffff)).sum())
+if pos + ce + be + l2:   # (only a build that counts them: MEASURED.md section 8 has the numbers of the one that did)
+    print("candidates dropped where they are decoded: position %d, the row's stop column %d, the similar column it has %d, level 2 %d" % (pos, ce, be, l2))
+raw = buf[: n.value].reshape(-1, 32) if n.value % 4 == 0 else None     # (a workgroup's 32 words: 8 stamps + the step timers of its one wavefront)
+if raw is not None:
+    m = (raw[:, 12] > 0) & (raw[:, 12] < 4096)
+    tt = raw[m][:, 8:12].astype(np.float64).sum(axis=0)
+    steps = float(raw[m][:, 12].sum()) if m.any() else 0.0
+    if steps > 0:
+      print("per step (cycles of s_memtime, mean over %d steps): operands still under way %.0f, MFMAs + sign bits %.0f, candidates extracted %.0f, evaluation batches %.0f" % (steps, tt[0] / steps, tt[1] / steps, tt[2] / steps, tt[3] / steps))
 print("last stamp after first start: %.1f us" % ((s[s > 0].max() - t0) / 100.0))
