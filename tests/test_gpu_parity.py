@@ -237,6 +237,7 @@ def algo(request, eng):
     "vector-screen" routes switch it off and run the packed-fp32 screen of sieve.hpp (what row tiles dealt to several ranks still use)."""
     eng.set_option("prune_algo", request.param[0])
     eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 2)
+    eng.set_option("sieve_mm16", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 1)
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
         eng.set_option("sieve_trim", 1 - SIEVE_TRIM_DEFAULT)
@@ -250,6 +251,7 @@ def algo(request, eng):
         eng.set_option("stage1_f32", 2)
     yield request.param[0]
     eng.set_option("sieve_mm", 1)
+    eng.set_option("sieve_mm16", 1)
     eng.set_option("stage1_f32", 1)
     eng.set_option("cull_min_pairs", 2.0e9)
     eng.set_option("cull", 1)

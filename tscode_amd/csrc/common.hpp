@@ -96,6 +96,7 @@ struct tsc_ctx {
                                           // packed-fp32 screen of sieve.hpp / cull.hpp), 1 for runs of at least mm_min_n structures, 2 always
     int64_t mm_min_n = 100000;            // (measured: at 57 000 structures a pass is a few thousand work items and bound by their chains of memory round trips, which
                                           // the longer 64-row items lengthen -- C3 0.80 - 0.89 ms against 0.79; at 483 000 the passes are bound by issue: C4 9.05 -> 7.8 ms)
+    int sieve_mm16 = 1;                   // runs below mm_min_n: the walked passes' pair kernel with the matrix-core screen on 16-row items (mm.hpp: k_rmsd_sieve_mm16); 0: the packed-fp32 kernel
     int mm_seg_cols = 0;                  // ... columns per work item of the walked passes' kernel (0: 1024 where rows' ranges reach 2048 columns, else 512)
     int sieve_cpl = 2;                    // columns per lane of the pair kernel's screen: 2 = 128-column tiles at 5 waves/SIMD (default), 4 = 256-column tiles at 4, 1 = 64-column tiles at 6
     int64_t pca_min_n = 6000;             // below this many structures the descriptors use the identity basis (no principal-axis estimate)

@@ -228,6 +228,11 @@ extern "C" __attribute__((visibility("default"))) int tsc_ctx_set_option(tsc_ctx
         c->sieve_mm = int(value);
         return 0;
     }
+    if (strcmp(name, "sieve_mm16") == 0) {
+        TSC_REQUIRE(value == 0 || value == 1, "sieve_mm16 must be 0 or 1");
+        c->sieve_mm16 = int(value);
+        return 0;
+    }
     if (strcmp(name, "mm_min_n") == 0) {
         TSC_REQUIRE(value >= 0 && value <= 4e9, "mm_min_n must be in [0, 4e9]");
         c->mm_min_n = int64_t(value);

@@ -90,9 +90,7 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
         if (g == 2 && 16 * rt + rc >= nrows) Ar[rt][0][0] = _Float16(__builtin_inff());
     }
     auto load_B = [&](int c0, f16x4 (&B)[NFAM]) __attribute__((always_inline)) {
-        const _Float16 *rec = cm.Dhs + int64_t(min(c0 + rc, A - 1)) * MM_REC_HALVES;
-#pragma unroll
-        for (int fam = 0; fam < NFAM; ++fam) B[fam] = mm_load_B(rec, fam, g);
+        mm_load_B2(cm.Dhs + int64_t(min(c0 + rc, A - 1)) * MM_REC_HALVES, g, B);
     };
 
     const int h3 = a.h * 3;

@@ -79,12 +79,19 @@ inline __global__ __launch_bounds__(256) void k_mm_records(const float *__restri
 
 // operand registers of a wavefront: lane = (k group g = lane / 16: slots 4 g .. 4 g + 3, row or column lane % 16)
 __device__ inline f16x4 mm_load_A(const _Float16 *__restrict__ col_rec, const _Float16 *__restrict__ rown_rec, int fam, int g) {   // the row's two records
-    if (g < 2) return *reinterpret_cast<const f16x4 *>(col_rec + 16 * fam + 4 * g) * _Float16(-0.5f);   // (-2 x) * (-1/2): exact
+    if (g < 2) return *reinterpret_cast<const f16x4 *>(col_rec + 8 * g + 4 * fam) * _Float16(-0.5f);   // (-2 x) * (-1/2): exact
     if (g == 2) return *reinterpret_cast<const f16x4 *>(rown_rec + 4 * fam);
     return f16x4{_Float16(1.0f), _Float16(1.0f), _Float16(0.0f), _Float16(0.0f)};
 }
 __device__ inline f16x4 mm_load_B(const _Float16 *__restrict__ col_rec, int fam, int g) {   // the column's record
-    return *reinterpret_cast<const f16x4 *>(col_rec + 16 * fam + 4 * g);
+    return *reinterpret_cast<const f16x4 *>(col_rec + 8 * g + 4 * fam);
+}
+// both families' operands of a column in one 16-byte load
+__device__ inline void mm_load_B2(const _Float16 *__restrict__ col_rec, int g, f16x4 (&B)[NFAM]) {
+    static_assert(NFAM == 2, "two families side by side");
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(col_rec + 8 * g);
+    const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    B[0] = __builtin_bit_cast(f16x4, lo), B[1] = __builtin_bit_cast(f16x4, hi);
 }
 
 // Level 2: the fp32 screen of sieve.hpp on one pair's stored descriptors (16 floats each, component 2 k + fam): true = the pair may be
@@ -193,9 +200,7 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
             }
         };
         auto load_B = [&](int c0, f16x4 (&B)[NFAM]) __attribute__((always_inline)) {
-            const _Float16 *rec = Dh + int64_t(min(c0 + rc, a.n - 1)) * MM_REC_HALVES;
-#pragma unroll
-            for (int fam = 0; fam < NFAM; ++fam) B[fam] = mm_load_B(rec, fam, g);
+            mm_load_B2(Dh + int64_t(min(c0 + rc, a.n - 1)) * MM_REC_HALVES, g, B);
         };
         // Rows that are not (or no longer) looking -- beyond the active count, their similar column found, their stop column passed --
         // carry +inf in the n0 slot of family 0 (lanes of k group 2 hold it, element 0): they never come below the limit.  Nothing
@@ -368,15 +373,22 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
                 }
             }
             unsigned hits = m0 & m1;
-            for (unsigned long long hm = __builtin_amdgcn_ballot_w64(hits != 0u); hm; hm = __builtin_amdgcn_ballot_w64(hits != 0u)) {
-                // one pair per lane and turn (a lane rarely holds two)
+            while (__builtin_amdgcn_ballot_w64(hits != 0u)) {
+                // one pair per lane and turn (a lane rarely holds two); kept if it lies right of the diagonal and before its row's stop
+                // column -- a batch of candidates is evaluated with 64 / (their number) lanes per pair, and what would be dropped where it
+                // is decoded makes the others' chains longer
+                bool keep = false;
+                unsigned ent = 0;
                 if (hits) {
                     const int j = __builtin_clz(hits);                     // the earliest value of the step among this lane's
                     hits &= ~(0x80000000u >> j);
-                    const int u = j >> 4, rt = (j >> 2) & 3, i = j & 3;
-                    queue[qn + __popcll(hm & lt_mask)] = (unsigned short)((unsigned(16 * rt + 4 * g + i) << 10) | unsigned(c0 + MM_STEP * u + rc - seg_lo));
+                    const int row = 16 * ((j >> 2) & 3) + 4 * g + (j & 3), col = c0 + MM_STEP * (j >> 4) + rc;
+                    keep = col > R0 + row && col < scend[row];
+                    ent = (unsigned(row) << 10) | unsigned(col - seg_lo);
                 }
-                qn += __popcll(hm);
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                if (keep) queue[qn + __popcll(km & lt_mask)] = (unsigned short)ent;
+                qn += __popcll(km);
             }
             n_screened += (unsigned long long)(2 * MM_STEP * __popcll(alive));
             __builtin_amdgcn_wave_barrier();
@@ -427,6 +439,296 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
         const bool fin = last && tickets_arrive(fa.tickets, unsigned(4 * grp + lane), fa.n_tiles, PT_GROUPS);
         TSC_STAMP(6);
         if (__ballot(fin)) {
+            pass_step_wave(fa.sc, fa.next);
+            TSC_STAMP(7);
+        }
+    }
+}
+
+// ---- the same screen for 16-ROW work items: k_rmsd_sieve's items, grid and tail (sieve.hpp) with level 1 in place of the packed-fp32
+// screen.  A column tile of 128 (8 KB of records, requested whole) against the item's 16 rows: 16 MFMAs, 64 sign-bit shifts -- against 16 x
+// 34 vector instructions.  Four times the column bytes per pair of the 64-row form (each row tile loads its own columns, as the
+// packed-fp32 kernel does): the form for runs that are NOT bound by that -- below mm_min_n, where the longer items of the 64-row form lose.
+#ifndef TSC_MM16_OCC
+#define TSC_MM16_OCC 4
+#endif
+constexpr int MM16_BLOCKS = 128 / MM_STEP;   // 16-column blocks of a column tile
+
+template <bool F32>
+__device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
+                                                const float *__restrict__ Dc, const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
+                                                const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
+                                                const PruneState *__restrict__ st, const SieveArgs &a, int &A_out, int &bitsel_out, const int tile, const int seg) {
+    constexpr int TI = 16, TILE_COLS = 128;
+    constexpr int QCAP = TI * TILE_COLS + 64;
+    __shared__ unsigned short s_queue[4][QCAP];
+    __shared__ unsigned short s_exq[4][128];
+    __shared__ double s_jacobi[4][32];
+    __shared__ int s_cend[4][TI];   // stop column of every row that was looking when the item began (else 0)
+    const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = tile;
+    const int r0 = tile * TI;
+    const int seg_lo = ((r0 + 1) & ~63) + seg * a.seg_cols;
+    const int seg_hi = seg_lo + a.seg_cols;
+    const int pass_on = st->pass_on, n_active = st->A;
+    A_out = n_active, bitsel_out = st->bitsel;
+    int my_cend = 0, my_best = 0;
+    if (lane < TI && r0 + lane < a.n) {
+        my_cend = cend[r0 + lane];
+        my_best = __hip_atomic_load(&best[r0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the rows' operands and the first column tile: requested with the stop columns (one trip for an item of a light pass)
+    f16x4 Ar[NFAM];
+    {
+        const int64_t row = min(r0 + rc, a.n - 1);
+#pragma unroll
+        for (int fam = 0; fam < NFAM; ++fam) Ar[fam] = mm_load_A(Dh + row * MM_REC_HALVES, Dn + row * MM_ROWN_HALVES, fam, g);
+    }
+    f16x4 B[MM16_BLOCKS][NFAM];
+    auto load_tile = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < MM16_BLOCKS; ++b) {
+            mm_load_B2(Dh + int64_t(min(c0 + MM_STEP * b + rc, a.n - 1)) * MM_REC_HALVES, g, B[b]);
+        }
+    };
+    load_tile(seg_lo);
+    if (pass_on == 0 || r0 >= n_active) return;
+    const int nrows = min(TI, n_active - r0);
+    const bool live0 = lane < nrows && my_cend > max(r0 + lane + 1, seg_lo) && my_best >= seg_lo;
+    unsigned alive = unsigned(__ballot(live0));
+    if (!alive) return;
+    const float limit_mm = screen_limit_mm(*a.dmax_bits, a.desc_limit);
+    int *scend = s_cend[wid];
+    if (lane < TI) scend[lane] = live0 ? my_cend : 0;
+    int cmax = live0 ? my_cend : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    cmax = min(__builtin_amdgcn_readfirstlane(cmax), seg_hi);
+    // rows that are not (or no longer) looking: +inf in the n0 slot of family 0 (lanes of k group 2, element 0): they never pass
+    auto mark_rows = [&]() __attribute__((always_inline)) {
+        if (g == 2 && !((alive >> rc) & 1u)) Ar[0][0] = _Float16(__builtin_inff());
+    };
+    mark_rows();
+    __builtin_amdgcn_wave_barrier();
+    TSC_STAMP(1);  // prologue data has arrived
+
+    const int h3 = a.h * 3;
+    unsigned short *queue = s_queue[wid], *exq = s_exq[wid];
+    int qn = 0, qe = 0;
+    unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int64_t si = 0, sj = 0;
+    // queue entry: row (4 bits) | column offset inside the segment (12 bits).  Returns whether the pair is still one to look at: right of
+    // the diagonal, before the row's stop column and the similar column it already has, within the limit of the fp32 screen (level 2)
+    auto decode = [&](unsigned e, int &t, int &col, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
+        t = int(e >> 12);
+        col = seg_lo + int(e & 0xfffu);
+        const int64_t i = act[r0 + t], j = act[col];
+        si = i, sj = j;
+        pp = heavy + i * h3, pq = heavy + j * h3;
+        Gi = Gall[i], Gj = Gall[j];
+        // (no level 2 here: the few per cent it would drop cost an item less as H than as eight more loads in front of every batch)
+        return col > r0 + t && col < scend[t] && col < __hip_atomic_load(&best[r0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto sign_stage = [&](int base, int cnt) __attribute__((always_inline)) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int gq = lane / lpp, sub = lane - gq * lpp;
+        bool cand = false, sim = false, counted = false;
+        unsigned e = 0;
+        int t = 0;
+        if (gq < cnt) {
+            e = queue[base + gq];
+            int col;
+            const double *pp, *pq;
+            double Gi, Gj;
+            if (decode(e, t, col, pp, pq, Gi, Gj)) {   // (the lanes of a group hold the same pair: they branch together)
+                const int verdict = pair_stage1<F32>(heavy, a.heavy32, si, sj, a.h, 0.5 * (Gi + Gj), a.half_h_thr2, a.two_thr2, sub, lpp);
+                cand = sub == 0 && verdict == PAIR_UNDECIDED;
+                sim = sub == 0 && verdict == PAIR_SIMILAR;
+                counted = sub == 0;
+                if (sim) atomicMin(&best[r0 + t], col);
+            }
+        }
+        unsigned long long sm = __builtin_amdgcn_ballot_w64(sim);
+        while (sm) {  // rows that found a similar column stop being screened (the reference returns there, :75-77)
+            const int l = __ffsll((long long)sm) - 1;
+            sm &= sm - 1;
+            alive &= ~(1u << __builtin_amdgcn_readlane(t, l));
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (m) {
+            if (cand) exq[qe + __popcll(m & lt_mask)] = (unsigned short)e;
+            qe += __popcll(m);
+        }
+        n_eval += __popcll(__builtin_amdgcn_ballot_w64(counted));
+        n_exact += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
+        int lpp = 64;
+        while (lpp > 1 && 64 / lpp < cnt) lpp >>= 1;
+        const int gq = lane / lpp, sub = lane - gq * lpp;
+        bool sim = false, degenerate = false;
+        int t = 0;
+        unsigned ent = 0;
+        if (gq < cnt) {
+            int col;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], e[4];
+            ent = exq[base + gq];
+            (void)decode(ent, t, col, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, sub, lpp, H);
+            if (rotation_quaternion_fast(H, Gi, Gj, e)) {
+                double rm, md;
+                residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, sub, lpp);
+                sim = sub == 0 && rm < a.thr && md < a.maxdev_thr;  // rmsd_pruning.py:75
+                if (sim) atomicMin(&best[r0 + t], col);
+            } else {
+                degenerate = sub == 0;
+            }
+        }
+        unsigned long long sm = __builtin_amdgcn_ballot_w64(sim);
+        while (sm) {
+            const int l = __ffsll((long long)sm) - 1;
+            sm &= sm - 1;
+            alive &= ~(1u << __builtin_amdgcn_readlane(t, l));
+        }
+        for (unsigned long long dm = __builtin_amdgcn_ballot_w64(degenerate); dm; dm &= dm - 1) {   // (sieve.hpp: the Jacobi fallback)
+            const unsigned e1 = unsigned(__builtin_amdgcn_readlane(int(ent), __ffsll((long long)dm) - 1));
+            int t2, col2;
+            const double *pp, *pq;
+            double Gi, Gj, H[9], e[4], rm, md;
+            (void)decode(e1, t2, col2, pp, pq, Gi, Gj);
+            pair_H(pp, pq, a.h, lane, 64, H);
+            double *jac = s_jacobi[wid];
+            if (lane == 0) {
+                horn_matrix(H, jac);
+                top_eigvec4_mem(jac, jac + 16, e);
+                jac[0] = e[0], jac[1] = e[1], jac[2] = e[2], jac[3] = e[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+            e[0] = jac[0], e[1] = jac[1], e[2] = jac[2], e[3] = jac[3];
+            __builtin_amdgcn_wave_barrier();
+            residual_rmsd_maxdev(pp, pq, a.h, e, rm, md, lane, 64);
+            if (rm < a.thr && md < a.maxdev_thr) {  // wave-uniform
+                if (lane == 0) atomicMin(&best[r0 + t2], col2);
+                alive &= ~(1u << t2);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto drain = [&](int base, int cnt) __attribute__((always_inline)) {
+        sign_stage(base, cnt);
+        if (qe >= 64) {
+            exact_stage(qe - 64, 64);
+            qe -= 64;
+        }
+    };
+
+    unsigned marked = alive;
+    for (int c0 = seg_lo; c0 < cmax;) {   // (alive != 0 here)
+        // every accumulator starts at -limit: a pair is kept iff both families come out negative; sign bits into a mask per family, value
+        // j = 4 b + i of the tile -- row 4 g + i, column 16 b + rc -- at bit 31 - j
+        unsigned m0 = 0, m1 = 0;
+#pragma unroll
+        for (int b = 0; b < MM16_BLOCKS; ++b) {
+            const f32x4 z = {-limit_mm, -limit_mm, -limit_mm, -limit_mm};
+            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[0], B[b][0], z, 0, 0, 0);
+            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(Ar[1], B[b][1], z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(s0[i]), 31);
+                m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(s1[i]), 31);
+            }
+        }
+        n_screened += (unsigned long long)(TILE_COLS * __popc(alive));
+        unsigned hits = m0 & m1;
+        while (__builtin_amdgcn_ballot_w64(hits != 0u)) {
+            // one pair per lane and turn; kept if it lies right of the diagonal and before its row's stop column (k_rmsd_sieve_mm)
+            bool keep = false;
+            unsigned ent = 0;
+            if (hits) {
+                const int j = __builtin_clz(hits);
+                hits &= ~(0x80000000u >> j);
+                const int row = 4 * g + (j & 3), col = c0 + MM_STEP * (j >> 2) + rc;
+                keep = col > r0 + row && col < scend[row];
+                ent = (unsigned(row) << 12) | unsigned(col - seg_lo);
+            }
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) queue[qn + __popcll(km & lt_mask)] = (unsigned short)ent;
+            qn += __popcll(km);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= a.drain_min) {
+            const int cnt = min(qn, 64);
+            drain(qn - cnt, cnt);
+            qn -= cnt;
+        }
+        c0 += TILE_COLS;
+        alive &= ~unsigned(__ballot(lane < TI && ((alive >> lane) & 1u) && my_cend <= c0));   // rows whose range ends here
+        if (!(c0 < cmax && alive)) break;
+        load_tile(c0);   // (here, after the batches, so that the tile does not occupy registers during them)
+        if (alive != marked) {
+            mark_rows();
+            marked = alive;
+        }
+    }
+    TSC_STAMP(2);  // screen done
+    if (qn > 0) drain(0, qn);
+    if (qe > 0) exact_stage(0, qe);
+    TSC_STAMP(3);  // candidates evaluated
+    if (lane == 0) {
+        count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
+        count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
+        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+    }
+}
+
+template <bool FUSED, bool F32>
+inline __global__ __launch_bounds__(256, TSC_MM16_OCC) void k_rmsd_sieve_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+                                                                        const double *__restrict__ Gall, const float *__restrict__ Dc,
+                                                                        const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
+                                                                        const int32_t *__restrict__ cend, int32_t *__restrict__ best,
+                                                                        PassCounters *__restrict__ counters, const PruneState *__restrict__ st, SieveArgs a,
+                                                                        FusedApply fa) {
+    constexpr int TI = 16;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = a.tile_begin + slot * a.tile_stride;
+    const int r0 = tile * TI;
+    const int seg_base = (r0 + 1) & ~63;
+    const int seg_lo = seg_base + int(blockIdx.y) * a.seg_cols;
+    TSC_STAMP(0);  // the wavefront has started
+    if (r0 >= a.n || seg_lo >= a.n) return;
+    const int tcm = a.tile_cmax[tile];
+    if (tcm <= seg_lo) return;
+    int A = 0, bitsel = 0;
+    sieve_item_mm16<F32>(heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, st, a, A, bitsel, tile, int(blockIdx.y));
+    if constexpr (FUSED) {   // (k_rmsd_sieve's tail, sieve.hpp)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int lim = min(a.n, tcm);
+        const int n_live = min(int(gridDim.y), (lim - seg_base + a.seg_cols - 1) / a.seg_cols);
+        if (n_live > 1) {
+            int last = 0;
+            if (lane == 0) last = (atomicAdd(&fa.tile_done[tile], 1) == n_live - 1) ? 1 : 0;
+            TSC_STAMP(4);
+            if (!__builtin_amdgcn_readfirstlane(last)) return;
+            if (lane == 0) fa.tile_done[tile] = 0;
+        }
+        unsigned long long ev_total = 0, rm_total = 0;
+        apply_wave_rows(fa.ap, bitsel, r0 + lane, lane < TI && r0 + lane < A, ev_total, rm_total);
+        int fin = 0;
+        if (lane == 0) {
+            count_add(counters, unsigned(tile), CNT_EVALUATED, ev_total);
+            count_add(counters, unsigned(tile), CNT_REMOVED, rm_total);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSC_STAMP(5);
+        if (lane == 0) fin = tickets_arrive(fa.tickets, unsigned(tile), fa.n_tiles, PT_GROUPS) ? 1 : 0;
+        TSC_STAMP(6);
+        if (__builtin_amdgcn_readfirstlane(fin)) {
             pass_step_wave(fa.sc, fa.next);
             TSC_STAMP(7);
         }

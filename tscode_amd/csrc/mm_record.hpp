@@ -8,7 +8,9 @@ namespace tsc {
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MM_KD = 8;                    // components per family (sieve.hpp: KD), two families
-constexpr int MM_REC_HALVES = 32;           // float16 per structure in the column records (64 bytes): per family [-2 x0 .. -2 x7 | 1 1 1 n0 | n1 n2 0 0]
+constexpr int MM_REC_HALVES = 32;           // float16 per structure in the column records (64 bytes): per family [-2 x0 .. -2 x7 | 1 1 1 n0 | n1 n2 0 0] in four
+                                            // chunks of 4, the two families' chunks SIDE BY SIDE (chunk g of family 0, chunk g of family 1: one 16-byte load
+                                            // gives a lane its K slots 4 g .. 4 g + 3 of both)
 constexpr int MM_ROWN_HALVES = 8;           // ... and in the row-side norm records (16 bytes): per family [n0 n1 n2 1]
 constexpr float MM_FLUSH = 6.103515625e-05f;  // 2^-14, the smallest normal float16: smaller norm pieces are dropped (and bounded) rather than left to subnormals
 
@@ -49,8 +51,8 @@ __device__ inline void mm_write_record(const float d[2 * MM_KD], float sigma, _F
         c2 = f16x4{one, one, one, np[0]};
         c3 = f16x4{np[1], np[2], zero, zero};
         an = f16x4{np[0], np[1], np[2], one};
-        f16x4 *o = reinterpret_cast<f16x4 *>(col_rec + 16 * fam);
-        o[0] = c0, o[1] = c1, o[2] = c2, o[3] = c3;
+        f16x4 *o = reinterpret_cast<f16x4 *>(col_rec + 4 * fam);
+        o[0] = c0, o[2] = c1, o[4] = c2, o[6] = c3;
         *reinterpret_cast<f16x4 *>(rown_rec + 4 * fam) = an;
     }
 }

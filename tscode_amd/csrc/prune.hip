@@ -264,7 +264,9 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
             p->Dall = ext->D, p->Gall = ext->G, p->dmax_bits = ext->dmax_bits;
         }
         if (!rc) rc = palloc(p, size_t(n) * DW, &p->Dc);
-        const bool want_mm = c->sieve_mm == 2 || (c->sieve_mm == 1 && n >= c->mm_min_n);   // (mm.hpp; decided per run)
+        // (mm.hpp; decided per run: the 64-row kernels for large runs, the 16-row form of the walked kernel -- "sieve_mm16" -- below that)
+        p->mm64 = c->sieve_mm == 2 || (c->sieve_mm == 1 && n >= c->mm_min_n);
+        const bool want_mm = p->mm64 || c->sieve_mm16 != 0;
         if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_REC_HALVES, &p->Dh);
         if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_ROWN_HALVES, &p->Dn);
         // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
@@ -404,7 +406,8 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     int seg_cols = c->seg_cols > 0 ? c->seg_cols : (n <= 100000 ? 512 : (n <= 400000 ? 1024 : 4096));
     while (seg_cols > 256 && max_range < seg_cols * 4) seg_cols /= 2;
     // the screen on the matrix cores (mm.hpp): one rank, 64 rows per work item and segments of their own length
-    const bool mm = p->algo == ALGO_SIEVE && p->Dh;
+    const bool mm = p->algo == ALGO_SIEVE && p->Dh && p->mm64;
+    const bool mm16 = p->algo == ALGO_SIEVE && p->Dh && !p->mm64 && c->sieve_cpl == 2 && c->sieve_trim != 0;
     if (mm) seg_cols = c->mm_seg_cols > 0 ? c->mm_seg_cols : (max_range >= 2048 ? 1024 : 512);
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
@@ -462,6 +465,12 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
             }
         }
         const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
+        if (mm16) {
+            TSC_TRY(launch_rmsd_sieve_mm16(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+                                           (const float *)p->Dc, (const _Float16 *)p->Dh, (const _Float16 *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
+                                           (const PruneState *)p->state, a, fa));
+            return 0;
+        }
         if (mm) {
             TSC_TRY(launch_rmsd_sieve_mm(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
                                          (const float *)p->Dc, (const _Float16 *)p->Dh, (const _Float16 *)p->Dn, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, fa));
@@ -569,8 +578,8 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, size_t(CULL_MAX_CHUNKS) + 1, &p->cfill);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_LAYOUT_ITEMS + 2) * CULL_MAX_CHUNKS, &p->blk_cnt);
         if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
-        if (!rc && p->Dh) rc = palloc(p, (size_t(n) + 256) * MM_REC_HALVES, &p->Dhs);
-        if (!rc && p->Dh) rc = palloc(p, (size_t(n) + 256) * MM_ROWN_HALVES, &p->Dns);
+        if (!rc && p->Dh && p->mm64) rc = palloc(p, (size_t(n) + 256) * MM_REC_HALVES, &p->Dhs);
+        if (!rc && p->Dh && p->mm64) rc = palloc(p, (size_t(n) + 256) * MM_ROWN_HALVES, &p->Dns);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
@@ -648,7 +657,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     }
     // (the culled pass with the screen on the matrix cores: one rank's own pass -- row tiles of a layout dealt to several ranks keep the
     // kernel of cull.hpp, whose items are single row tiles)
-    const bool cull_mm = run_culled && p->Dhs;
+    const bool cull_mm = run_culled && p->Dhs && p->mm64;
     if (run_culled) {
         p->cur_fused = false;  // rows collect verdicts as columns of other tiles too: the pass is applied behind the pair kernel (k_apply_pass)
         const int n_lb = int(ceil_div<int64_t>(n, CULL_LAYOUT_ITEMS));

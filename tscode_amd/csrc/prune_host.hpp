@@ -45,6 +45,7 @@ struct tsc_prune {
     double *Xr = nullptr, *Xc = nullptr, *G = nullptr;                       // register-tiled kernel
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     float *Dc = nullptr;     // ... in active order, rewritten by k_open_rows every pass: what the pair kernel reads
+    bool mm64 = false;                      // this run takes the 64-row matrix-core kernels (mm.hpp, cull_mm.hpp); else, with records, the 16-row form
     _Float16 *Dh = nullptr, *Dn = nullptr;  // ... and as the float16 records of the matrix-core screen (mm.hpp), in active order too ("sieve_mm")
     double *Gall = nullptr;
     struct Tickets {
@@ -176,6 +177,10 @@ int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEve
 int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                              const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
                              int my_tiles, int n_seg);
+// k_rmsd_sieve_mm16<fused, f32> (pairs_mm.hip): the matrix-core screen for 16-row items (k_rmsd_sieve's grid)
+int launch_rmsd_sieve_mm16(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
+                           const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
+                           const SieveArgs &a, const FusedApply &fa);
 // k_rmsd_sieve_sorted_mm<f32> (pairs_mm.hip): the culled pass with the screen on the matrix cores
 int launch_rmsd_sieve_sorted_mm(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                                 const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
