@@ -273,9 +273,8 @@ inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, Layou
                                                         const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
                                                         const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
                                                         int32_t *__restrict__ crank, const _Float16 *__restrict__ Dh = nullptr,
-                                                        const _Float16 *__restrict__ Dn = nullptr, _Float16 *__restrict__ Dhs = nullptr,
-                                                        _Float16 *__restrict__ Dns = nullptr) {
-    // Dh / Dn -> Dhs / Dns (optional): the float16 records of the matrix-core screen (mm_record.hpp) move along with the descriptors
+                                                        _Float16 *__restrict__ Dhs = nullptr) {
+    // Dh -> Dhs (optional): the float16 records of the matrix-core screen (mm_record.hpp) move along with the descriptors
     __shared__ int s_cnt[CULL_LAYOUT_SLOTS][CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
     const unsigned long long *X = bits + size_t(st->bitsel) * bit_words;
@@ -315,7 +314,6 @@ inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, Layou
             f32x4 *hd = reinterpret_cast<f32x4 *>(Dhs + int64_t(pos) * MM_REC_HALVES);
 #pragma unroll
             for (int q = 0; q < MM_REC_HALVES / 8; ++q) hd[q] = hs[q];
-            *reinterpret_cast<f32x4 *>(Dns + int64_t(pos) * MM_ROWN_HALVES) = *reinterpret_cast<const f32x4 *>(Dn + int64_t(r) * MM_ROWN_HALVES);
         }
     }
 }

@@ -13,7 +13,7 @@ constexpr int CMM_SEG = 1024;             // columns per work item (queue entrie
 constexpr int CMM_TILES = CMM_SEG / CULL_COLS;
 
 struct CullMmArgs {
-    const _Float16 *Dhs, *Dns;   // the float16 records (mm_record.hpp) by sorted position, like CullArgs::Ds
+    const _Float16 *Dhs;         // the float16 records (mm_record.hpp) by sorted position, like CullArgs::Ds
 };
 
 #ifndef TSC_CMM_OCC
@@ -86,7 +86,7 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
     for (int rt = 0; rt < 4; ++rt) {
         const int64_t row = min(p0 + 16 * rt + rc, A - 1);
 #pragma unroll
-        for (int fam = 0; fam < NFAM; ++fam) Ar[rt][fam] = mm_load_A(cm.Dhs + row * MM_REC_HALVES, cm.Dns + row * MM_ROWN_HALVES, fam, g);
+        for (int fam = 0; fam < NFAM; ++fam) Ar[rt][fam] = mm_load_A(cm.Dhs + row * MM_REC_HALVES, fam, g);
         if (g == 2 && 16 * rt + rc >= nrows) Ar[rt][0][0] = _Float16(__builtin_inff());
     }
     auto load_B = [&](int c0, f16x4 (&B)[NFAM]) __attribute__((always_inline)) {

@@ -63,8 +63,7 @@ __device__ inline float screen_limit_mm(unsigned dmax_bits, double limit) {
 }
 
 // records of n structures from their descriptors (runs that get their records outside k_open_rows: the screen's self-test)
-inline __global__ __launch_bounds__(256) void k_mm_records(const float *__restrict__ D, int64_t n, const unsigned *__restrict__ dmax_bits, _Float16 *__restrict__ col_rec,
-                                                     _Float16 *__restrict__ rown_rec) {
+inline __global__ __launch_bounds__(256) void k_mm_records(const float *__restrict__ D, int64_t n, const unsigned *__restrict__ dmax_bits, _Float16 *__restrict__ col_rec) {
     const float sigma = mm_scale(*dmax_bits);
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
         float d[DW];
@@ -73,14 +72,17 @@ inline __global__ __launch_bounds__(256) void k_mm_records(const float *__restri
             const f32x4 v = *reinterpret_cast<const f32x4 *>(D + i * DW + 4 * q);
             d[4 * q] = v.x, d[4 * q + 1] = v.y, d[4 * q + 2] = v.z, d[4 * q + 3] = v.w;
         }
-        mm_write_record(d, sigma, col_rec + i * MM_REC_HALVES, rown_rec + i * MM_ROWN_HALVES);
+        mm_write_record(d, sigma, col_rec + i * MM_REC_HALVES);
     }
 }
 
 // operand registers of a wavefront: lane = (k group g = lane / 16: slots 4 g .. 4 g + 3, row or column lane % 16)
-__device__ inline f16x4 mm_load_A(const _Float16 *__restrict__ col_rec, const _Float16 *__restrict__ rown_rec, int fam, int g) {   // the row's two records
+__device__ inline f16x4 mm_load_A(const _Float16 *__restrict__ col_rec, int fam, int g) {   // the row's record
     if (g < 2) return *reinterpret_cast<const f16x4 *>(col_rec + 8 * g + 4 * fam) * _Float16(-0.5f);   // (-2 x) * (-1/2): exact
-    if (g == 2) return *reinterpret_cast<const f16x4 *>(rown_rec + 4 * fam);
+    if (g == 2) {   // [n0 n1 n2 1] from the column form's [1 1 1 n0 | n1 n2 0 0]
+        const f16x4 c2 = *reinterpret_cast<const f16x4 *>(col_rec + 16 + 4 * fam), c3 = *reinterpret_cast<const f16x4 *>(col_rec + 24 + 4 * fam);
+        return f16x4{c2[3], c3[0], c3[1], _Float16(1.0f)};
+    }
     return f16x4{_Float16(1.0f), _Float16(1.0f), _Float16(0.0f), _Float16(0.0f)};
 }
 __device__ inline f16x4 mm_load_B(const _Float16 *__restrict__ col_rec, int fam, int g) {   // the column's record
@@ -111,7 +113,7 @@ __device__ inline bool mm_pair_within32(const float *__restrict__ da, const floa
 
 // The screen's values themselves, for tests: S[fam][r][c] of rows [0, 64) against columns [0, n_cols) of the records (one wavefront
 // per 16 columns), and the limit's bit pattern.
-inline __global__ __launch_bounds__(64) void k_mm_screen_dump(const _Float16 *__restrict__ recs, const _Float16 *__restrict__ rown, int n_cols,
+inline __global__ __launch_bounds__(64) void k_mm_screen_dump(const _Float16 *__restrict__ recs, int n_cols,
                                                         const unsigned *__restrict__ dmax_bits, double limit, float *__restrict__ S, int *__restrict__ limit_bits) {
     const int lane = threadIdx.x, g = lane >> 4, rc = lane & 15, c0 = blockIdx.x * MM_STEP;
     if (blockIdx.x == 0 && lane == 0) *limit_bits = __float_as_int(screen_limit_mm(*dmax_bits, limit));
@@ -122,7 +124,7 @@ inline __global__ __launch_bounds__(64) void k_mm_screen_dump(const _Float16 *__
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const int row = min(16 * rt + rc, n_cols - 1);
-            const f16x4 a = mm_load_A(recs + int64_t(row) * MM_REC_HALVES, rown + int64_t(row) * MM_ROWN_HALVES, fam, g);
+            const f16x4 a = mm_load_A(recs + int64_t(row) * MM_REC_HALVES, fam, g);
             const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, z, 0, 0, 0);
 #pragma unroll
@@ -146,7 +148,7 @@ constexpr int MM_WAVES = TSC_MM_WAVES;   // wavefronts (work items) per workgrou
 template <bool FUSED, bool F32>
 inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve_mm(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                     const double *__restrict__ Gall, const float *__restrict__ Dc,
-                                                                    const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
+                                                                    const _Float16 *__restrict__ Dh,
                                                                     const int32_t *__restrict__ cend, int32_t *__restrict__ best,
                                                                     PassCounters *__restrict__ counters, const PruneState *__restrict__ st, SieveArgs a,
                                                                     FusedApply fa) {
@@ -196,7 +198,7 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
             for (int rt = 0; rt < 4; ++rt) {
                 const int64_t row = min(R0 + 16 * rt + rc, a.n - 1);
 #pragma unroll
-                for (int fam = 0; fam < NFAM; ++fam) Ar[rt][fam] = mm_load_A(Dh + row * MM_REC_HALVES, Dn + row * MM_ROWN_HALVES, fam, g);
+                for (int fam = 0; fam < NFAM; ++fam) Ar[rt][fam] = mm_load_A(Dh + row * MM_REC_HALVES, fam, g);
             }
         };
         auto load_B = [&](int c0, f16x4 (&B)[NFAM]) __attribute__((always_inline)) {
@@ -456,7 +458,7 @@ constexpr int MM16_BLOCKS = 128 / MM_STEP;   // 16-column blocks of a column til
 
 template <bool F32>
 __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
-                                                const float *__restrict__ Dc, const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
+                                                const _Float16 *__restrict__ Dh,
                                                 const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                 const PruneState *__restrict__ st, const SieveArgs &a, int &A_out, int &bitsel_out, const int tile, const int seg) {
     constexpr int TI = 16, TILE_COLS = 128;
@@ -483,7 +485,7 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
     {
         const int64_t row = min(r0 + rc, a.n - 1);
 #pragma unroll
-        for (int fam = 0; fam < NFAM; ++fam) Ar[fam] = mm_load_A(Dh + row * MM_REC_HALVES, Dn + row * MM_ROWN_HALVES, fam, g);
+        for (int fam = 0; fam < NFAM; ++fam) Ar[fam] = mm_load_A(Dh + row * MM_REC_HALVES, fam, g);
     }
     f16x4 B[MM16_BLOCKS][NFAM];
     auto load_tile = [&](int c0) __attribute__((always_inline)) {
@@ -688,8 +690,7 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
 
 template <bool FUSED, bool F32>
 inline __global__ __launch_bounds__(256, TSC_MM16_OCC) void k_rmsd_sieve_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act,
-                                                                        const double *__restrict__ Gall, const float *__restrict__ Dc,
-                                                                        const _Float16 *__restrict__ Dh, const _Float16 *__restrict__ Dn,
+                                                                        const double *__restrict__ Gall,                                                                         const _Float16 *__restrict__ Dh,
                                                                         const int32_t *__restrict__ cend, int32_t *__restrict__ best,
                                                                         PassCounters *__restrict__ counters, const PruneState *__restrict__ st, SieveArgs a,
                                                                         FusedApply fa) {
@@ -705,7 +706,7 @@ inline __global__ __launch_bounds__(256, TSC_MM16_OCC) void k_rmsd_sieve_mm16(co
     const int tcm = a.tile_cmax[tile];
     if (tcm <= seg_lo) return;
     int A = 0, bitsel = 0;
-    sieve_item_mm16<F32>(heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, st, a, A, bitsel, tile, int(blockIdx.y));
+    sieve_item_mm16<F32>(heavy, act, Gall, Dh, cend, best, counters, st, a, A, bitsel, tile, int(blockIdx.y));
     if constexpr (FUSED) {   // (k_rmsd_sieve's tail, sieve.hpp)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const int lim = min(a.n, tcm);

@@ -11,7 +11,6 @@ constexpr int MM_KD = 8;                    // components per family (sieve.hpp:
 constexpr int MM_REC_HALVES = 32;           // float16 per structure in the column records (64 bytes): per family [-2 x0 .. -2 x7 | 1 1 1 n0 | n1 n2 0 0] in four
                                             // chunks of 4, the two families' chunks SIDE BY SIDE (chunk g of family 0, chunk g of family 1: one 16-byte load
                                             // gives a lane its K slots 4 g .. 4 g + 3 of both)
-constexpr int MM_ROWN_HALVES = 8;           // ... and in the row-side norm records (16 bytes): per family [n0 n1 n2 1]
 constexpr float MM_FLUSH = 6.103515625e-05f;  // 2^-14, the smallest normal float16: smaller norm pieces are dropped (and bounded) rather than left to subnormals
 
 // sigma: the power of two that takes the largest |component| of the run (bit pattern of a non-negative float) into [32, 64)
@@ -26,10 +25,10 @@ __host__ __device__ inline float mm_scale(unsigned dmax_bits) {
 
 // The records of one structure from its 16 stored components (d[2k + fam], sieve.hpp): x = the nearest float16 of sigma * d, and
 // |x|^2 (of the ROUNDED vector: exact in float64) in three float16 pieces that leave 2^-14 at most.
-__device__ inline void mm_write_record(const float d[2 * MM_KD], float sigma, _Float16 *__restrict__ col_rec, _Float16 *__restrict__ rown_rec) {
+__device__ inline void mm_write_record(const float d[2 * MM_KD], float sigma, _Float16 *__restrict__ col_rec) {
 #pragma unroll
     for (int fam = 0; fam < 2; ++fam) {
-        f16x4 c0, c1, c2, c3, an;
+        f16x4 c0, c1, c2, c3;
         double n = 0.0;
 #pragma unroll
         for (int k = 0; k < MM_KD; ++k) {
@@ -50,10 +49,8 @@ __device__ inline void mm_write_record(const float d[2 * MM_KD], float sigma, _F
         const _Float16 one = _Float16(1.0f), zero = _Float16(0.0f);
         c2 = f16x4{one, one, one, np[0]};
         c3 = f16x4{np[1], np[2], zero, zero};
-        an = f16x4{np[0], np[1], np[2], one};
         f16x4 *o = reinterpret_cast<f16x4 *>(col_rec + 4 * fam);
         o[0] = c0, o[2] = c1, o[4] = c2, o[6] = c3;
-        *reinterpret_cast<f16x4 *>(rown_rec + 4 * fam) = an;
     }
 }
 

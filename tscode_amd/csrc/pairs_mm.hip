@@ -2,10 +2,10 @@
 #include "prune_host.hpp"
 
 int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
-                         const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
+                         const float *Dc, const _Float16 *Dh, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
                          const FusedApply &fa) {
 #define TSC_LAUNCH_MM(FUSED, F32) \
-    hipExtLaunchKernelGGL((k_rmsd_sieve_mm<FUSED, F32>), grid, dim3(64 * MM_WAVES), 0, st, e0, e1, 0, heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, state, a, fa)
+    hipExtLaunchKernelGGL((k_rmsd_sieve_mm<FUSED, F32>), grid, dim3(64 * MM_WAVES), 0, st, e0, e1, 0, heavy, act, Gall, Dc, Dh, cend, best, counters, state, a, fa)
     if (fused && f32) TSC_LAUNCH_MM(true, true);
     else if (fused) TSC_LAUNCH_MM(true, false);
     else if (f32) TSC_LAUNCH_MM(false, true);
@@ -25,10 +25,10 @@ int launch_rmsd_sieve_sorted_mm(bool f32, hipStream_t st, dim3 grid, hipEvent_t 
 }
 
 int launch_rmsd_sieve_mm16(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
-                           const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
+                           const _Float16 *Dh, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
                            const SieveArgs &a, const FusedApply &fa) {
 #define TSC_LAUNCH_MM16(FUSED, F32) \
-    hipExtLaunchKernelGGL((k_rmsd_sieve_mm16<FUSED, F32>), grid, dim3(256), 0, st, e0, e1, 0, heavy, act, Gall, Dc, Dh, Dn, cend, best, counters, state, a, fa)
+    hipExtLaunchKernelGGL((k_rmsd_sieve_mm16<FUSED, F32>), grid, dim3(256), 0, st, e0, e1, 0, heavy, act, Gall, Dh, cend, best, counters, state, a, fa)
     if (fused && f32) TSC_LAUNCH_MM16(true, true);
     else if (fused) TSC_LAUNCH_MM16(true, false);
     else if (f32) TSC_LAUNCH_MM16(false, true);

@@ -57,15 +57,14 @@ extern "C" __attribute__((visibility("default"))) int tsc_screen_mm_values(tsc_c
     float *d_D, *d_S;
     unsigned *d_bits;
     int *d_lim;
-    _Float16 *d_rec, *d_rown;
+    _Float16 *d_rec;
     TSC_TRY(upload(c, s, D, size_t(n) * DW, &d_D));
     TSC_TRY(upload(c, s, &bits, 1, &d_bits));
     TSC_TRY(s.get(size_t(n) * MM_REC_HALVES, &d_rec));
-    TSC_TRY(s.get(size_t(n) * MM_ROWN_HALVES, &d_rown));
     TSC_TRY(s.get(size_t(NFAM) * MM_ROWS * n, &d_S));
     TSC_TRY(s.get(1, &d_lim));
-    hipLaunchKernelGGL(k_mm_records, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const float *)d_D, n, (const unsigned *)d_bits, d_rec, d_rown);
-    hipLaunchKernelGGL(k_mm_screen_dump, dim3(unsigned(ceil_div<int64_t>(n, MM_STEP))), dim3(64), 0, c->stream, (const _Float16 *)d_rec, (const _Float16 *)d_rown, int(n), (const unsigned *)d_bits,
+    hipLaunchKernelGGL(k_mm_records, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const float *)d_D, n, (const unsigned *)d_bits, d_rec);
+    hipLaunchKernelGGL(k_mm_screen_dump, dim3(unsigned(ceil_div<int64_t>(n, MM_STEP))), dim3(64), 0, c->stream, (const _Float16 *)d_rec, int(n), (const unsigned *)d_bits,
                        limit, d_S, d_lim);
     TSC_HIP(hipGetLastError());
     TSC_HIP(hipMemcpyAsync(S, d_S, size_t(NFAM) * MM_ROWS * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -268,7 +267,6 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         p->mm64 = c->sieve_mm == 2 || (c->sieve_mm == 1 && n >= c->mm_min_n);
         const bool want_mm = p->mm64 || c->sieve_mm16 != 0;
         if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_REC_HALVES, &p->Dh);
-        if (!rc && want_mm) rc = palloc(p, size_t(n) * MM_ROWN_HALVES, &p->Dn);
         // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
         // (it pays where the gathers come from HBM: 41 MB of heavy atoms at C3 sit in the 256 MB infinity cache and the conversions cost the
         // VALU-bound kernel 2 %; at C4's 348 MB a step goes from 12.1 to 10.6 ms.  "stage1_f32": 0 never, 1 from 128 MB on, 2 always)
@@ -467,13 +465,13 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
         const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
         if (mm16) {
             TSC_TRY(launch_rmsd_sieve_mm16(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                                           (const float *)p->Dc, (const _Float16 *)p->Dh, (const _Float16 *)p->Dn, (const int32_t *)p->cend, p->best, p->counters,
+                                           (const _Float16 *)p->Dh, (const int32_t *)p->cend, p->best, p->counters,
                                            (const PruneState *)p->state, a, fa));
             return 0;
         }
         if (mm) {
             TSC_TRY(launch_rmsd_sieve_mm(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
-                                         (const float *)p->Dc, (const _Float16 *)p->Dh, (const _Float16 *)p->Dn, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, fa));
+                                         (const float *)p->Dc, (const _Float16 *)p->Dh, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, fa));
             return 0;
         }
         // (stage 1 on the float32 copy exists for the default shape of the kernel only)
@@ -579,7 +577,6 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, (size_t(n) / CULL_LAYOUT_ITEMS + 2) * CULL_MAX_CHUNKS, &p->blk_cnt);
         if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
         if (!rc && p->Dh && p->mm64) rc = palloc(p, (size_t(n) + 256) * MM_REC_HALVES, &p->Dhs);
-        if (!rc && p->Dh && p->mm64) rc = palloc(p, (size_t(n) + 256) * MM_ROWN_HALVES, &p->Dns);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
@@ -587,13 +584,15 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
     p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
     {
+        // (the fp32 rows by position: read by the packed-fp32 kernels, by level 2 of the 64-row matrix-core kernels and by a culled pass's layout)
+        const bool need_dc = !(p->algo == ALGO_SIEVE && p->Dh && !p->mm64 && c->sieve_cpl == 2 && c->sieve_trim != 0 && !culled);
         OpenArgs oa;
         oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
         oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
         oa.boff = p->boff, oa.n_blocks = p->n_blocks, oa.block_items = SCAN_TILE;
         oa.n_tiles = unsigned(ceil_div(A, 16)), oa.tickets = &p->tickets->pass;
         oa.rank_of = culled ? p->rank_of : nullptr;
-        oa.Dh = p->Dh, oa.Dn = p->Dn, oa.dmax_bits = p->dmax_bits;
+        oa.Dh = p->Dh, oa.dmax_bits = p->dmax_bits;
         oa.dbg = nullptr;
 #ifdef TSC_DBG_STAMPS
         if (c->dbg_stamp_k == -k) {  // (a negative k selects k_open_rows of pass k)
@@ -612,7 +611,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         const StepArgs sa = p->cur_fused ? next_step_args(p, &nxt) : StepArgs{-1, -1, 0ll, 0, -1};
         static_assert(SCAN_TILE == 64 * SCAN_BLOCK_WORDS && DW == DESC_WORDS, "k_open_rows");
         hipLaunchKernelGGL(k_open_rows, dim3(ceil_div(ceil_div(A, 16), 16)), dim3(256), 0, st, g, oa, step_ctx(p, range), sa, p->act, p->cend, p->best, p->tile_cmax,
-                           (const float *)p->Dall, p->Dc);
+                           (const float *)p->Dall, need_dc ? p->Dc : nullptr);
     }
     if (p->algo == ALGO_TILE) {
         const int hp3 = p->hp * 3;
@@ -667,8 +666,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         hipLaunchKernelGGL(k_layout_scan, dim3(unsigned(k)), dim3(64), 0, st, (const PruneState *)p->state, n_lb, (const int32_t *)p->cbase, p->blk_cnt);
         hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, lr, (const PruneState *)p->state, (const int32_t *)p->morton_order,
                            (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of, (const float *)p->Dc,
-                           (const int32_t *)p->blk_cnt, p->Ds, p->crank, (const _Float16 *)(cull_mm ? p->Dh : nullptr), (const _Float16 *)p->Dn,
-                           cull_mm ? p->Dhs : nullptr, p->Dns);
+                           (const int32_t *)p->blk_cnt, p->Ds, p->crank, (const _Float16 *)(cull_mm ? p->Dh : nullptr), cull_mm ? p->Dhs : nullptr);
         hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
                            p->cbox, p->rbox);
         SieveArgs a;
@@ -712,7 +710,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                 a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
             }
 #endif
-            CullMmArgs cm{p->Dhs, p->Dns};
+            CullMmArgs cm{p->Dhs};
             TSC_TRY(launch_rmsd_sieve_sorted_mm(a.heavy32 != nullptr, st, dim3(unsigned(std::max<int64_t>(1, grid_mm))), e0, e1, p->heavy, (const int32_t *)p->act,
                                                 (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, cm,
                                                 n_groups, n_seg_mm));

@@ -46,7 +46,7 @@ struct tsc_prune {
     float *Dall = nullptr;   // sieve kernel: fp32 descriptors of every structure, [n][DW]
     float *Dc = nullptr;     // ... in active order, rewritten by k_open_rows every pass: what the pair kernel reads
     bool mm64 = false;                      // this run takes the 64-row matrix-core kernels (mm.hpp, cull_mm.hpp); else, with records, the 16-row form
-    _Float16 *Dh = nullptr, *Dn = nullptr;  // ... and as the float16 records of the matrix-core screen (mm.hpp), in active order too ("sieve_mm")
+    _Float16 *Dh = nullptr;                 // ... and as the float16 records of the matrix-core screen (mm.hpp), in active order too ("sieve_mm")
     double *Gall = nullptr;
     struct Tickets {
         PassTickets pass;
@@ -56,7 +56,7 @@ struct tsc_prune {
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
-    _Float16 *Dhs = nullptr, *Dns = nullptr;   // the float16 records of the matrix-core screen by sorted position (cull_mm.hpp)
+    _Float16 *Dhs = nullptr;                   // the float16 records of the matrix-core screen by sorted position (cull_mm.hpp)
     float *heavy32 = nullptr;            // float32 copy of the heavy atoms for stage 1 of the pair kernels (sieve.hpp: pair_stage1)
     bool morton_sorted = false;          // the run's Morton order exists (made when the first pass is really culled)
     // rank-partitioned passes (rmsd.hpp, k_pass_merge): set by tsc_prune_set_partition
@@ -171,7 +171,7 @@ int launch_rmsd_sieve_plain(int cpl, bool trim, bool f32, hipStream_t st, dim3 g
                             const SieveArgs &a, const FusedApply &fa);
 // k_rmsd_sieve_mm<fused, f32> (pairs_mm.hip): the screen on the matrix cores, 64 rows per work item
 int launch_rmsd_sieve_mm(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
-                         const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
+                         const float *Dc, const _Float16 *Dh, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a,
                          const FusedApply &fa);
 // k_rmsd_sieve_sorted<f32> and k_pass_chunks (pairs_sorted.hip)
 int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
@@ -179,7 +179,7 @@ int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0,
                              int my_tiles, int n_seg);
 // k_rmsd_sieve_mm16<fused, f32> (pairs_mm.hip): the matrix-core screen for 16-row items (k_rmsd_sieve's grid)
 int launch_rmsd_sieve_mm16(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
-                           const float *Dc, const _Float16 *Dh, const _Float16 *Dn, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
+                           const _Float16 *Dh, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
                            const SieveArgs &a, const FusedApply &fa);
 // k_rmsd_sieve_sorted_mm<f32> (pairs_mm.hip): the culled pass with the screen on the matrix cores
 int launch_rmsd_sieve_sorted_mm(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,

@@ -644,7 +644,7 @@ struct OpenArgs {
     unsigned n_tiles;                // row tiles of the pass (arrival count of a fused pass)
     PassTickets *tickets;
     int32_t *rank_of;                // (optional) rank_of[structure] = its active rank: what a culled pass (cull.hpp) lays its sorted order out from
-    _Float16 *Dh, *Dn;               // (optional) the float16 records of the matrix-core screen (mm.hpp: columns, row-side norms), by position like Dc
+    _Float16 *Dh;                    // (optional) the float16 records of the matrix-core screen (mm.hpp), by position like Dc
     const unsigned *dmax_bits;       // ... and the largest |descriptor component| of the run that scales them
     unsigned long long *dbg;         // -DTSC_DBG_STAMPS builds only: 8 time stamps per wavefront (tools/stamps.py), else null
 };
@@ -950,13 +950,14 @@ inline __global__ __launch_bounds__(256) void k_open_rows(PassGeom g, OpenArgs o
         TSC_OPEN_STAMP(4);  // stop column's rank
         if (mine) {
             if (D) {
+                if (Dc)   // (null where nothing reads the fp32 rows by position: the 16-row matrix-core kernel of a pass that cannot be culled)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * q) = dval[q];
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(Dc + int64_t(r) * 16 + 4 * q) = dval[q];
                 if (oa.Dh) {   // (made here every pass; copying them from records made once per run was measured: no faster, 80 B more per structure)
                     float dv[16];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dv[4 * q] = dval[q].x, dv[4 * q + 1] = dval[q].y, dv[4 * q + 2] = dval[q].z, dv[4 * q + 3] = dval[q].w;
-                    mm_write_record(dv, mm_scale(*oa.dmax_bits), oa.Dh + int64_t(r) * MM_REC_HALVES, oa.Dn + int64_t(r) * MM_ROWN_HALVES);
+                    mm_write_record(dv, mm_scale(*oa.dmax_bits), oa.Dh + int64_t(r) * MM_REC_HALVES);
                 }
             }
             act[r] = int32_t(i);
