@@ -650,6 +650,17 @@ def main():
         b_k12 = n * len(ens.frag_coords) * 96 + n_pass * ens.n_atoms * 24 + n
         ms_per_step = dt / args.steps * 1e3
         kernel = "k_rmsd_sieve" if res["stats"] and res["stats"][0]["algo"] == 2 else "k_rmsd_tile"
+        # which form of the descriptor screen the sieve's pair kernel ran (csrc/prune.hip: decided per run from its size and the options)
+        opts = dict(o.split("=") for o in args.opt)
+        if kernel != "k_rmsd_sieve":
+            screen = None
+        elif float(opts.get("sieve_mm", 1)) == 2 or (float(opts.get("sieve_mm", 1)) == 1 and n_pass >= float(opts.get("mm_min_n", 100000))):
+            screen = "mfma64"      # k_rmsd_sieve_mm (+ k_rmsd_sieve_sorted_mm): 64 rows per work item
+        elif float(opts.get("sieve_mm16", 1)) == 1:
+            screen = "mfma16"      # k_rmsd_sieve_mm16: k_rmsd_sieve's 16-row items
+        else:
+            screen = "pk_fp32"     # k_rmsd_sieve: the packed-fp32 screen
+        kernel_label = {"mfma64": "k_rmsd_sieve_mm", "mfma16": "k_rmsd_sieve_mm16", "pk_fp32": "k_rmsd_sieve<16,2,...>", None: kernel}[screen]
         # HBM bytes per launch: NOT measurable inside this process (rocprofv3 --pmc wraps the whole command, one counter per
         # pass); taken from the committed PMC passes of this same command (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in
         # separate runs, KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- and only if that profile was
@@ -685,14 +696,21 @@ def main():
         evals_big = sum(s["pairs_evaluated"] for s in big)
         screened_big, computed_big = sum(s["pairs_screened"] for s in big), sum(s["pairs_computed"] for s in big)
         ref_equiv = evals_big * flops_per_eval / (tile_s / ev_steps) / 1e12 if tile_s > 0 else None
-        if screened_big:
+        f16_mfma_flops = 0.0
+        if screened_big and screen in ("mfma16", "mfma64"):
+            # the screen on the matrix cores: per pair and family one row of a 16 x 16 x 16 MFMA = 16 multiply-adds (8 components, 3 + 3 norm
+            # pieces, 2 idle slots); no fp32 vector flops in it (its VALU work is integer: the results' sign bits)
+            f32_flops = 0.0
+            f16_mfma_flops = screened_big * 2 * 16 * 2
+            f64_flops = computed_big * (18 * h + 110)
+        elif screened_big:
             f32_flops = screened_big * SCREEN_FLOP_PER_PAIR
             f64_flops = computed_big * (18 * h + 110)
         else:
             f32_flops = 0.0
             f64_flops = computed_big * (18 * ((h + 3) // 4 * 4) + 110)
         per_s = (lambda x: x / (tile_s / ev_steps) / 1e12) if tile_s > 0 else (lambda x: None)
-        ex32, ex64 = per_s(f32_flops), per_s(f64_flops)
+        ex32, ex64, ex16 = per_s(f32_flops), per_s(f64_flops), per_s(f16_mfma_flops)
         # the part of the path SURVEY.md 8(d) calls HBM-streaming: fused embed + clash verdicts, ordered compaction, the passing poses embedded
         # with their descriptors.  Algorithmic bytes B_K12 over the two stages' own HIP events (the 3 steps with every library event on,
         # outside the timed region: each stage carries some 4 us of event cost, so the figure is a lower bound)
@@ -757,7 +775,8 @@ def main():
                                  if args.config in ("C5", "C5chain") else "synthetic rigid-body transforms (tscode_amd/synthetic.py, SURVEY.md 8d)"),
                        "library_events_in_timed_region": args.pass_timing},
             "roofline": {
-                "kernel": kernel + " (all-pairs Kabsch RMSD of one pass; one launch per pass)",
+                "kernel": kernel_label + " (all-pairs Kabsch RMSD of one pass; one launch per pass)" +
+                          ("; descriptor screen on the matrix cores: v_mfma_f32_16x16x16_f16 on float16 records (csrc/mm.hpp)" if screen in ("mfma16", "mfma64") else ""),
                 # what binds the kernel -- NOT HBM: its 33 MB per launch sit in the infinity cache.  `achieved` / `peak` / `frac`
                 # below stay the bench contract's HBM figure (algorithmic bytes over the launch against 8 TB/s); `issue_frac` is the kernel against
                 # the roof that does bind it
@@ -780,8 +799,15 @@ def main():
                 "timing": f"HIP start/stop events attached to the kernel's dispatches (hipExtLaunchKernel) inside the timed region, in every {EVENT_EVERY}th step "
                           f"of it ({acc.get('evented_steps')} of {args.steps} steps): a pair of events costs a launch about 6 us",
                 "passes_in_chunk_local_kernel": len(res["stats"]) - n_launch,
-                "executed": {"what": "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
-                                     "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers",
+                "executed": {"what": ("what the kernel's instructions do (the screen as float16 MFMAs with fp32 accumulation, 64 flop per pair -- a per cent of the "
+                                      "matrix cores' 2.5 PFLOP/s: the screen is no longer what the kernel is made of --, H and the quartic tests in fp64): the "
+                                      "kernel is bound by the VALU issue of the sign-bit collection behind the MFMAs and of the evaluation stages, and by the "
+                                      "latency of the candidates' gathers" if screen in ("mfma16", "mfma64") else
+                                      "what the kernel's instructions do (the screen in packed fp32, H and the quartic tests in fp64): the compute "
+                                      "figure to read; the kernel is bound by VALU issue of the screen and by the latency of the candidates' gathers"),
+                             "screen": screen,
+                             "f16_mfma_TFLOPs": ex16 if f16_mfma_flops else None, "f16_mfma_peak_TFLOPs": 2500.0,
+                             "f16_mfma_frac": (ex16 / 2500.0) if (f16_mfma_flops and ex16) else None,
                              "fp32_TFLOPs": ex32, "fp32_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS, "fp32_frac": (ex32 / FP32_VALU_PEAK_TFLOPS) if ex32 else None,
                              "fp64_TFLOPs": ex64, "fp64_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS, "fp64_frac": (ex64 / FP64_VALU_PEAK_TFLOPS) if ex64 else None,
                              "pairs_screened_per_step": screened_big, "pairs_with_H_formed_per_step": computed_big},

@@ -85,9 +85,10 @@ int tsc_ctx_synchronize(tsc_ctx *ctx);
  * principal axes (three launches and about 45 us less per run; any basis gives the same verdicts).
  * "local_pass": 1 (default) lets passes whose longest chunk has at most "local_max_chunk" (default 384, up to 2048) structures
  * run in the one-launch chunk-local kernel; "sieve_trim": 1 (default) = the screen's shorter instruction sequence;
- * "sieve_mm": the pair kernels of a one-rank run with the descriptor screen on the matrix cores (csrc/mm.hpp, cull_mm.hpp): 0 never,
- * 1 (default) in runs of at least "mm_min_n" structures (default 150000), 2 always; "mm_seg_cols": columns per work item of the
- * walked passes' matrix-core kernel (a multiple of 64 up to 1024; 0 = automatic);
+ * "sieve_mm": the pair kernels with the descriptor screen on the matrix cores and 64 rows per work item (csrc/mm.hpp, cull_mm.hpp):
+ * 0 never, 1 (default) in runs of at least "mm_min_n" structures (default 100000), 2 always; "sieve_mm16": 1 (default) = smaller runs
+ * take the matrix-core screen on 16-row work items (k_rmsd_sieve_mm16), 0 = the packed-fp32 screen; "mm_seg_cols": columns per work
+ * item of the walked passes' 64-row kernel (a multiple of 64 up to 1024; 0 = automatic);
  * "fused_apply": 1 (default) lets the sieve kernel of a single-rank pass apply a row tile's verdicts itself when the tile's last
  * work item finishes and close the pass (two launches per pass); 0 = tsc_prune_pass_finish launches k_apply_pass (always so for the
  * register-tiled kernel and for passes searched by several ranks);  "open_lds_blocks": scan blocks (2048 structures each) up to which

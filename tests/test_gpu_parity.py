@@ -1136,7 +1136,10 @@ def test_prune_when_descriptors_cannot_separate(eng, oracle):
         mask, stats = eng.prune_heavy(heavy, 0.5, mode)
         assert np.array_equal(mask, ref["mask"])
         assert [s["pairs_evaluated"] for s in stats] == [s["pairs_evaluated"] for s in ref["stats"]]
-        assert sum(s["pairs_computed"] for s in stats) >= 0.9 * sum(s["pairs_screened"] for s in stats)   # nothing screened out
+        # nothing is screened out: H is formed for every pair the reference evaluates (the kernels may stop a row's OTHER candidates once
+        # it has its first similar column: those are screened and never formed)
+        assert sum(s["pairs_computed"] for s in stats) >= sum(s["pairs_evaluated"] for s in stats)
+        assert sum(s["pairs_screened"] for s in stats) >= sum(s["pairs_evaluated"] for s in stats)
     assert 30 < ref["mask"].sum() < 400
 
 

@@ -226,7 +226,8 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
         unsigned short *queue = s_queue[wid];
         unsigned short *exq = s_exq[wid];
         int qn = 0, qe = 0;
-        unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
+        unsigned long long n_eval = 0, n_exact = 0;
+        int my_screened = 0;
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         int64_t si = 0, sj = 0;
         // queue entry: row (6 bits) | column offset inside the segment (10 bits: segments are <= 1024 columns).
@@ -392,7 +393,8 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
                 if (keep) queue[qn + __popcll(km & lt_mask)] = (unsigned short)ent;
                 qn += __popcll(km);
             }
-            n_screened += (unsigned long long)(2 * MM_STEP * __popcll(alive));
+            // (statistics: the pairs of this step inside the live rows' ranges)
+            my_screened += ((alive >> lane) & 1ull) ? max(0, min(my_cend, c0 + 2 * MM_STEP) - max(R0 + lane + 1, c0)) : 0;
             __builtin_amdgcn_wave_barrier();
             c0 += 2 * MM_STEP;
             while (qn >= 64) {
@@ -410,10 +412,11 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
         if (qn > 0) drain(0, qn);
         if (qe > 0) exact_stage(0, qe);
         TSC_STAMP(3);
+        for (int off = 32; off > 0; off >>= 1) my_screened += __shfl_xor(my_screened, off);
         if (lane == 0) {
             count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
             count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
-            count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+            count_add(counters, unsigned(slot), CNT_SCREENED, (unsigned long long)my_screened);
         }
     } while (false);
 
@@ -518,7 +521,8 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
     const int h3 = a.h * 3;
     unsigned short *queue = s_queue[wid], *exq = s_exq[wid];
     int qn = 0, qe = 0;
-    unsigned long long n_eval = 0, n_exact = 0, n_screened = 0;
+    unsigned long long n_eval = 0, n_exact = 0;
+    int my_screened = 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int64_t si = 0, sj = 0;
     // queue entry: row (4 bits) | column offset inside the segment (12 bits).  Returns whether the pair is still one to look at: right of
@@ -645,7 +649,8 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
                 m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(s1[i]), 31);
             }
         }
-        n_screened += (unsigned long long)(TILE_COLS * __popc(alive));
+        // (statistics: the pairs of this tile inside the live rows' ranges, as k_rmsd_sieve counts them)
+        my_screened += (lane < TI && ((alive >> lane) & 1u)) ? max(0, min(my_cend, c0 + TILE_COLS) - max(r0 + lane + 1, c0)) : 0;
         unsigned hits = m0 & m1;
         while (__builtin_amdgcn_ballot_w64(hits != 0u)) {
             // one pair per lane and turn; kept if it lies right of the diagonal and before its row's stop column (k_rmsd_sieve_mm)
@@ -681,10 +686,11 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
     if (qn > 0) drain(0, qn);
     if (qe > 0) exact_stage(0, qe);
     TSC_STAMP(3);  // candidates evaluated
+    for (int off = 8; off > 0; off >>= 1) my_screened += __shfl_xor(my_screened, off);
     if (lane == 0) {
         count_add(counters, unsigned(slot), CNT_FORMED, n_eval);
         count_add(counters, unsigned(slot), CNT_EXACT, n_exact);
-        count_add(counters, unsigned(slot), CNT_SCREENED, n_screened);
+        count_add(counters, unsigned(slot), CNT_SCREENED, (unsigned long long)my_screened);
     }
 }
 
