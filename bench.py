@@ -780,7 +780,12 @@ def main():
                 # what binds the kernel -- NOT HBM: its 33 MB per launch sit in the infinity cache.  `achieved` / `peak` / `frac`
                 # below stay the bench contract's HBM figure (algorithmic bytes over the launch against 8 TB/s); `issue_frac` is the kernel against
                 # the roof that does bind it
-                "bound": "valu_issue",
+                "bound": "latency" if screen in ("mfma16", "mfma64") else "valu_issue",
+                "bound_what": ("with the screen on the matrix cores the kernel is no longer bound by VALU issue (issue_frac below: a third of the ceiling; the MFMA "
+                               "pipe a few per cent busy): a work item is a chain of dependent memory round trips -- stop columns and operands, the column "
+                               "tiles, the candidates' indices, their coordinates, the atomics on the way out -- at four wavefronts per SIMD (MEASURED.md "
+                               "section 8: per item 3.3 us prologue, 4.0 screen, 5.2 evaluation, 1.3 tail)" if screen in ("mfma16", "mfma64") else
+                               "VALU issue of the packed-fp32 screen (issue_frac: wave64 VALU instructions per CU-cycle, ceiling 1)"),
                 "frac_resource": "hbm",
                 "issue_frac": issue.get("issue_frac") if issue else None,
                 "issue": issue,

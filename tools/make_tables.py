@@ -72,15 +72,18 @@ def roofline():
         return f"(no roofline in profiles/{R}_final_bench.json)"
     r = b["roofline"]
     ex = r.get("executed", {})
-    rows = ["| `roofline` of the dominant kernel (`k_rmsd_sieve`, per launch) | |", "|---|---|",
+    kname = r.get("kernel", "k_rmsd_sieve").split(" ")[0].split("<")[0]
+    rows = [f"| `roofline` of the dominant kernel (`{kname}`, per launch) | |", "|---|---|",
             f"| algorithmic bytes per launch (SURVEY 8d: `A_p h 24 + 2 N`, mean over the {r['launches_per_step']} launches of a step) | {r['algorithmic_bytes_per_launch'] / 1e6:.2f} MB |",
             f"| average launch (HIP events on the dispatches of the timed region) | {r['avg_launch_us']:.2f} us |",
             f"| achieved / peak | {r['achieved']:.0f} / {r['peak']:.0f} GB/s = **{r['frac']:.4f}** |",
             f"| HBM traffic per launch (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE) | {f(r['traffic'] / 1e6 if r.get('traffic') else None, 1)} MB"
             + (f" = {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f} x the algorithmic bytes" if r.get("traffic") else f" ({r.get('traffic_source')})") + " |",
-            f"| what binds the kernel (`roofline.bound`) and how close it comes (`roofline.issue_frac`: wave64 VALU instructions per CU-cycle of its launches, ceiling 1; SQ counters) | {r.get('bound')}: "
-            + (f"{r['issue_frac']:.3f} ({r['issue']['issue_frac_while_busy']:.3f} of the cycles a CU is busy; {r['issue']['fma_f32_share_of_valu']:.2f} of the instructions are `v_pk_fma_f32`)" if r.get('issue_frac') else f"— ({(r.get('issue') or {}).get('source', 'no SQ profile of these kernels')})") + " |",
-            f"| what the instructions execute | {ex.get('fp32_TFLOPs', 0):.1f} TFLOP/s packed fp32 = {ex.get('fp32_frac', 0):.3f} of {ex.get('fp32_peak_TFLOPs')} + {ex.get('fp64_TFLOPs', 0):.2f} TFLOP/s fp64 |",
+            f"| what binds the kernel (`roofline.bound`) and how close it comes (`roofline.issue_frac`: wave64 VALU instructions per CU-cycle of its launches, ceiling 1; SQ counters) | {r.get('bound')} -- VALU issue at "
+            + (f"{r['issue_frac']:.3f} ({r['issue']['issue_frac_while_busy']:.3f} of the cycles a CU is busy; {r['issue']['fma_f32_share_of_valu']:.2f} of the instructions are fp32 FMAs)" if r.get('issue_frac') else f"— ({(r.get('issue') or {}).get('source', 'no SQ profile of these kernels')})") + " |",
+            ("| what the instructions execute | " + (f"{ex['f16_mfma_TFLOPs']:.1f} TFLOP/s float16 MFMA (the screen: 64 flop per pair) = {ex['f16_mfma_frac']:.3f} of {ex['f16_mfma_peak_TFLOPs']:.0f}"
+                                                   if ex.get("f16_mfma_TFLOPs") else f"{ex.get('fp32_TFLOPs') or 0:.1f} TFLOP/s packed fp32 = {ex.get('fp32_frac') or 0:.3f} of {ex.get('fp32_peak_TFLOPs')}")
+             + f" + {ex.get('fp64_TFLOPs') or 0:.2f} TFLOP/s fp64 |"),
             f"| pairs screened / H formed per step | {ex.get('pairs_screened_per_step', 0):.3g} / {ex.get('pairs_with_H_formed_per_step', 0):.3g} |"]
     fr = b.get("roofline_front")
     if fr:
@@ -88,7 +91,7 @@ def roofline():
                     f"over {fr['ms'] * 1e3:.0f} us of stage events | {fr['achieved']:.0f} / {fr['peak']:.0f} GB/s = {fr['frac']:.3f} |")
     c4 = b.get("c4") or {}
     if c4.get("traffic_over_algorithmic"):
-        rows.append(f"| C4 (1M x 50), pair kernels (`k_rmsd_sieve` + `k_rmsd_sieve_sorted`): HBM traffic / algorithmic bytes per step | "
+        rows.append(f"| C4 (1M x 50), pair kernels (`k_rmsd_sieve_mm` + `k_rmsd_sieve_sorted_mm`): HBM traffic / algorithmic bytes per step | "
                     f"{c4['pair_kernels_traffic_bytes_per_step'] / 1e9:.2f} GB / {c4['pair_kernels_algorithmic_bytes_per_step'] / 1e9:.2f} GB = {c4['traffic_over_algorithmic']:.2f} x |")
     ph = b.get("pipeline_hbm")
     if ph:
