@@ -72,6 +72,9 @@ __host__ __device__ inline T ceil_div(T a, T b) {
 
 }  // namespace tsc
 
+struct tsc_ctx;
+static inline bool want_heavy32(const tsc_ctx *c, double heavy_bytes);
+
 // One per (process, device).  All work is enqueued on `stream`; scratch blocks are recycled in
 // stream order, so a block handed back by one call can be reused by the next without a sync.
 struct tsc_ctx {
@@ -104,7 +107,8 @@ struct tsc_ctx {
     int early_basis = 1;                  // tsc_pipeline_dev: descriptor basis from a sample of unfiltered poses, on its own stream
     int clash_first = 0;                  // ... whose chain is enqueued in front of the clash launch (0) or behind it (1: rounds 1 - 3)
     int cull_tile_block = 256;             // culled passes dealt by row tiles: consecutive tiles of the sorted layout per rank and turn
-    int stage1_f32 = 1;                   // stage 1 of the pair kernels reads a float32 copy of the coordinates first (sieve.hpp: pair_stage1)
+    int stage1_f32 = 1;                   // stage 1 of the pair kernels reads a float32 copy of the coordinates first (sieve.hpp: pair_stage1): 0 never, 2 always,
+                                          // 1: from 128 MB of heavy atoms on -- and from 8 MB on where the matrix-core kernels run (want_heavy32 below)
     int local_max_chunk = 384;            // longest chunk (structures) of a pass that the chunk-local kernel takes
     int local_pass = 1;                   // passes with short chunks run in one launch (local_pass.hpp)
     void *dbg_buf = nullptr;              // -DTSC_DBG_STAMPS builds: time stamps of the pair kernel's wavefronts
@@ -190,6 +194,16 @@ struct tsc_ctx {
         cache.clear();
     }
 };
+
+// Does a run over `heavy_bytes` of heavy atoms (n * h * 24) keep the float32 copy that stage 1 of the pair kernels reads?  It pays where the
+// candidates' gathers come from HBM (128 MB and more: C4 12.1 -> 10.6 ms in round 4) and where the pair kernel is a chain of round trips rather
+// than VALU issue -- the matrix-core kernels: half the bytes and half the trips per evaluation batch (C3: 0.745 -> 0.704 ms); the packed-fp32
+// kernel at C3's size lost 2 % to the conversions.
+static inline bool want_heavy32(const tsc_ctx *c, double heavy_bytes) {
+    if (c->stage1_f32 != 1) return c->stage1_f32 == 2;
+    return heavy_bytes >= 128e6 || (heavy_bytes >= 8e6 && (c->sieve_mm != 0 || c->sieve_mm16 != 0));
+}
+
 
 namespace tsc {
 

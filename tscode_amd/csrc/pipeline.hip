@@ -157,7 +157,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_embed_masked_dev(tsc_c
         const int nf0 = n_features(n_heavy, 0), nf1 = n_features(n_heavy, 1);
         // the float32 copy for stage 1 of the pair kernels, where the run can be large enough for it (the count is not known yet)
         float *h32 = nullptr;
-        if (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n_poses) * n_heavy * 24.0 >= 128e6)) {
+        if (want_heavy32(c, double(n_poses) * n_heavy * 24.0)) {
             const int64_t need = n_poses * heavy32_pitch(n_heavy);
             if (c->xd_h32_cap < need) {
                 if (c->xd_borrowers > 0)
@@ -290,7 +290,7 @@ extern "C" __attribute__((visibility("default"))) int tsc_pipeline_dev(tsc_ctx *
             TSC_TRY(s.get(size_t(n_poses), &ext.G));
             TSC_TRY(s.get(4, &ext.dmax_bits));
             // (the float32 copy for stage 1 of the pair kernels, where the run can be large enough for it: the count is not known yet)
-            if (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n_poses) * n_heavy * 24.0 >= 128e6))
+            if (want_heavy32(c, double(n_poses) * n_heavy * 24.0))
                 TSC_TRY(s.get(size_t(n_poses) * heavy32_pitch(n_heavy), &ext.heavy32));
         }
         // one device: the sample is embedded and reduced by ONE kernel into accumulators the context keeps zero between runs (sieve.hpp,

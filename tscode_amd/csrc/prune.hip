@@ -270,7 +270,7 @@ static int prune_create_impl(tsc_ctx *c, const double *heavy_dev, int64_t n, int
         // the float32 copy stage 1 reads (sieve.hpp, pair_stage1): from the embedding kernel where there was one, else converted here
         // (it pays where the gathers come from HBM: 41 MB of heavy atoms at C3 sit in the 256 MB infinity cache and the conversions cost the
         // VALU-bound kernel 2 %; at C4's 348 MB a step goes from 12.1 to 10.6 ms.  "stage1_f32": 0 never, 1 from 128 MB on, 2 always)
-        if (!rc && (c->stage1_f32 == 2 || (c->stage1_f32 == 1 && double(n) * h * 24.0 >= 128e6))) {
+        if (!rc && want_heavy32(c, double(n) * h * 24.0)) {
             if (ext && ext->heavy32) {  // written by the kernel that embedded the structures
                 p->heavy32 = ext->heavy32;
             } else {
