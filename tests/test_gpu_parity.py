@@ -218,10 +218,10 @@ SIEVE_TRIM_DEFAULT = 1   # the library's default of option sieve_trim; the fixtu
 
 
 @pytest.fixture(params=[(0, 1, False, 1), (1, 1, False, 1), (2, 0, False, 1), (2, 0, True, 1), (2, 0, False, 0), (0, 1, False, 2), (2, 0, False, 3),
-                        (2, 0, False, 4), (2, 0, False, 5), (2, 0, False, 6), (0, 1, False, 7), (2, 0, False, 8)],
+                        (2, 0, False, 4), (2, 0, False, 5), (2, 0, False, 6), (0, 1, False, 7), (2, 0, False, 8), (2, 0, False, 9), (2, 0, False, 10)],
                 ids=["algo-auto", "algo-tile", "algo-sieve-global", "algo-sieve-other-screen", "algo-sieve-separate-apply", "algo-auto-ranks-from-memory",
                      "algo-sieve-culled", "algo-sieve-f32-stage1", "algo-sieve-culled-f32-stage1", "algo-sieve-vector-screen", "algo-auto-vector-screen-f32-stage1",
-                     "algo-sieve-culled-vector-screen"])
+                     "algo-sieve-culled-vector-screen", "algo-sieve-16-row-matrix-core", "algo-sieve-16-row-matrix-core-separate-apply"])
 def algo(request, eng):
     """Runs a test once per route through the prune: automatic choice (descriptor sieve whose pair kernel applies the verdicts
     tile by tile; passes with short chunks in the chunk-local kernel), register-tiled all-pairs (its passes are applied by
@@ -233,15 +233,16 @@ def algo(request, eng):
     of the coordinates (what runs of 128 MB of heavy atoms and more do by default).  Since round 5 the walked passes of the sieve
     screen on the matrix cores in runs of 150 000 structures and more (mm.hpp, option sieve_mm = 1, the default; 2 = always, what the
     fixture sets): every sieve route above takes that kernel -- fused and with
-    its own apply launch, walked and culled (cull_mm.hpp), with stage 1 in float64 and on the float32 copy; "other-screen" and the three
-    "vector-screen" routes switch it off and run the packed-fp32 screen of sieve.hpp (what row tiles dealt to several ranks still use)."""
+    its own apply launch, walked and culled (cull_mm.hpp), with stage 1 in float64 and on the float32 copy; the two "16-row" routes leave the choice to the library, which gives
+    ensembles of this size the matrix-core screen on 16-row items (k_rmsd_sieve_mm16: what C3 runs); "other-screen" and the three
+    "vector-screen" routes switch both off and run the packed-fp32 screen of sieve.hpp (what row tiles dealt to several ranks still use)."""
     eng.set_option("prune_algo", request.param[0])
-    eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 2)
+    eng.set_option("sieve_mm", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else (1 if request.param[3] in (9, 10) else 2))
     eng.set_option("sieve_mm16", 0 if (request.param[2] or request.param[3] in (6, 7, 8)) else 1)
     eng.set_option("local_pass", request.param[1])
     if request.param[2]:
         eng.set_option("sieve_trim", 1 - SIEVE_TRIM_DEFAULT)
-    eng.set_option("fused_apply", 1 if request.param[3] else 0)
+    eng.set_option("fused_apply", 1 if request.param[3] not in (0, 10) else 0)
     if request.param[3] == 2:
         eng.set_option("open_lds_blocks", 0)
     if request.param[3] in (3, 5, 8):      # every pass of fewer than 64 chunks laid out along the Morton curve, tile pairs skipped by bounding box (cull.hpp)
@@ -281,12 +282,12 @@ def test_prune_large_golden(eng, algo, name):
     assert all(s["algo"] in (1, 2, 3) and (algo == 0 or s["algo"] == algo) for s in stats)
 
 
-@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
+@pytest.mark.parametrize("mm", [1, 2], ids=["automatic-16-row-matrix-core", "64-row-matrix-core"])
 @pytest.mark.parametrize("name", LARGE_PRUNE_CASES)
 def test_prune_large_golden_every_pass_mask(eng, name, mm):
     """The same runs pass by pass (the stepping API): the mask after EVERY pass against the mask the reference's own
-    _similarity_mask_rmsd_group returned for it -- with the packed-fp32 screen (what runs of this size take) and with the screen on the
-    matrix cores (csrc/mm.hpp; sieve_mm = 2 forces it)."""
+    _similarity_mask_rmsd_group returned for it -- with the kernel runs of this size take (the matrix-core screen on 16-row items) and with
+    the 64-row matrix-core kernels of large runs (csrc/mm.hpp; sieve_mm = 2 forces them)."""
     import ctypes as C
 
     from tscode_amd import _lib
@@ -390,7 +391,7 @@ def test_prune_many_heavy_atoms(eng, oracle):
         assert np.array_equal(mask, ref["mask"]), h
 
 
-@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
+@pytest.mark.parametrize("mm", [1, 2], ids=["automatic-16-row-matrix-core", "64-row-matrix-core"])
 def test_prune_sharded_rows_equal_single(eng, oracle, mm):
     """The stepping API with the row tiles of each pass dealt to 3 'ranks' (run one after the other on
     this GPU, merging through the atomicMin target) gives the same mask as the one-shot call -- also with the matrix-core
@@ -500,7 +501,7 @@ def test_non_finite_coordinates_have_a_defined_outcome(eng, oracle):
         assert np.array_equal(got, oracle.compenetration_mask(cp, ens.ids, 1.5, max_clashes)), max_clashes
 
 
-@pytest.mark.parametrize("mm", [1, 2], ids=["vector-screen", "matrix-core-screen"])
+@pytest.mark.parametrize("mm", [1, 2], ids=["automatic", "64-row-matrix-core"])
 @pytest.mark.parametrize("world,n_poses,tile_block,det", [(3, 20_000, 256, 1), (8, 30_000, 256, 1), (5, 9_000, 16, 1), (4, 12_000, 1, 1), (3, 20_000, 256, 0)])
 def test_culled_row_tiles_dealt_to_emulated_ranks(eng, oracle, world, n_poses, tile_block, det, mm):
     """Passes sharded by ROW TILES with every pass culled (sorted layout + bounding boxes, cull.hpp): `world` prune runs over one array stand
