@@ -24,6 +24,22 @@ __global__ void k_probe(const _Float16 *A, const _Float16 *B, float *C, int n_ma
     }
 }
 
+// the K = 16 form the library uses (v_mfma_f32_16x16x16_f16): A[16][16], B[16][16], accumulator started at -limit
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__global__ void k_probe16(const _Float16 *A, const _Float16 *B, float *C, int n_mats, float c0) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
+    for (int m = blockIdx.x; m < n_mats; m += gridDim.x) {
+        h4 a, b;
+        for (int j = 0; j < 4; ++j) {
+            a[j] = A[(size_t(m) * 16 + rc) * 16 + 4 * g + j];
+            b[j] = B[(size_t(m) * 16 + 4 * g + j) * 16 + rc];
+        }
+        f4 z = {c0, c0, c0, c0};
+        f4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, z, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) C[(size_t(m) * 16 + 4 * g + i) * 16 + rc] = c[i];
+    }
+}
+
 static float h2f(_Float16 h) { return float(h); }
 
 int main() {
@@ -137,5 +153,61 @@ int main() {
     printf("layout mismatches (matrix 0): %d of 256\n", layout_bad);
     printf("subnormal f16 inputs: expect %.10g got %.10g (%s)\n", sub_expect, sub_got, sub_got == 0.0 ? "FLUSHED" : "kept");
     printf("screen-like sums (%d x 256): worst |err| / sum|terms| = %.3g = 2^%.2f  (abs %.3g at sum|terms| %.6g)\n", NM - 3, worst_rel, log2(worst_rel), worst_abs, worst_terms);
+    // ---- the K = 16 form: rows x (8 components up to 64, rounded to float16), norms of the rounded vectors in three pieces, -limit in the accumulator
+    {
+        std::vector<_Float16> A16(size_t(NM) * 256), B16(size_t(NM) * 256);
+        std::vector<float> C16(size_t(NM) * 256);
+        const float limit = 480.0f;
+        for (int m = 0; m < NM; ++m) {
+            const double M = (m & 1) ? 63.0 : 40.0, spread = (m & 2) ? 0.5 : 6.0;
+            double X[16][8], Y[16][8];
+            for (int r = 0; r < 16; ++r)
+                for (int k = 0; k < 8; ++k) X[r][k] = rnd() * M;
+            for (int c = 0; c < 16; ++c)
+                for (int k = 0; k < 8; ++k) Y[c][k] = X[c][k] + rnd() * spread;
+            auto split3 = [](double n, _Float16 p[3]) {
+                double rest = n;
+                for (int q = 0; q < 3; ++q) {
+                    float f = float(rest);
+                    p[q] = fabsf(f) < 6.103515625e-05f ? _Float16(0.f) : _Float16(f);
+                    rest -= double(float(p[q]));
+                }
+            };
+            for (int r = 0; r < 16; ++r) {
+                _Float16 np[3], *a = &A16[(size_t(m) * 16 + r) * 16];
+                double n = 0;
+                for (int k = 0; k < 8; ++k) a[k] = _Float16(float(X[r][k])), n += double(h2f(a[k])) * double(h2f(a[k]));
+                split3(n, np);
+                a[8] = np[0], a[9] = np[1], a[10] = np[2], a[11] = a[12] = a[13] = _Float16(1.f), a[14] = a[15] = _Float16(0.f);
+            }
+            for (int c = 0; c < 16; ++c) {
+                _Float16 np[3], yh[8], *b = &B16[size_t(m) * 256];
+                double n = 0;
+                for (int k = 0; k < 8; ++k) yh[k] = _Float16(float(Y[c][k])), n += double(h2f(yh[k])) * double(h2f(yh[k])), b[k * 16 + c] = _Float16(-2.f * h2f(yh[k]));
+                split3(n, np);
+                b[8 * 16 + c] = b[9 * 16 + c] = b[10 * 16 + c] = _Float16(1.f);
+                b[11 * 16 + c] = np[0], b[12 * 16 + c] = np[1], b[13 * 16 + c] = np[2], b[14 * 16 + c] = b[15 * 16 + c] = _Float16(0.f);
+            }
+        }
+        _Float16 *dA16, *dB16;
+        float *dC16;
+        (void)hipMalloc(&dA16, A16.size() * 2), (void)hipMalloc(&dB16, B16.size() * 2), (void)hipMalloc(&dC16, C16.size() * 4);
+        (void)hipMemcpy(dA16, A16.data(), A16.size() * 2, hipMemcpyHostToDevice), (void)hipMemcpy(dB16, B16.data(), B16.size() * 2, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_probe16, dim3(256), dim3(64), 0, 0, dA16, dB16, dC16, NM, -limit);
+        if (hipMemcpy(C16.data(), dC16, C16.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { printf("HIP error\n"); return 1; }
+        double w_rel = 0, w_abs = 0, w_terms = 0;
+        for (int m = 0; m < NM; ++m)
+            for (int r = 0; r < 16; ++r)
+                for (int c = 0; c < 16; ++c) {
+                    double s = -double(limit), sa = double(limit);
+                    for (int k = 0; k < 16; ++k) {
+                        const double a = double(h2f(A16[(size_t(m) * 16 + r) * 16 + k])), b = double(h2f(B16[(size_t(m) * 16 + k) * 16 + c]));
+                        s += a * b, sa += fabs(a * b);
+                    }
+                    const double e = fabs(double(C16[(size_t(m) * 16 + r) * 16 + c]) - s);
+                    if (e / sa > w_rel) w_rel = e / sa, w_abs = e, w_terms = sa;
+                }
+        printf("K = 16 form with the accumulator at -limit (%d x 256 sums): worst |err| / sum|terms| = %.3g = 2^%.2f  (abs %.3g at sum|terms| %.6g)\n", NM, w_rel, log2(w_rel), w_abs, w_terms);
+    }
     return layout_bad ? 2 : 0;
 }
