@@ -113,7 +113,7 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
         // visited once (from the earlier position), inside the segment; the column inside the row's range (rows of another chunk, or
         // behind a cache hit, are not) and before the similar column the row already has; within the fp32 screen's limit (level 2)
         return pcol > prow && pcol < seg_hi && hi < cend[lo] && hi < __hip_atomic_load(&best[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
-               mm_pair_within32(ca.Ds + int64_t(prow) * DW, ca.Ds + int64_t(pcol) * DW, limit32);
+               (!TSC_MM_LEVEL2 || mm_pair_within32(ca.Ds + int64_t(prow) * DW, ca.Ds + int64_t(pcol) * DW, limit32));
     };
     auto exact_stage = [&](int base, int cnt) __attribute__((always_inline)) {
         int lpp = 64;

@@ -13,8 +13,9 @@
 //        B     -2 y      1  1  1    m0 m1 m2   0  0        (columns)
 //   so that  A.B = |x|^2 + |y|^2 - 2 x.y = |x - y|^2 of the rounded vectors, up to the norms' residuals and the accumulation.
 //   A pair whose A.B exceeds screen_limit_mm in EITHER family certainly has h rmsd^2 > h thr^2 (bound below): dropped.
-//   level 2, the few pairs level 1 lets through (a few per thousand), where they are decoded for evaluation: the fp32 screen of
-//   sieve.hpp itself on the two stored descriptors (screen_limit32_dot), 40 instructions per pair beside the 600 of H.
+//   level 2 (a build option, TSC_MM_LEVEL2; off: see there), the few pairs level 1 lets through (a few per thousand), where they are decoded
+//   for evaluation: the fp32 screen of sieve.hpp itself on the two stored descriptors (screen_limit32_dot), 40 instructions per pair
+//   beside the 600 of H.  It drops 2 - 7 % of what level 1 lets through: the float16 form is nearly as tight as the fp32 screen.
 //
 // Error bound of level 1 (screen_limit_mm_bits; scaled units, M' = sigma * max |component| < 64):
 //   * products of two float16 are exact in the fp32 accumulator; the accumulation of the 30-term form was measured on MI355X at
@@ -137,6 +138,10 @@ inline __global__ __launch_bounds__(64) void k_mm_screen_dump(const _Float16 *__
 #ifndef TSC_MM_OCC
 #define TSC_MM_OCC 4
 #endif
+#ifndef TSC_MM_LEVEL2
+#define TSC_MM_LEVEL2 0   // 1: level 2 (below) where a pair is decoded in the 64-row kernels.  Measured at C4: 6.95 ms with it, 6.74 without -- the 7 %
+                          // more pairs that reach H cost less than its eight loads in front of every batch; the 16-row kernel never had it
+#endif
 #ifndef TSC_MM_WAVES
 #define TSC_MM_WAVES 4
 #endif
@@ -241,7 +246,7 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
             pp = heavy + i * h3, pq = heavy + j * h3;
             Gi = Gall[i], Gj = Gall[j];
             return col > R0 + t && col < scend[t] && col < __hip_atomic_load(&best[R0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
-                   mm_pair_within32(Dc + int64_t(R0 + t) * DW, Dc + int64_t(col) * DW, limit32);
+                   (!TSC_MM_LEVEL2 || mm_pair_within32(Dc + int64_t(R0 + t) * DW, Dc + int64_t(col) * DW, limit32));
         };
         auto sign_stage = [&](int base, int cnt) __attribute__((always_inline)) {
             int lpp = 64;

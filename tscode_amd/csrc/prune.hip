@@ -584,8 +584,9 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
     // 1. per row: which structure it is, its stop column, best[] = none, its descriptor by position (k_open_rows, rmsd.hpp)
     p->cur_fused = p->algo == ALGO_SIEVE && world == 1 && (c->fused_apply != 0 || range);
     {
-        // (the fp32 rows by position: read by the packed-fp32 kernels, by level 2 of the 64-row matrix-core kernels and by a culled pass's layout)
-        const bool need_dc = !(p->algo == ALGO_SIEVE && p->Dh && !p->mm64 && c->sieve_cpl == 2 && c->sieve_trim != 0 && !culled);
+        // (the fp32 rows by position: read by the packed-fp32 kernels, by level 2 of the 64-row matrix-core kernels where it is built in, and by a
+        // culled pass's layout)
+        const bool need_dc = !(p->algo == ALGO_SIEVE && p->Dh && (p->mm64 ? !TSC_MM_LEVEL2 : (c->sieve_cpl == 2 && c->sieve_trim != 0)) && !culled);
         OpenArgs oa;
         oa.use_cache = use_cache, oa.fused = p->cur_fused ? 1 : 0, oa.lds_cap = std::min(c->open_lds_blocks, OPEN_LDS_BLOCKS);
         oa.view = view_of_open_pass(p), oa.bits = p->bits, oa.bit_words = int(p->bit_words);
