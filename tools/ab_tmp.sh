@@ -1,6 +1,6 @@
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests_r5m.log 2>&1; tail -2 gpurun_out/gpu_tests_r5m.log
-for c in C4 C5 C5chain C3; do timeout -k 10 200 python3 bench.py --config $c --no-cpu --no-side-leg --no-selftest > gpurun_out/x.json 2>/dev/null; python3 - "$c" <<'PY'
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "culled or partitioned or full_size or prune_large_golden or sharded" > gpurun_out/t_wl.log 2>&1; tail -2 gpurun_out/t_wl.log
+for i in 1 2; do timeout -k 10 200 python3 bench.py --config C4 --steps 8 --warmup 2 --no-cpu --no-side-leg --no-selftest > gpurun_out/x.json 2>/dev/null; python3 - <<'PY'
 import json,sys
-d=json.loads(open('gpurun_out/x.json').read().strip().split('\n')[-1]);print(sys.argv[1], round(d['ms_per_step'],4), round(d["events_off"]["ms_per_step"],4) if d.get("events_off") else None, d["config"].get("parity_vs_recorded_oracle"))
+d=json.loads(open('gpurun_out/x.json').read().strip().split('\n')[-1]);print("C4", round(d['ms_per_step'],4), d["config"].get("parity_vs_recorded_oracle"), [(p["k"], p["tile_ms"]) for p in d["passes"] if p["tile_ms"]>0.3])
 PY
 done

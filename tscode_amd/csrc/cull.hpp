@@ -273,7 +273,9 @@ inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, Layou
                                                         const unsigned long long *__restrict__ bits, int bit_words, const int32_t *__restrict__ rank_of,
                                                         const float *__restrict__ Dc, const int32_t *__restrict__ blk_base, float *__restrict__ Ds,
                                                         int32_t *__restrict__ crank, const _Float16 *__restrict__ Dh = nullptr,
-                                                        _Float16 *__restrict__ Dhs = nullptr) {
+                                                        _Float16 *__restrict__ Dhs = nullptr, int32_t *__restrict__ cstruct = nullptr) {
+    // cstruct (optional): the structure at every sorted position (= act[crank[pos]]: cull_mm.hpp reads a candidate's coordinates one
+    // round trip earlier with it)
     // Dh -> Dhs (optional): the float16 records of the matrix-core screen (mm_record.hpp) move along with the descriptors
     __shared__ int s_cnt[CULL_LAYOUT_SLOTS][CULL_MAX_CHUNKS];
     if (st->pass_on == 0) return;
@@ -305,6 +307,7 @@ inline __global__ __launch_bounds__(256) void k_layout_scatter(PassGeom g, Layou
         const int pos = s_cnt[u * 4 + wv][my_c[u]] + my_rank[u];
         const int r = rank_of[my_i[u]];
         crank[pos] = r;
+        if (cstruct) cstruct[pos] = my_i[u];
         const f32x4 *src = reinterpret_cast<const f32x4 *>(Dc + int64_t(r) * DW);
         f32x4 *dst = reinterpret_cast<f32x4 *>(Ds + int64_t(pos) * DW);
 #pragma unroll

@@ -14,6 +14,7 @@ constexpr int CMM_TILES = CMM_SEG / CULL_COLS;
 
 struct CullMmArgs {
     const _Float16 *Dhs;         // the float16 records (mm_record.hpp) by sorted position, like CullArgs::Ds
+    const int32_t *cstruct;      // the structure at every sorted position (act[crank[pos]])
 };
 
 #ifndef TSC_CMM_OCC
@@ -105,8 +106,9 @@ __device__ __forceinline__ void sieve_item_sorted_mm(const double *__restrict__ 
     auto decode = [&](unsigned e, int &lo, int &hi, const double *&pp, const double *&pq, double &Gi, double &Gj) __attribute__((always_inline)) {
         const int prow = p0 + int(e >> 10), pcol = seg_lo + int(e & 0x3ffu);
         const int r1 = ca.crank[prow], r2 = ca.crank[pcol];
+        const int s1 = cm.cstruct[prow], s2 = cm.cstruct[pcol];   // (with the ranks, not behind them: act[] would be a round trip more)
         lo = min(r1, r2), hi = max(r1, r2);
-        const int64_t i = act[lo], j = act[hi];
+        const int64_t i = r1 < r2 ? s1 : s2, j = r1 < r2 ? s2 : s1;
         si = i, sj = j;
         pp = heavy + i * h3, pq = heavy + j * h3;
         Gi = Gall[i], Gj = Gall[j];

@@ -577,6 +577,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         if (!rc) rc = palloc(p, (size_t(n) / CULL_LAYOUT_ITEMS + 2) * CULL_MAX_CHUNKS, &p->blk_cnt);
         if (!rc) rc = palloc(p, (size_t(n) + 256) * DW, &p->Ds);
         if (!rc && p->Dh && p->mm64) rc = palloc(p, (size_t(n) + 256) * MM_REC_HALVES, &p->Dhs);
+        if (!rc && p->Dh && p->mm64) rc = palloc(p, size_t(n) + 256, &p->cstruct);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * CULL_BOX, &p->cbox);
         if (!rc) rc = palloc(p, (size_t(n) / CULL_COLS + 2) * 8 * CULL_BOX, &p->rbox);
         if (rc) return rc;
@@ -667,7 +668,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         hipLaunchKernelGGL(k_layout_scan, dim3(unsigned(k)), dim3(64), 0, st, (const PruneState *)p->state, n_lb, (const int32_t *)p->cbase, p->blk_cnt);
         hipLaunchKernelGGL(k_layout_scatter, dim3(unsigned(n_lb)), dim3(256), 0, st, g, lr, (const PruneState *)p->state, (const int32_t *)p->morton_order,
                            (const unsigned long long *)p->bits, int(p->bit_words), (const int32_t *)p->rank_of, (const float *)p->Dc,
-                           (const int32_t *)p->blk_cnt, p->Ds, p->crank, (const _Float16 *)(cull_mm ? p->Dh : nullptr), cull_mm ? p->Dhs : nullptr);
+                           (const int32_t *)p->blk_cnt, p->Ds, p->crank, (const _Float16 *)(cull_mm ? p->Dh : nullptr), cull_mm ? p->Dhs : nullptr, cull_mm ? p->cstruct : nullptr);
         hipLaunchKernelGGL(k_tile_boxes, dim3(unsigned(ceil_div<int64_t>(n, CULL_COLS))), dim3(128), 0, st, (const PruneState *)p->state, (const float *)p->Ds,
                            p->cbox, p->rbox);
         SieveArgs a;
@@ -711,7 +712,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                 a.dbg = static_cast<unsigned long long *>(c->dbg_buf);
             }
 #endif
-            CullMmArgs cm{p->Dhs};
+            CullMmArgs cm{p->Dhs, p->cstruct};
             TSC_TRY(launch_rmsd_sieve_sorted_mm(a.heavy32 != nullptr, st, dim3(unsigned(std::max<int64_t>(1, grid_mm))), e0, e1, p->heavy, (const int32_t *)p->act,
                                                 (const double *)p->Gall, (const int32_t *)p->cend, p->best, p->counters, (const PruneState *)p->state, a, ca, cm,
                                                 n_groups, n_seg_mm));

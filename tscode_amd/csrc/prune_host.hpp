@@ -56,6 +56,7 @@ struct tsc_prune {
     // culled passes (cull.hpp): allocated when the first one comes up
     int32_t *morton_order = nullptr, *rank_of = nullptr, *crank = nullptr, *cbase = nullptr, *cfill = nullptr, *blk_cnt = nullptr;
     float *Ds = nullptr, *cbox = nullptr, *rbox = nullptr;
+    int32_t *cstruct = nullptr;                // the structure at every sorted position (cull_mm.hpp)
     _Float16 *Dhs = nullptr;                   // the float16 records of the matrix-core screen by sorted position (cull_mm.hpp)
     float *heavy32 = nullptr;            // float32 copy of the heavy atoms for stage 1 of the pair kernels (sieve.hpp: pair_stage1)
     bool morton_sorted = false;          // the run's Morton order exists (made when the first pass is really culled)
