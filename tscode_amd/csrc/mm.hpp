@@ -462,19 +462,23 @@ inline __global__ __launch_bounds__(64 * MM_WAVES, TSC_MM_OCC) void k_rmsd_sieve
 #ifndef TSC_MM16_OCC
 #define TSC_MM16_OCC 4
 #endif
+// work items (wavefronts) per workgroup of the 16-row kernel: 2 where most workgroups of the grid have work (a workgroup keeps its slot until
+// its longest item is through: C3's k = 100 .. 2 passes 2 - 4 us shorter than with 4), 4 where most are empty and the launch is its dispatch
+// (C3's last pass: 28 us against 44) -- the host picks by the number of column segments (launch_pair_search)
+constexpr int MM16_LONG_SEGS = 64;
 constexpr int MM16_BLOCKS = 128 / MM_STEP;   // 16-column blocks of a column tile
 
-template <bool F32>
+template <bool F32, int MM16_WAVES>
 __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act, const double *__restrict__ Gall,
                                                 const _Float16 *__restrict__ Dh,
                                                 const int32_t *__restrict__ cend, int32_t *__restrict__ best, PassCounters *__restrict__ counters,
                                                 const PruneState *__restrict__ st, const SieveArgs &a, int &A_out, int &bitsel_out, const int tile, const int seg) {
     constexpr int TI = 16, TILE_COLS = 128;
     constexpr int QCAP = TI * TILE_COLS + 64;
-    __shared__ unsigned short s_queue[4][QCAP];
-    __shared__ unsigned short s_exq[4][128];
-    __shared__ double s_jacobi[4][32];
-    __shared__ int s_cend[4][TI];   // stop column of every row that was looking when the item began (else 0)
+    __shared__ unsigned short s_queue[MM16_WAVES][QCAP];
+    __shared__ unsigned short s_exq[MM16_WAVES][128];
+    __shared__ double s_jacobi[MM16_WAVES][32];
+    __shared__ int s_cend[MM16_WAVES][TI];   // stop column of every row that was looking when the item began (else 0)
     const int lane = threadIdx.x & 63, g = lane >> 4, rc = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = tile;
@@ -699,15 +703,15 @@ __device__ __forceinline__ void sieve_item_mm16(const double *__restrict__ heavy
     }
 }
 
-template <bool FUSED, bool F32>
-inline __global__ __launch_bounds__(256, TSC_MM16_OCC) void k_rmsd_sieve_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act,
+template <bool FUSED, bool F32, int MM16_WAVES>
+inline __global__ __launch_bounds__(64 * MM16_WAVES, TSC_MM16_OCC) void k_rmsd_sieve_mm16(const double *__restrict__ heavy, const int32_t *__restrict__ act,
                                                                         const double *__restrict__ Gall,                                                                         const _Float16 *__restrict__ Dh,
                                                                         const int32_t *__restrict__ cend, int32_t *__restrict__ best,
                                                                         PassCounters *__restrict__ counters, const PruneState *__restrict__ st, SieveArgs a,
                                                                         FusedApply fa) {
     constexpr int TI = 16;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * MM16_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = a.tile_begin + slot * a.tile_stride;
     const int r0 = tile * TI;
     const int seg_base = (r0 + 1) & ~63;
@@ -717,7 +721,7 @@ inline __global__ __launch_bounds__(256, TSC_MM16_OCC) void k_rmsd_sieve_mm16(co
     const int tcm = a.tile_cmax[tile];
     if (tcm <= seg_lo) return;
     int A = 0, bitsel = 0;
-    sieve_item_mm16<F32>(heavy, act, Gall, Dh, cend, best, counters, st, a, A, bitsel, tile, int(blockIdx.y));
+    sieve_item_mm16<F32, MM16_WAVES>(heavy, act, Gall, Dh, cend, best, counters, st, a, A, bitsel, tile, int(blockIdx.y));
     if constexpr (FUSED) {   // (k_rmsd_sieve's tail, sieve.hpp)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const int lim = min(a.n, tcm);

@@ -409,8 +409,9 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     if (mm) seg_cols = c->mm_seg_cols > 0 ? c->mm_seg_cols : (max_range >= 2048 ? 1024 : 512);
     const int n_seg = ceil_div(max_range + 64, seg_cols);  // + 64: a segment starts at the 64-aligned column below r0 + 1
     const int my_tiles = (n_tiles - rank + world - 1) / world;
-    // (mm: groups of 64 rows dealt round-robin to the ranks)
-    dim3 grid(std::max(1, mm ? ceil_div((ceil_div(A, MM_ROWS) - rank + world - 1) / world, MM_WAVES) : ceil_div(my_tiles, 4)), n_seg);
+    // (mm: groups of 64 rows dealt round-robin to the ranks; the 16-row matrix-core kernel: two items per workgroup, four where most workgroups are empty)
+    const int mm16_waves = mm16 ? (n_seg <= MM16_LONG_SEGS ? 2 : 4) : 4;
+    dim3 grid(std::max(1, mm ? ceil_div((ceil_div(A, MM_ROWS) - rank + world - 1) / world, MM_WAVES) : ceil_div(my_tiles, mm16_waves)), n_seg);
     // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
     // hipEventRecord before and after it costs about 4 us each on MI355X)
     hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -464,7 +465,7 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
         }
         const bool trim = c->sieve_cpl == 2 && c->sieve_trim;
         if (mm16) {
-            TSC_TRY(launch_rmsd_sieve_mm16(p->cur_fused, a.heavy32 != nullptr, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
+            TSC_TRY(launch_rmsd_sieve_mm16(p->cur_fused, a.heavy32 != nullptr, mm16_waves, st, grid, e0, e1, p->heavy, (const int32_t *)p->act, (const double *)p->Gall,
                                            (const _Float16 *)p->Dh, (const int32_t *)p->cend, p->best, p->counters,
                                            (const PruneState *)p->state, a, fa));
             return 0;

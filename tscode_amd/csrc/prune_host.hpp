@@ -179,7 +179,7 @@ int launch_rmsd_sieve_sorted(bool f32, hipStream_t st, dim3 grid, hipEvent_t e0,
                              const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state, const SieveArgs &a, const CullArgs &ca,
                              int my_tiles, int n_seg);
 // k_rmsd_sieve_mm16<fused, f32> (pairs_mm.hip): the matrix-core screen for 16-row items (k_rmsd_sieve's grid)
-int launch_rmsd_sieve_mm16(bool fused, bool f32, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
+int launch_rmsd_sieve_mm16(bool fused, bool f32, int waves, hipStream_t st, dim3 grid, hipEvent_t e0, hipEvent_t e1, const double *heavy, const int32_t *act, const double *Gall,
                            const _Float16 *Dh, const int32_t *cend, int32_t *best, PassCounters *counters, const PruneState *state,
                            const SieveArgs &a, const FusedApply &fa);
 // k_rmsd_sieve_sorted_mm<f32> (pairs_mm.hip): the culled pass with the screen on the matrix cores
