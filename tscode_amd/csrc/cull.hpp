@@ -187,6 +187,7 @@ inline __global__ __launch_bounds__(64) void k_cull_decide(PruneState *__restric
         const double f = 0.27 * cbrt(22000.0 / fmax(longest, 1.0));
         const int on = (w > 0 && (force || double(w) > 1.5 * f * all)) ? 1 : 0;  // (force: option "cull" = 2, tests; w = 0: a pass that is gated off, or whose rows have no columns left)
         st->cull_on = on;
+        flag_host[1] = st->A;   // (the rows of the pass: a pass that is WALKED is launched for these, not for the ensemble the run began with)
         *flag_host = on;
         __threadfence_system();
     }

@@ -387,7 +387,9 @@ extern "C" __attribute__((visibility("default"))) int tsc_prune_pass_estimate(ts
 
 // The pair search of one rank's row tiles of the open pass (step 3 of a pass; steps 1-2 have run).
 // rows_ub: upper bound of the rows of the pass on this device (n; in a rank-partitioned pass the structures of this rank's chunks)
-static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub) {
+// rows_now (optional, <= rows_ub): the rows the pass really has, where the host has learnt it (a pass that waited for k_cull_decide): the grid is
+// sized for them; everything the kernels COUNT arrivals by stays with rows_ub, which k_open_rows was launched with
+static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub, int64_t rows_now = -1) {
     tsc_ctx *c = p->ctx;
     hipStream_t st = c->stream;
     const int64_t n = p->n, k = p->cur_k;
@@ -411,7 +413,9 @@ static int launch_pair_search(tsc_prune *p, int rank, int world, int64_t rows_ub
     const int my_tiles = (n_tiles - rank + world - 1) / world;
     // (mm: groups of 64 rows dealt round-robin to the ranks; the 16-row matrix-core kernel: two items per workgroup, four where most workgroups are empty)
     const int mm16_waves = mm16 ? (n_seg <= MM16_LONG_SEGS ? 2 : 4) : 4;
-    dim3 grid(std::max(1, mm ? ceil_div((ceil_div(A, MM_ROWS) - rank + world - 1) / world, MM_WAVES) : ceil_div(my_tiles, mm16_waves)), n_seg);
+    const int A_grid = rows_now >= 0 ? int(std::min<int64_t>(std::max<int64_t>(rows_now, 1), A)) : A;
+    const int grid_tiles = (ceil_div(A_grid, TILE_ROWS) - rank + world - 1) / world;
+    dim3 grid(std::max(1, mm ? ceil_div((ceil_div(A_grid, MM_ROWS) - rank + world - 1) / world, MM_WAVES) : ceil_div(std::min(my_tiles, grid_tiles), mm16_waves)), n_seg);
     // the pair kernel's own start / stop events ride on its dispatch packet (no extra packets in the stream; a
     // hipEventRecord before and after it costs about 4 us each on MI355X)
     hipEvent_t e0 = c->pass_timing >= 1 ? p->ev[slot][1] : nullptr, e1 = c->pass_timing >= 1 ? p->ev[slot][2] : nullptr;
@@ -623,6 +627,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                            p->Xr, p->Xc, p->npad, p->G);
     }
     bool run_culled = false;
+    int64_t rows_now = -1;   // (the pass's rows, where the host has waited for the device anyway)
     if (culled) {
         // culled, or walked in index order?  The rows' ranges decide (k_cull_decide); the host waits for the verdict -- a pass this
         // large takes a millisecond or more, the round trip some 20 us
@@ -634,6 +639,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
                            c->cull == 2 ? 1 : 0, const_cast<int *>(flag));
         TSC_HIP(hipStreamSynchronize(st));
         run_culled = *flag != 0;
+        rows_now = flag[1];
     }
     if (run_culled && !p->morton_sorted) {
         // once per run: the structures in coarse Morton order of their descriptors -- a stable two-digit radix sort by cell, so that
@@ -732,7 +738,7 @@ static int pass_launch(tsc_prune *p, int rank, int world, bool range) {
         p->local_done = true;
         return 0;
     }
-    TSC_TRY(launch_pair_search(p, rank, world, A));
+    TSC_TRY(launch_pair_search(p, rank, world, A, rows_now));
     p->local_done = true;
     return 0;
 }
