@@ -925,6 +925,26 @@ def test_prune_random_small_ensembles(eng, oracle, algo):
     assert checked > 100
 
 
+def test_prune_random_medium_ensembles(eng, oracle):
+    """Three fixed cases of tests/soak_mm.py (random ensembles of a few thousand structures: several passes, chunks of every kind) through the
+    64-row walked, the culled and the 16-row matrix-core kernels and the packed-fp32 one, stage 1 in float64 and float32: masks, the passes' k
+    and the reference's pair-evaluation counts (rmsd_pruning.py:65-75) equal the oracle's.  The soak itself ran 38 such cases (profiles/r05_soak_mm.txt)."""
+    import soak_mm
+    rng = np.random.default_rng(77)
+    checked = 0
+    for _ in range(3):
+        heavy, thr, what = soak_mm.make_case(rng, sizes=(1500, 2048, 3001, 6000))
+        for mode in (0, 1):
+            mr, mm = oracle.prune_margins(heavy, thr, mode)
+            if min(mr, mm) < 1e-7:
+                continue
+            ref = oracle.prune_heavy(heavy, thr, mode=mode, row_parallel=True)
+            res = soak_mm.run_routes(eng, heavy, thr, mode, ref)
+            assert all(res.values()), (what, mode, res)
+            checked += 1
+    assert checked >= 4
+
+
 def _blocks_of_near_duplicates(n_parents, children, h, seed):
     rng = np.random.default_rng(seed)
     parents = rng.normal(size=(n_parents, h, 3)) * 3.0
